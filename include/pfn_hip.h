@@ -1,0 +1,157 @@
+/*
+ * pfn_hip.h -- C ABI of libpfn_hip.so, the MI355X (gfx950) implementation of the PFN training
+ * hot path of automl/TransformersCanDoBayesianInference.
+ *
+ * The reference is pure Python and has no FFI of its own; the drop-in
+ * boundary is its Python module surface.  Every entry point below names the reference code it
+ * replaces (paths relative to the reference checkout).  A binding needs nothing but dlopen /
+ * ctypes.CDLL: plain pointers, sizes, and a HIP stream handle passed as void*.
+ *
+ * Contract (all entry points):
+ *   - every pointer is DEVICE memory owned by the caller unless stated otherwise; the library
+ *     never allocates or frees device memory and never synchronises the device;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t; NULL = the legacy default stream);
+ *   - return value: PFN_OK (0) or a negative PFN_ERR_* code; pfn_last_error_string() gives detail;
+ *     no C++ exception crosses the boundary;
+ *   - re-entrant for distinct streams; no global mutable state besides the per-thread error string.
+ *
+ * Internal activation layout is batch-major [B, S, E] (one synthetic dataset = one contiguous
+ * block); the reference layout [S, B, ...] is converted at the boundary kernels.
+ */
+#ifndef PFN_HIP_H
+#define PFN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFN_ABI_VERSION 1
+
+enum {
+  PFN_OK = 0,
+  PFN_ERR_UNSUPPORTED = -1, /* shape / option outside what the kernels implement */
+  PFN_ERR_ALIGNMENT = -2,   /* pointer or leading dimension not 16-byte aligned */
+  PFN_ERR_LAUNCH = -3,      /* hipGetLastError() after a launch */
+  PFN_ERR_ARGUMENT = -4,    /* NULL pointer, negative size, workspace too small ... */
+};
+
+enum { PFN_PREC_BF16 = 0, /* bf16 MFMA operands, f32 accumulate / residual / statistics */
+       PFN_PREC_F32 = 1 /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity / debugging mode */ };
+
+/* Architecture of TransformerModel (transformer.py:14-26) with the default Linear encoders
+ * (encoders.py:8), NoPositionalEncoding (positional_encodings.py:12-18) and the default
+ * decoder Linear-GELU-Linear (transformer.py:23). */
+typedef struct pfn_model_desc {
+  int32_t num_features; /* x-encoder input width (train.py:33) */
+  int32_t emsize;       /* ninp */
+  int32_t nhead;
+  int32_t nhid;         /* FFN width and decoder hidden width (transformer.py:17,23) */
+  int32_t nlayers;
+  int32_t n_out;        /* decoder output width (criterion.num_bars for bar losses, train.py:39) */
+  int32_t precision;    /* PFN_PREC_* */
+  float ln_eps;         /* 1e-5 (torch LayerNorm default) */
+} pfn_model_desc;
+
+int pfn_abi_version(void);
+const char* pfn_last_error_string(void);
+
+/* ---- parameter packing ------------------------------------------------------------------------
+ * All parameters live in ONE flat f32 buffer (and one flat f32 gradient buffer) in state-dict
+ * order: encoder.{weight,bias}, y_encoder.{weight,bias}, then per layer
+ * self_attn.in_proj_{weight,bias}, self_attn.out_proj.{weight,bias}, linear1.{weight,bias},
+ * linear2.{weight,bias}, norm1.{weight,bias}, norm2.{weight,bias}, then decoder.0.{weight,bias},
+ * decoder.2.{weight,bias} (SURVEY.md 8(b) key list).  Each tensor starts at a multiple of 64
+ * elements.  pfn_param_layout fills offsets[i] (elements) for tensor i; returns the tensor count
+ * (4 + 12*nlayers + 4) or a negative error.  offsets may be NULL to query the count. */
+int pfn_param_layout(const pfn_model_desc* d, int64_t* offsets, int64_t* numels, int max_tensors);
+int64_t pfn_param_count(const pfn_model_desc* d);
+/* operand-precision shadow of the weights (+ transposed copies for the data-gradient GEMMs) */
+int64_t pfn_shadow_bytes(const pfn_model_desc* d);
+int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shadow, void* stream);
+
+/* ---- encoder stack: replaces TransformerModel.forward (transformer.py:55-91) -------------------
+ * x: [T,B,F] f32 with element strides (x_st, x_sb, 1); y: [T,B] f32 with strides (y_st, y_sb).
+ * sep = single_eval_pos, already normalised to [0,T].  Attention mask semantics of
+ * generate_D_q_matrix (transformer.py:34-41): query i may attend key j iff j < sep or j == i.
+ * logits: [(T-sep)*B, n_out] f32, row (t-sep)*B + b  (== output[single_eval_pos:] of the reference).
+ * workspace: pfn_workspace_bytes() bytes; holds the activations pfn_stack_backward needs.
+ * src_sbe: optional [T,B,E] f32 pre-embedded input (custom encoders / positional encodings run
+ * in PyTorch); when non-NULL x/y are ignored and pfn_stack_backward returns d(src) in dsrc_sbe. */
+int64_t pfn_workspace_bytes(const pfn_model_desc* d, int B, int S);
+int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* shadow,
+                      const float* x, int64_t x_st, int64_t x_sb,
+                      const float* y, int64_t y_st, int64_t y_sb,
+                      const float* src_sbe,
+                      int B, int S, int sep,
+                      void* workspace, int64_t workspace_bytes,
+                      float* logits, void* stream);
+/* replaces loss.backward() through the model (train.py:93).  dlogits: [(T-sep)*B, n_out] f32.
+ * grads: flat f32 buffer in pfn_param_layout order; gradients are ACCUMULATED into it
+ * (train.py:92-97 sums micro-batch gradients). */
+int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void* shadow,
+                       const float* x, int64_t x_st, int64_t x_sb,
+                       const float* y, int64_t y_st, int64_t y_sb,
+                       int B, int S, int sep,
+                       void* workspace, int64_t workspace_bytes,
+                       const float* dlogits, float* grads, float* dsrc_sbe, void* stream);
+
+/* ---- bar distribution: replaces BarDistribution / FullSupportBarDistribution.forward and .mean
+ * (bar_distribution.py:19-38, 83-117).  logits [R, nbars] f32 (row stride ld), y [R], borders
+ * [nbars+1] sorted.  nll [R].  lse [R] and bucket [R] are saved for the backward. */
+int pfn_bar_nll_forward(const float* logits, int64_t ld, const float* y, const float* borders,
+                        int64_t R, int nbars, int full_support,
+                        float* nll, float* lse, int32_t* bucket, void* stream);
+/* dlogits[r,:] = gout[r] * (softmax(logits[r,:]) - onehot(bucket[r])) */
+int pfn_bar_nll_backward(const float* logits, int64_t ld, const float* lse, const int32_t* bucket,
+                         const float* gout, int64_t R, int nbars, float* dlogits, void* stream);
+int pfn_bar_mean(const float* logits, int64_t ld, const float* borders, int64_t R, int nbars,
+                 int full_support, float* mean, void* stream);
+
+/* ---- optimizer: replaces clip_grad_norm_(params, 1.) + Adam.step() + zero_grad()
+ * (train.py:55,95-97).  One fused pass over the flat buffers; the clip coefficient is computed on
+ * the device (no host sync).  grad_scale multiplies g first (1/world for DP averaging).
+ * scratch: >= 8192 bytes; scratch[0] (f32) receives the global gradient norm before clipping.
+ * zero_grad != 0 clears g after the update. */
+int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float max_norm,
+                       float grad_scale, int step, int zero_grad, float* scratch, void* stream);
+
+/* ---- GP prior sampler: replaces priors.fast_gp.get_batch (priors/fast_gp.py:35-58) and the
+ * sampling half of priors.fast_gp_mix.get_batch (priors/fast_gp_mix.py:85-99).
+ * y_b ~ N(0, outputscale_b * k(x_b, x_b; lengthscale_b) + noise_b * I) by Gram -> Cholesky -> L z.
+ * x [B,S,nf] f32: filled with U[0,1) from the counter-based generator when gen_x != 0, else input.
+ * z [B,S] f32 base normals: generated when gen_z != 0 (and written back), else input.
+ * lengthscale [B,nf], outputscale [B], noise [B].  kernel: 0 = RBF, 1 = Matern nu=2.5.
+ * K_ws: [B,S,S] f32 workspace.  info [B]: 0 or (index+1) of the first non-positive pivot. */
+int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws,
+                        const float* lengthscale, const float* outputscale, const float* noise,
+                        int B, int S, int nf, int kernel, int gen_x, int gen_z,
+                        uint64_t seed, uint64_t offset, int32_t* info, void* stream);
+
+/* ---- single-op entry points (unit tests / profiling of individual kernels) --------------------
+ * prec selects operand element type T: bf16 (2 bytes) or f32. */
+int pfn_op_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                   int flags, const float* bias, const void* aux, int64_t ld_aux,
+                   const float* resid, int64_t ld_resid, float* out_f32, int64_t ld_out_f32,
+                   void* out_t, int64_t ld_out_t, void* out2_t, int64_t ld_out2, int prec, void* stream);
+int pfn_op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                   int M, int P, int Q, int atomic, int prec, void* stream);
+int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep,
+                         int prec, void* stream);
+int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx,
+                         void* dqkv, float* delta_ws, int B, int S, int E, int H, int sep,
+                         int prec, void* stream);
+int pfn_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
+                         float* mean, float* rstd, int64_t rows, int E, float eps, int prec, void* stream);
+int pfn_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                         const float* rstd, float* dx_f32, void* dx_t, float* dgamma, float* dbeta,
+                         float* dbias_extra, int64_t rows, int E, int prec, void* stream);
+int pfn_op_cast(const float* src, void* dst, int64_t n, int prec, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFN_HIP_H */

@@ -1,0 +1,156 @@
+"""Generates tests/golden/*.pt by running the REFERENCE ITSELF (imported from /root/reference) on
+fixed-seed inputs.  Test infrastructure; run in the build container only (the reference does not
+travel to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python oracle/make_golden.py
+
+The reference imports gpytorch in priors/__init__.py:1 (absent here), so a stub `priors` package
+is registered first; only reference modules that import cleanly are used:
+transformer.TransformerModel, bar_distribution.*, encoders, positional_encodings, utils, train.
+Weights: the reference zero-initialises out_proj / linear2 (transformer.py:49-53), which would make
+attention and the MLP invisible, so those tensors are re-drawn N(0, 0.05) before recording.
+"""
+import os
+import random
+import sys
+import types
+
+import torch
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    pk = types.ModuleType('priors')
+    pk.__path__ = [os.path.join(REF, 'priors')]
+    sys.modules['priors'] = pk
+    import bar_distribution, encoders, positional_encodings, train, transformer, utils  # noqa
+    return dict(bar_distribution=bar_distribution, encoders=encoders, positional_encodings=positional_encodings,
+                train=train, transformer=transformer, utils=utils)
+
+
+def gp_draw(B, T, F, gen, ls=0.6, os_=1.0, noise=1e-4):
+    """Plain-torch statement of priors/fast_gp.py:41-58 (gpytorch absent): f64 Cholesky draw."""
+    x = torch.rand(B, T, F, generator=gen)
+    z = torch.randn(B, T, generator=gen)
+    xs = x.double() / ls
+    d2 = (xs.unsqueeze(2) - xs.unsqueeze(1)).pow(2).sum(-1)
+    K = os_ * torch.exp(-0.5 * d2) + noise * torch.eye(T, dtype=torch.float64)
+    y = (torch.linalg.cholesky(K) @ z.double().unsqueeze(-1)).squeeze(-1).float()
+    return x.transpose(0, 1).contiguous(), y.transpose(0, 1).contiguous(), z
+
+
+def model_case(ref, name, T, B, F, E, H, nhid, L, nbars, seps, seed):
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed)
+    x, y, _ = gp_draw(B, T, F, gen)
+    ys_for_borders = gp_draw(200, 20, F, gen)[1]
+    borders = ref['bar_distribution'].get_bucket_limits(nbars, ys=ys_for_borders)
+    criterion = ref['bar_distribution'].FullSupportBarDistribution(borders)
+    model = ref['transformer'].TransformerModel(ref['encoders'].Linear(F, E), nbars, E, H, nhid, L, 0.0,
+                                                y_encoder=ref['encoders'].Linear(1, E),
+                                                pos_encoder=ref['positional_encodings'].NoPositionalEncoding(E, T * 2))
+    model.criterion = criterion
+    with torch.no_grad():
+        for layer in model.transformer_encoder.layers:
+            for t in (layer.linear2.weight, layer.linear2.bias, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias):
+                t.normal_(0, 0.05)
+            for t in (layer.norm1.weight, layer.norm2.weight):
+                t.add_(0.1 * torch.randn_like(t))
+            for t in (layer.norm1.bias, layer.norm2.bias, layer.self_attn.in_proj_bias):
+                t.normal_(0, 0.05)
+    model.train()
+    rec = dict(config=dict(T=T, B=B, F=F, E=E, H=H, nhid=nhid, L=L, nbars=nbars), x=x, y=y, target_y=y.clone(),
+               state_dict={k: v.clone() for k, v in model.state_dict().items()}, per_sep={})
+    for sep in seps:
+        model.zero_grad()
+        logits = model((x, y), single_eval_pos=sep)                       # reference forward, transformer.py:55-91
+        targets = y[sep:]
+        losses = criterion(logits.reshape(-1, nbars), targets.flatten()).view(*logits.shape[:2])   # train.py:88-89
+        loss = losses.mean()
+        loss.backward()
+        rec['per_sep'][sep] = dict(logits=logits.detach().clone(), losses=losses.detach().clone(), loss=loss.detach().clone(),
+                                   mean=criterion.mean(logits.detach()).clone())
+        if sep in seps[:2]:  # gradients for the first two positions only (fixture size)
+            rec['per_sep'][sep]['grads'] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    # two optimisation steps exactly as train.py:92-97 (Adam lr 1e-3, clip 1.0), at seps[0]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    traj = []
+    for step in range(2):
+        opt.zero_grad()
+        logits = model((x, y), single_eval_pos=seps[0])
+        losses = criterion(logits.reshape(-1, nbars), y[seps[0]:].flatten())
+        loss = losses.mean()
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.)
+        opt.step()
+        traj.append(dict(loss=loss.detach().clone(), grad_norm=norm.detach().clone()))
+    rec['train'] = dict(sep=seps[0], steps=traj, final_state_dict={k: v.clone() for k, v in model.state_dict().items()})
+    torch.save(rec, os.path.join(OUT, f'{name}.pt'))
+    print(name, 'losses', {s: float(r['loss']) for s, r in rec['per_sep'].items()}, 'train', [float(t['loss']) for t in traj])
+
+
+def bar_case(ref):
+    gen = torch.Generator().manual_seed(7)
+    rec = {}
+    for nb, full in [(10, True), (100, True), (1000, True), (10, False), (100, False)]:
+        ys = torch.randn(nb * 50, generator=gen)
+        borders = ref['bar_distribution'].get_bucket_limits(nb, ys=ys)
+        cls = ref['bar_distribution'].FullSupportBarDistribution if full else ref['bar_distribution'].BarDistribution
+        crit = cls(borders)
+        R = 64
+        logits = torch.randn(R, nb, generator=gen) * 2
+        lo, hi = borders[0].item(), borders[-1].item()
+        y = torch.rand(R, generator=gen) * (hi - lo) + lo
+        if full:
+            y[:8] = lo - torch.rand(8, generator=gen) * 2
+            y[8:16] = hi + torch.rand(8, generator=gen) * 2
+        y[16], y[17], y[18] = borders[0], borders[-1], borders[nb // 2]
+        logits.requires_grad_(True)
+        nll = crit(logits, y)
+        w = torch.rand(R, generator=gen)
+        (nll * w).sum().backward()
+        rec[(nb, full)] = dict(borders=borders, logits=logits.detach().clone(), y=y, nll=nll.detach().clone(), w=w,
+                               dlogits=logits.grad.clone(), mean=crit.mean(logits.detach()).clone(),
+                               bucket=crit.map_to_bucket_idx(y).clamp(0, nb - 1))
+    rec['bucket_limits_uniform'] = ref['bar_distribution'].get_bucket_limits(8, full_range=(-2., 6.))
+    torch.save(rec, os.path.join(OUT, 'bar_distribution.pt'))
+    print('bar cases', list(k for k in rec if isinstance(k, tuple)))
+
+
+def utils_case(ref):
+    u = ref['utils']
+    p = torch.nn.Parameter(torch.zeros(1))
+    rec = {}
+    for name, fn, args in [('cosine', u.get_cosine_schedule_with_warmup, (5, 20)), ('linear', u.get_linear_schedule_with_warmup, (5, 20))]:
+        opt = torch.optim.SGD([p], lr=1.0)
+        sch = fn(opt, *args)
+        vals = []
+        for _ in range(22):
+            vals.append(sch.get_last_lr()[0])
+            opt.step()
+            sch.step()
+        rec[name] = vals
+    random.seed(123)
+    s = u.get_weighted_single_eval_pos_sampler(50)
+    rec['weighted_draws'] = [s() for _ in range(200)]
+    random.seed(123)
+    s = u.get_uniform_single_eval_pos_sampler(50)
+    rec['uniform_draws'] = [s() for _ in range(200)]
+    m = torch.nn.Linear(10, 10)
+    rec['openai_lr_110'] = u.get_openai_lr(m)
+    rec['d_q_mask_6_2'] = ref['transformer'].TransformerModel.generate_D_q_matrix(6, 2)
+    torch.save(rec, os.path.join(OUT, 'utils.pt'))
+    print('utils ok')
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    torch.set_num_threads(4)
+    model_case(ref, 'model_small_h32', T=60, B=3, F=5, E=64, H=2, nhid=128, L=2, nbars=50, seps=[41, 0, 59, 7], seed=11)
+    model_case(ref, 'model_small_h64', T=100, B=4, F=5, E=128, H=2, nhid=72, L=1, nbars=100, seps=[70, 33], seed=12)
+    bar_case(ref)
+    utils_case(ref)

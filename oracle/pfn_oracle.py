@@ -1,0 +1,188 @@
+"""CPU oracle (test infrastructure only; see oracle/__init__.py).
+
+Explicit-math restatement, in plain PyTorch on CPU tensors (f64 by default), of
+  * TransformerModel.forward                      reference transformer.py:55-91
+    with nn.TransformerEncoderLayer (post-norm, GELU-erf, eps 1e-5)
+                                                  torch nn/modules/transformer.py:952-982
+    and multi_head_attention_forward              torch nn/functional.py:6435, 5964-5968, 6637
+    under the mask of generate_D_q_matrix         reference transformer.py:34-41
+  * (FullSupport)BarDistribution.forward / mean   reference bar_distribution.py:19-38, 83-117
+  * one optimisation step of train()              reference train.py:88-97 (mean loss, backward,
+                                                  clip_grad_norm_(1.0), Adam)
+  * priors.fast_gp.get_batch                      reference priors/fast_gp.py:13-58 (gpytorch
+    semantics restated: K = outputscale * exp(-0.5 |dx/l|^2) + noise I, y = chol(K) z)
+  * priors.fast_gp_mix kernel                     reference priors/fast_gp_mix.py:28-47 (Matern-5/2 ARD)
+Nothing here calls nn.TransformerEncoder: the layer math is written out, and is pinned against the
+real reference modules by tests/golden (oracle/make_golden.py).
+"""
+import math
+
+import torch
+
+
+def _linear(x, w, b):
+    return x @ w.t() + b
+
+
+def _layer_norm(x, w, b, eps=1e-5):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def d_q_mask(T, sep, dtype, device):
+    """Additive 0/-inf mask: key j visible to query i iff j < sep or i == j (transformer.py:34-41)."""
+    allowed = torch.zeros(T, T, dtype=torch.bool, device=device)
+    allowed[:, :sep] = True
+    allowed |= torch.eye(T, dtype=torch.bool, device=device)
+    return torch.zeros(T, T, dtype=dtype, device=device).masked_fill(~allowed, float('-inf'))
+
+
+def forward(sd, x, y, sep, nhead, dtype=torch.float64, return_hidden=False):
+    """logits[T-sep, B, n_out] from a reference-format state dict `sd` (keys as in SURVEY.md 8(b))."""
+    p = {k: v.detach().to(dtype) if not v.requires_grad else v.to(dtype) for k, v in sd.items()}
+    x, y = x.to(dtype), y.to(dtype)
+    T, B, _ = x.shape
+    if sep < 0:
+        sep += T
+    x_emb = _linear(x, p['encoder.weight'], p['encoder.bias'])                    # transformer.py:68
+    y_emb = _linear(y.unsqueeze(-1), p['y_encoder.weight'], p['y_encoder.bias'])  # :69
+    h = torch.cat([x_emb[:sep] + y_emb[:sep], x_emb[sep:]], 0)                    # :73-74
+    E = h.shape[-1]
+    D = E // nhead
+    mask = d_q_mask(T, sep, dtype, h.device)
+    nlayers = 1 + max(int(k.split('.')[2]) for k in p if k.startswith('transformer_encoder.layers.'))
+    for l in range(nlayers):
+        pre = f'transformer_encoder.layers.{l}.'
+        qkv = _linear(h, p[pre + 'self_attn.in_proj_weight'], p[pre + 'self_attn.in_proj_bias'])   # [T,B,3E]
+        q, k, v = [t.reshape(T, B, nhead, D).permute(1, 2, 0, 3) for t in qkv.split(E, -1)]        # [B,H,T,D]
+        scores = q @ k.transpose(-1, -2) / math.sqrt(D) + mask
+        ctx = (torch.softmax(scores, -1) @ v).permute(2, 0, 1, 3).reshape(T, B, E)
+        att = _linear(ctx, p[pre + 'self_attn.out_proj.weight'], p[pre + 'self_attn.out_proj.bias'])
+        h = _layer_norm(h + att, p[pre + 'norm1.weight'], p[pre + 'norm1.bias'])
+        ff = _linear(_gelu(_linear(h, p[pre + 'linear1.weight'], p[pre + 'linear1.bias'])), p[pre + 'linear2.weight'], p[pre + 'linear2.bias'])
+        h = _layer_norm(h + ff, p[pre + 'norm2.weight'], p[pre + 'norm2.bias'])
+    if return_hidden:
+        return h
+    out = _linear(_gelu(_linear(h, p['decoder.0.weight'], p['decoder.0.bias'])), p['decoder.2.weight'], p['decoder.2.bias'])  # :85
+    return out[sep:]                                                                                                          # :91
+
+
+# ---- bar distribution -----------------------------------------------------------------------------
+_HN_ICDF_HALF = 0.6744897501960817  # HalfNormal(1).icdf(0.5) = Normal.icdf(0.75)
+
+
+def bar_bucket(borders, y):
+    """map_to_bucket_idx (bar_distribution.py:19-23) + the clamp of the full-support variant (:92)."""
+    nb = len(borders) - 1
+    t = torch.searchsorted(borders, y) - 1
+    t[y == borders[0]] = 0
+    t[y == borders[-1]] = nb - 1
+    return t.clamp(0, nb - 1)
+
+
+def bar_nll(logits, y, borders, full_support=True):
+    """FullSupportBarDistribution.forward (bar_distribution.py:89-108) / BarDistribution.forward (:25-33)."""
+    dtype = logits.dtype
+    borders = borders.to(dtype)
+    y = y.to(dtype)
+    nb = len(borders) - 1
+    widths = borders[1:] - borders[:-1]
+    t = bar_bucket(borders, y)
+    lp = (torch.log_softmax(logits, -1) - torch.log(widths)).gather(-1, t.unsqueeze(-1)).squeeze(-1)
+    if full_support:
+        def halfnormal_logprob(scale, v):  # torch.distributions.HalfNormal(scale).log_prob(v), v >= 0
+            return math.log(2.0) - torch.log(scale) - 0.5 * math.log(2 * math.pi) - 0.5 * (v / scale) ** 2
+        s0, s1 = widths[0] / _HN_ICDF_HALF, widths[-1] / _HN_ICDF_HALF
+        first, last = (t == 0), (t == nb - 1)
+        lp = lp + first * (halfnormal_logprob(s0, (borders[1] - y).clamp(min=1e-8)) + torch.log(widths[0]))
+        lp = lp + last * (halfnormal_logprob(s1, (y - borders[-2]).clamp(min=0)) + torch.log(widths[-1]))
+    return -lp
+
+
+def bar_mean(logits, borders, full_support=True):
+    """FullSupportBarDistribution.mean (bar_distribution.py:110-117) / BarDistribution.mean (:35-38)."""
+    borders = borders.to(logits.dtype)
+    widths = borders[1:] - borders[:-1]
+    means = borders[:-1] + widths / 2
+    if full_support:
+        means = means.clone()
+        means[0] = borders[1] - widths[0] / _HN_ICDF_HALF * math.sqrt(2 / math.pi)
+        means[-1] = borders[-2] + widths[-1] / _HN_ICDF_HALF * math.sqrt(2 / math.pi)
+    return torch.softmax(logits, -1) @ means
+
+
+# ---- one training step ------------------------------------------------------------------------------
+def loss_and_grads(sd, x, y, target_y, sep, nhead, borders, full_support=True, dtype=torch.float64):
+    """mean bar-NLL over the test rows and d loss / d parameter for every state-dict tensor
+    (train.py:70-93 with criterion = FullSupportBarDistribution)."""
+    leaves = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items() if not k.startswith('criterion.')}
+    logits = forward(leaves, x, y, sep, nhead, dtype)
+    T = x.shape[0]
+    s = sep if sep >= 0 else sep + T
+    losses = bar_nll(logits.reshape(-1, logits.shape[-1]), target_y[s:].reshape(-1), borders, full_support).view(logits.shape[:2])
+    loss = losses.mean()
+    loss.backward()
+    return loss.detach(), logits.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
+    """clip_grad_norm_(params, max_norm) then torch.optim.Adam.step() (train.py:95-96), dict-of-tensors in place."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))
+    coef = min(1.0, max_norm / (total.item() + 1e-6))
+    bc1, bc2 = 1 - betas[0] ** step, 1 - betas[1] ** step
+    for k in params:
+        g = grads[k] * coef
+        exp_avg[k].mul_(betas[0]).add_(g, alpha=1 - betas[0])
+        exp_avg_sq[k].mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        denom = exp_avg_sq[k].sqrt() / math.sqrt(bc2) + eps
+        params[k].addcdiv_(exp_avg[k], denom, value=-lr / bc1)
+    return total
+
+
+# ---- GP priors ----------------------------------------------------------------------------------------
+def gp_gram(x, lengthscale, outputscale, noise, kernel='rbf'):
+    """x [B,T,F]; lengthscale broadcastable to [B,1,F]; outputscale / noise broadcastable to [B,1,1].
+    RBF: ScaleKernel(RBFKernel) of priors/fast_gp.py:17 (k = exp(-0.5 |dx/l|^2)); Matern-5/2 ARD:
+    priors/fast_gp_mix.py:28-34; + GaussianLikelihood noise on the diagonal."""
+    xs = x / lengthscale
+    d2 = (xs.unsqueeze(2) - xs.unsqueeze(1)).pow(2).sum(-1).clamp_min(0)
+    if kernel == 'rbf':
+        k = torch.exp(-0.5 * d2)
+    else:
+        r = torch.sqrt(5.0 * d2)
+        k = (1 + r + r * r / 3) * torch.exp(-r)
+    eye = torch.eye(x.shape[1], dtype=x.dtype, device=x.device)
+    return outputscale * k + noise * eye
+
+
+def gp_sample(x, z, lengthscale, outputscale, noise, kernel='rbf', dtype=torch.float64):
+    """y = chol(K) z  -- the draw of `likelihood(model(x)).sample()` in prior mode (fast_gp.py:53-56)
+    for given uniform features x [B,T,F] and base normals z [B,T]."""
+    x, z = x.to(dtype), z.to(dtype)
+    B, T, F = x.shape
+    as_t = lambda v: torch.as_tensor(v, dtype=dtype)
+    ls = as_t(lengthscale)
+    ls = ls.reshape(B, 1, -1) if ls.dim() > 0 and ls.numel() > 1 else ls.reshape(1, 1, 1)
+    os_ = as_t(outputscale).reshape(-1, 1, 1)
+    nz = as_t(noise).reshape(-1, 1, 1)
+    K = gp_gram(x, ls, os_, nz, kernel)
+    L = torch.linalg.cholesky(K)
+    return (L @ z.unsqueeze(-1)).squeeze(-1)
+
+
+def get_batch_fast_gp(batch_size, seq_len, num_features, hyperparameters=None, generator=None, dtype=torch.float32):
+    """CPU statement of priors.fast_gp.get_batch (fast_gp.py:35-58): returns (x[T,B,F], y[T,B], y[T,B])."""
+    if isinstance(hyperparameters, (tuple, list)):
+        hyperparameters = {"noise": hyperparameters[0], "outputscale": hyperparameters[1], "lengthscale": hyperparameters[2]}
+    elif hyperparameters is None:
+        hyperparameters = {"noise": .1, "outputscale": .1, "lengthscale": .1}
+    x = torch.rand(batch_size, seq_len, num_features, generator=generator)
+    z = torch.randn(batch_size, seq_len, generator=generator)
+    y = gp_sample(x, z, hyperparameters["lengthscale"], hyperparameters["outputscale"], max(hyperparameters["noise"], 1e-9), 'rbf', dtype)
+    y = y.float()
+    return x.transpose(0, 1), y.transpose(0, 1), y.transpose(0, 1)

@@ -1,0 +1,70 @@
+"""Thin test-side wrappers around the single-op C-ABI entry points (pfn_op_*)."""
+import torch
+
+from transformerscandobayesianinference_amd import _hip
+
+TDT = {_hip.PREC_BF16: torch.bfloat16, _hip.PREC_F32: torch.float32}
+
+
+def sp():
+    return _hip.stream_ptr()
+
+
+def gemm_nt(A, B, flags, prec, bias=None, aux=None, resid=None, out_f32=None, out_t=None, out2_t=None):
+    M, K = A.shape
+    N = B.shape[0]
+    p = _hip.ptr
+    ld = lambda t: 0 if t is None else t.stride(0)
+    _hip.check(_hip.lib().pfn_op_gemm_nt(p(A), A.stride(0), p(B), B.stride(0), M, N, K, flags, p(bias), p(aux), ld(aux),
+                                         p(resid), ld(resid), p(out_f32), ld(out_f32), p(out_t), ld(out_t), p(out2_t), ld(out2_t),
+                                         prec, sp()), 'pfn_op_gemm_nt')
+
+
+def gemm_tn(A, B, C, prec, atomic=1):
+    M, P = A.shape
+    Q = B.shape[1]
+    _hip.check(_hip.lib().pfn_op_gemm_tn(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0), M, P, Q,
+                                         atomic, prec, sp()), 'pfn_op_gemm_tn')
+
+
+def attention_fwd(qkv, H, sep, prec):
+    B, S, E3 = qkv.shape
+    E = E3 // 3
+    ctx = torch.empty(B, S, E, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
+    _hip.check(_hip.lib().pfn_op_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, S, E, H, sep, prec, sp()), 'attn fwd')
+    return ctx, lse
+
+
+def attention_bwd(qkv, ctx, lse, dctx, H, sep, prec):
+    B, S, E3 = qkv.shape
+    E = E3 // 3
+    dqkv = torch.full_like(qkv, float('nan'))
+    delta = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
+    _hip.check(_hip.lib().pfn_op_attention_bwd(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(),
+                                               delta.data_ptr(), B, S, E, H, sep, prec, sp()), 'attn bwd')
+    return dqkv
+
+
+def layernorm_fwd(x, gamma, beta, eps, prec):
+    rows, E = x.shape
+    y32 = torch.empty_like(x)
+    yt = torch.empty(rows, E, dtype=TDT[prec], device=x.device)
+    mean = torch.empty(rows, device=x.device)
+    rstd = torch.empty(rows, device=x.device)
+    _hip.check(_hip.lib().pfn_op_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y32.data_ptr(), yt.data_ptr(),
+                                               mean.data_ptr(), rstd.data_ptr(), rows, E, eps, prec, sp()), 'ln fwd')
+    return y32, yt, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, prec):
+    rows, E = x.shape
+    dx32 = torch.empty_like(x)
+    dxt = torch.empty(rows, E, dtype=TDT[prec], device=x.device)
+    dg = torch.zeros(E, device=x.device)
+    db = torch.zeros(E, device=x.device)
+    dbias = torch.zeros(E, device=x.device)
+    _hip.check(_hip.lib().pfn_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               dx32.data_ptr(), dxt.data_ptr(), dg.data_ptr(), db.data_ptr(), dbias.data_ptr(),
+                                               rows, E, prec, sp()), 'ln bwd')
+    return dx32, dxt, dg, db, dbias

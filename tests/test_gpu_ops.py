@@ -1,0 +1,251 @@
+"""GPU unit tests of the individual HIP kernels against plain PyTorch references of the same op.
+
+bf16 cases are compared against an f64 reference computed from the SAME bf16-rounded inputs, so
+the tolerance only has to cover accumulation-order effects and the bf16 rounding of the outputs;
+the exact-f32 MFMA path is held to f32 round-off.
+"""
+import math
+
+import pytest
+import torch
+
+from transformerscandobayesianinference_amd import _hip
+import hipops
+
+pytestmark = pytest.mark.gpu
+BF, F32 = _hip.PREC_BF16, _hip.PREC_F32
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=None):
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xffff))
+    return (torch.randn(*shape, generator=g) * scale).to(dev()).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def maxerr(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+GEMM_SHAPES = [(128, 128, 64), (256, 512, 512), (300, 200, 136), (4000, 1536, 512), (77, 1000, 1024), (1024, 8, 200), (130, 1, 64)]
+
+
+@pytest.mark.parametrize('prec', [BF, F32])
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+def test_gemm_nt_plain(M, N, K, prec):
+    dt = hipops.TDT[prec]
+    A, B = rnd(M, K, dtype=dt, seed=1), rnd(N, K, dtype=dt, seed=2)
+    out = torch.full((M, N), float('nan'), device=dev())
+    hipops.gemm_nt(A, B, _hip.EPI_OUT_F32, prec, out_f32=out)
+    ref = A.double() @ B.double().t()
+    tol = 1e-5
+    assert relerr(out, ref) < tol, relerr(out, ref)
+
+
+@pytest.mark.parametrize('prec', [BF, F32])
+def test_gemm_nt_asymmetric_identity(prec):
+    """A = I against an asymmetric B catches a transposed output layout (guide G9)."""
+    dt = hipops.TDT[prec]
+    A = torch.eye(128, device=dev()).to(dt)
+    B = (torch.arange(256 * 128, device=dev()).float().view(256, 128) % 251 / 16).to(dt)
+    out = torch.empty(128, 256, device=dev())
+    hipops.gemm_nt(A, B, _hip.EPI_OUT_F32, prec, out_f32=out)
+    assert torch.equal(out, B.float().t())
+
+
+@pytest.mark.parametrize('prec', [BF, F32])
+def test_gemm_nt_epilogues(prec):
+    dt = hipops.TDT[prec]
+    M, N, K = 500, 264, 192
+    A, B = rnd(M, K, dtype=dt, seed=3), rnd(N, K, dtype=dt, seed=4, scale=0.1)
+    bias, resid = rnd(N, seed=5), rnd(M, N, seed=6)
+    aux = rnd(M, N, dtype=dt, seed=7)
+    base = A.double() @ B.double().t()
+    tol_t = 4e-3 if prec == BF else 1e-6
+    # bias + gelu, both outputs
+    out_t = torch.empty(M, N, dtype=dt, device=dev()); out2 = torch.empty_like(out_t)
+    hipops.gemm_nt(A, B, _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_T | _hip.EPI_OUT2_T, prec, bias=bias, out_t=out_t, out2_t=out2)
+    pre = base + bias.double()
+    assert relerr(out2, pre) < tol_t
+    assert relerr(out_t, torch.nn.functional.gelu(pre)) < tol_t
+    # bias + residual -> f32
+    out = torch.empty(M, N, device=dev())
+    hipops.gemm_nt(A, B, _hip.EPI_BIAS | _hip.EPI_RESID | _hip.EPI_OUT_F32, prec, bias=bias, resid=resid, out_f32=out)
+    assert relerr(out, pre + resid.double()) < 2e-6
+    # gelu backward multiply
+    hipops.gemm_nt(A, B, _hip.EPI_GELU_BWD | _hip.EPI_OUT_T, prec, aux=aux, out_t=out_t)
+    a = aux.double().requires_grad_(True)
+    torch.nn.functional.gelu(a).sum().backward()
+    assert relerr(out_t, base * a.grad) < tol_t
+    # accumulate
+    out.fill_(1.0)
+    hipops.gemm_nt(A, B, _hip.EPI_OUT_F32 | _hip.EPI_ACCUM, prec, out_f32=out)
+    assert relerr(out, base + 1.0) < 2e-6
+
+
+@pytest.mark.parametrize('prec', [BF, F32])
+@pytest.mark.parametrize('M,P,Q', [(64, 128, 128), (1000, 512, 1024), (4096, 1000, 200), (333, 1, 72), (16000, 1536, 512)])
+def test_gemm_tn(M, P, Q, prec):
+    dt = hipops.TDT[prec]
+    # A may carry a padded leading dimension (decoder dlogits)
+    ldp = (P + 7) // 8 * 8
+    Afull = torch.zeros(M, ldp, dtype=dt, device=dev())
+    Afull[:, :P] = rnd(M, P, dtype=dt, seed=8)
+    A = Afull[:, :P]
+    B = rnd(M, Q, dtype=dt, seed=9)
+    C = torch.ones(P, Q, device=dev())
+    hipops.gemm_tn(A, B, C, prec)
+    ref = A.double().t() @ B.double() + 1.0
+    assert relerr(C, ref) < 3e-6, relerr(C, ref)
+
+
+def test_gemm_tn_asymmetric():
+    M = 64
+    A = torch.zeros(M, 128, dtype=torch.bfloat16, device=dev()); A[torch.arange(M), torch.arange(M)] = 1
+    B = (torch.arange(M * 128, device=dev()).float().view(M, 128) % 127 / 8).to(torch.bfloat16)
+    C = torch.zeros(128, 128, device=dev())
+    hipops.gemm_tn(A, B, C, BF)
+    ref = A.float().t() @ B.float()
+    assert torch.equal(C, ref)
+
+
+@pytest.mark.parametrize('prec', [BF, F32])
+@pytest.mark.parametrize('rows,E', [(1000, 512), (37, 128), (513, 1024), (64, 200)])
+def test_layernorm(rows, E, prec):
+    x = rnd(rows, E, seed=10) * 2 + 0.5
+    gamma, beta = rnd(E, seed=11) + 1, rnd(E, seed=12)
+    y32, yt, mean, rstd = hipops.layernorm_fwd(x, gamma, beta, 1e-5, prec)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (E,), gd, bd, 1e-5)
+    assert maxerr(y32, ref) < 1e-5
+    assert relerr(yt, ref) < (4e-3 if prec == BF else 1e-6)
+    dy = rnd(rows, E, seed=13)
+    ref.backward(dy.double())
+    dx32, dxt, dg, db, dbias = hipops.layernorm_bwd(dy, x, gamma, mean, rstd, prec)
+    assert relerr(dx32, xd.grad) < 1e-5
+    assert relerr(dg, gd.grad) < 1e-5 and relerr(db, bd.grad) < 1e-5
+    assert relerr(dbias, xd.grad.sum(0)) < 1e-4
+
+
+def attention_reference(qkv, H, sep):
+    """Dense masked attention in f64 with the mask of generate_D_q_matrix (transformer.py:34-41)."""
+    B, S, E3 = qkv.shape
+    E = E3 // 3
+    D = E // H
+    q, k, v = [t.view(B, S, H, D).transpose(1, 2) for t in qkv.double().split(E, dim=-1)]  # [B,H,S,D]
+    scores = q @ k.transpose(-1, -2) / math.sqrt(D)
+    allowed = torch.zeros(S, S, dtype=torch.bool, device=qkv.device)
+    allowed[:, :sep] = True
+    allowed |= torch.eye(S, dtype=torch.bool, device=qkv.device)
+    scores = scores.masked_fill(~allowed, float('-inf'))
+    lse = torch.logsumexp(scores, -1)
+    out = torch.softmax(scores, -1) @ v
+    return out.transpose(1, 2).reshape(B, S, E), lse
+
+
+ATTN_CASES = [  # B, S, E, H, sep
+    (2, 100, 128, 4, 70), (1, 256, 256, 2, 256), (2, 130, 128, 2, 0), (1, 333, 512, 4, 301), (2, 200, 128, 2, 1),
+    (1, 2000, 512, 4, 1755), (1, 257, 64, 2, 64), (1, 300, 512, 2, 129),
+]
+
+
+@pytest.mark.parametrize('prec', [BF, F32])
+@pytest.mark.parametrize('B,S,E,H,sep', ATTN_CASES)
+def test_attention_forward_backward(B, S, E, H, sep, prec):
+    if prec == F32 and E // H == 256:
+        pytest.skip('head dim 256 is bf16 only')
+    dt = hipops.TDT[prec]
+    qkv = rnd(B, S, 3 * E, dtype=dt, seed=20)
+    ctx, lse = hipops.attention_fwd(qkv, H, sep, prec)
+    qd = qkv.double().requires_grad_(True)
+    ref, ref_lse = attention_reference(qd, H, sep)
+    tol = 6e-3 if prec == BF else 2e-5
+    assert relerr(ctx, ref) < tol, relerr(ctx, ref)
+    assert maxerr(lse, ref_lse) < (2e-2 if prec == BF else 1e-4)
+    dctx = rnd(B, S, E, dtype=dt, seed=21)
+    ref.backward(dctx.double())
+    dqkv = hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, prec)
+    assert not torch.isnan(dqkv.float()).any()
+    floor = 1e-2 * dctx.double().norm().item()  # dq is exactly 0 when sep == 0 (one key per row)
+    for name, got, want in zip('qkv', dqkv.float().split(E, -1), qd.grad.split(E, -1)):
+        err = (got.double() - want).norm().item() / max(want.norm().item(), floor)
+        assert err < (1.5e-2 if prec == BF else 5e-5), (name, err)
+
+
+def test_attention_online_softmax_rescale():
+    """A late, very large score forces the running-max rescale branch (guide 5.4 rule 26)."""
+    B, S, E, H, sep = 1, 256, 128, 1, 256
+    qkv = rnd(B, S, 3 * E, seed=22) * 0.2
+    qkv[0, 5, :E] *= 40.0
+    qkv[0, 200, E:2 * E] = qkv[0, 5, :E] / 8
+    ctx, lse = hipops.attention_fwd(qkv, H, sep, F32)
+    ref, ref_lse = attention_reference(qkv, H, sep)
+    assert relerr(ctx, ref) < 2e-5 and maxerr(lse, ref_lse) < 1e-3
+
+
+def test_bar_distribution_kernels():
+    from transformerscandobayesianinference_amd import bar_distribution as bd
+    torch.manual_seed(0)
+    for nb, R, full in [(100, 257, True), (1000, 500, True), (10, 33, False), (7, 64, True)]:
+        borders = torch.sort(torch.randn(nb + 1))[0].to(dev())
+        crit = (bd.FullSupportBarDistribution if full else bd.BarDistribution)(borders)
+        logits = rnd(R, nb, seed=30).requires_grad_(True)
+        lo, hi = borders[0].item(), borders[-1].item()
+        y = torch.empty(R, device=dev()).uniform_(lo - (1.0 if full else 0.0), hi + (1.0 if full else 0.0))
+        if not full:
+            y = y.clamp(lo, hi)
+        y[0], y[1] = borders[0], borders[-1]
+        y[2] = borders[3]
+        nll = crit(logits, y)
+        # PyTorch statement of the reference math (bar_distribution.py:19-33, 89-108)
+        ld = logits.detach().double().requires_grad_(True)
+        bw = (borders[1:] - borders[:-1]).double()
+        t = torch.searchsorted(borders, y) - 1
+        t[y == borders[0]] = 0
+        t[y == borders[-1]] = nb - 1
+        t = t.clamp(0, nb - 1)
+        lp = (torch.log_softmax(ld, -1) - torch.log(bw)).gather(-1, t[:, None]).squeeze(-1)
+        if full:
+            icdf = torch.distributions.HalfNormal(torch.tensor(1., dtype=torch.float64)).icdf(torch.tensor(.5, dtype=torch.float64))
+            hn0 = torch.distributions.HalfNormal((bw[0] / icdf).to(dev()))
+            hn1 = torch.distributions.HalfNormal((bw[-1] / icdf).to(dev()))
+            m0, m1 = t == 0, t == nb - 1
+            lp = lp + m0 * (hn0.log_prob((borders[1] - y).clamp(min=1e-8).double()) + torch.log(bw[0]))
+            lp = lp + m1 * (hn1.log_prob((y - borders[-2]).clamp(min=0).double()) + torch.log(bw[-1]))
+        assert maxerr(nll, -lp) < 2e-4, maxerr(nll, -lp)
+        w = rnd(R, seed=31)
+        (nll * w).sum().backward()
+        (-lp * w.double()).sum().backward()
+        assert relerr(logits.grad, ld.grad) < 1e-5
+        means = crit.mean(logits)
+        ref_mean = torch.softmax(ld.detach(), -1) @ crit.bucket_means().double()
+        assert maxerr(means, ref_mean) < 1e-4
+
+
+def test_clip_adam_matches_torch():
+    n = 100_000
+    p0, g0 = rnd(n, seed=40), rnd(n, seed=41) * 0.05
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    scratch = torch.zeros(2048, device=dev())
+    for step in range(1, 4):
+        g = g0 * step
+        ref_p.grad = g.clone()
+        norm_ref = torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        gg = g.clone()
+        _hip.check(_hip.lib().pfn_clip_adam_step(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8,
+                                                 1.0, 1.0, step, 1, scratch.data_ptr(), _hip.stream_ptr()), 'adam')
+        assert abs(scratch[0].item() - norm_ref.item()) < 1e-3 * norm_ref.item()
+        assert gg.abs().max().item() == 0.0
+        assert maxerr(p, ref_p.detach()) < 2e-6

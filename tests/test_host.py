@@ -1,0 +1,240 @@
+"""CPU tests of the host-side logic: C-ABI surface, parameter packing, the prior DataLoader
+protocol, schedules / samplers against the reference's recorded values, the train() loop plumbing
+(with the CPU oracle standing in for the HIP model), and the data-parallel helpers over gloo."""
+import ctypes
+import os
+import random
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+from torch import nn
+
+from oracle import pfn_oracle
+from transformerscandobayesianinference_amd import _hip, dp, utils
+from transformerscandobayesianinference_amd.priors.utils import get_batch_to_dataloader
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'pfn_hip.h')).read()
+    declared = set(re.findall(r'\b(pfn_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    lib = _hip.lib()           # loads without a GPU; resolves and type-checks every symbol
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.pfn_abi_version() == _hip.ABI_VERSION
+
+
+def test_param_layout_matches_reference_state_dict_order():
+    lib = _hip.lib()
+    d = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5)
+    n = lib.pfn_param_layout(ctypes.byref(d), None, None, 0)
+    assert n == 4 + 12 * 6 + 4
+    offs, nums = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+    assert lib.pfn_param_layout(ctypes.byref(d), offs, nums, n) == n
+    assert sum(nums) == 14_177_768      # parameters of the north-star model (14.18 M)
+    assert all(o % 64 == 0 for o in offs) and all(offs[i] + nums[i] <= offs[i + 1] for i in range(n - 1))
+    assert list(nums[:4]) == [512 * 18, 512, 512, 512] and list(nums[4:8]) == [3 * 512 * 512, 3 * 512, 512 * 512, 512]
+    assert lib.pfn_param_count(ctypes.byref(d)) >= offs[n - 1] + nums[n - 1]
+    assert lib.pfn_workspace_bytes(ctypes.byref(d), 8, 2000) > 0
+    bad = _hip.ModelDesc(18, 200, 2, 200, 6, 100, _hip.PREC_BF16, 1e-5)   # head dim 100 (reference train() default)
+    assert lib.pfn_param_count(ctypes.byref(bad)) < 0 and b'head dim' in lib.pfn_last_error_string()
+
+
+def test_model_state_dict_keys_match_reference():
+    from transformerscandobayesianinference_amd import bar_distribution, encoders
+    from transformerscandobayesianinference_amd.transformer import TransformerModel
+    rec = torch.load(os.path.join(GOLD, 'model_small_h32.pt'))
+    cfg = rec['config']
+    m = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], 0.0,
+                         y_encoder=encoders.Linear(1, cfg['E']))
+    m.criterion = bar_distribution.FullSupportBarDistribution(rec['state_dict']['criterion.borders'])
+    assert list(m.state_dict().keys()) == list(rec['state_dict'].keys())
+    m.load_state_dict(rec['state_dict'])
+    for layer in TransformerModel(encoders.Linear(2, 64), 4, 64, 2, 64, 2, y_encoder=encoders.Linear(1, 64)).transformer_encoder.layers:
+        assert layer.linear2.weight.abs().sum() == 0 and layer.self_attn.out_proj.weight.abs().sum() == 0   # transformer.py:49-53
+    with pytest.raises(_hip.HipExtensionError):   # CPU tensors never fall back to PyTorch
+        m((rec['x'], rec['y']), single_eval_pos=5)
+
+
+def test_schedules_and_samplers_match_reference_values():
+    rec = torch.load(os.path.join(GOLD, 'utils.pt'))
+    p = nn.Parameter(torch.zeros(1))
+    for name, fn in [('cosine', utils.get_cosine_schedule_with_warmup), ('linear', utils.get_linear_schedule_with_warmup)]:
+        opt = torch.optim.SGD([p], lr=1.0)
+        sch = fn(opt, 5, 20)
+        vals = []
+        for _ in range(22):
+            vals.append(sch.get_last_lr()[0])
+            opt.step()
+            sch.step()
+        assert vals == pytest.approx(rec[name], abs=1e-12)
+        assert vals[0] == 0.0     # lr is 0 during the first epoch
+    random.seed(123)
+    s = utils.get_weighted_single_eval_pos_sampler(50)
+    assert [s() for _ in range(200)] == rec['weighted_draws']
+    random.seed(123)
+    s = utils.get_uniform_single_eval_pos_sampler(50)
+    assert [s() for _ in range(200)] == rec['uniform_draws']
+    assert utils.get_openai_lr(nn.Linear(10, 10)) == pytest.approx(rec['openai_lr_110'])
+    from transformerscandobayesianinference_amd.transformer import TransformerModel
+    assert torch.equal(TransformerModel.generate_D_q_matrix(6, 2), rec['d_q_mask_6_2'])
+
+
+def test_bucket_limits_and_cli_dict_action():
+    from transformerscandobayesianinference_amd.bar_distribution import get_bucket_limits
+    rec = torch.load(os.path.join(GOLD, 'bar_distribution.pt'))
+    assert torch.allclose(get_bucket_limits(8, full_range=(-2., 6.)), rec['bucket_limits_uniform'])
+    ys = torch.randn(1003, generator=torch.Generator().manual_seed(1))
+    lim = get_bucket_limits(10, ys=ys)
+    assert lim[0] == ys[:1000].min() and lim[-1] == ys[:1000].max()
+    counts = torch.histc(ys[:1000], bins=10, min=-10, max=10)  # noqa: F841  (smoke)
+    inner = torch.bucketize(ys[:1000], lim[1:-1])
+    assert torch.bincount(inner, minlength=10).tolist() == [100] * 10      # equal-count buckets
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--kw', action=utils.StoreDictKeyPair, nargs='+')
+    ns = ap.parse_args(['--kw', 'num_features=5', 'name=gp', 'hps=(1e-4,1.0,0.6)', 'evil=__import__("os").system("true")'])
+    assert ns.kw == {'num_features': 5, 'name': 'gp', 'hps': (1e-4, 1.0, 0.6), 'evil': '__import__("os").system("true")'}
+
+
+def test_prior_dataloader_protocol():
+    calls = []
+
+    def get_batch(batch_size, seq_len, num_features, hyperparameters=None):
+        calls.append((batch_size, seq_len, num_features))
+        return pfn_oracle.get_batch_fast_gp(batch_size, seq_len, num_features, hyperparameters)
+
+    DL = get_batch_to_dataloader(get_batch)
+    DL.num_outputs = 1
+    dl = DL(num_steps=3, batch_size=4, seq_len=9, num_features=2, hyperparameters=(0.1, 0.1, 0.1))
+    assert len(dl) == 3 and dl.num_features == 2 and dl.num_outputs == 1 and dl.fuse_x_y is False
+    items = list(dl)
+    assert len(items) == 3 and calls == [(4, 9, 2)] * 3
+    (x, y), t = items[0]
+    assert x.shape == (9, 4, 2) and y.shape == (9, 4) and t.shape == (9, 4)
+    fused = DL(num_steps=1, fuse_x_y=True, batch_size=2, seq_len=5, num_features=3)
+    xf, tf = next(iter(fused))
+    assert xf.shape == (5, 2, 4) and torch.equal(xf[0, :, -1], torch.zeros(2)) and torch.equal(xf[1:, :, -1], tf[:-1])
+    assert isinstance(dl, torch.utils.data.DataLoader)
+    assert DL.get_batch_method(2, 5, 3)[0].shape == (5, 2, 3)      # the notebook calls it unbound
+
+
+class _OracleModel(nn.Module):
+    """Stand-in for TransformerModel in the CPU test of the train() plumbing: same constructor and
+    forward signature, arithmetic by the oracle (tests only; the product model has no CPU path)."""
+
+    def __init__(self, encoder, n_out, ninp, nhead, nhid, nlayers, dropout=0.0, y_encoder=None, pos_encoder=None, decoder=None,
+                 input_normalization=False, precision='bf16'):
+        super().__init__()
+        from transformerscandobayesianinference_amd.transformer import _EncoderParams
+        self.encoder, self.y_encoder, self.nhead = encoder, y_encoder, nhead
+        self.transformer_encoder = _EncoderParams(ninp, nhid, nlayers)
+        self.decoder = nn.Sequential(nn.Linear(ninp, nhid), nn.GELU(), nn.Linear(nhid, n_out))
+        self._flat = self._grad = None
+
+    def flat_parameters(self):
+        if self._flat is None:
+            ps = list(self.parameters())
+            self._flat = torch.cat([p.detach().reshape(-1) for p in ps])
+            self._grad = torch.zeros_like(self._flat)
+            o = 0
+            for p in ps:
+                p.data = self._flat[o:o + p.numel()].view(p.shape)
+                p.grad = self._grad[o:o + p.numel()].view(p.shape)
+                o += p.numel()
+        return self._flat, self._grad
+
+    def mark_params_updated(self):
+        pass
+
+    def forward(self, src, src_mask=None, single_eval_pos=None):
+        sd = {k: v for k, v in self.named_parameters()}
+        return pfn_oracle.forward(sd, src[0], src[1], single_eval_pos, self.nhead, dtype=torch.float32)
+
+
+class _TorchAdam(torch.optim.Adam):
+    def __init__(self, model, lr, max_grad_norm=1.0):
+        super().__init__(model.parameters(), lr=lr)
+        self.model, self.grad_multiplier = model, 1.0
+
+    def step(self, zero_grad=False):
+        for p in self.model.parameters():
+            p.grad.mul_(self.grad_multiplier)
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
+        super().step()
+        if zero_grad:
+            for p in self.model.parameters():
+                p.grad.zero_()
+
+
+def _cpu_train(monkeypatch, **kw):
+    from transformerscandobayesianinference_amd import bar_distribution, encoders, train as train_mod
+    monkeypatch.setattr(train_mod, 'TransformerModel', _OracleModel)
+    monkeypatch.setattr(train_mod, 'FusedClipAdam', _TorchAdam)
+
+    class CpuBar(bar_distribution.FullSupportBarDistribution):
+        def forward(self, logits, y):
+            return pfn_oracle.bar_nll(logits, y, self.borders, True)
+
+    DL = get_batch_to_dataloader(lambda batch_size, seq_len, num_features, hyperparameters=None:
+                                 pfn_oracle.get_batch_fast_gp(batch_size, seq_len, num_features, hyperparameters))
+    DL.num_outputs = 1
+    borders = bar_distribution.get_bucket_limits(10, ys=pfn_oracle.get_batch_fast_gp(50, 10, 2)[1])
+    return train_mod.train(DL, CpuBar(borders), encoders.Linear, emsize=32, nhid=32, nlayers=1, nhead=1, dropout=0.0,
+                           y_encoder_generator=encoders.Linear, extra_prior_kwargs_dict={'num_features': 2, 'fuse_x_y': False},
+                           single_eval_pos_gen=utils.get_weighted_single_eval_pos_sampler(10), bptt=12, verbose=False, **kw)
+
+
+def test_train_loop_plumbing_on_cpu(monkeypatch):
+    torch.manual_seed(0)
+    random.seed(0)
+    loss, pos, model = _cpu_train(monkeypatch, epochs=3, steps_per_epoch=4, batch_size=4, lr=1e-2, warmup_epochs=1, aggregate_k_gradients=2)
+    assert isinstance(loss, float) and loss == loss and len(pos) == 12
+    assert next(model.parameters()).device.type == 'cpu'
+    with pytest.raises(AssertionError):
+        _cpu_train(monkeypatch, epochs=1, steps_per_epoch=3, batch_size=4, aggregate_k_gradients=2)
+
+
+_DP_SCRIPT = r'''
+import os, sys, random, torch
+sys.path.insert(0, sys.argv[1])
+from transformerscandobayesianinference_amd import dp
+rank, world, local = dp.init_from_env(backend='gloo')
+assert dp.world_size() == 2 and dp.rank() == rank and dp.local_batch_size(8) == 4
+seed = dp.seed_ranks()
+shared = [random.random() for _ in range(3)]           # python stream (single_eval_pos) is rank-shared
+own = torch.rand(3)                                    # torch stream (prior draws) is rank-distinct
+gathered = [None, None]
+torch.distributed.all_gather_object(gathered, (shared, own.tolist()))
+assert gathered[0][0] == gathered[1][0] and gathered[0][1] != gathered[1][1]
+# gradient all-reduce of the flat buffer: mean over ranks == gradient of the global batch
+torch.manual_seed(0)
+w = torch.randn(5, requires_grad=True)
+data = torch.arange(16, dtype=torch.float32).view(8, 2)[rank * 4:(rank + 1) * 4]
+loss = ((data @ w[:2]) ** 2).mean()
+loss.backward()
+flat = w.grad.clone()
+dp.all_reduce_gradients(flat)
+flat /= world
+full = torch.arange(16, dtype=torch.float32).view(8, 2)
+w2 = w.detach().clone().requires_grad_(True)
+((full @ w2[:2]) ** 2).mean().backward()
+assert torch.allclose(flat, w2.grad, rtol=1e-6), (flat, w2.grad)
+print('rank', rank, 'ok')
+'''
+
+
+def test_data_parallel_helpers_over_gloo(tmp_path):
+    script = tmp_path / 'dp_check.py'
+    script.write_text(_DP_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29533', str(script), ROOT], capture_output=True, text=True, env=env, timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count('ok') == 2

@@ -1,0 +1,119 @@
+"""CPU tests (no GPU): the oracle (oracle/pfn_oracle.py) against the golden vectors recorded from the
+reference itself (oracle/make_golden.py -> tests/golden), plus algebraic properties the reference
+implies.  This is what pins the checker that the GPU parity tests rely on."""
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import pfn_oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('case', ['model_small_h32', 'model_small_h64'])
+def test_oracle_forward_loss_grads_match_reference(case):
+    rec = torch.load(os.path.join(GOLD, case + '.pt'))
+    cfg, sd = rec['config'], rec['state_dict']
+    for sep, want in rec['per_sep'].items():
+        loss, logits, grads = pfn_oracle.loss_and_grads(sd, rec['x'], rec['y'], rec['target_y'], sep, cfg['H'], sd['criterion.borders'])
+        assert relerr(logits, want['logits']) < 2e-5          # reference ran in f32, oracle in f64
+        assert abs(loss.item() - want['loss'].item()) < 2e-5 * abs(want['loss'].item())
+        losses = pfn_oracle.bar_nll(logits.reshape(-1, cfg['nbars']), rec['target_y'][sep:].reshape(-1), sd['criterion.borders'])
+        assert relerr(losses.view(want['losses'].shape), want['losses']) < 2e-5
+        assert relerr(pfn_oracle.bar_mean(logits, sd['criterion.borders']), want['mean']) < 2e-5
+        if 'grads' in want:
+            for k, g in want['grads'].items():
+                if g.norm() > 1e-7:
+                    assert relerr(grads[k], g) < 5e-4, (sep, k, relerr(grads[k], g))
+
+
+def test_oracle_training_steps_match_reference():
+    rec = torch.load(os.path.join(GOLD, 'model_small_h32.pt'))
+    cfg, tr = rec['config'], rec['train']
+    params = {k: v.double().clone() for k, v in rec['state_dict'].items() if not k.startswith('criterion.')}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    borders = rec['state_dict']['criterion.borders']
+    for step in range(2):
+        loss, _, grads = pfn_oracle.loss_and_grads(params, rec['x'], rec['y'], rec['target_y'], tr['sep'], cfg['H'], borders)
+        norm = pfn_oracle.clip_adam_step(params, grads, m, v2, step + 1, 1e-3)
+        assert abs(loss.item() - tr['steps'][step]['loss'].item()) < 5e-5 * abs(loss.item())
+        assert abs(norm.item() - tr['steps'][step]['grad_norm'].item()) < 1e-4 * norm.item()
+    # Adam divides each element by its own gradient history: elements whose gradient sits at the f32
+    # rounding-noise level of the reference move differently, so compare the update as a whole.
+    num = den = 0.0
+    for k, v in params.items():
+        d_ref = tr['final_state_dict'][k].double() - rec['state_dict'][k].double()
+        num += ((v - rec['state_dict'][k].double() - d_ref) ** 2).sum().item()
+        den += (d_ref ** 2).sum().item()
+        assert (v - tr['final_state_dict'][k].double()).abs().max().item() < 2e-4, k   # well inside one step (lr = 1e-3)
+    assert math.sqrt(num / den) < 1e-2
+
+
+def test_oracle_bar_distribution_matches_reference():
+    rec = torch.load(os.path.join(GOLD, 'bar_distribution.pt'))
+    for key, c in rec.items():
+        if not isinstance(key, tuple):
+            continue
+        nb, full = key
+        logits = c['logits'].double().requires_grad_(True)
+        nll = pfn_oracle.bar_nll(logits, c['y'], c['borders'], full)
+        assert (nll - c['nll'].double()).abs().max().item() < 2e-5, key
+        (nll * c['w'].double()).sum().backward()
+        assert relerr(logits.grad, c['dlogits']) < 1e-5
+        assert relerr(pfn_oracle.bar_mean(logits.detach(), c['borders'], full), c['mean']) < 1e-5
+        assert torch.equal(pfn_oracle.bar_bucket(c['borders'], c['y']), c['bucket'])
+
+
+def test_bar_density_integrates_to_one():
+    """Uniform logits give density 1/(num_bars * width_k) inside bucket k (bar_distribution.py:30-33)."""
+    borders = torch.tensor([-1.0, -0.5, 0.25, 0.5, 2.0], dtype=torch.float64)
+    logits = torch.zeros(1, 4, dtype=torch.float64)
+    ys = torch.linspace(-0.999, 1.999, 30001, dtype=torch.float64)
+    dens = torch.exp(-pfn_oracle.bar_nll(logits.expand(len(ys), 4), ys, borders, full_support=False))
+    assert abs(torch.trapz(dens, ys).item() - 1.0) < 2e-3
+    mid = torch.tensor([-0.75], dtype=torch.float64)
+    assert abs(torch.exp(-pfn_oracle.bar_nll(logits, mid, borders, False)).item() - 1 / (4 * 0.5)) < 1e-12
+
+
+def test_mask_properties_of_the_oracle():
+    """Test-row outputs ignore other test rows and the order of the train rows (transformer.py:34-41, no positional encoding)."""
+    rec = torch.load(os.path.join(GOLD, 'model_small_h32.pt'))
+    cfg, sd, x, y = rec['config'], rec['state_dict'], rec['x'], rec['y']
+    sep = 41
+    base = pfn_oracle.forward(sd, x, y, sep, cfg['H'])
+    perm = torch.randperm(sep, generator=torch.Generator().manual_seed(0))
+    xp, yp = x.clone(), y.clone()
+    xp[:sep], yp[:sep] = x[perm], y[perm]
+    assert relerr(pfn_oracle.forward(sd, xp, yp, sep, cfg['H']), base) < 1e-12
+    x2 = x.clone()
+    x2[sep + 3] += 1.0
+    other = pfn_oracle.forward(sd, x2, y, sep, cfg['H'])
+    keep = torch.ones(cfg['T'] - sep, dtype=torch.bool)
+    keep[3] = False
+    assert relerr(other[keep], base[keep]) < 1e-12 and relerr(other[3], base[3]) > 1e-6
+    y2 = y.clone()
+    y2[sep:] += 5.0   # test rows never see their own y (transformer.py:73-74)
+    assert relerr(pfn_oracle.forward(sd, x, y2, sep, cfg['H']), base) < 1e-12
+    assert torch.equal(pfn_oracle.d_q_mask(6, 4, torch.float32, 'cpu'), torch.load(os.path.join(GOLD, 'utils.pt'))['d_q_mask_6_2'])
+
+
+def test_gp_oracle_covariance():
+    """Sample covariance of the restated GP draw equals outputscale*RBF + noise*I (fast_gp.py:13-32,53-56)."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(1, 12, 2, generator=g).expand(20000, 12, 2)
+    z = torch.randn(20000, 12, generator=g)
+    y = pfn_oracle.gp_sample(x, z, 0.7, 1.3, 0.2)
+    emp = y.t() @ y / 20000
+    K = pfn_oracle.gp_gram(x[:1].double(), torch.tensor(0.7).reshape(1, 1, 1), torch.tensor(1.3).reshape(1, 1, 1), torch.tensor(0.2).reshape(1, 1, 1))[0]
+    assert (emp - K).abs().max().item() < 0.05
+    assert abs(K[0, 0].item() - 1.5) < 1e-6
+    xs, ys, ts = pfn_oracle.get_batch_fast_gp(4, 10, 3, (0.1, 0.1, 0.1), g)
+    assert xs.shape == (10, 4, 3) and ys.shape == (10, 4) and ts.shape == (10, 4)

@@ -1,0 +1,607 @@
+// Fused QK^T -> masked online softmax -> PV ("flash") attention for the PFN eval-position mask,
+// forward and backward, on gfx950 MFMA.
+//
+// Replaces the scores/softmax/PV part of torch multi_head_attention_forward as called from
+// nn.TransformerEncoderLayer inside TransformerModel.forward (reference transformer.py:84) with the
+// additive mask of TransformerModel.generate_D_q_matrix (transformer.py:34-41):
+//     query i may attend key j   iff   j < sep   or   j == i
+// The [S,S] mask is never built: the kernels stream key tiles over [0, sep) and treat the
+// "self" key of a test row (i >= sep) as the initial state of the online softmax (forward) or
+// as a row-wise correction term (backward).
+//
+// Formulation (all MFMAs are 32x32, "swapped" so softmax statistics are lane-local):
+//   fwd / dQ kernels : lane <-> query.   S^T = K.Q^T, O^T = V^T.P^T, dP^T = V.dO^T, dQ^T = K^T.dS^T
+//   dK/dV kernel     : lane <-> key.     S = Q.K^T, dP = dO.V^T, dV^T = dO^T.P, dK^T = Q^T.dS
+// Operands that are k-major in memory (V, K^T, Q^T, dO^T) come from LDS through
+// ds_read_b64_tr_b16 (bf16) in the accumulator-order slot mapping M2, so P / dS never move
+// between lanes.
+#include <algorithm>
+#include "pfn_device.h"
+#include "pfn_kernels.h"
+
+namespace pfn {
+
+template <typename T, int D> struct AttnCfg {
+  static constexpr int RB = D * (int)sizeof(T);              // bytes per K/V/Q row of one head
+  static constexpr int KVB = (sizeof(T) == 2 && D <= 128) ? 64 : 32;  // keys per LDS tile
+  static constexpr int NKB = KVB / 32;
+  static constexpr int NKK = D / 16;
+  static constexpr int NDB = D / 32;
+  static constexpr int TILE = KVB * RB;
+};
+
+template <typename T> PFN_DEV Frag<T> load_frag_global(const T* p) {
+  Frag<T> f;
+  if constexpr (sizeof(T) == 2) {
+    f.v = *reinterpret_cast<const bf16x8*>(p);
+  } else {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f.v[e] = a[e]; f.v[4 + e] = b[e]; }
+  }
+  return f;
+}
+template <typename T> PFN_DEV void store_frag_global(T* p, const float (&x)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)x[e];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  } else {
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = x[e]; b[e] = x[4 + e]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+}
+template <typename T> PFN_DEV float frag_get(const Frag<T>& f, int e) { return (float)f.v[e]; }
+template <typename T> PFN_DEV float dot8(const Frag<T>& a, const Frag<T>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += frag_get(a, e) * frag_get(b, e);
+  return s;
+}
+template <typename T> PFN_DEV f32x4 load4(const T* p) {
+  f32x4 r;
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (float)v[e];
+  } else r = *reinterpret_cast<const f32x4*>(p);
+  return r;
+}
+template <typename T> PFN_DEV void store4(T* p, f32x4 x) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (bf16)x[e];
+    *reinterpret_cast<bf16x4*>(p) = v;
+  } else *reinterpret_cast<f32x4*>(p) = x;
+}
+PFN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  using C = AttnCfg<T, D>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  auto Kt = [&](int buf) { return smem + buf * 2 * C::TILE; };
+  auto Vt = [&](int buf) { return smem + buf * 2 * C::TILE + C::TILE; };
+
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
+  const long rs = 3L * a.E;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
+  const T* Qp = base + hd * D;
+  const T* Kp = base + a.E + hd * D;
+  const T* Vp = base + 2 * a.E + hd * D;
+  const int qi = blockIdx.x * 128 + wave * 32 + li;
+  const bool qvalid = qi < a.S;
+  const int qc = min(qi, a.S - 1);
+  const int sep = a.sep;
+  const float scale_log2 = rsqrtf((float)D) * LOG2E;
+
+  Frag<T> qf[C::NKK];
+#pragma unroll
+  for (int kk = 0; kk < C::NKK; ++kk) qf[kk] = load_frag_global<T>(Qp + (long)qc * rs + kk * 16 + 8 * h);
+
+  // initial state: the self key for test rows, empty for train rows
+  const bool is_test = qc >= sep;
+  float m, lsum;
+  f32x16 o[C::NDB];
+  {
+    float part = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) part += dot8(qf[kk], load_frag_global<T>(Kp + (long)qc * rs + kk * 16 + 8 * h));
+    part += __shfl_xor(part, 32, 64);
+    m = is_test ? part * scale_log2 : -1e30f;
+    lsum = (is_test && h == 0) ? 1.f : 0.f;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        f32x4 v = load4<T>(Vp + (long)qc * rs + db * 32 + 8 * rg + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[db][4 * rg + e] = is_test ? v[e] : 0.f;
+      }
+  }
+
+  const int ntiles = (sep + C::KVB - 1) / C::KVB;
+  TileStage<T, C::KVB, C::RB, 256> sk, sv;
+  if (ntiles > 0) {
+    sk.issue(Kp, rs, sep, D);
+    sv.issue(Vp, rs, sep, D);
+    sk.template commit<false>(Kt(0));
+    sv.template commit<true>(Vt(0));
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1, k0 = t * C::KVB;
+    if (t + 1 < ntiles) {
+      const long k1 = k0 + C::KVB;
+      sk.issue(Kp + k1 * rs, rs, sep - (int)k1, D);
+      sv.issue(Vp + k1 * rs, rs, sep - (int)k1, D);
+    }
+    const lds_char* kt = Kt(cur);
+    const lds_char* vt = Vt(cur);
+    f32x16 st[C::NKB];
+#pragma unroll
+    for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk)
+#pragma unroll
+      for (int kb = 0; kb < C::NKB; ++kb)
+        st[kb] = mma32(load_frag_row<T, C::RB>(kt, kb * 32 + li, kk * 16), qf[kk], st[kb]);
+
+    float mx = -1e30f;
+    const bool edge = k0 + C::KVB > sep;
+#pragma unroll
+    for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float tv = st[kb][r] * scale_log2;
+        if (edge && (k0 + kb * 32 + acc_row(r, lane) >= sep)) tv = -INFINITY;
+        st[kb][r] = tv;
+        mx = fmaxf(mx, tv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = fast_exp2(m - m_new);
+    m = m_new;
+    float rsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(st[kb][r] - m);
+        st[kb][r] = p;
+        rsum += p;
+      }
+    lsum = lsum * alpha + rsum;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+    for (int c = 0; c < C::KVB / 16; ++c) {
+      const Frag<T> pf = acc_to_frag<T>(st[c >> 1], c & 1);
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db)
+        o[db] = mma32(load_frag_tr<T, C::RB, 2>(vt, c * 16, db * 32), pf, o[db]);
+    }
+    if (t + 1 < ntiles) {
+      sk.template commit<false>(Kt(cur ^ 1));
+      sv.template commit<true>(Vt(cur ^ 1));
+    }
+    __syncthreads();
+  }
+
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float inv = 1.f / lsum;
+  if (qvalid) {
+    T* out = reinterpret_cast<T*>(a.ctx) + ((long)b * a.S + qi) * a.E + hd * D;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[db][4 * rg + e] * inv;
+        store4<T>(out + db * 32 + 8 * rg + 4 * h, v);
+      }
+    if (h == 0) a.lse[((long)b * a.H + hd) * a.S + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;
+  }
+}
+
+// =============================================================================================
+// backward, step 0: delta[b,h,i] = sum_d dO[i,d] * O[i,d]
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, int D) {
+  // one 16-lane group per (token, head) pair; grid-stride over B*S*H pairs
+  const long pairs = (long)a.B * a.S * a.H;
+  const int sub = threadIdx.x & 15;
+  for (long pr = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pr < pairs; pr += (long)gridDim.x * 16) {
+    const long tok = pr / a.H;
+    const int hd = (int)(pr % a.H);
+    const T* o = reinterpret_cast<const T*>(a.ctx) + tok * a.E + hd * D;
+    const T* d = reinterpret_cast<const T*>(a.dctx) + tok * a.E + hd * D;
+    float s = 0.f;
+    for (int c = sub * 4; c < D; c += 64) {
+      f32x4 x = load4<T>(o + c), y = load4<T>(d + c);
+      s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (sub == 0) {
+      const long bb = tok / a.S, i = tok % a.S;
+      a.delta[(bb * a.H + hd) * a.S + i] = s;
+    }
+  }
+}
+
+// =============================================================================================
+// backward, dQ (+ the self-key terms of test rows: dQ_i, dK_i, dV_i for i >= sep)
+// =============================================================================================
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  using C = AttnCfg<T, D>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  // per buffer: K (swz16, row frags), K (swz64, transposed frags), V (swz16)
+  auto Kr = [&](int buf) { return smem + buf * 3 * C::TILE; };
+  auto Kc = [&](int buf) { return smem + buf * 3 * C::TILE + C::TILE; };
+  auto Vr = [&](int buf) { return smem + buf * 3 * C::TILE + 2 * C::TILE; };
+
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
+  const long rs = 3L * a.E;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
+  const T* Qp = base + hd * D;
+  const T* Kp = base + a.E + hd * D;
+  const T* Vp = base + 2 * a.E + hd * D;
+  T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
+  const int qi = blockIdx.x * 128 + wave * 32 + li;
+  const bool qvalid = qi < a.S;
+  const int qc = min(qi, a.S - 1);
+  const int sep = a.sep;
+  const float scale = rsqrtf((float)D);
+  const float scale_log2 = scale * LOG2E;
+  const T* dOp = reinterpret_cast<const T*>(a.dctx) + ((long)b * a.S + qc) * a.E + hd * D;
+
+  Frag<T> qf[C::NKK], dof[C::NKK];
+#pragma unroll
+  for (int kk = 0; kk < C::NKK; ++kk) {
+    qf[kk] = load_frag_global<T>(Qp + (long)qc * rs + kk * 16 + 8 * h);
+    dof[kk] = load_frag_global<T>(dOp + kk * 16 + 8 * h);
+  }
+  const long stat = ((long)b * a.H + hd) * a.S + qc;
+  const float lse2 = a.lse[stat] * LOG2E;
+  const float delta = a.delta[stat];
+
+  f32x16 dq[C::NDB];
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+
+  const int ntiles = (sep + C::KVB - 1) / C::KVB;
+  TileStage<T, C::KVB, C::RB, 256> sk, sv;
+  if (ntiles > 0) {
+    sk.issue(Kp, rs, sep, D);
+    sv.issue(Vp, rs, sep, D);
+    sk.template commit<false>(Kr(0));
+    sk.template commit<true>(Kc(0));
+    sv.template commit<false>(Vr(0));
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1, k0 = t * C::KVB;
+    if (t + 1 < ntiles) {
+      const long k1 = k0 + C::KVB;
+      sk.issue(Kp + k1 * rs, rs, sep - (int)k1, D);
+      sv.issue(Vp + k1 * rs, rs, sep - (int)k1, D);
+    }
+    const lds_char* kr = Kr(cur);
+    const lds_char* kc = Kc(cur);
+    const lds_char* vr = Vr(cur);
+    f32x16 st[C::NKB], dp[C::NKB];
+#pragma unroll
+    for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk)
+#pragma unroll
+      for (int kb = 0; kb < C::NKB; ++kb) {
+        st[kb] = mma32(load_frag_row<T, C::RB>(kr, kb * 32 + li, kk * 16), qf[kk], st[kb]);
+        dp[kb] = mma32(load_frag_row<T, C::RB>(vr, kb * 32 + li, kk * 16), dof[kk], dp[kb]);
+      }
+    const bool edge = k0 + C::KVB > sep;
+#pragma unroll
+    for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = fast_exp2(st[kb][r] * scale_log2 - lse2);
+        if (edge && (k0 + kb * 32 + acc_row(r, lane) >= sep)) p = 0.f;
+        st[kb][r] = p * (dp[kb][r] - delta);  // dS (unscaled)
+      }
+#pragma unroll
+    for (int c = 0; c < C::KVB / 16; ++c) {
+      const Frag<T> dsf = acc_to_frag<T>(st[c >> 1], c & 1);
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db)
+        dq[db] = mma32(load_frag_tr<T, C::RB, 2>(kc, c * 16, db * 32), dsf, dq[db]);
+    }
+    if (t + 1 < ntiles) {
+      sk.template commit<false>(Kr(cur ^ 1));
+      sk.template commit<true>(Kc(cur ^ 1));
+      sv.template commit<false>(Vr(cur ^ 1));
+    }
+    __syncthreads();
+  }
+
+  // self key of test rows
+  const bool is_test = qc >= sep;
+  float ds_self = 0.f, p_self = 0.f;
+  {
+    float tq = 0.f, dpv = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) {
+      tq += dot8(qf[kk], load_frag_global<T>(Kp + (long)qc * rs + kk * 16 + 8 * h));
+      dpv += dot8(dof[kk], load_frag_global<T>(Vp + (long)qc * rs + kk * 16 + 8 * h));
+    }
+    tq += __shfl_xor(tq, 32, 64);
+    dpv += __shfl_xor(dpv, 32, 64);
+    if (is_test) {
+      p_self = fast_exp2(tq * scale_log2 - lse2);
+      ds_self = p_self * (dpv - delta);
+    }
+  }
+  if (qvalid) {
+    T* dQo = dbase + (long)qi * rs + hd * D;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = db * 32 + 8 * rg + 4 * h;
+        f32x4 kv = load4<T>(Kp + (long)qc * rs + d0);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (dq[db][4 * rg + e] + ds_self * kv[e]) * scale;
+        store4<T>(dQo + d0, v);
+      }
+    if (is_test) {
+      T* dKo = dbase + (long)qi * rs + a.E + hd * D;
+      T* dVo = dbase + (long)qi * rs + 2 * a.E + hd * D;
+#pragma unroll
+      for (int kk = 0; kk < C::NKK; ++kk) {
+        float xk[8], xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xk[e] = ds_self * scale * frag_get(qf[kk], e);
+          xv[e] = p_self * frag_get(dof[kk], e);
+        }
+        store_frag_global<T>(dKo + kk * 16 + 8 * h, xk);
+        store_frag_global<T>(dVo + kk * 16 + 8 * h, xv);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// backward, dK and dV for the train keys [0, sep): one workgroup owns 128 keys and streams all
+// S queries.
+// =============================================================================================
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
+  using C = AttnCfg<T, D>;
+  constexpr int QB = 32;                     // queries per tile
+  constexpr int QT = QB * C::RB;             // bytes of one Q (or dO) tile image
+  constexpr int BUF = 4 * QT + 2 * QB * 4;   // Q row, Q col, dO row, dO col images + lse + delta
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  auto Qr = [&](int buf) { return smem + buf * BUF; };
+  auto Qc = [&](int buf) { return smem + buf * BUF + QT; };
+  auto Or = [&](int buf) { return smem + buf * BUF + 2 * QT; };
+  auto Oc = [&](int buf) { return smem + buf * BUF + 3 * QT; };
+  auto St = [&](int buf) { return smem + buf * BUF + 4 * QT; };  // [lse2 x QB][delta x QB]
+
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
+  const long rs = 3L * a.E;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
+  const T* Qp = base + hd * D;
+  const T* Kp = base + a.E + hd * D;
+  const T* Vp = base + 2 * a.E + hd * D;
+  const T* dOp = reinterpret_cast<const T*>(a.dctx) + (long)b * a.S * a.E + hd * D;
+  T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
+  const int sep = a.sep;
+  const int key = blockIdx.x * 128 + wave * 32 + li;
+  const bool kvalid = key < sep;
+  const int kc = min(key, a.S - 1);
+  const float scale = rsqrtf((float)D);
+  const float scale_log2 = scale * LOG2E;
+  const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
+  const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
+
+  Frag<T> kf[C::NKK], vf[C::NKK];
+#pragma unroll
+  for (int kk = 0; kk < C::NKK; ++kk) {
+    kf[kk] = load_frag_global<T>(Kp + (long)kc * rs + kk * 16 + 8 * h);
+    vf[kk] = load_frag_global<T>(Vp + (long)kc * rs + kk * 16 + 8 * h);
+  }
+  f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+  const int ntiles = (a.S + QB - 1) / QB;
+  TileStage<T, QB, C::RB, 256> sq, so;
+  float st_reg = 0.f;  // threads 0..2*QB-1 stage lse2 / delta
+  auto stage_stats = [&](int q0) {
+    if (threadIdx.x < 2 * QB) {
+      const int q = q0 + (threadIdx.x & (QB - 1));
+      if (threadIdx.x < QB) st_reg = (q < a.S) ? lse_g[q] * LOG2E : 1e30f;
+      else st_reg = (q < a.S) ? delta_g[q] : 0.f;
+    }
+  };
+  auto commit_all = [&](int buf) {
+    sq.template commit<false>(Qr(buf));
+    sq.template commit<true>(Qc(buf));
+    so.template commit<false>(Or(buf));
+    so.template commit<true>(Oc(buf));
+    if (threadIdx.x < 2 * QB) lds_write_f32(St(buf) + threadIdx.x * 4, st_reg);
+  };
+  sq.issue(Qp, rs, a.S, D);
+  so.issue(dOp, a.E, a.S, D);
+  stage_stats(0);
+  commit_all(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) {
+      const long q1 = (long)(t + 1) * QB;
+      sq.issue(Qp + q1 * rs, rs, a.S - (int)q1, D);
+      so.issue(dOp + q1 * a.E, a.E, a.S - (int)q1, D);
+      stage_stats((int)q1);
+    }
+    const lds_char* qr = Qr(cur);
+    const lds_char* qcol = Qc(cur);
+    const lds_char* orow = Or(cur);
+    const lds_char* ocol = Oc(cur);
+    const lds_char* stt = St(cur);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) {
+      s = mma32(load_frag_row<T, C::RB>(qr, li, kk * 16), kf[kk], s);
+      dp = mma32(load_frag_row<T, C::RB>(orow, li, kk * 16), vf[kk], dp);
+    }
+    // rows of s/dp are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (8 * rg + 4 * h) * 4));
+      const f32x4 dl = __builtin_bit_cast(f32x4, lds_read16(stt + (QB + 8 * rg + 4 * h) * 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * rg + e;
+        float p = fast_exp2(s[r] * scale_log2 - l2[e]);
+        if (!kvalid) p = 0.f;
+        s[r] = p;
+        dp[r] = p * (dp[r] - dl[e]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < QB / 16; ++c) {
+      const Frag<T> pf = acc_to_frag<T>(s, c);
+      const Frag<T> dsf = acc_to_frag<T>(dp, c);
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) {
+        dv[db] = mma32(load_frag_tr<T, C::RB, 2>(ocol, c * 16, db * 32), pf, dv[db]);
+        dk[db] = mma32(load_frag_tr<T, C::RB, 2>(qcol, c * 16, db * 32), dsf, dk[db]);
+      }
+    }
+    if (t + 1 < ntiles) commit_all(cur ^ 1);
+    __syncthreads();
+  }
+
+  if (kvalid) {
+    T* dKo = dbase + (long)key * rs + a.E + hd * D;
+    T* dVo = dbase + (long)key * rs + 2 * a.E + hd * D;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = db * 32 + 8 * rg + 4 * h;
+        f32x4 x, y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = dk[db][4 * rg + e] * scale; y[e] = dv[db][4 * rg + e]; }
+        store4<T>(dKo + d0, x);
+        store4<T>(dVo + d0, y);
+      }
+  }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
+  using C = AttnCfg<T, D>;
+  const size_t lds = 4 * C::TILE;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), lds, s, a);
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
+  using C = AttnCfg<T, D>;
+  {
+    const long pairs = (long)a.B * a.S * a.H;
+    int grid = (int)std::min<long>((pairs + 15) / 16, 4096);
+    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, s, a, D);
+  }
+  {
+    const size_t lds = 6 * C::TILE;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), lds, s, a);
+  }
+  if (a.sep > 0) {
+    const size_t lds = 2 * (4 * 32 * C::RB + 2 * 32 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D>), dim3((a.sep + 127) / 128, a.H, a.B), dim3(256), lds, s, a);
+  }
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+
+static int check_attn(const AttnArgs& a, int precision) {
+  if (a.B <= 0 || a.S <= 0 || a.H <= 0 || a.E % a.H) return PFN_ERR_ARGUMENT;
+  if (a.sep < 0 || a.sep > a.S) return PFN_ERR_ARGUMENT;
+  const int es = precision == PFN_PREC_BF16 ? 2 : 4;
+  if ((a.E * es) % 16) return PFN_ERR_ALIGNMENT;
+  return PFN_OK;
+}
+
+#define PFN_ATTN_DISPATCH(FN)                                                             \
+  const int D = a.E / a.H;                                                                 \
+  if (precision == PFN_PREC_BF16) {                                                        \
+    switch (D) {                                                                           \
+      case 32: return FN<bf16, 32>(a, s);                                                  \
+      case 64: return FN<bf16, 64>(a, s);                                                  \
+      case 128: return FN<bf16, 128>(a, s);                                                \
+      case 256: return FN<bf16, 256>(a, s);                                                \
+      default: return PFN_ERR_UNSUPPORTED;                                                 \
+    }                                                                                      \
+  } else {                                                                                 \
+    switch (D) {                                                                           \
+      case 32: return FN<float, 32>(a, s);                                                 \
+      case 64: return FN<float, 64>(a, s);                                                 \
+      case 128: return FN<float, 128>(a, s);                                               \
+      default: return PFN_ERR_UNSUPPORTED;                                                 \
+    }                                                                                      \
+  }
+
+int launch_attn_fwd(const AttnArgs& a, int precision, hipStream_t s) {
+  int rc = check_attn(a, precision);
+  if (rc != PFN_OK) return rc;
+  PFN_ATTN_DISPATCH(launch_fwd_t)
+}
+int launch_attn_bwd(const AttnArgs& a, int precision, hipStream_t s) {
+  int rc = check_attn(a, precision);
+  if (rc != PFN_OK) return rc;
+  PFN_ATTN_DISPATCH(launch_bwd_t)
+}
+
+}  // namespace pfn

@@ -1,0 +1,297 @@
+// Batched Gaussian-process prior sampler (gfx950):  y_b = chol(K_b) z_b,
+//   K_b = outputscale_b * k(x_b, x_b; lengthscale_b) + noise_b * I,   k = RBF or Matern-5/2 (ARD).
+//
+// Replaces the gpytorch ExactGP prior-mode draw of the reference (priors/fast_gp.py:41-58:
+// ScaleKernel(RBFKernel) + GaussianLikelihood, sample = MultivariateNormal.sample()) and the
+// sampling half of priors/fast_gp_mix.py:85-99 (Matern nu=2.5, ARD lengthscales, per-dataset
+// hyper-parameters).  Everything is f32 like the reference.
+//
+// Schedule per call (all datasets of the batch advance together, grid.y / grid.z = dataset):
+//   rng    : Philox4x32-10 -> x ~ U[0,1), z ~ N(0,1) (Box-Muller); y = 0
+//   gram   : lower-triangular 64x64 tiles of K                      (HBM-bound, 4 S^2/2 bytes written)
+//   for each 64-wide panel k:   (right-looking blocked Cholesky, S/64 panels)
+//     potrf : factor the diagonal block in LDS, y[blk] += L_kk z[blk]
+//     trsm  : one thread per row below the block: row <- row . L_kk^-T; y[row] += row . z[blk]
+//     syrk  : trailing lower tiles  C_ij -= L_ik L_jk^T  on exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+// so L.z (the "TRMV") costs no extra pass over the matrix.  Algorithmic work per dataset:
+// S^3/3 flop (Cholesky) + S^2 (nf+2) (Gram); the matrix (4 S^2 bytes) lives in K_ws.
+#include <algorithm>
+#include "pfn_device.h"
+#include "pfn_kernels.h"
+
+namespace pfn {
+
+constexpr int NB = 64;  // panel width
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter = (index, stream), key = seed
+// ---------------------------------------------------------------------------------------------
+struct U4 { unsigned x, y, z, w; };
+PFN_DEV U4 philox4x32_10(unsigned long long idx, unsigned long long stream, unsigned long long seed) {
+  unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)stream, c3 = (unsigned)(stream >> 32);
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+PFN_DEV float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }             // [0,1)
+PFN_DEV float u01_open(unsigned r) { return ((float)(r >> 8) + 1.f) * 5.9604644775390625e-8f; }  // (0,1]
+
+__global__ __launch_bounds__(256) void gp_rng_kernel(GpArgs a) {
+  const long nx = (long)a.B * a.S * a.nf, nz = (long)a.B * a.S;
+  const long nx4 = (nx + 3) / 4, nz4 = (nz + 3) / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nx4 + nz4; i += (long)gridDim.x * 256) {
+    if (i < nx4) {
+      if (!a.gen_x) continue;
+      const U4 r = philox4x32_10((unsigned long long)i, a.offset * 2, a.seed);
+      const unsigned v[4] = {r.x, r.y, r.z, r.w};
+      for (int e = 0; e < 4; ++e) if (4 * i + e < nx) a.x[4 * i + e] = u01(v[e]);
+    } else {
+      const long j = i - nx4;
+      float n[4] = {0, 0, 0, 0};
+      if (a.gen_z) {
+        const U4 r = philox4x32_10((unsigned long long)j, a.offset * 2 + 1, a.seed);
+        const float r0 = sqrtf(-2.f * __logf(u01_open(r.x))), r1 = sqrtf(-2.f * __logf(u01_open(r.z)));
+        float s0, c0, s1, c1;
+        __sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+        __sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+        n[0] = r0 * c0; n[1] = r0 * s0; n[2] = r1 * c1; n[3] = r1 * s1;
+      }
+      for (int e = 0; e < 4; ++e)
+        if (4 * j + e < nz) {
+          if (a.gen_z) const_cast<float*>(a.z)[4 * j + e] = n[e];
+          a.y[4 * j + e] = 0.f;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram matrix, lower-triangular 64x64 tiles.  blockIdx.x enumerates (ti >= tj), blockIdx.y = b.
+// ---------------------------------------------------------------------------------------------
+PFN_DEV void tri_decode(int t, int& ti, int& tj) {  // t = ti*(ti+1)/2 + tj, tj <= ti
+  ti = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
+  while (ti * (ti + 1) / 2 > t) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  tj = t - ti * (ti + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void gp_gram_kernel(GpArgs a) {
+  extern __shared__ float gs[];  // xi[64][nf+1], xj[64][nf+1], inv_ls[nf]
+  const int nf = a.nf, ldx = nf + 1;
+  float* xi = gs; float* xj = gs + 64 * ldx; float* ils = gs + 128 * ldx;
+  int ti, tj;
+  tri_decode(blockIdx.x, ti, tj);
+  const int b = blockIdx.y, S = a.S;
+  const float* xb = a.x + (long)b * S * nf;
+  for (int i = threadIdx.x; i < 64 * nf; i += 256) {
+    const int r = i / nf, f = i % nf;
+    xi[r * ldx + f] = (ti * 64 + r < S) ? xb[(long)(ti * 64 + r) * nf + f] : 0.f;
+    xj[r * ldx + f] = (tj * 64 + r < S) ? xb[(long)(tj * 64 + r) * nf + f] : 0.f;
+  }
+  for (int f = threadIdx.x; f < nf; f += 256) ils[f] = 1.f / a.lengthscale[(long)b * nf + f];
+  __syncthreads();
+  const int r0 = (threadIdx.x >> 4) * 4, c0 = (threadIdx.x & 15) * 4;
+  float d2[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d2[i][j] = 0.f;
+  for (int f = 0; f < nf; ++f) {
+    const float s = ils[f];
+    float xa[4], xc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xa[i] = xi[(r0 + i) * ldx + f] * s; xc[i] = xj[(c0 + i) * ldx + f] * s; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = xa[i] - xc[j]; d2[i][j] += d * d; }
+  }
+  const float os = a.outputscale[b], nz = a.noise[b];
+  float* Kb = a.K + (long)b * S * S;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gi = ti * 64 + r0 + i;
+    if (gi >= S) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gj = tj * 64 + c0 + j;
+      if (gj >= S) continue;
+      float k;
+      if (a.kernel == 0) k = __expf(-0.5f * d2[i][j]);
+      else { const float r = sqrtf(5.f * d2[i][j]); k = (1.f + r + r * r * (1.f / 3.f)) * __expf(-r); }
+      Kb[(long)gi * S + gj] = os * k + (gi == gj ? nz : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// potrf: factor the diagonal block of panel k (one workgroup per dataset)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_potrf_kernel(GpArgs a, int k0) {
+  __shared__ float L[NB][NB + 1];
+  __shared__ float zs[NB];
+  const int b = blockIdx.x, S = a.S, nb = min(NB, S - k0);
+  float* Kb = a.K + (long)b * S * S + (long)k0 * S + k0;
+  for (int i = threadIdx.x; i < NB * NB; i += 256) {
+    const int r = i / NB, c = i % NB;
+    L[r][c] = (r < nb && c <= r) ? Kb[(long)r * S + c] : 0.f;
+  }
+  if (threadIdx.x < NB) zs[threadIdx.x] = (threadIdx.x < nb) ? a.z[(long)b * S + k0 + threadIdx.x] : 0.f;
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    const float piv = L[j][j];
+    if (threadIdx.x == 0 && !(piv > 0.f) && a.info[b] == 0) a.info[b] = k0 + j + 1;
+    const float d = sqrtf(fmaxf(piv, 1e-20f));
+    const float invd = 1.f / d;
+    __syncthreads();
+    if (threadIdx.x < nb) {
+      const int r = threadIdx.x;
+      if (r == j) L[j][j] = d;
+      else if (r > j) L[r][j] *= invd;
+    }
+    __syncthreads();
+    // trailing update of the block: (r, c) with r >= c > j
+    for (int i = threadIdx.x; i < NB * NB; i += 256) {
+      const int r = i / NB, c = i % NB;
+      if (c > j && r >= c && r < nb) L[r][c] -= L[r][j] * L[c][j];
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < NB * NB; i += 256) {
+    const int r = i / NB, c = i % NB;
+    if (r < nb && c <= r) Kb[(long)r * S + c] = L[r][c];
+  }
+  if (threadIdx.x < nb) {
+    const int r = threadIdx.x;
+    float acc = 0.f;
+    for (int c = 0; c <= r; ++c) acc += L[r][c] * zs[c];
+    a.y[(long)b * S + k0 + r] += acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trsm: rows below the diagonal block.  One thread per row; row . L_kk^-T by forward substitution
+// with L_kk broadcast from LDS.  Also the panel's contribution to y = L z.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0) {
+  __shared__ float L[NB][NB];  // L[j][m], m <= j
+  __shared__ float zs[NB];
+  const int b = blockIdx.y, S = a.S;
+  float* Kb = a.K + (long)b * S * S;
+  for (int i = threadIdx.x; i < NB * NB; i += 256) {
+    const int r = i / NB, c = i % NB;
+    L[r][c] = (c <= r) ? Kb[(long)(k0 + r) * S + k0 + c] : 0.f;
+  }
+  if (threadIdx.x < NB) zs[threadIdx.x] = a.z[(long)b * S + k0 + threadIdx.x];
+  __syncthreads();
+  const int row = k0 + NB + blockIdx.x * 256 + threadIdx.x;
+  if (row >= S) return;
+  float* p = Kb + (long)row * S + k0;
+  float v[NB];
+#pragma unroll
+  for (int c = 0; c < NB; c += 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + c);
+    v[c] = t[0]; v[c + 1] = t[1]; v[c + 2] = t[2]; v[c + 3] = t[3];
+  }
+  float ydot = 0.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    float s = v[j];
+#pragma unroll
+    for (int m = 0; m < j; ++m) s -= v[m] * L[j][m];
+    s /= L[j][j];
+    v[j] = s;
+    ydot += s * zs[j];
+  }
+#pragma unroll
+  for (int c = 0; c < NB; c += 4) *reinterpret_cast<f32x4*>(p + c) = f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]};
+  a.y[(long)b * S + row] += ydot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// syrk: C_ij -= P_i P_j^T for the lower-triangular 128x128 tiles of the trailing matrix, where
+// P = the freshly solved panel (rows >= k0+NB, columns k0..k0+63).  Exact-f32 MFMA.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_syrk_kernel(GpArgs a, int k0) {
+  constexpr int RB = NB * 4;  // 256-byte panel rows
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr tA = lds_cast(smem_raw);
+  LdsPtr tB = tA + 128 * RB;
+  int ti, tj;
+  tri_decode(blockIdx.x, ti, tj);
+  const int b = blockIdx.y, S = a.S, t0 = k0 + NB;
+  float* Kb = a.K + (long)b * S * S;
+  const int i0 = t0 + ti * 128, j0 = t0 + tj * 128;
+  TileStage<float, 128, RB, 256> sa, sb;
+  sa.issue(Kb + (long)i0 * S + k0, S, S - i0, NB);
+  sb.issue(Kb + (long)j0 * S + k0, S, S - j0, NB);
+  sa.template commit<false>(tA);
+  sb.template commit<false>(tB);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NB; ks += 16) {
+    Frag<float> fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = load_frag_row<float, RB>(tA, wm * 64 + i * 32 + (lane & 31), ks);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<float, RB>(tB, wn * 64 + j * 32 + (lane & 31), ks);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fa[i], fb[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gi = i0 + wm * 64 + i * 32 + acc_row(r, lane);
+        const int gj = j0 + wn * 64 + j * 32 + (lane & 31);
+        if (gi < S && gj < S && gj <= gi) Kb[(long)gi * S + gj] -= acc[i][j][r];
+      }
+}
+
+int launch_gp_sample(const GpArgs& a, hipStream_t s) {
+  const int S = a.S, B = a.B;
+  if (S % 4) return PFN_ERR_UNSUPPORTED;  // 16-byte aligned matrix rows
+  {
+    const long work = ((long)B * S * a.nf + 3) / 4 + ((long)B * S + 3) / 4;
+    const int grid = (int)std::max<long>(1, std::min<long>((work + 255) / 256, 4096));
+    hipLaunchKernelGGL(gp_rng_kernel, dim3(grid), dim3(256), 0, s, a);
+  }
+  {
+    const int t = (S + 63) / 64;
+    const size_t lds = (128 * (a.nf + 1) + a.nf) * sizeof(float);
+    if (lds > 64 * 1024) return PFN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gp_gram_kernel, dim3(t * (t + 1) / 2, B), dim3(256), lds, s, a);
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_syrk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  for (int k0 = 0; k0 < S; k0 += NB) {
+    hipLaunchKernelGGL(gp_potrf_kernel, dim3(B), dim3(256), 0, s, a, k0);
+    const int below = S - k0 - NB;
+    if (below > 0) {
+      hipLaunchKernelGGL(gp_trsm_kernel, dim3((below + 255) / 256, B), dim3(256), 0, s, a, k0);
+      const int t = (below + 127) / 128;
+      hipLaunchKernelGGL(gp_syrk_kernel, dim3(t * (t + 1) / 2, B), dim3(256), 65536, s, a, k0);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+
+}  // namespace pfn

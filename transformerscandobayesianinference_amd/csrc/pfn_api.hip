@@ -1,0 +1,460 @@
+// C-ABI layer of libpfn_hip.so: parameter packing, workspace carving, and the forward/backward
+// schedules of the PFN encoder stack (see include/pfn_hip.h for the contract).
+//
+// Forward schedule  == TransformerModel.forward (reference transformer.py:55-91) with
+// nn.TransformerEncoderLayer in post-norm form (torch nn/modules/transformer.py:952-957):
+//     x = LN1(x + out_proj(attn(in_proj(x))));  x = LN2(x + linear2(gelu(linear1(x))))
+// Backward schedule == autograd of the same graph (train.py:93), written out by hand.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "pfn_kernels.h"
+
+using namespace pfn;
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define PFN_TRY(expr)                                                                   \
+  do {                                                                                  \
+    int rc_ = (expr);                                                                   \
+    if (rc_ != PFN_OK) return fail(rc_, "%s failed with %d at %s:%d", #expr, rc_, __FILE__, __LINE__); \
+  } while (0)
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+inline int esize(int prec) { return prec == PFN_PREC_BF16 ? 2 : 4; }
+
+int check_desc(const pfn_model_desc* d) {
+  if (!d) return fail(PFN_ERR_ARGUMENT, "null model descriptor");
+  if (d->precision != PFN_PREC_BF16 && d->precision != PFN_PREC_F32) return fail(PFN_ERR_ARGUMENT, "bad precision %d", d->precision);
+  if (d->num_features < 1 || d->emsize < 8 || d->nhead < 1 || d->nhid < 8 || d->nlayers < 0 || d->n_out < 1)
+    return fail(PFN_ERR_ARGUMENT, "bad model dimensions");
+  if (d->emsize % d->nhead) return fail(PFN_ERR_ARGUMENT, "emsize %d not divisible by nhead %d", d->emsize, d->nhead);
+  if (d->emsize % 8 || d->nhid % 8) return fail(PFN_ERR_UNSUPPORTED, "emsize and nhid must be multiples of 8 (16-byte operand rows)");
+  const int dh = d->emsize / d->nhead;
+  const bool ok = dh == 32 || dh == 64 || dh == 128 || (dh == 256 && d->precision == PFN_PREC_BF16);
+  if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128, 256 in bf16)", dh);
+  if (d->emsize > 2048) return fail(PFN_ERR_UNSUPPORTED, "emsize > 2048 unsupported by the LayerNorm kernels");
+  return PFN_OK;
+}
+
+// ---- parameter layout ---------------------------------------------------------------------------
+struct LayerP { int64_t w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2; };
+struct Layout {
+  int64_t enc_w, enc_b, yenc_w, yenc_b;
+  std::vector<LayerP> layer;
+  int64_t dec0_w, dec0_b, dec2_w, dec2_b;
+  int64_t total;                       // elements of the flat f32 buffer
+  // transposed operand-precision copies (element offsets into the shadow's second region)
+  std::vector<LayerP> layer_t;         // only w_in, w_o, w1, w2 used
+  int64_t dec0_wt, dec2_wt, total_t;
+  int n_out_pad;
+  std::vector<int64_t> offsets, numels;  // state-dict order
+};
+
+Layout make_layout(const pfn_model_desc& d) {
+  Layout L;
+  const int64_t E = d.emsize, F = d.nhid, nf = d.num_features, O = d.n_out;
+  int64_t cur = 0;
+  auto take = [&](int64_t n) { int64_t o = cur; L.offsets.push_back(o); L.numels.push_back(n); cur = align_up(cur + n, 64); return o; };
+  L.enc_w = take(E * nf); L.enc_b = take(E); L.yenc_w = take(E); L.yenc_b = take(E);
+  L.layer.resize(d.nlayers);
+  for (auto& p : L.layer) {
+    p.w_in = take(3 * E * E); p.b_in = take(3 * E); p.w_o = take(E * E); p.b_o = take(E);
+    p.w1 = take(F * E); p.b1 = take(F); p.w2 = take(E * F); p.b2 = take(E);
+    p.g1 = take(E); p.be1 = take(E); p.g2 = take(E); p.be2 = take(E);
+  }
+  L.dec0_w = take(F * E); L.dec0_b = take(F); L.dec2_w = take(O * F); L.dec2_b = take(O);
+  L.total = cur;
+  L.n_out_pad = (int)align_up(O, 8);
+  int64_t ct = 0;
+  auto take_t = [&](int64_t n) { int64_t o = ct; ct = align_up(ct + n, 64); return o; };
+  L.layer_t.resize(d.nlayers);
+  for (auto& p : L.layer_t) { p.w_in = take_t(3 * E * E); p.w_o = take_t(E * E); p.w1 = take_t(F * E); p.w2 = take_t(E * F); }
+  L.dec0_wt = take_t(F * E);
+  L.dec2_wt = take_t(F * (int64_t)L.n_out_pad);
+  L.total_t = ct;
+  return L;
+}
+
+// ---- workspace ------------------------------------------------------------------------------------
+struct LayerWs { char *qkv, *ctx, *x1_t, *hpre, *h, *x2_t; float *lse, *y1, *mean1, *rstd1, *x1, *y2, *mean2, *rstd2, *x2; };
+struct Ws {
+  float* x0; char* x0_t;
+  std::vector<LayerWs> layer;
+  char *xt_t, *dpre, *dt;
+  // backward scratch
+  char *dlog_t, *dd_t, *dy_t, *dh_t, *dctx_t, *dqkv_t;
+  float *dxt, *gA, *gB, *delta;
+  int64_t bytes;
+};
+
+Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
+  Ws w;
+  const int64_t M = (int64_t)B * S, E = d.emsize, F = d.nhid, es = esize(d.precision);
+  const int64_t npad = align_up(d.n_out, 8);
+  int64_t cur = 0;
+  auto take = [&](int64_t nbytes) { char* p = base ? base + cur : nullptr; cur = align_up(cur + nbytes, 256); return p; };
+  w.x0 = (float*)take(M * E * 4); w.x0_t = take(M * E * es);
+  w.layer.resize(d.nlayers);
+  for (auto& l : w.layer) {
+    l.qkv = take(M * 3 * E * es); l.ctx = take(M * E * es); l.lse = (float*)take((int64_t)B * d.nhead * S * 4);
+    l.y1 = (float*)take(M * E * 4); l.mean1 = (float*)take(M * 4); l.rstd1 = (float*)take(M * 4);
+    l.x1 = (float*)take(M * E * 4); l.x1_t = take(M * E * es);
+    l.hpre = take(M * F * es); l.h = take(M * F * es);
+    l.y2 = (float*)take(M * E * 4); l.mean2 = (float*)take(M * 4); l.rstd2 = (float*)take(M * 4);
+    l.x2 = (float*)take(M * E * 4); l.x2_t = take(M * E * es);
+  }
+  w.xt_t = take(M * E * es); w.dpre = take(M * F * es); w.dt = take(M * F * es);
+  w.dlog_t = take(M * npad * es); w.dd_t = take(M * F * es); w.dxt = (float*)take(M * E * 4);
+  w.gA = (float*)take(M * E * 4); w.gB = (float*)take(M * E * 4);
+  w.dy_t = take(M * E * es); w.dh_t = take(M * F * es); w.dctx_t = take(M * E * es); w.dqkv_t = take(M * 3 * E * es);
+  w.delta = (float*)take((int64_t)B * d.nhead * S * 4);
+  w.bytes = cur;
+  return w;
+}
+
+GemmNT nt(const void* A, long lda, const void* B, long ldb, int M, int N, int K, int flags) {
+  GemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.flags = flags;
+  return g;
+}
+GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int P, int Q) {
+  GemmTN g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.P = P; g.Q = Q; g.atomic = 1;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pfn_abi_version(void) { return PFN_ABI_VERSION; }
+const char* pfn_last_error_string(void) { return g_err; }
+
+int pfn_param_layout(const pfn_model_desc* d, int64_t* offsets, int64_t* numels, int max_tensors) {
+  int rc = check_desc(d);
+  if (rc != PFN_OK) return rc;
+  Layout L = make_layout(*d);
+  const int n = (int)L.offsets.size();
+  if (offsets || numels) {
+    if (max_tensors < n) return fail(PFN_ERR_ARGUMENT, "need room for %d tensors, got %d", n, max_tensors);
+    for (int i = 0; i < n; ++i) { if (offsets) offsets[i] = L.offsets[i]; if (numels) numels[i] = L.numels[i]; }
+  }
+  return n;
+}
+int64_t pfn_param_count(const pfn_model_desc* d) {
+  if (check_desc(d) != PFN_OK) return -1;
+  return make_layout(*d).total;
+}
+int64_t pfn_shadow_bytes(const pfn_model_desc* d) {
+  if (check_desc(d) != PFN_OK) return -1;
+  Layout L = make_layout(*d);
+  return (L.total + L.total_t) * esize(d->precision);
+}
+int64_t pfn_workspace_bytes(const pfn_model_desc* d, int B, int S) {
+  if (check_desc(d) != PFN_OK || B < 1 || S < 1) return -1;
+  return carve(*d, B, S, nullptr).bytes;
+}
+
+int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shadow, void* stream) {
+  PFN_TRY(check_desc(d));
+  if (!params || !shadow) return fail(PFN_ERR_ARGUMENT, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  Layout L = make_layout(*d);
+  const int prec = d->precision, es = esize(prec);
+  const int E = d->emsize, F = d->nhid;
+  char* sh = (char*)shadow;
+  PFN_TRY(launch_cast_params(params, sh, L.total, prec, s));
+  char* tr = sh + L.total * es;
+  for (int l = 0; l < d->nlayers; ++l) {
+    const LayerP &p = L.layer[l], &t = L.layer_t[l];
+    PFN_TRY(launch_transpose_cast(params + p.w_in, tr + t.w_in * es, 3 * E, E, 3 * E, prec, s));  // [3E,E] -> [E,3E]
+    PFN_TRY(launch_transpose_cast(params + p.w_o, tr + t.w_o * es, E, E, E, prec, s));
+    PFN_TRY(launch_transpose_cast(params + p.w1, tr + t.w1 * es, F, E, F, prec, s));               // [F,E] -> [E,F]
+    PFN_TRY(launch_transpose_cast(params + p.w2, tr + t.w2 * es, E, F, E, prec, s));               // [E,F] -> [F,E]
+  }
+  PFN_TRY(launch_transpose_cast(params + L.dec0_w, tr + L.dec0_wt * es, F, E, F, prec, s));
+  PFN_TRY(launch_transpose_cast(params + L.dec2_w, tr + L.dec2_wt * es, d->n_out, F, L.n_out_pad, prec, s));  // [O,F] -> [F,Opad]
+  return PFN_OK;
+}
+
+int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* shadow,
+                      const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                      const float* src_sbe, int B, int S, int sep, void* workspace, int64_t workspace_bytes,
+                      float* logits, void* stream) {
+  PFN_TRY(check_desc(d));
+  if (!params || !shadow || !workspace) return fail(PFN_ERR_ARGUMENT, "null pointer");
+  if (!src_sbe && (!x || !y)) return fail(PFN_ERR_ARGUMENT, "need x and y (or src_sbe)");
+  if (B < 1 || S < 1 || sep < 0 || sep > S) return fail(PFN_ERR_ARGUMENT, "bad B=%d S=%d sep=%d", B, S, sep);
+  if (!logits && sep < S) return fail(PFN_ERR_ARGUMENT, "null logits");
+  hipStream_t s = (hipStream_t)stream;
+  const int prec = d->precision, es = esize(prec);
+  const int E = d->emsize, F = d->nhid, H = d->nhead, O = d->n_out;
+  Layout L = make_layout(*d);
+  Ws w = carve(*d, B, S, (char*)workspace);
+  if (workspace_bytes < w.bytes) return fail(PFN_ERR_ARGUMENT, "workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)w.bytes);
+  const int M = B * S, Mt = (S - sep) * B;
+  const char* sh = (const char*)shadow;
+  auto W = [&](int64_t off) { return (const void*)(sh + off * es); };
+
+  if (src_sbe) {
+    PFN_TRY(launch_sbe_to_bse(src_sbe, w.x0, w.x0_t, S, B, E, prec, s));
+  } else {
+    EmbedArgs e;
+    e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;
+    e.wx = params + L.enc_w; e.bx = params + L.enc_b; e.wy = params + L.yenc_w; e.by = params + L.yenc_b;
+    e.out_f32 = w.x0; e.out_t = w.x0_t; e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep;
+    PFN_TRY(launch_embed_fwd(e, prec, s));
+  }
+  const float* xin = w.x0;
+  const char* xin_t = w.x0_t;
+  for (int l = 0; l < d->nlayers; ++l) {
+    const LayerP& p = L.layer[l];
+    LayerWs& a = w.layer[l];
+    {  // packed q/k/v projection
+      GemmNT g = nt(xin_t, E, W(p.w_in), E, M, 3 * E, E, EPI_BIAS | EPI_OUT_T);
+      g.bias = params + p.b_in; g.out_t = a.qkv; g.ld_out_t = 3 * E;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    {
+      AttnArgs at; memset(&at, 0, sizeof(at));
+      at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
+      PFN_TRY(launch_attn_fwd(at, prec, s));
+    }
+    {  // out_proj + residual
+      GemmNT g = nt(a.ctx, E, W(p.w_o), E, M, E, E, EPI_BIAS | EPI_RESID | EPI_OUT_F32);
+      g.bias = params + p.b_o; g.resid = xin; g.ld_resid = E; g.out_f32 = a.y1; g.ld_out_f32 = E;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, a.x1, a.x1_t, a.mean1, a.rstd1, M, E, d->ln_eps, prec, s));
+    {  // linear1 + GELU (pre-activation kept for the backward)
+      GemmNT g = nt(a.x1_t, E, W(p.w1), E, M, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
+      g.bias = params + p.b1; g.out_t = a.h; g.ld_out_t = F; g.out2_t = a.hpre; g.ld_out2 = F;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    {  // linear2 + residual
+      GemmNT g = nt(a.h, F, W(p.w2), F, M, E, F, EPI_BIAS | EPI_RESID | EPI_OUT_F32);
+      g.bias = params + p.b2; g.resid = a.x1; g.ld_resid = E; g.out_f32 = a.y2; g.ld_out_f32 = E;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    PFN_TRY(launch_layernorm_fwd(a.y2, params + p.g2, params + p.be2, a.x2, a.x2_t, a.mean2, a.rstd2, M, E, d->ln_eps, prec, s));
+    xin = a.x2; xin_t = a.x2_t;
+  }
+  // decoder on the test rows only (the reference decodes all rows, then slices: transformer.py:85,91)
+  if (Mt > 0) {
+    PFN_TRY(launch_gather_test_rows(xin, w.xt_t, S, B, E, sep, prec, s));
+    {
+      GemmNT g = nt(w.xt_t, E, W(L.dec0_w), E, Mt, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
+      g.bias = params + L.dec0_b; g.out_t = w.dt; g.ld_out_t = F; g.out2_t = w.dpre; g.ld_out2 = F;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    {
+      GemmNT g = nt(w.dt, F, W(L.dec2_w), F, Mt, O, F, EPI_BIAS | EPI_OUT_F32);
+      g.bias = params + L.dec2_b; g.out_f32 = logits; g.ld_out_f32 = O;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+  }
+  return PFN_OK;
+}
+
+int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void* shadow,
+                       const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                       int B, int S, int sep, void* workspace, int64_t workspace_bytes,
+                       const float* dlogits, float* grads, float* dsrc_sbe, void* stream) {
+  PFN_TRY(check_desc(d));
+  if (!params || !shadow || !workspace || !grads) return fail(PFN_ERR_ARGUMENT, "null pointer");
+  if (!dsrc_sbe && (!x || !y)) return fail(PFN_ERR_ARGUMENT, "need x and y (or dsrc_sbe)");
+  if (B < 1 || S < 1 || sep < 0 || sep > S) return fail(PFN_ERR_ARGUMENT, "bad B=%d S=%d sep=%d", B, S, sep);
+  hipStream_t s = (hipStream_t)stream;
+  const int prec = d->precision, es = esize(prec);
+  const int E = d->emsize, F = d->nhid, H = d->nhead, O = d->n_out;
+  Layout L = make_layout(*d);
+  Ws w = carve(*d, B, S, (char*)workspace);
+  if (workspace_bytes < w.bytes) return fail(PFN_ERR_ARGUMENT, "workspace too small");
+  const int M = B * S, Mt = (S - sep) * B, npad = L.n_out_pad;
+  const char* sh = (const char*)shadow;
+  auto W = [&](int64_t off) { return (const void*)(sh + off * es); };
+  auto WT = [&](int64_t off) { return (const void*)(sh + (L.total + off) * es); };
+
+  // ---- decoder ----
+  if (Mt > 0) {
+    if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
+    PFN_TRY(launch_cast_rows(dlogits, O, w.dlog_t, npad, Mt, O, prec, s));
+    PFN_TRY(launch_colsum(w.dlog_t, npad, Mt, O, grads + L.dec2_b, prec, s));
+    PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F), prec, s));
+    {
+      GemmNT g = nt(w.dlog_t, npad, WT(L.dec2_wt), npad, Mt, F, O, EPI_GELU_BWD | EPI_OUT_T);
+      g.aux = w.dpre; g.ld_aux = F; g.out_t = w.dd_t; g.ld_out_t = F;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    PFN_TRY(launch_colsum(w.dd_t, F, Mt, F, grads + L.dec0_b, prec, s));
+    PFN_TRY(launch_gemm_tn(tn(w.dd_t, F, w.xt_t, E, grads + L.dec0_w, E, Mt, F, E), prec, s));
+    {
+      GemmNT g = nt(w.dd_t, F, WT(L.dec0_wt), F, Mt, E, F, EPI_OUT_F32);
+      g.out_f32 = w.dxt; g.ld_out_f32 = E;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+  }
+  PFN_TRY(launch_scatter_test_rows(w.dxt, w.gA, S, B, E, sep, s));
+
+  // ---- encoder layers, last to first; gA holds d(loss)/d(layer output) ----
+  for (int l = d->nlayers - 1; l >= 0; --l) {
+    const LayerP &p = L.layer[l], &t = L.layer_t[l];
+    LayerWs& a = w.layer[l];
+    const char* xin_t = (l == 0) ? w.x0_t : w.layer[l - 1].x2_t;
+    // LN2
+    PFN_TRY(launch_layernorm_bwd(w.gA, a.y2, params + p.g2, a.mean2, a.rstd2, w.gB, w.dy_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
+    {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
+      GemmNT g = nt(w.dy_t, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
+      g.aux = a.hpre; g.ld_aux = F; g.out_t = w.dh_t; g.ld_out_t = F;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    PFN_TRY(launch_gemm_tn(tn(w.dy_t, E, a.h, F, grads + p.w2, F, M, E, F), prec, s));
+    PFN_TRY(launch_gemm_tn(tn(w.dh_t, F, a.x1_t, E, grads + p.w1, E, M, F, E), prec, s));
+    PFN_TRY(launch_colsum(w.dh_t, F, M, F, grads + p.b1, prec, s));
+    {  // dx1 = dh . W1 + dy2
+      GemmNT g = nt(w.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID | EPI_OUT_F32);
+      g.resid = w.gB; g.ld_resid = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    // LN1
+    PFN_TRY(launch_layernorm_bwd(w.gA, a.y1, params + p.g1, a.mean1, a.rstd1, w.gB, w.dy_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
+    {  // d(ctx) = dy1 . Wo
+      GemmNT g = nt(w.dy_t, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
+      g.out_t = w.dctx_t; g.ld_out_t = E;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    PFN_TRY(launch_gemm_tn(tn(w.dy_t, E, a.ctx, E, grads + p.w_o, E, M, E, E), prec, s));
+    {
+      AttnArgs at; memset(&at, 0, sizeof(at));
+      at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
+      at.dctx = w.dctx_t; at.dqkv = w.dqkv_t; at.delta = w.delta;
+      PFN_TRY(launch_attn_bwd(at, prec, s));
+    }
+    PFN_TRY(launch_gemm_tn(tn(w.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, M, 3 * E, E), prec, s));
+    PFN_TRY(launch_colsum(w.dqkv_t, 3 * E, M, 3 * E, grads + p.b_in, prec, s));
+    {  // dx = dqkv . Win + dy1
+      GemmNT g = nt(w.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID | EPI_OUT_F32);
+      g.resid = w.gB; g.ld_resid = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
+      PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+  }
+  // ---- embedding ----
+  if (dsrc_sbe) {
+    PFN_TRY(launch_bse_to_sbe(w.gA, dsrc_sbe, S, B, E, s));
+  } else {
+    EmbedBwdArgs e;
+    e.dsrc = w.gA; e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;
+    e.dwx = grads + L.enc_w; e.dbx = grads + L.enc_b; e.dwy = grads + L.yenc_w; e.dby = grads + L.yenc_b;
+    e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep;
+    PFN_TRY(launch_embed_bwd(e, s));
+  }
+  return PFN_OK;
+}
+
+int pfn_bar_nll_forward(const float* logits, int64_t ld, const float* y, const float* borders, int64_t R, int nbars,
+                        int full_support, float* nll, float* lse, int32_t* bucket, void* stream) {
+  if (R < 0 || nbars < 1 || (R > 0 && (!logits || !y || !borders || !nll || !lse || !bucket))) return fail(PFN_ERR_ARGUMENT, "bad bar_nll_forward arguments");
+  BarArgs a; memset(&a, 0, sizeof(a));
+  a.logits = logits; a.ld = ld; a.y = y; a.borders = borders; a.R = R; a.nbars = nbars; a.full_support = full_support;
+  a.nll = nll; a.lse = lse; a.bucket = bucket;
+  PFN_TRY(launch_bar_nll_fwd(a, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_bar_nll_backward(const float* logits, int64_t ld, const float* lse, const int32_t* bucket, const float* gout,
+                         int64_t R, int nbars, float* dlogits, void* stream) {
+  if (R < 0 || nbars < 1 || (R > 0 && (!logits || !lse || !bucket || !gout || !dlogits))) return fail(PFN_ERR_ARGUMENT, "bad bar_nll_backward arguments");
+  BarArgs a; memset(&a, 0, sizeof(a));
+  a.logits = logits; a.ld = ld; a.R = R; a.nbars = nbars; a.lse = const_cast<float*>(lse); a.bucket = const_cast<int*>(bucket);
+  a.gout = gout; a.dlogits = dlogits;
+  PFN_TRY(launch_bar_nll_bwd(a, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_bar_mean(const float* logits, int64_t ld, const float* borders, int64_t R, int nbars, int full_support, float* mean, void* stream) {
+  if (R < 0 || nbars < 1 || (R > 0 && (!logits || !borders || !mean))) return fail(PFN_ERR_ARGUMENT, "bad bar_mean arguments");
+  BarArgs a; memset(&a, 0, sizeof(a));
+  a.logits = logits; a.ld = ld; a.borders = borders; a.R = R; a.nbars = nbars; a.full_support = full_support; a.mean_out = mean;
+  PFN_TRY(launch_bar_mean(a, (hipStream_t)stream));
+  return PFN_OK;
+}
+
+int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                       float beta2, float eps, float max_norm, float grad_scale, int step, int zero_grad, float* scratch, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n < 0 || step < 1) return fail(PFN_ERR_ARGUMENT, "bad clip_adam arguments");
+  AdamArgs a;
+  a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.max_norm = max_norm; a.grad_scale = grad_scale; a.step = step; a.zero_grad = zero_grad; a.scratch = scratch;
+  PFN_TRY(launch_clip_adam(a, (hipStream_t)stream));
+  return PFN_OK;
+}
+
+int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws, const float* lengthscale, const float* outputscale,
+                        const float* noise, int B, int S, int nf, int kernel, int gen_x, int gen_z, uint64_t seed, uint64_t offset,
+                        int32_t* info, void* stream) {
+  if (!x || !z || !y || !K_ws || !lengthscale || !outputscale || !noise || !info || B < 1 || S < 1 || nf < 1) return fail(PFN_ERR_ARGUMENT, "bad gp_prior_sample arguments");
+  if (kernel != 0 && kernel != 1) return fail(PFN_ERR_UNSUPPORTED, "kernel %d (0 = RBF, 1 = Matern-5/2)", kernel);
+  GpArgs a;
+  a.x = x; a.z = z; a.y = y; a.K = K_ws; a.lengthscale = lengthscale; a.outputscale = outputscale; a.noise = noise;
+  a.B = B; a.S = S; a.nf = nf; a.kernel = kernel; a.seed = seed; a.offset = offset; a.gen_x = gen_x; a.gen_z = gen_z; a.info = info;
+  PFN_TRY(launch_gp_sample(a, (hipStream_t)stream));
+  return PFN_OK;
+}
+
+// ---- single-op entry points -------------------------------------------------------------------------
+int pfn_op_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int flags, const float* bias,
+                   const void* aux, int64_t ld_aux, const float* resid, int64_t ld_resid, float* out_f32, int64_t ld_out_f32,
+                   void* out_t, int64_t ld_out_t, void* out2_t, int64_t ld_out2, int prec, void* stream) {
+  GemmNT g = nt(A, lda, B, ldb, M, N, K, flags);
+  g.bias = bias; g.aux = aux; g.ld_aux = ld_aux; g.resid = resid; g.ld_resid = ld_resid; g.out_f32 = out_f32; g.ld_out_f32 = ld_out_f32;
+  g.out_t = out_t; g.ld_out_t = ld_out_t; g.out2_t = out2_t; g.ld_out2 = ld_out2;
+  PFN_TRY(launch_gemm_nt(g, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int M, int P, int Q, int atomic, int prec, void* stream) {
+  GemmTN g = tn(A, lda, B, ldb, C, ldc, M, P, Q);
+  g.atomic = atomic;
+  PFN_TRY(launch_gemm_tn(g, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep, int prec, void* stream) {
+  AttnArgs at; memset(&at, 0, sizeof(at));
+  at.qkv = qkv; at.ctx = ctx; at.lse = lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
+  PFN_TRY(launch_attn_fwd(at, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta_ws,
+                         int B, int S, int E, int H, int sep, int prec, void* stream) {
+  AttnArgs at; memset(&at, 0, sizeof(at));
+  at.qkv = qkv; at.ctx = const_cast<void*>(ctx); at.lse = const_cast<float*>(lse); at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
+  at.dctx = dctx; at.dqkv = dqkv; at.delta = delta_ws;
+  PFN_TRY(launch_attn_bwd(at, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, float* mean, float* rstd,
+                         int64_t rows, int E, float eps, int prec, void* stream) {
+  PFN_TRY(launch_layernorm_fwd(x, gamma, beta, y_f32, y_t, mean, rstd, rows, E, eps, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx_f32,
+                         void* dx_t, float* dgamma, float* dbeta, float* dbias_extra, int64_t rows, int E, int prec, void* stream) {
+  PFN_TRY(launch_layernorm_bwd(dy, x, gamma, mean, rstd, dx_f32, dx_t, dgamma, dbeta, dbias_extra, rows, E, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_cast(const float* src, void* dst, int64_t n, int prec, void* stream) {
+  PFN_TRY(launch_cast_params(src, dst, n, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+
+}  // extern "C"

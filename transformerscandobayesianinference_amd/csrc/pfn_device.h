@@ -1,0 +1,225 @@
+// Device-side building blocks shared by every gfx950 kernel in this library.
+//
+// Hardware facts used here were verified on an MI355X by tools/probe_layouts.hip
+// (profiles/r01_probe_layouts.txt):
+//   * v_mfma_f32_32x32x16_bf16 : A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31],
+//                                D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31], r in [0,16)
+//   * v_mfma_f32_32x32x2_f32   : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], same D map
+//   * ds_read_b64_tr_b16       : inside each 16-lane group, lane i supplies the address of
+//                                4 consecutive b16 (R[i][0..3]); lane i receives
+//                                R[4j + (i>>2)][i&3] for j = 0..3, i.e. column i of the
+//                                4x16 block whose row j is held by lanes 4j..4j+3.
+//
+// A "fragment" is what one lane feeds one 32x32 MFMA step that contracts 16 indices:
+// 8 contraction "slots" (h = lane>>5, e = 0..7).  Slot (h,e) of the A operand always pairs
+// with slot (h,e) of the B operand, so any mapping slot -> contraction index is legal as long
+// as both operands use the same one.  Two mappings are used:
+//   M1 (memory order)      : k = 8h + e
+//   M2 (accumulator order) : k = 8*(e>>2) + 4h + (e&3)   -- what a lane already holds when the
+//                            operand is a just-computed 32x32 accumulator tile (P, dS)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pfn {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define PFN_DEV __device__ __forceinline__
+
+PFN_DEV int lane_id() { return threadIdx.x & 63; }
+
+// ---------------------------------------------------------------------------------------------
+// Fragments and the MFMA step
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+  bf16x8 v;
+  PFN_DEV void set(int e, float x) { v[e] = (bf16)x; }
+};
+template <> struct Frag<float> {
+  float v[8];
+  PFN_DEV void set(int e, float x) { v[e] = x; }
+};
+
+PFN_DEV f32x16 mma32(const Frag<bf16>& a, const Frag<bf16>& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+}
+// exact-f32 path: eight 32x32x2 steps; step e contracts slots (0,e) and (1,e).
+PFN_DEV f32x16 mma32(const Frag<float>& a, const Frag<float>& b, f32x16 c) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[e], b.v[e], c, 0, 0, 0);
+  return c;
+}
+
+// row index inside a 32x32 accumulator tile held by (lane, r)
+PFN_DEV int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// An accumulator tile re-used as an operand: slots follow mapping M2, chunk c = 0/1 selects
+// tile rows 16c..16c+15.  Lane keeps its column (l&31).
+template <typename T> PFN_DEV Frag<T> acc_to_frag(const f32x16& p, int c) {
+  Frag<T> f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f.set(e, p[8 * c + e]);
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS tiles.  Everything is addressed in bytes relative to a tile base; rows are RB bytes.
+// ---------------------------------------------------------------------------------------------
+// 16-byte-chunk XOR swizzle that makes "32 lanes read the same chunk column of 32 different
+// rows" (ds_read_b128) conflict free for power-of-two row sizes.
+template <int RB> PFN_DEV int swz16(int row, int chunk) {
+  constexpr int NCH = RB / 16;
+  if constexpr (NCH >= 16) return chunk ^ (row & 15);
+  else if constexpr (NCH == 8) return chunk ^ ((row >> 1) & 7);
+  else if constexpr (NCH == 4) return chunk ^ ((row >> 2) & 3);
+  else if constexpr (NCH == 2) return chunk ^ ((row >> 3) & 1);
+  else return chunk;
+}
+template <int RB> PFN_DEV int lds_off16(int row, int chunk) { return row * RB + swz16<RB>(row, chunk) * 16; }
+
+// 64-byte-unit XOR swizzle for tiles consumed by ds_read_b64_tr_b16 (4 consecutive rows must
+// land in 4 different 16-bank quarters).
+template <int RB> PFN_DEV int swz64(int row, int unit) {
+  constexpr int U = RB / 64;
+  if constexpr (U >= 4) return unit ^ (row & 3);
+  else if constexpr (U == 2) return unit ^ ((row >> 1) & 1);
+  else return unit;
+}
+template <int RB> PFN_DEV int lds_off64(int row, int byte_in_row) {
+  return row * RB + swz64<RB>(row, byte_in_row >> 6) * 64 + (byte_in_row & 63);
+}
+
+// LDS pointers are kept in address space 3 so every access lowers to a ds_* instruction.
+typedef __attribute__((address_space(3))) char lds_char;
+typedef lds_char* LdsPtr;
+PFN_DEV LdsPtr lds_cast(void* generic_shared) { return (LdsPtr)generic_shared; }
+
+PFN_DEV u32x4 lds_read16(const lds_char* p) { return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(p); }
+PFN_DEV void lds_write16(LdsPtr p, u32x4 v) { *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(p) = v; }
+PFN_DEV float lds_read_f32(const lds_char* p) { return *reinterpret_cast<const __attribute__((address_space(3))) float*>(p); }
+PFN_DEV void lds_write_f32(LdsPtr p, float v) { *reinterpret_cast<__attribute__((address_space(3))) float*>(p) = v; }
+
+// Row fragment (mapping M1): lane wants row `row`, contraction elements k0 + 8h + e from a
+// swz16 tile whose rows hold the contraction index contiguously.
+template <typename T, int RB> PFN_DEV Frag<T> load_frag_row(const lds_char* tile, int row, int k0) {
+  const int h = lane_id() >> 5;
+  Frag<T> f;
+  if constexpr (sizeof(T) == 2) {
+    u32x4 raw = lds_read16(tile + lds_off16<RB>(row, (k0 >> 3) + h));
+    f.v = __builtin_bit_cast(bf16x8, raw);
+  } else {
+    const int c = (k0 >> 2) + 2 * h;
+    u32x4 r0 = lds_read16(tile + lds_off16<RB>(row, c));
+    u32x4 r1 = lds_read16(tile + lds_off16<RB>(row, c + 1));
+    f32x4 a = __builtin_bit_cast(f32x4, r0), b = __builtin_bit_cast(f32x4, r1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f.v[e] = a[e]; f.v[4 + e] = b[e]; }
+  }
+  return f;
+}
+
+PFN_DEV bf16x4 ds_read_tr16_b64(const lds_char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+
+// Transposed fragment from a swz64 tile whose ROWS are the contraction index and whose columns
+// are the operand's i/j index.  Lane wants column col0 + (l&31).  MAP 1: rows k0+8h+e,
+// MAP 2: rows k0 + 8*(e>>2) + 4h + (e&3).  bf16 uses the hardware transpose read; f32 uses
+// eight b32 reads.
+template <typename T, int RB, int MAP> PFN_DEV Frag<T> load_frag_tr(const lds_char* tile, int k0, int col0) {
+  const int l = lane_id(), h = l >> 5;
+  Frag<T> f;
+  if constexpr (sizeof(T) == 2) {
+    const int i = l & 15, g = (l >> 4) & 1;
+    const int colb = (col0 + 16 * g + 4 * (i & 3)) * 2;
+    const int ra = (MAP == 1) ? (k0 + 8 * h) : (k0 + 4 * h);
+    const int rb = (MAP == 1) ? (k0 + 8 * h + 4) : (k0 + 8 + 4 * h);
+    bf16x4 lo = ds_read_tr16_b64(tile + lds_off64<RB>(ra + (i >> 2), colb));
+    bf16x4 hi = ds_read_tr16_b64(tile + lds_off64<RB>(rb + (i >> 2), colb));
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+    const int colb = (col0 + (l & 31)) * 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = (MAP == 1) ? (k0 + 8 * h + e) : (k0 + 8 * (e >> 2) + 4 * h + (e & 3));
+      f.v[e] = lds_read_f32(tile + lds_off64<RB>(row, colb));
+    }
+  }
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cooperative global -> LDS tile copy in 16-byte chunks (register staged so the issue and the
+// LDS write can be split around compute).  ROWS x RB bytes, NT threads.
+// Source: row r of the tile starts at src + r*ld (elements of T); columns beyond `cols_valid`
+// and rows beyond `rows_valid` read as zero.  Requires 16-byte aligned rows (ld*sizeof(T)%16==0).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ROWS, int RB, int NT> struct TileStage {
+  static constexpr int NCH = RB / 16;
+  static constexpr int TOTAL = ROWS * NCH;
+  static constexpr int PER = (TOTAL + NT - 1) / NT;
+  static constexpr int EPC = 16 / sizeof(T);  // elements per chunk
+  u32x4 regs[PER];
+
+  PFN_DEV void issue(const T* src, long ld, int rows_valid, int cols_valid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = threadIdx.x + i * NT;
+      const int row = id / NCH, c = id % NCH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if ((TOTAL % NT == 0 || id < TOTAL) && row < rows_valid && (c + 1) * EPC <= cols_valid)
+        v = *reinterpret_cast<const u32x4*>(src + (long)row * ld + c * EPC);
+      else if ((TOTAL % NT == 0 || id < TOTAL) && row < rows_valid && c * EPC < cols_valid) {
+        // ragged tail inside a chunk: element-wise
+        T tmp[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) tmp[e] = (c * EPC + e < cols_valid) ? src[(long)row * ld + c * EPC + e] : (T)0.f;
+        v = *reinterpret_cast<u32x4*>(tmp);
+      }
+      regs[i] = v;
+    }
+  }
+  template <bool SWZ64> PFN_DEV void commit(LdsPtr tile) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = threadIdx.x + i * NT;
+      if (TOTAL % NT != 0 && id >= TOTAL) break;
+      const int row = id / NCH, c = id % NCH;
+      const int off = SWZ64 ? lds_off64<RB>(row, c * 16) : lds_off16<RB>(row, c);
+      lds_write16(tile + off, regs[i]);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// math helpers
+// ---------------------------------------------------------------------------------------------
+PFN_DEV float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+PFN_DEV float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+PFN_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+PFN_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+template <typename T> PFN_DEV float to_f(T x) { return (float)x; }
+
+}  // namespace pfn

@@ -1,0 +1,148 @@
+// Internal (C++) launcher interface between the kernels (*.hip) and the C-ABI layer (pfn_api.hip).
+// Nothing here crosses the shared-library boundary; see include/pfn_hip.h for the exported ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pfn_hip.h"
+
+namespace pfn {
+
+// ---- GEMM -----------------------------------------------------------------------------------
+enum : int {
+  EPI_BIAS = 1,      // + bias[n] (f32)
+  EPI_GELU = 2,      // out = gelu(v)   (exact erf GELU, torch nn.GELU default)
+  EPI_GELU_BWD = 4,  // v *= gelu'(aux[m,n])
+  EPI_RESID = 8,     // + resid[m,n] (f32)
+  EPI_OUT_F32 = 16,  // store f32
+  EPI_OUT_T = 32,    // store operand type T
+  EPI_OUT2_T = 64,   // store pre-activation (before GELU) as T
+  EPI_ACCUM = 128,   // out_f32 += v
+};
+
+struct GemmNT {
+  const void* A; long lda;  // [M,K] T
+  const void* B; long ldb;  // [N,K] T
+  int M, N, K;
+  int flags;
+  const float* bias;
+  const void* aux; long ld_aux;
+  const float* resid; long ld_resid;
+  float* out_f32; long ld_out_f32;
+  void* out_t; long ld_out_t;
+  void* out2_t; long ld_out2;
+  int vec_ok;  // filled by the launcher
+};
+int launch_gemm_nt(const GemmNT& g, int precision, hipStream_t stream);
+
+struct GemmTN {
+  const void* A; long lda;  // [M,P] T
+  const void* B; long ldb;  // [M,Q] T
+  float* C; long ldc;       // [P,Q] f32
+  int M, P, Q;
+  int atomic;               // 1: C += (split over M, f32 atomics); 0: C = (single split)
+  int m_chunk;              // filled by the launcher
+};
+int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream);
+
+// ---- attention (attention.hip) ---------------------------------------------------------------
+// qkv: [B, S, 3E] T (q | k | v, heads contiguous inside each E), ctx: [B, S, E] T,
+// lse: [B, H, S] f32 (natural-log LSE of the scaled scores over the allowed keys).
+// Allowed keys for query i: j < sep, plus j == i when i >= sep (reference transformer.py:34-41).
+struct AttnArgs {
+  const void* qkv; void* ctx; float* lse;
+  int B, S, E, H, sep;
+  // backward
+  const void* dctx; void* dqkv; float* delta;  // delta: [B,H,S] f32 scratch
+};
+int launch_attn_fwd(const AttnArgs& a, int precision, hipStream_t stream);
+int launch_attn_bwd(const AttnArgs& a, int precision, hipStream_t stream);
+
+// ---- row-wise / element-wise kernels (rowwise.hip) --------------------------------------------
+int launch_cast_params(const float* src, void* dst_t, long n, int precision, hipStream_t s);
+int launch_transpose_cast(const float* src, void* dst_t, int rows, int cols, long ld_dst, int precision, hipStream_t s);
+// dst[r, 0:C] = (T) src[r, 0:C], dst[r, C:ld_dst] = 0
+int launch_cast_rows(const float* src, long ld_src, void* dst_t, long ld_dst, long R, int C, int precision, hipStream_t s);
+
+// x:[T,B,nf] (strides given in elements), y:[T,B]; out f32 + T in [B,S,E]
+struct EmbedArgs {
+  const float* x; long x_st, x_sb;  // x[t,b,f] = x[t*x_st + b*x_sb + f]
+  const float* y; long y_st, y_sb;
+  const float* wx; const float* bx;  // [E,nf], [E]
+  const float* wy; const float* by;  // [E,1],  [E]
+  float* out_f32; void* out_t;
+  int S, B, nf, E, sep;
+};
+int launch_embed_fwd(const EmbedArgs& a, int precision, hipStream_t s);
+// backward: dsrc [B,S,E] f32 -> dwx, dbx, dwy, dby (accumulated, f32)
+struct EmbedBwdArgs {
+  const float* dsrc; const float* x; long x_st, x_sb; const float* y; long y_st, y_sb;
+  float* dwx; float* dbx; float* dwy; float* dby;
+  int S, B, nf, E, sep;
+};
+int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s);
+
+// src given in the reference layout [S,B,E] f32 (custom encoders): copy into [B,S,E] f32 + T
+int launch_sbe_to_bse(const float* src, float* out_f32, void* out_t, int S, int B, int E, int precision, hipStream_t s);
+int launch_bse_to_sbe(const float* src_bse, float* dst_sbe, int S, int B, int E, hipStream_t s);
+
+// y = LN(x) * gamma + beta over E; writes f32 and T copies, mean/rstd per row
+int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
+                         float* mean, float* rstd, long rows, int E, float eps, int precision, hipStream_t s);
+// dx = LN'(dy); dx written f32 + T; dgamma/dbeta accumulated with atomics; optional dbias_extra
+// accumulates colsum(dx) (the bias gradient of the linear that produced x's pre-LN sum).
+int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         float* dx_f32, void* dx_t, float* dgamma, float* dbeta, float* dbias_extra,
+                         long rows, int E, int precision, hipStream_t s);
+// out[n] += sum_m a[m,n]
+int launch_colsum(const void* a_t, long lda, long rows, int cols, float* out, int precision, hipStream_t s);
+
+// gather test rows: dst[(s-sep)*B + b, :] = src[b, s, :]  (f32 in, T out)  and its transpose
+int launch_gather_test_rows(const float* src_bse, void* dst_t, int S, int B, int E, int sep, int precision, hipStream_t s);
+// dst[b, s, :] = (s >= sep) ? src[(s-sep)*B + b, :] : 0
+int launch_scatter_test_rows(const float* src, float* dst_bse, int S, int B, int E, int sep, hipStream_t s);
+
+// ---- bar distribution (bar.hip) ----------------------------------------------------------------
+struct BarArgs {
+  const float* logits; long ld;  // [R, nbars]
+  const float* y;                // [R]
+  const float* borders;          // [nbars+1]
+  float* nll;                    // [R]
+  float* lse;                    // [R] saved for backward
+  int* bucket;                   // [R] saved for backward
+  long R; int nbars; int full_support;
+  // backward
+  const float* gout; float* dlogits;
+  // mean
+  float* mean_out;
+};
+int launch_bar_nll_fwd(const BarArgs& a, hipStream_t s);
+int launch_bar_nll_bwd(const BarArgs& a, hipStream_t s);
+int launch_bar_mean(const BarArgs& a, hipStream_t s);
+
+// ---- optimizer (optim.hip) ----------------------------------------------------------------------
+struct AdamArgs {
+  float* p; float* g; float* m; float* v; long n;
+  float lr, beta1, beta2, eps, max_norm, grad_scale;
+  int step;
+  int zero_grad;
+  float* scratch;  // >= 1025 floats; scratch[0] receives the pre-clip global grad norm
+};
+int launch_clip_adam(const AdamArgs& a, hipStream_t s);
+
+// ---- GP prior sampler (gp_prior.hip) ------------------------------------------------------------
+struct GpArgs {
+  float* x;        // [B,S,nf] uniform(0,1) features: generated when seed_x != 0, else taken as input
+  const float* z;  // [B,S] base normals: taken as input when non-null, else generated
+  float* y;        // [B,S] output sample
+  float* K;        // [B,S,S] workspace (f32)
+  const float* lengthscale;  // [B,nf] per dataset / per feature
+  const float* outputscale;  // [B]
+  const float* noise;        // [B]
+  int B, S, nf, kernel;      // kernel: 0 RBF, 1 Matern-5/2
+  unsigned long long seed, offset;
+  int gen_x, gen_z;
+  int* info;                 // [B] 0 ok, else index+1 of the first non-positive pivot
+};
+int launch_gp_sample(const GpArgs& a, hipStream_t s);
+
+}  // namespace pfn

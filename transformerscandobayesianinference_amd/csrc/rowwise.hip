@@ -1,0 +1,443 @@
+// HBM-bound row-wise / element-wise kernels of the PFN stack (gfx950): parameter shadow casts,
+// x/y embedding (reference transformer.py:66-74), LayerNorm forward/backward (the norm1/norm2 of
+// nn.TransformerEncoderLayer, torch nn/modules/transformer.py:952-957), bias-gradient column
+// sums, and the train/test row gather of `output[single_eval_pos:]` (transformer.py:91).
+// All of them move 16 bytes per lane per access; none is worth an MFMA.
+#include <algorithm>
+#include "pfn_device.h"
+#include "pfn_kernels.h"
+
+namespace pfn {
+
+template <typename T> PFN_DEV void st4(T* p, f32x4 x) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (bf16)x[e];
+    *reinterpret_cast<bf16x4*>(p) = v;
+  } else *reinterpret_cast<f32x4*>(p) = x;
+}
+template <typename T> PFN_DEV f32x4 ld4(const T* p) {
+  f32x4 r;
+  if constexpr (sizeof(T) == 2) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (float)v[e];
+  } else r = *reinterpret_cast<const f32x4*>(p);
+  return r;
+}
+
+static int grid_for(long work_items, int per_block, int cap = 4096) {
+  long g = (work_items + per_block - 1) / per_block;
+  return (int)std::max<long>(1, std::min<long>(g, cap));
+}
+#define PFN_LAUNCH_OK() (hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH)
+
+// ---------------------------------------------------------------------------------------------
+// f32 -> T casts
+// ---------------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void cast_kernel(const float* src, T* dst, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+    st4<T>(dst + 4 * i, *reinterpret_cast<const f32x4*>(src + 4 * i));
+}
+int launch_cast_params(const float* src, void* dst, long n, int precision, hipStream_t s) {
+  if (n % 4) return PFN_ERR_ALIGNMENT;
+  const long n4 = n / 4;
+  if (n4 == 0) return PFN_OK;
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(cast_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, n4);
+  else hipLaunchKernelGGL(cast_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, n4);
+  return PFN_LAUNCH_OK();
+}
+
+template <typename T> __global__ __launch_bounds__(256) void cast_rows_kernel(const float* src, long ld_src, T* dst, long ld_dst, long R, int C) {
+  const long total = R * ld_dst;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / ld_dst; const int c = (int)(i % ld_dst);
+    dst[i] = (T)(c < C ? src[r * ld_src + c] : 0.f);
+  }
+}
+int launch_cast_rows(const float* src, long ld_src, void* dst, long ld_dst, long R, int C, int precision, hipStream_t s) {
+  const long total = R * ld_dst;
+  if (total == 0) return PFN_OK;
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(cast_rows_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, ld_src, (bf16*)dst, ld_dst, R, C);
+  else hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, ld_src, (float*)dst, ld_dst, R, C);
+  return PFN_LAUNCH_OK();
+}
+
+// dst[c, r] = (T) src[r, c], dst row stride ld_dst >= rows (padding columns zeroed by the caller's
+// memset-free contract: they are written here as zero)   (32x32 LDS tile transpose)
+template <typename T> __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, T* dst, int rows, int cols, long ld_dst) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < cols && r < ld_dst) dst[(long)c * ld_dst + r] = (T)tile[tx][j];  // r >= rows writes the zero padding
+  }
+}
+int launch_transpose_cast(const float* src, void* dst, int rows, int cols, long ld_dst, int precision, hipStream_t s) {
+  dim3 grid((cols + 31) / 32, (unsigned)((ld_dst + 31) / 32));
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16>, grid, dim3(256), 0, s, src, (bf16*)dst, rows, cols, ld_dst);
+  else hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, rows, cols, ld_dst);
+  return PFN_LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding: src[b,s,:] = Wx x[s,b,:] + bx  (+ Wy y[s,b] + by  when s < sep)
+// ---------------------------------------------------------------------------------------------
+constexpr int EMB_TOK = 16;
+template <typename T> __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
+  extern __shared__ float xs[];  // [EMB_TOK][nf + 1]  (last column: y or 0, plus flag in sign-free form)
+  const long ntok = (long)a.B * a.S;
+  const long t0 = (long)blockIdx.x * EMB_TOK;
+  const int nfp = a.nf + 2;
+  for (int i = threadIdx.x; i < EMB_TOK * nfp; i += 256) {
+    const int tk = i / nfp, f = i % nfp;
+    const long tok = t0 + tk;
+    float v = 0.f;
+    if (tok < ntok) {
+      const long b = tok / a.S, sidx = tok % a.S;
+      if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
+      else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
+      else v = (sidx < a.sep) ? 1.f : 0.f;
+    }
+    xs[i] = v;
+  }
+  __syncthreads();
+  T* out_t = reinterpret_cast<T*>(a.out_t);
+  for (int e = threadIdx.x; e < a.E; e += 256) {
+    const float be = a.bx[e], wye = a.wy[e], bye = a.by[e];
+    float acc[EMB_TOK];
+#pragma unroll
+    for (int tk = 0; tk < EMB_TOK; ++tk) acc[tk] = be + xs[tk * nfp + a.nf] * wye + xs[tk * nfp + a.nf + 1] * bye;
+    for (int f = 0; f < a.nf; ++f) {
+      const float w = a.wx[(long)e * a.nf + f];
+#pragma unroll
+      for (int tk = 0; tk < EMB_TOK; ++tk) acc[tk] += w * xs[tk * nfp + f];
+    }
+#pragma unroll
+    for (int tk = 0; tk < EMB_TOK; ++tk) {
+      const long tok = t0 + tk;
+      if (tok < ntok) {
+        a.out_f32[tok * a.E + e] = acc[tk];
+        out_t[tok * a.E + e] = (T)acc[tk];
+      }
+    }
+  }
+}
+int launch_embed_fwd(const EmbedArgs& a, int precision, hipStream_t s) {
+  const long ntok = (long)a.B * a.S;
+  const int grid = (int)((ntok + EMB_TOK - 1) / EMB_TOK);
+  const size_t lds = EMB_TOK * (a.nf + 2) * sizeof(float);
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(grid), dim3(256), lds, s, a);
+  return PFN_LAUNCH_OK();
+}
+
+constexpr int EMBB_TOK = 128;
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
+  extern __shared__ float xs[];  // [EMBB_TOK][nfp] : x features, y (masked), train flag, zero pad to 8
+  const long ntok = (long)a.B * a.S;
+  const long t0 = (long)blockIdx.x * EMBB_TOK;
+  const int nf8 = (a.nf + 2 + 7) / 8 * 8;
+  for (int i = threadIdx.x; i < EMBB_TOK * nf8; i += 256) {
+    const int tk = i / nf8, f = i % nf8;
+    const long tok = t0 + tk;
+    float v = 0.f;
+    if (tok < ntok) {
+      const long b = tok / a.S, sidx = tok % a.S;
+      if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
+      else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
+      else if (f == a.nf + 1) v = (sidx < a.sep) ? 1.f : 0.f;
+    }
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int ntk = (int)std::min<long>(EMBB_TOK, ntok - t0);
+  for (int e = threadIdx.x; e < a.E; e += 256) {
+    float db = 0.f;
+    for (int f0 = 0; f0 < nf8; f0 += 8) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int tk = 0; tk < ntk; ++tk) {
+        const float d = a.dsrc[(t0 + tk) * a.E + e];
+        if (f0 == 0) db += d;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += d * xs[tk * nf8 + f0 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int f = f0 + j;
+        if (f < a.nf) unsafeAtomicAdd(a.dwx + (long)e * a.nf + f, acc[j]);
+        else if (f == a.nf) unsafeAtomicAdd(a.dwy + e, acc[j]);
+        else if (f == a.nf + 1) unsafeAtomicAdd(a.dby + e, acc[j]);
+      }
+    }
+    unsafeAtomicAdd(a.dbx + e, db);
+  }
+}
+int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s) {
+  const long ntok = (long)a.B * a.S;
+  const int grid = (int)((ntok + EMBB_TOK - 1) / EMBB_TOK);
+  const size_t lds = EMBB_TOK * ((a.nf + 2 + 7) / 8 * 8) * sizeof(float);
+  if (lds > 64 * 1024) return PFN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), lds, s, a);
+  return PFN_LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout copies between the reference [S,B,E] and the internal [B,S,E]
+// ---------------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void sbe_to_bse_kernel(const float* src, float* o32, T* ot, int S, int B, int E) {
+  const long n4 = (long)S * B * E / 4;
+  const int e4 = E / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long tok = i / e4; const int c = (int)(i % e4) * 4;
+    const long b = tok / S, sidx = tok % S;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + (sidx * B + b) * E + c);
+    *reinterpret_cast<f32x4*>(o32 + tok * E + c) = v;
+    st4<T>(ot + tok * E + c, v);
+  }
+}
+int launch_sbe_to_bse(const float* src, float* o32, void* ot, int S, int B, int E, int precision, hipStream_t s) {
+  if (E % 4) return PFN_ERR_ALIGNMENT;
+  const long n4 = (long)S * B * E / 4;
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(sbe_to_bse_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, o32, (bf16*)ot, S, B, E);
+  else hipLaunchKernelGGL(sbe_to_bse_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, o32, (float*)ot, S, B, E);
+  return PFN_LAUNCH_OK();
+}
+__global__ __launch_bounds__(256) void bse_to_sbe_kernel(const float* src, float* dst, int S, int B, int E) {
+  const long n4 = (long)S * B * E / 4;
+  const int e4 = E / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long tok = i / e4; const int c = (int)(i % e4) * 4;
+    const long b = tok / S, sidx = tok % S;
+    *reinterpret_cast<f32x4*>(dst + (sidx * B + b) * E + c) = *reinterpret_cast<const f32x4*>(src + tok * E + c);
+  }
+}
+int launch_bse_to_sbe(const float* src, float* dst, int S, int B, int E, hipStream_t s) {
+  if (E % 4) return PFN_ERR_ALIGNMENT;
+  const long n4 = (long)S * B * E / 4;
+  hipLaunchKernelGGL(bse_to_sbe_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, dst, S, B, E);
+  return PFN_LAUNCH_OK();
+}
+
+// gather / scatter of the test rows (s >= sep) into the decoder's compact [(S-sep)*B, E] matrix
+template <typename T> __global__ __launch_bounds__(256) void gather_test_kernel(const float* src, T* dst, int S, int B, int E, int sep) {
+  const int e4 = E / 4;
+  const long n4 = (long)(S - sep) * B * e4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long row = i / e4; const int c = (int)(i % e4) * 4;
+    const long sidx = sep + row / B, b = row % B;
+    st4<T>(dst + row * E + c, *reinterpret_cast<const f32x4*>(src + (b * S + sidx) * E + c));
+  }
+}
+int launch_gather_test_rows(const float* src, void* dst, int S, int B, int E, int sep, int precision, hipStream_t s) {
+  if (E % 4) return PFN_ERR_ALIGNMENT;
+  const long n4 = (long)(S - sep) * B * E / 4;
+  if (n4 == 0) return PFN_OK;
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gather_test_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep);
+  else hipLaunchKernelGGL(gather_test_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep);
+  return PFN_LAUNCH_OK();
+}
+__global__ __launch_bounds__(256) void scatter_test_kernel(const float* src, float* dst, int S, int B, int E, int sep) {
+  const int e4 = E / 4;
+  const long n4 = (long)S * B * e4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long tok = i / e4; const int c = (int)(i % e4) * 4;
+    const long b = tok / S, sidx = tok % S;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (sidx >= sep) v = *reinterpret_cast<const f32x4*>(src + ((sidx - sep) * B + b) * E + c);
+    *reinterpret_cast<f32x4*>(dst + tok * E + c) = v;
+  }
+}
+int launch_scatter_test_rows(const float* src, float* dst, int S, int B, int E, int sep, hipStream_t s) {
+  if (E % 4) return PFN_ERR_ALIGNMENT;
+  const long n4 = (long)S * B * E / 4;
+  hipLaunchKernelGGL(scatter_test_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, dst, S, B, E, sep);
+  return PFN_LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row lives in registers (NV float4 per lane, E <= 256*NV)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, const float* gamma, const float* beta, float* y32, T* yt,
+                                                            float* mean_o, float* rstd_o, long rows, int E, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const float invE = 1.f / (float)E;
+  for (long row = wave0; row < rows; row += (long)gridDim.x * 4) {
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      v[k] = (c < E) ? *reinterpret_cast<const f32x4*>(x + row * E + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+    const float mu = wave_sum(s) * invE;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < E) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mu; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invE + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < E) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), bb = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu) * rstd * g[e] + bb[e];
+        *reinterpret_cast<f32x4*>(y32 + row * E + c) = o;
+        if (yt) st4<T>(yt + row * E + c, o);
+      }
+    }
+    if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rstd; }
+  }
+}
+int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, void* yt, float* mean, float* rstd,
+                         long rows, int E, float eps, int precision, hipStream_t s) {
+  if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
+  if (rows == 0) return PFN_OK;
+  const int grid = grid_for(rows, 4, 8192);
+#define LN_FWD(TT, NV) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, NV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, y32, (TT*)yt, mean, rstd, rows, E, eps)
+#define LN_FWD_NV(TT) do { if (E <= 256) LN_FWD(TT, 1); else if (E <= 512) LN_FWD(TT, 2); else if (E <= 1024) LN_FWD(TT, 4); else LN_FWD(TT, 8); } while (0)
+  if (precision == PFN_PREC_BF16) LN_FWD_NV(bf16); else LN_FWD_NV(float);
+  return PFN_LAUNCH_OK();
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                                            float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E) {
+  extern __shared__ float part[];  // [3][4 waves][E]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wave0 = (long)blockIdx.x * 4 + wave;
+  const float invE = 1.f / (float)E;
+  f32x4 ag[NV], ab[NV], ax[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { ag[k] = f32x4{0, 0, 0, 0}; ab[k] = f32x4{0, 0, 0, 0}; ax[k] = f32x4{0, 0, 0, 0}; }
+  for (long row = wave0; row < rows; row += (long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NV], gdy[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < E) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * E + c);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * E + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[k][e] = (xv[e] - mu) * rs;
+          gdy[k][e] = d[e] * g[e];
+          s1 += gdy[k][e];
+          s2 += gdy[k][e] * xh[k][e];
+          ag[k][e] += d[e] * xh[k][e];
+          ab[k][e] += d[e];
+        }
+      } else { xh[k] = f32x4{0, 0, 0, 0}; gdy[k] = f32x4{0, 0, 0, 0}; }
+    }
+    s1 = wave_sum(s1) * invE;
+    s2 = wave_sum(s2) * invE;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < E) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = rs * (gdy[k][e] - s1 - xh[k][e] * s2); ax[k][e] += o[e]; }
+        *reinterpret_cast<f32x4*>(dx32 + row * E + c) = o;
+        if (dxt) st4<T>(dxt + row * E + c, o);
+      }
+    }
+  }
+  // block reduction of the column partials, then one atomic per column per block
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < E) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        part[(0 * 4 + wave) * E + c + e] = ag[k][e];
+        part[(1 * 4 + wave) * E + c + e] = ab[k][e];
+        part[(2 * 4 + wave) * E + c + e] = ax[k][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < E; c += 256) {
+    float g = 0.f, b = 0.f, xx = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { g += part[(0 * 4 + w) * E + c]; b += part[(1 * 4 + w) * E + c]; xx += part[(2 * 4 + w) * E + c]; }
+    unsafeAtomicAdd(dgamma + c, g);
+    unsafeAtomicAdd(dbeta + c, b);
+    if (dbias) unsafeAtomicAdd(dbias + c, xx);
+  }
+}
+int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, void* dxt,
+                         float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s) {
+  if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
+  if (rows == 0) return PFN_OK;
+  const int grid = grid_for(rows, 4 * 16, 1024);
+  const size_t lds = 12 * E * sizeof(float);
+#define LN_BWD(TT, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV>), dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E)
+#define LN_BWD_NV(TT) do { if (E <= 256) LN_BWD(TT, 1); else if (E <= 512) LN_BWD(TT, 2); else if (E <= 1024) LN_BWD(TT, 4); else LN_BWD(TT, 8); } while (0)
+  if (precision == PFN_PREC_BF16) LN_BWD_NV(bf16); else LN_BWD_NV(float);
+  return PFN_LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[n] += sum_m a[m, n]     (bias gradients of linears whose dY is stored in T)
+// ---------------------------------------------------------------------------------------------
+constexpr int CS_ROWS = 256;
+template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* a, long lda, long rows, int cols, float* out) {
+  __shared__ float red[256 * 4];
+  const int cg = (cols + 3) / 4;                 // column groups of 4
+  const int CG = cg < 256 ? cg : 256;            // groups handled per block pass
+  const int rsub = threadIdx.x / CG, nrs = 256 / CG;
+  const int g = blockIdx.y * CG + threadIdx.x % CG;
+  const long r0 = (long)blockIdx.x * CS_ROWS;
+  const long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (rsub < nrs && g < cg) {
+    const int c = g * 4;
+    for (long r = r0 + rsub; r < r1; r += nrs) {
+      if (c + 3 < cols) acc += ld4<T>(a + r * lda + c);
+      else for (int e = 0; e < 4 && c + e < cols; ++e) acc[e] += (float)a[r * lda + c + e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < CG && g < cg) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < nrs; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += red[(j * CG + threadIdx.x) * 4 + e];
+    for (int e = 0; e < 4 && g * 4 + e < cols; ++e) unsafeAtomicAdd(out + g * 4 + e, t[e]);
+  }
+}
+int launch_colsum(const void* a, long lda, long rows, int cols, float* out, int precision, hipStream_t s) {
+  if (rows == 0 || cols == 0) return PFN_OK;
+  const int es = precision == PFN_PREC_BF16 ? 2 : 4;
+  if ((lda * es) % 8) return PFN_ERR_ALIGNMENT;
+  const int cg = (cols + 3) / 4;
+  dim3 grid((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (cg + 255) / 256);
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)a, lda, rows, cols, out);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)a, lda, rows, cols, out);
+  return PFN_LAUNCH_OK();
+}
+
+}  // namespace pfn

@@ -1,0 +1,49 @@
+"""Fused global-norm clip + Adam on the model's flat parameter buffer.
+
+Replaces `clip_grad_norm_(model.parameters(), 1.)` + `torch.optim.Adam.step()` +
+`optimizer.zero_grad()` of the reference loop (train.py:55,95-97) by ONE call into libpfn_hip.so
+(`pfn_clip_adam_step`, csrc/optim.hip).  It is a torch.optim.Optimizer only so the reference's
+LambdaLR schedulers (utils.py:10-51) can drive `param_groups[0]['lr']` unchanged.
+"""
+import torch
+
+from transformerscandobayesianinference_amd import _hip
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0):
+        self.model = model
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, max_grad_norm=max_grad_norm))
+        self._step = 0
+        self._m = self._v = self._scratch = None
+        self.grad_multiplier = 1.0  # set to 1/world_size by the data-parallel wrapper (gradient averaging)
+
+    def _buffers(self):
+        flat, grad = self.model.flat_parameters()
+        if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
+            self._scratch = torch.zeros(2048, dtype=torch.float32, device=flat.device)
+        return flat, grad
+
+    @torch.no_grad()
+    def step(self, closure=None, zero_grad=False):
+        """One optimizer step; with zero_grad=True the gradient buffer is cleared in the same pass."""
+        assert closure is None
+        flat, grad = self._buffers()
+        g = self.param_groups[0]
+        self._step += 1
+        _hip.check(_hip.lib().pfn_clip_adam_step(flat.data_ptr(), grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                                                 flat.numel(), float(g['lr']), g['betas'][0], g['betas'][1], g['eps'],
+                                                 float(g['max_grad_norm'] or 0.0), float(self.grad_multiplier), self._step,
+                                                 int(zero_grad), self._scratch.data_ptr(), _hip.stream_ptr(flat.device)),
+                   'pfn_clip_adam_step')
+        self.model.mark_params_updated()
+
+    def zero_grad(self, set_to_none=False):
+        _, grad = self._buffers()
+        grad.zero_()
+
+    def last_grad_norm(self):
+        """Global gradient norm seen by the last step (before clipping); forces a device sync."""
+        return float(self._scratch[0].item())

@@ -1,0 +1,77 @@
+"""GP prior sampler: x ~ U[0,1)^{B x T x F},  y_b ~ N(0, outputscale * RBF_lengthscale(x_b, x_b) + noise * I).
+
+Replaces reference priors/fast_gp.py `get_batch` (:35-58), whose numerics live in gpytorch 1.5.0
+(ExactGP in prior mode: ConstantMean(0) + ScaleKernel(RBFKernel) + GaussianLikelihood, :13-32,
+:53-56).  Here the whole draw is one call into libpfn_hip.so (`pfn_gp_prior_sample`): uniform
+features and base normals from a counter-based generator, Gram matrix, blocked f32 Cholesky and
+the L.z product, batched over the B datasets.  The sampler always uses the exact Cholesky root --
+what the reference notebook forces with `'fast_computations': (False, False, False)`
+(SetupForGPFittingExperiments.ipynb:140); gpytorch's Lanczos shortcut for T > 800 is deliberately
+not reproduced.  No CPU fallback.
+"""
+import torch
+
+from transformerscandobayesianinference_amd import _hip
+from transformerscandobayesianinference_amd.priors.utils import get_batch_to_dataloader
+from transformerscandobayesianinference_amd.utils import default_device
+
+KERNEL_RBF, KERNEL_MATERN52 = 0, 1
+
+_DEFAULT_HPS = {"noise": .1, "outputscale": .1, "lengthscale": .1}  # reference fast_gp.py:40
+_call_counter = [0]
+
+
+def gp_sample(batch_size, seq_len, num_features, device, lengthscale, outputscale, noise, kernel=KERNEL_RBF,
+              x=None, z=None, seed=None):
+    """Batched draw through the C ABI.  lengthscale: float | [B] | [B,F]; outputscale, noise: float | [B].
+    x ([B,T,F]) and z ([B,T] base normals) may be injected for parity tests; otherwise they come from
+    the device generator, seeded from torch's global seed plus a per-call counter.
+    Returns (x[B,T,F], y[B,T], z[B,T])."""
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise _hip.HipExtensionError(f'the GP prior sampler runs on the GPU only (got device {device}); no CPU fallback')
+    lib = _hip.lib()
+    B, T, F = batch_size, seq_len, num_features
+
+    def per_dataset(v, shape):
+        t = torch.as_tensor(v, dtype=torch.float32, device=dev)
+        return t.expand(shape).contiguous() if t.dim() == 0 else t.reshape(B, -1).expand(shape).contiguous() if len(shape) == 2 else t.reshape(B).contiguous()
+
+    ls = per_dataset(lengthscale, (B, F))
+    osc = per_dataset(outputscale, (B,))
+    nz = per_dataset(noise, (B,))
+    gen_x, gen_z = x is None, z is None
+    x = torch.empty(B, T, F, dtype=torch.float32, device=dev) if gen_x else x.to(dev).float().contiguous()
+    z = torch.empty(B, T, dtype=torch.float32, device=dev) if gen_z else z.to(dev).float().contiguous()
+    y = torch.empty(B, T, dtype=torch.float32, device=dev)
+    K = torch.empty(B, T, T, dtype=torch.float32, device=dev)
+    info = torch.zeros(B, dtype=torch.int32, device=dev)
+    if seed is None:
+        seed = torch.initial_seed()
+    _call_counter[0] += 1
+    _hip.check(lib.pfn_gp_prior_sample(x.data_ptr(), z.data_ptr(), y.data_ptr(), K.data_ptr(), ls.data_ptr(), osc.data_ptr(),
+                                       nz.data_ptr(), B, T, F, kernel, int(gen_x), int(gen_z), seed & (2 ** 64 - 1),
+                                       _call_counter[0], info.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_prior_sample')
+    return x, y, z, info
+
+
+@torch.no_grad()
+def get_batch(batch_size, seq_len, num_features, device=default_device, hyperparameters=None, equidistant_x=False):
+    """Same signature and return layout as the reference: (x[T,B,F], y[T,B], target_y[T,B])."""
+    if isinstance(hyperparameters, (tuple, list)):
+        hyperparameters = {"noise": hyperparameters[0], "outputscale": hyperparameters[1], "lengthscale": hyperparameters[2]}
+    elif hyperparameters is None:
+        hyperparameters = dict(_DEFAULT_HPS)
+    x = None
+    if equidistant_x:
+        assert num_features == 1
+        x = torch.linspace(0, 1., seq_len).unsqueeze(0).repeat(batch_size, 1).unsqueeze(-1)
+    noise = max(float(hyperparameters["noise"]), 1e-9)  # GaussianLikelihood(noise_constraint=GreaterThan(1e-9)), reference :25
+    x, y, _, _ = gp_sample(batch_size, seq_len, num_features, device, hyperparameters["lengthscale"],
+                           hyperparameters["outputscale"], noise, KERNEL_RBF, x=x)
+    sample = y.transpose(0, 1)
+    return x.transpose(0, 1), sample, sample
+
+
+DataLoader = get_batch_to_dataloader(get_batch)
+DataLoader.num_outputs = 1

@@ -1,0 +1,98 @@
+"""Prior plumbing (reference priors/utils.py): the get_batch -> DataLoader factory (:14-42), the
+scalar hyper-parameter samplers (:64-70) and the small tensor helpers used by priors.mlp (:73-100).
+Plotting helpers of the reference (:45-62) are out of scope.
+"""
+import random
+
+import numpy as np
+import scipy.stats as stats
+import torch
+from torch import nn
+
+from transformerscandobayesianinference_amd.priors.prior import PriorDataLoader
+from transformerscandobayesianinference_amd.utils import set_locals_in_self
+
+
+def get_batch_to_dataloader(get_batch_method_):
+    """Wrap `get_batch(batch_size, seq_len, num_features, ...) -> (x, y, target_y)` into a loader class."""
+
+    class DL(PriorDataLoader):
+        get_batch_method = get_batch_method_
+
+        def __init__(self, num_steps, fuse_x_y=False, **get_batch_kwargs):
+            set_locals_in_self(locals())
+            # class-level defaults (e.g. DataLoader.num_outputs = 1) apply when the kwarg is absent
+            self.num_features = get_batch_kwargs.get('num_features') or self.num_features
+            self.num_outputs = get_batch_kwargs.get('num_outputs') or self.num_outputs
+            print('DataLoader.__dict__', self.__dict__)
+
+        @staticmethod
+        def gbm(*args, fuse_x_y=True, **kwargs):
+            x, y, target_y = get_batch_method_(*args, **kwargs)
+            if not fuse_x_y:
+                return (x, y), target_y
+            shifted_y = torch.cat([torch.zeros_like(y[:1]), y[:-1]], 0).unsqueeze(-1).float()
+            return torch.cat([x, shifted_y], -1), target_y
+
+        def __len__(self):
+            return self.num_steps
+
+        def __iter__(self):
+            return iter(self.gbm(**self.get_batch_kwargs, fuse_x_y=self.fuse_x_y) for _ in range(self.num_steps))
+
+    return DL
+
+
+def trunc_norm_sampler_f(mu, sigma):
+    return lambda: stats.truncnorm((0 - mu) / sigma, (1 - mu) / sigma, loc=mu, scale=sigma).rvs(1)[0]
+
+
+def beta_sampler_f(a, b):
+    return lambda: np.random.beta(a, b)
+
+
+def gamma_sampler_f(a, b):
+    return lambda: np.random.gamma(a, b)
+
+
+def uniform_sampler_f(a, b):
+    return lambda: np.random.uniform(a, b)
+
+
+def uniform_int_sampler_f(a, b):
+    return lambda: np.random.randint(a, b)
+
+
+def zipf_sampler_f(a, b, c):
+    return lambda: min(b + np.random.zipf(a), c)
+
+
+def scaled_beta_sampler_f(a, b, scale, minimum):
+    return lambda: minimum + round(beta_sampler_f(a, b)() * (scale - minimum + 1) - 0.5)
+
+
+def normalize_data(data):
+    """Standardise over the sequence axis (reference :73-78)."""
+    return (data - data.mean(0)) / (data.std(0) + .000001)
+
+
+def normalize_by_used_features_f(x, num_features_used, num_features):
+    return x / (num_features_used / num_features)
+
+
+class Binarize(nn.Module):
+    """1 where x exceeds its median (reference :85-91)."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        return (x > torch.median(x)).float()
+
+
+def order_by_y(x, y):
+    """Sort rows by (+/-) y and interleave the two halves (reference :94-100)."""
+    order = torch.argsort(y if random.randint(0, 1) else -y, dim=0)[:, 0, 0]
+    order = order.reshape(2, -1).transpose(0, 1).reshape(-1)
+    return x[order], y[order]

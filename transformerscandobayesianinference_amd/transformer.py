@@ -1,0 +1,296 @@
+"""TransformerModel: the PFN encoder-only transformer, running on hand-written gfx950 kernels.
+
+API and state-dict parity with the reference `transformer.py` (constructor :14, forward :55-91,
+init :43-53); the call `self.transformer_encoder(src, src_mask)` (:84) and everything around it
+(embedding :66-74, decoder :85, test-row slice :91) is replaced by ONE autograd node that drives
+libpfn_hip.so through the C ABI (`pfn_stack_forward` / `pfn_stack_backward`).
+
+PyTorch's role here is plumbing only: it owns the parameter / gradient / activation memory and the
+stream.  All parameters are views into one flat f32 buffer (and their .grad into one flat gradient
+buffer) so the optimizer and the data-parallel all-reduce touch a single contiguous range.
+There is no PyTorch fallback: CPU tensors or a missing library raise `HipExtensionError`.
+"""
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from transformerscandobayesianinference_amd import _hip
+from transformerscandobayesianinference_amd.positional_encodings import NoPositionalEncoding
+from transformerscandobayesianinference_amd.utils import SeqBN
+
+_ALIGN = 64  # elements; must match make_layout() in csrc/pfn_api.hip
+
+
+class _SelfAttentionParams(nn.Module):
+    """Parameter container with the key names of torch.nn.MultiheadAttention
+    (`in_proj_weight`, `in_proj_bias`, `out_proj.{weight,bias}`) and its default initialisation."""
+
+    def __init__(self, emsize):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * emsize, emsize))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * emsize))
+        self.out_proj = nn.Linear(emsize, emsize)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _EncoderLayerParams(nn.Module):
+    """Parameter container with the key names of torch.nn.TransformerEncoderLayer."""
+
+    def __init__(self, emsize, nhid):
+        super().__init__()
+        self.self_attn = _SelfAttentionParams(emsize)
+        self.linear1 = nn.Linear(emsize, nhid)
+        self.linear2 = nn.Linear(nhid, emsize)
+        self.norm1 = nn.LayerNorm(emsize, eps=1e-5)
+        self.norm2 = nn.LayerNorm(emsize, eps=1e-5)
+
+
+class _EncoderParams(nn.Module):
+    def __init__(self, emsize, nhid, nlayers):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayerParams(emsize, nhid) for _ in range(nlayers)])
+
+
+class _StackFunction(torch.autograd.Function):
+    """logits = stack(x, y | src); one node for embedding + L layers + decoder."""
+
+    @staticmethod
+    def forward(ctx, flat_params, model, x, y, src, sep):
+        lib = _hip.lib()
+        dev = flat_params.device
+        stream = _hip.stream_ptr(dev)
+        desc = model._desc
+        model._refresh_shadow(stream)
+        if src is not None:
+            src = src.contiguous().float()
+            S, B = src.shape[0], src.shape[1]
+            xs = ys = None
+            x_ptr = y_ptr = 0
+            x_st = x_sb = y_st = y_sb = 0
+        else:
+            if x.dtype != torch.float32 or x.stride(-1) != 1:
+                x = x.float().contiguous()
+            if y.dtype != torch.float32:
+                y = y.float()
+            S, B = x.shape[0], x.shape[1]
+            x_ptr, y_ptr = x.data_ptr(), y.data_ptr()
+            x_st, x_sb = x.stride(0), x.stride(1)
+            y_st, y_sb = y.stride(0), y.stride(1)
+        ws_bytes = lib.pfn_workspace_bytes(ctypes.byref(desc), B, S)
+        _hip.check(ws_bytes, 'pfn_workspace_bytes')
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        logits = torch.empty((S - sep, B, desc.n_out), dtype=torch.float32, device=dev)
+        _hip.check(lib.pfn_stack_forward(ctypes.byref(desc), flat_params.data_ptr(), model._shadow.data_ptr(),
+                                         x_ptr, x_st, x_sb, y_ptr, y_st, y_sb, _hip.ptr(src), B, S, sep,
+                                         ws.data_ptr(), ws_bytes, logits.data_ptr(), stream), 'pfn_stack_forward')
+        ctx.model, ctx.ws, ctx.dims = model, ws, (B, S, sep)
+        ctx.inputs = (x, y, src)
+        ctx.src_needs_grad = src is not None and ctx.needs_input_grad[4]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _hip.lib()
+        model, ws = ctx.model, ctx.ws
+        B, S, sep = ctx.dims
+        x, y, src = ctx.inputs
+        dev = ws.device
+        stream = _hip.stream_ptr(dev)
+        desc = model._desc
+        model._attach_grads()
+        dlogits = dlogits.contiguous().float()
+        dsrc = None
+        if src is not None:
+            dsrc = torch.empty_like(src)
+            args = (0, 0, 0, 0, 0, 0)
+        else:
+            args = (x.data_ptr(), x.stride(0), x.stride(1), y.data_ptr(), y.stride(0), y.stride(1))
+        _hip.check(lib.pfn_stack_backward(ctypes.byref(desc), model._flat.data_ptr(), model._shadow.data_ptr(), *args,
+                                          B, S, sep, ws.data_ptr(), ws.numel(), dlogits.data_ptr(),
+                                          model._flat_grad.data_ptr(), _hip.ptr(dsrc), stream), 'pfn_stack_backward')
+        ctx.ws = None
+        return None, None, None, None, (dsrc if ctx.src_needs_grad else None), None
+
+
+class TransformerModel(nn.Module):
+    def __init__(self, encoder, n_out, ninp, nhead, nhid, nlayers, dropout=0.0, y_encoder=None, pos_encoder=None,
+                 decoder=None, input_normalization=False, precision='bf16'):
+        super().__init__()
+        self.model_type = 'Transformer'
+        if decoder is not None:
+            raise NotImplementedError('custom decoder modules are not wired into the HIP stack yet; use the default decoder')
+        self.transformer_encoder = _EncoderParams(ninp, nhid, nlayers)
+        self.ninp, self.nhead, self.nhid, self.nlayers, self.n_out = ninp, nhead, nhid, nlayers, n_out
+        self.dropout = dropout
+        self.encoder = encoder
+        self.y_encoder = y_encoder
+        self.pos_encoder = pos_encoder
+        self.decoder = nn.Sequential(nn.Linear(ninp, nhid), nn.GELU(), nn.Linear(nhid, n_out))
+        self.input_ln = SeqBN(ninp) if input_normalization else None
+        self.precision = precision
+        self._flat = self._flat_grad = self._shadow = None
+        self._shadow_version = None
+        self._desc = None
+        self.init_weights()
+
+    # ---- reference helpers kept for API parity (host-side, unused by the kernels) ----
+    @staticmethod
+    def generate_square_subsequent_mask(sz):
+        allowed = torch.tril(torch.ones(sz, sz, dtype=torch.bool))
+        return torch.zeros(sz, sz).masked_fill(~allowed, float('-inf'))
+
+    @staticmethod
+    def generate_D_q_matrix(sz, query_size):
+        """0/-inf mask: key j visible to query i iff j < sz - query_size or i == j (reference :34-41).
+        The kernels never build it -- they take the integer `single_eval_pos`."""
+        train_size = sz - query_size
+        allowed = torch.zeros(sz, sz, dtype=torch.bool)
+        allowed[:, :train_size] = True
+        allowed |= torch.eye(sz, dtype=torch.bool)
+        return torch.zeros(sz, sz).masked_fill(~allowed, float('-inf'))
+
+    def init_weights(self):
+        """Zero the two residual-branch output projections of every layer (reference :43-53)."""
+        for layer in self.transformer_encoder.layers:
+            nn.init.zeros_(layer.linear2.weight)
+            nn.init.zeros_(layer.linear2.bias)
+            nn.init.zeros_(layer.self_attn.out_proj.weight)
+            nn.init.zeros_(layer.self_attn.out_proj.bias)
+
+    # ---- flat parameter storage ----
+    def _fused_embedding(self):
+        return (type(self.encoder) is nn.Linear and type(self.y_encoder) is nn.Linear and self.input_ln is None
+                and (self.pos_encoder is None or isinstance(self.pos_encoder, NoPositionalEncoding)))
+
+    def _stack_parameters(self):
+        """Parameters in the order of pfn_param_layout (state-dict order of the reference model)."""
+        ps = []
+        if self._fused_embedding():
+            ps += [self.encoder.weight, self.encoder.bias, self.y_encoder.weight, self.y_encoder.bias]
+        else:
+            ps += [None, None, None, None]
+        for l in self.transformer_encoder.layers:
+            ps += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias,
+                   l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias,
+                   l.norm1.weight, l.norm1.bias, l.norm2.weight, l.norm2.bias]
+        ps += [self.decoder[0].weight, self.decoder[0].bias, self.decoder[2].weight, self.decoder[2].bias]
+        return ps
+
+    def _make_desc(self):
+        nf = self.encoder.in_features if self._fused_embedding() else 1
+        prec = {'bf16': _hip.PREC_BF16, 'f32': _hip.PREC_F32, 'fp32': _hip.PREC_F32}[self.precision]
+        return _hip.ModelDesc(nf, self.ninp, self.nhead, self.nhid, self.nlayers, self.n_out, prec, 1e-5)
+
+    def _is_flat(self):
+        if self._flat is None:
+            return False
+        first = next(p for p in self._stack_parameters() if p is not None)
+        last = self.decoder[2].bias
+        lo, hi = self._flat.data_ptr(), self._flat.data_ptr() + self._flat.numel() * 4
+        return all(p.is_cuda and p.device == self._flat.device and lo <= p.data_ptr() < hi for p in (first, last))
+
+    def _flatten(self, device):
+        """(Re)pack every parameter into one flat f32 buffer; parameters become views of it."""
+        lib = _hip.lib()
+        desc = self._make_desc()
+        n = _hip.check(lib.pfn_param_layout(ctypes.byref(desc), None, None, 0), 'pfn_param_layout')
+        offs = (ctypes.c_int64 * n)()
+        nums = (ctypes.c_int64 * n)()
+        _hip.check(lib.pfn_param_layout(ctypes.byref(desc), offs, nums, n), 'pfn_param_layout')
+        stack = self._stack_parameters()
+        assert len(stack) == n
+        total = lib.pfn_param_count(ctypes.byref(desc))
+        placed = {id(p) for p in stack if p is not None}
+        extras, cursor = [], total
+        for p in self.parameters():
+            if id(p) not in placed:
+                extras.append((p, cursor))
+                placed.add(id(p))
+                cursor = (cursor + p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.zeros(cursor, dtype=torch.float32, device=device)
+        grad = torch.zeros(cursor, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, off, num in list(zip(stack, offs, nums)) + [(p, o, p.numel()) for p, o in extras]:
+                if p is None:
+                    continue
+                assert p.numel() == num, f'parameter of {p.numel()} elements does not fit its slot of {num}'
+                old_grad = p.grad
+                flat[off:off + num].copy_(p.detach().reshape(-1).to(device))
+                p.data = flat[off:off + num].view(p.shape)
+                if old_grad is not None:
+                    grad[off:off + num].copy_(old_grad.reshape(-1).to(device))
+                p.grad = grad[off:off + num].view(p.shape)
+        self._flat, self._flat_grad, self._desc = flat, grad, desc
+        self._views = [(p, off, num) for p, off, num in list(zip(stack, offs, nums)) + [(p, o, p.numel()) for p, o in extras] if p is not None]
+        self._stack_numel = total
+        self._shadow = torch.empty(lib.pfn_shadow_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=device)
+        self._shadow_version = None
+
+    def _attach_grads(self):
+        """Point every .grad at its slice of the flat gradient buffer (after zero_grad(set_to_none=True)
+        the buffer is cleared first, so stale values are not re-used)."""
+        first = self._views[0][0]
+        if first.grad is not None and first.grad.data_ptr() == self._flat_grad.data_ptr() + self._views[0][1] * 4:
+            return
+        if first.grad is None:
+            self._flat_grad.zero_()
+        for p, off, num in self._views:
+            if p.grad is not None and p.grad.data_ptr() != self._flat_grad.data_ptr() + off * 4:
+                self._flat_grad[off:off + num].add_(p.grad.reshape(-1))
+            p.grad = self._flat_grad[off:off + num].view(p.shape)
+
+    def mark_params_updated(self):
+        """Called by optimizers that update the flat buffer through raw pointers."""
+        self._shadow_version = None
+
+    def _refresh_shadow(self, stream):
+        version = self._flat._version
+        if self._shadow_version != version:
+            _hip.check(_hip.lib().pfn_prepare_params(ctypes.byref(self._desc), self._flat.data_ptr(), self._shadow.data_ptr(), stream),
+                       'pfn_prepare_params')
+            self._shadow_version = version
+
+    def flat_parameters(self):
+        """(flat f32 parameter buffer, flat f32 gradient buffer); packs the model on first use."""
+        if not self._is_flat():
+            dev = next(self.parameters()).device
+            _hip.require_gpu_tensor(next(self.parameters()), 'model parameters')
+            self._flatten(dev)
+        self._attach_grads()
+        return self._flat, self._flat_grad
+
+    # ---- forward ----
+    def forward(self, src, src_mask=None, single_eval_pos=None):
+        assert single_eval_pos is not None, 'Single eval pos is required now.'
+        assert isinstance(src, tuple), 'pass src as an (x, y) tuple together with single_eval_pos (the fuse_x_y path of the reference is dead code: transformer.py:56-59)'
+        if src_mask is not None:
+            raise NotImplementedError('explicit src_mask is not supported: the kernels implement the single_eval_pos mask of generate_D_q_matrix')
+        if self.training and self.dropout > 0:
+            raise NotImplementedError('dropout > 0 is not implemented in the HIP stack (all BASELINE configs train with dropout=0)')
+        x_src, y_src = src
+        _hip.require_gpu_tensor(x_src, 'x')
+        _hip.require_gpu_tensor(next(self.parameters()), 'model parameters')
+        T = x_src.shape[0]
+        sep = int(single_eval_pos)
+        if sep < 0:
+            sep += T  # negative positions work through slicing in the reference
+        sep = max(0, min(T, sep))
+        if not self._is_flat():
+            self._flatten(x_src.device)
+        flat = self._flat
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            flat = flat.detach().requires_grad_(True)  # connects the node to autograd; grads go to the flat buffer directly
+        if self._fused_embedding():
+            return _StackFunction.apply(flat, self, x_src, y_src.to(x_src.device), None, sep)
+        # custom encoders / positional encodings / SeqBN: PyTorch computes the embedding, HIP runs the stack
+        x_emb = self.encoder(x_src)
+        y_emb = self.y_encoder(y_src.unsqueeze(-1))
+        emb = torch.cat([x_emb[:sep] + y_emb[:sep], x_emb[sep:]], 0)
+        if self.input_ln is not None:
+            emb = self.input_ln(emb)
+        if self.pos_encoder is not None:
+            emb = self.pos_encoder(emb)
+        return _StackFunction.apply(flat, self, None, None, emb, sep)
