@@ -197,8 +197,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
   TileStage<T, TN_BMK, RB, 256> sa, sb;
   const int rows_total = (int)(mend - mbeg);
   const int nt = (rows_total + TN_BMK - 1) / TN_BMK;
+  // fused bias gradient: column sums of A (= dY) ride along in the workgroups of the first Q tile.
+  // Every thread always stages the same 16-byte column chunk (256 % chunks-per-row == 0).
+  const bool do_colsum = g.colsum != nullptr && blockIdx.x == 0;
+  constexpr int EPC = 16 / sizeof(T);
+  float csum[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) csum[e] = 0.f;
+  auto add_colsum = [&]() {
+    if (!do_colsum) return;
+#pragma unroll
+    for (int i = 0; i < sa.PER; ++i) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, sa.regs[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += (float)v[e];
+      } else {
+        const f32x4 v = __builtin_bit_cast(f32x4, sa.regs[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] += v[e];
+      }
+    }
+  };
   sa.issue(A, g.lda, rows_total, colsA);
   sb.issue(B, g.ldb, rows_total, colsB);
+  add_colsum();
   sa.template commit<true>(tileA(0));
   sb.template commit<true>(tileB(0));
   __syncthreads();
@@ -208,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
       const long r1 = (long)(t + 1) * TN_BMK;
       sa.issue(A + r1 * g.lda, g.lda, rows_total - (int)r1, colsA);
       sb.issue(B + r1 * g.ldb, g.ldb, rows_total - (int)r1, colsB);
+      add_colsum();
     }
     const lds_char* ta = tileA(cur);
     const lds_char* tb = tileB(cur);
@@ -230,6 +254,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
     __syncthreads();
   }
 
+  if (do_colsum) {
+    // threads tid, tid+NCH, ... share a column chunk: reduce over the 256/NCH row groups through LDS
+    constexpr int NCH = RB / 16;
+    float* red = reinterpret_cast<float*>(smem_raw);  // all tiles are dead after the last barrier
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[threadIdx.x * EPC + e] = csum[e];
+    __syncthreads();
+    if (threadIdx.x < NCH) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float t = 0.f;
+        for (int j = 0; j < 256 / NCH; ++j) t += red[(j * NCH + threadIdx.x) * EPC + e];
+        const int col = p0 + threadIdx.x * EPC + e;
+        if (col < g.P) unsafeAtomicAdd(g.colsum + col, t);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

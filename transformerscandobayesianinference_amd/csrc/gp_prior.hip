@@ -132,46 +132,66 @@ __global__ __launch_bounds__(256) void gp_gram_kernel(GpArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// potrf: factor the diagonal block of panel k (one workgroup per dataset)
+// potrf: factor the 64x64 diagonal block of panel k.  ONE wave per dataset, lane r keeps row r of
+// the block in registers; column j of L is broadcast lane-by-lane with v_readlane, so the 64-step
+// dependency chain runs without LDS round trips or barriers (the whole Cholesky is latency-bound on
+// this chain: S/64 panels x 64 columns).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_potrf_kernel(GpArgs a, int k0) {
-  __shared__ float L[NB][NB + 1];
-  __shared__ float zs[NB];
-  const int b = blockIdx.x, S = a.S, nb = min(NB, S - k0);
+PFN_DEV float lane_bcast(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+__global__ __launch_bounds__(64) void gp_potrf_kernel(GpArgs a, int k0) {
+  const int b = blockIdx.x, S = a.S, nb = min(NB, S - k0), r = threadIdx.x;
   float* Kb = a.K + (long)b * S * S + (long)k0 * S + k0;
-  for (int i = threadIdx.x; i < NB * NB; i += 256) {
-    const int r = i / NB, c = i % NB;
-    L[r][c] = (r < nb && c <= r) ? Kb[(long)r * S + c] : 0.f;
+  float row[NB];
+  const bool live = r < nb;
+  if (nb == NB) {
+#pragma unroll
+    for (int c = 0; c < NB; c += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(Kb + (long)r * S + c);
+      row[c] = t[0]; row[c + 1] = t[1]; row[c + 2] = t[2]; row[c + 3] = t[3];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) row[c] = (live && c < nb) ? Kb[(long)r * S + c] : 0.f;
   }
-  if (threadIdx.x < NB) zs[threadIdx.x] = (threadIdx.x < nb) ? a.z[(long)b * S + k0 + threadIdx.x] : 0.f;
-  __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    const float piv = L[j][j];
-    if (threadIdx.x == 0 && !(piv > 0.f) && a.info[b] == 0) a.info[b] = k0 + j + 1;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    if (c > r) row[c] = 0.f;                    // only the lower triangle is defined
+    if (c == r && !live) row[c] = 1.f;          // padding rows of the last (partial) panel: identity
+  }
+  const float zr = live ? a.z[(long)b * S + k0 + r] : 0.f;
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const float piv = lane_bcast(row[j], j);
+    if (!(piv > 0.f) && bad == 0) bad = k0 + j + 1;
     const float d = sqrtf(fmaxf(piv, 1e-20f));
-    const float invd = 1.f / d;
-    __syncthreads();
-    if (threadIdx.x < nb) {
-      const int r = threadIdx.x;
-      if (r == j) L[j][j] = d;
-      else if (r > j) L[r][j] *= invd;
-    }
-    __syncthreads();
-    // trailing update of the block: (r, c) with r >= c > j
-    for (int i = threadIdx.x; i < NB * NB; i += 256) {
-      const int r = i / NB, c = i % NB;
-      if (c > j && r >= c && r < nb) L[r][c] -= L[r][j] * L[c][j];
-    }
-    __syncthreads();
+    const float l = (r == j) ? d : row[j] / d;
+    row[j] = l;
+#pragma unroll
+    for (int c = j + 1; c < NB; ++c) row[c] -= l * lane_bcast(l, c);
   }
-  for (int i = threadIdx.x; i < NB * NB; i += 256) {
-    const int r = i / NB, c = i % NB;
-    if (r < nb && c <= r) Kb[(long)r * S + c] = L[r][c];
+  if (r == 0 && bad && a.info[b] == 0) a.info[b] = bad;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const float zc = lane_bcast(zr, c);
+    if (c <= r) acc += row[c] * zc;
   }
-  if (threadIdx.x < nb) {
-    const int r = threadIdx.x;
-    float acc = 0.f;
-    for (int c = 0; c <= r; ++c) acc += L[r][c] * zs[c];
+  if (live) {
+    if (nb == NB) {
+#pragma unroll
+      for (int c = 0; c < NB; c += 4) {
+        // the strictly-upper part is never read again; store zeros there
+        *reinterpret_cast<f32x4*>(Kb + (long)r * S + c) = f32x4{c <= r ? row[c] : 0.f, c + 1 <= r ? row[c + 1] : 0.f,
+                                                              c + 2 <= r ? row[c + 2] : 0.f, c + 3 <= r ? row[c + 3] : 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) if (c <= r) Kb[(long)r * S + c] = row[c];
+    }
     a.y[(long)b * S + k0 + r] += acc;
   }
 }
@@ -283,7 +303,7 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
   }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_syrk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   for (int k0 = 0; k0 < S; k0 += NB) {
-    hipLaunchKernelGGL(gp_potrf_kernel, dim3(B), dim3(256), 0, s, a, k0);
+    hipLaunchKernelGGL(gp_potrf_kernel, dim3(B), dim3(64), 0, s, a, k0);
     const int below = S - k0 - NB;
     if (below > 0) {
       hipLaunchKernelGGL(gp_trsm_kernel, dim3((below + 255) / 256, B), dim3(256), 0, s, a, k0);

@@ -129,10 +129,10 @@ GemmNT nt(const void* A, long lda, const void* B, long ldb, int M, int N, int K,
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.flags = flags;
   return g;
 }
-GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int P, int Q) {
+GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int P, int Q, float* colsum = nullptr) {
   GemmTN g;
   memset(&g, 0, sizeof(g));
-  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.P = P; g.Q = Q; g.atomic = 1;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.P = P; g.Q = Q; g.atomic = 1; g.colsum = colsum;
   return g;
 }
 
@@ -292,15 +292,13 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
   if (Mt > 0) {
     if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
     PFN_TRY(launch_cast_rows(dlogits, O, w.dlog_t, npad, Mt, O, prec, s));
-    PFN_TRY(launch_colsum(w.dlog_t, npad, Mt, O, grads + L.dec2_b, prec, s));
-    PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F), prec, s));
+    PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b), prec, s));
     {
       GemmNT g = nt(w.dlog_t, npad, WT(L.dec2_wt), npad, Mt, F, O, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = w.dpre; g.ld_aux = F; g.out_t = w.dd_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
-    PFN_TRY(launch_colsum(w.dd_t, F, Mt, F, grads + L.dec0_b, prec, s));
-    PFN_TRY(launch_gemm_tn(tn(w.dd_t, F, w.xt_t, E, grads + L.dec0_w, E, Mt, F, E), prec, s));
+    PFN_TRY(launch_gemm_tn(tn(w.dd_t, F, w.xt_t, E, grads + L.dec0_w, E, Mt, F, E, grads + L.dec0_b), prec, s));
     {
       GemmNT g = nt(w.dd_t, F, WT(L.dec0_wt), F, Mt, E, F, EPI_OUT_F32);
       g.out_f32 = w.dxt; g.ld_out_f32 = E;
@@ -322,8 +320,7 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     PFN_TRY(launch_gemm_tn(tn(w.dy_t, E, a.h, F, grads + p.w2, F, M, E, F), prec, s));
-    PFN_TRY(launch_gemm_tn(tn(w.dh_t, F, a.x1_t, E, grads + p.w1, E, M, F, E), prec, s));
-    PFN_TRY(launch_colsum(w.dh_t, F, M, F, grads + p.b1, prec, s));
+    PFN_TRY(launch_gemm_tn(tn(w.dh_t, F, a.x1_t, E, grads + p.w1, E, M, F, E, grads + p.b1), prec, s));
     {  // dx1 = dh . W1 + dy2
       GemmNT g = nt(w.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID | EPI_OUT_F32);
       g.resid = w.gB; g.ld_resid = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
@@ -343,8 +340,7 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       at.dctx = w.dctx_t; at.dqkv = w.dqkv_t; at.delta = w.delta;
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
-    PFN_TRY(launch_gemm_tn(tn(w.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, M, 3 * E, E), prec, s));
-    PFN_TRY(launch_colsum(w.dqkv_t, 3 * E, M, 3 * E, grads + p.b_in, prec, s));
+    PFN_TRY(launch_gemm_tn(tn(w.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, M, 3 * E, E, grads + p.b_in), prec, s));
     {  // dx = dqkv . Win + dy1
       GemmNT g = nt(w.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID | EPI_OUT_F32);
       g.resid = w.gB; g.ld_resid = E; g.out_f32 = w.gA; g.ld_out_f32 = E;

@@ -41,6 +41,7 @@ struct GemmTN {
   int M, P, Q;
   int atomic;               // 1: C += (split over M, f32 atomics); 0: C = (single split)
   int m_chunk;              // filled by the launcher
+  float* colsum;            // optional [P]: += column sums of A (bias gradient), atomically
 };
 int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream);
 

@@ -390,7 +390,7 @@ int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
                          float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s) {
   if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
   if (rows == 0) return PFN_OK;
-  const int grid = grid_for(rows, 4 * 16, 1024);
+  const int grid = grid_for(rows, 4 * 4, 2048);
   const size_t lds = 12 * E * sizeof(float);
 #define LN_BWD(TT, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV>), dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E)
 #define LN_BWD_NV(TT) do { if (E <= 256) LN_BWD(TT, 1); else if (E <= 512) LN_BWD(TT, 2); else if (E <= 1024) LN_BWD(TT, 4); else LN_BWD(TT, 8); } while (0)

@@ -75,3 +75,4 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
 
 DataLoader = get_batch_to_dataloader(get_batch)
 DataLoader.num_outputs = 1
+DataLoader.prefetch = True   # draws run one step ahead on a side stream (priors/utils.py)

@@ -38,9 +38,47 @@ def get_batch_to_dataloader(get_batch_method_):
             return self.num_steps
 
         def __iter__(self):
-            return iter(self.gbm(**self.get_batch_kwargs, fuse_x_y=self.fuse_x_y) for _ in range(self.num_steps))
+            draw = lambda: self.gbm(**self.get_batch_kwargs, fuse_x_y=self.fuse_x_y)
+            if getattr(self, 'prefetch', False) and torch.cuda.is_available():
+                return prefetch_on_side_stream(draw, self.num_steps)
+            return iter(draw() for _ in range(self.num_steps))
 
     return DL
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            yield from _tensors(o)
+
+
+def prefetch_on_side_stream(draw, num_steps):
+    """Generator over `num_steps` batches whose draw for step t+1 is enqueued on a side HIP stream
+    before step t is handed out, so the (latency-bound) prior sampler overlaps the training step of
+    the previous batch instead of serialising with it (the reference samples synchronously,
+    SURVEY.md 3.3).  The consumer's stream waits on the batch's event; tensors are marked as used
+    by the consumer stream so the caching allocator cannot recycle them early."""
+    side = torch.cuda.Stream()
+
+    def enqueue():
+        with torch.cuda.stream(side):
+            batch = draw()
+            done = torch.cuda.Event()
+            done.record(side)
+        return batch, done
+
+    pending = enqueue() if num_steps > 0 else None
+    for step in range(num_steps):
+        batch, done = pending
+        pending = enqueue() if step + 1 < num_steps else None
+        main = torch.cuda.current_stream()
+        main.wait_event(done)
+        for t in _tensors(batch):
+            if t.is_cuda:
+                t.record_stream(main)
+        yield batch
 
 
 def trunc_norm_sampler_f(mu, sigma):
