@@ -57,6 +57,12 @@ typedef struct pfn_model_desc {
 
 int pfn_abi_version(void);
 const char* pfn_last_error_string(void);
+/* Process-wide kernel-selection knobs for tests and profiling (results are identical up to rounding
+ * order).  PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
+ * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it. */
+enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
+       PFN_TUNE_GEMM_TN_WRAP = 1 /* profiling only: > 0 makes the grouped TN kernel re-read its first `value` token rows (wrong results, cache-resident operands) */ };
+int pfn_set_tuning(int key, int value);
 
 /* ---- parameter packing ------------------------------------------------------------------------
  * All parameters live in ONE flat f32 buffer (and one flat f32 gradient buffer) in state-dict
@@ -139,6 +145,13 @@ int pfn_op_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M
                    void* out_t, int64_t ld_out_t, void* out2_t, int64_t ld_out2, int prec, void* stream);
 int pfn_op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                    int M, int P, int Q, int atomic, int prec, void* stream);
+/* grouped weight-gradient GEMMs (bf16 only): for i < n, C[i][P[i],Q[i]] += A[i][M,P[i]]^T . B[i][M,Q[i]] and, when
+ * colsum && colsum[i], colsum[i][P[i]] += column sums of A[i]; one launch of 256x256 tiles.  The pointer / size
+ * tables are HOST arrays.  splits: 0 automatic, 1 no split (deterministic, no atomics), > 1 token-axis splits.
+ * P[i] and Q[i] must be multiples of 256 (PFN_ERR_UNSUPPORTED otherwise). */
+int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb,
+                         float* const* C, const int64_t* ldc, const int32_t* P, const int32_t* Q,
+                         float* const* colsum, int M, int splits, void* stream);
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep,
                          int prec, void* stream);
 int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx,

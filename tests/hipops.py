@@ -27,6 +27,20 @@ def gemm_tn(A, B, C, prec, atomic=1):
                                          atomic, prec, sp()), 'pfn_op_gemm_tn')
 
 
+def gemm_tn_group(problems, splits=0):
+    """problems: list of (A[M,P], B[M,Q], C[P,Q], colsum[P] or None), all bf16 operands with the same M."""
+    import ctypes
+    n = len(problems)
+    M = problems[0][0].shape[0]
+    VP, L, I = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+    A = VP(*[p[0].data_ptr() for p in problems]); lda = L(*[p[0].stride(0) for p in problems])
+    B = VP(*[p[1].data_ptr() for p in problems]); ldb = L(*[p[1].stride(0) for p in problems])
+    C = VP(*[p[2].data_ptr() for p in problems]); ldc = L(*[p[2].stride(0) for p in problems])
+    P = I(*[p[0].shape[1] for p in problems]); Q = I(*[p[1].shape[1] for p in problems])
+    cs = VP(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems])
+    _hip.check(_hip.lib().pfn_op_gemm_tn_group(n, A, lda, B, ldb, C, ldc, P, Q, cs, M, splits, sp()), 'pfn_op_gemm_tn_group')
+
+
 def attention_fwd(qkv, H, sep, prec):
     B, S, E3 = qkv.shape
     E = E3 // 3

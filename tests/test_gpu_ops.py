@@ -91,6 +91,65 @@ def test_gemm_nt_epilogues(prec):
     assert relerr(out, base + 1.0) < 2e-6
 
 
+@pytest.fixture
+def big_gemm():
+    """Force the 256x256 LDS-DMA NT kernel (pfn_set_tuning) for the duration of a test."""
+    _hip.check(_hip.lib().pfn_set_tuning(0, 2), 'pfn_set_tuning')
+    yield
+    _hip.check(_hip.lib().pfn_set_tuning(0, 0), 'pfn_set_tuning')
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (256, 512, 512), (300, 200, 128), (4000, 1536, 512), (77, 1000, 1024), (1023, 516, 192), (2048, 512, 1536)])
+def test_gemm_nt_big_plain(M, N, K, big_gemm):
+    A, B = rnd(M, K, dtype=torch.bfloat16, seed=1), rnd(N, K, dtype=torch.bfloat16, seed=2)
+    out = torch.full((M + 3, N), float('nan'), device=dev())
+    hipops.gemm_nt(A, B, _hip.EPI_OUT_F32, BF, out_f32=out[:M])
+    ref = A.double() @ B.double().t()
+    assert relerr(out[:M], ref) < 1e-5, relerr(out[:M], ref)
+    assert torch.isnan(out[M:]).all()          # nothing written past the last row
+    # same stage order and MFMA shape as the 128x128 kernel: the two must agree to accumulation order
+    _hip.lib().pfn_set_tuning(0, 1)
+    out_small = torch.empty(M, N, device=dev())
+    hipops.gemm_nt(A, B, _hip.EPI_OUT_F32, BF, out_f32=out_small)
+    assert relerr(out[:M], out_small) < 1e-6
+
+
+def test_gemm_nt_big_asymmetric_identity(big_gemm):
+    A = torch.eye(256, device=dev()).to(torch.bfloat16)
+    B = (torch.arange(512 * 256, device=dev()).float().view(512, 256) % 251 / 16).to(torch.bfloat16)
+    out = torch.empty(256, 512, device=dev())
+    hipops.gemm_nt(A, B, _hip.EPI_OUT_F32, BF, out_f32=out)
+    assert torch.equal(out, B.float().t())
+
+
+def test_gemm_nt_big_epilogues(big_gemm):
+    dt = torch.bfloat16
+    M, N, K = 700, 520, 192
+    A, B = rnd(M, K, dtype=dt, seed=3), rnd(N, K, dtype=dt, seed=4, scale=0.1)
+    bias, resid = rnd(N, seed=5), rnd(M, N, seed=6)
+    aux = rnd(M, N, dtype=dt, seed=7)
+    base = A.double() @ B.double().t()
+    tol_t = 4e-3
+    out_t = torch.empty(M, N, dtype=dt, device=dev()); out2 = torch.empty_like(out_t)
+    hipops.gemm_nt(A, B, _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_T | _hip.EPI_OUT2_T, BF, bias=bias, out_t=out_t, out2_t=out2)
+    pre = base + bias.double()
+    assert relerr(out2, pre) < tol_t
+    assert relerr(out_t, torch.nn.functional.gelu(pre)) < tol_t
+    out = torch.empty(M, N, device=dev())
+    hipops.gemm_nt(A, B, _hip.EPI_BIAS | _hip.EPI_RESID | _hip.EPI_OUT_F32, BF, bias=bias, resid=resid, out_f32=out)
+    assert relerr(out, pre + resid.double()) < 1e-5
+    hipops.gemm_nt(A, B, _hip.EPI_RESID | _hip.EPI_OUT_F32, BF, resid=resid, out_f32=out)
+    assert relerr(out, base + resid.double()) < 1e-5
+    hipops.gemm_nt(A, B, _hip.EPI_BIAS | _hip.EPI_OUT_T, BF, bias=bias, out_t=out_t)
+    assert relerr(out_t, pre) < tol_t
+    hipops.gemm_nt(A, B, _hip.EPI_OUT_T, BF, out_t=out_t)
+    assert relerr(out_t, base) < tol_t
+    x = aux.double()
+    gp = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    hipops.gemm_nt(A, B, _hip.EPI_GELU_BWD | _hip.EPI_OUT_T, BF, aux=aux, out_t=out_t)
+    assert relerr(out_t, base * gp) < tol_t
+
+
 @pytest.mark.parametrize('prec', [BF, F32])
 @pytest.mark.parametrize('M,P,Q', [(64, 128, 128), (1000, 512, 1024), (4096, 1000, 200), (333, 1, 72), (16000, 1536, 512)])
 def test_gemm_tn(M, P, Q, prec):
@@ -105,6 +164,33 @@ def test_gemm_tn(M, P, Q, prec):
     hipops.gemm_tn(A, B, C, prec)
     ref = A.double().t() @ B.double() + 1.0
     assert relerr(C, ref) < 3e-6, relerr(C, ref)
+
+
+@pytest.mark.parametrize('M,splits', [(64, 1), (1000, 1), (1000, 0), (4100, 3), (37, 1)])
+def test_gemm_tn_group(M, splits):
+    """Grouped 256x256 weight-gradient kernel: several problems in one launch, ragged token tail, fused bias gradient."""
+    shapes = [(512, 256), (256, 768), (256, 256)]
+    probs, refs = [], []
+    for i, (P, Q) in enumerate(shapes):
+        A, B = rnd(M, P, dtype=torch.bfloat16, seed=20 + i), rnd(M, Q, dtype=torch.bfloat16, seed=30 + i)
+        C = torch.ones(P, Q, device=dev())
+        cs = torch.full((P,), 2.0, device=dev()) if i != 1 else None
+        probs.append((A, B, C, cs))
+        refs.append((A.double().t() @ B.double() + 1.0, A.double().sum(0) + 2.0))
+    hipops.gemm_tn_group(probs, splits)
+    for (A, B, C, cs), (rc, rs) in zip(probs, refs):
+        assert relerr(C, rc) < 3e-6, relerr(C, rc)
+        if cs is not None:
+            assert relerr(cs, rs) < 3e-6, relerr(cs, rs)
+
+
+def test_gemm_tn_group_asymmetric():
+    M = 256
+    A = torch.zeros(M, 256, dtype=torch.bfloat16, device=dev()); A[torch.arange(M), torch.arange(M)] = 1
+    B = (torch.arange(M * 512, device=dev()).float().view(M, 512) % 127 / 8).to(torch.bfloat16)
+    C = torch.zeros(256, 512, device=dev())
+    hipops.gemm_tn_group([(A, B, C, None)], 1)
+    assert torch.equal(C, A.float().t() @ B.float())
 
 
 def test_gemm_tn_asymmetric():

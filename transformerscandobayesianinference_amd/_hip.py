@@ -46,6 +46,7 @@ _D = _c.POINTER(ModelDesc)
 SIGNATURES = {
     'pfn_abi_version': (_I, []),
     'pfn_last_error_string': (_c.c_char_p, []),
+    'pfn_set_tuning': (_I, [_I, _I]),
     'pfn_param_layout': (_I, [_D, _c.POINTER(_L), _c.POINTER(_L), _I]),
     'pfn_param_count': (_L, [_D]),
     'pfn_shadow_bytes': (_L, [_D]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     'pfn_gp_prior_sample': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P, _P]),
     'pfn_op_gemm_nt': (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _P]),
     'pfn_op_gemm_tn': (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
+    'pfn_op_gemm_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'pfn_op_attention_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_attention_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_layernorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),

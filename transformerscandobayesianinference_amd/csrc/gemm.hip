@@ -9,6 +9,7 @@
 // algorithmic from rounding error in the parity tests.  Replaces the torch.nn.Linear calls
 // inside nn.TransformerEncoderLayer (reference transformer.py:17-18,84; torch
 // nn/modules/transformer.py:952-982, nn/functional.py:6435,6637).
+#include <type_traits>
 #include "pfn_device.h"
 #include "pfn_kernels.h"
 
@@ -161,6 +162,144 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_nt_big_kernel: the product-path NT GEMM for large token counts (bf16 only).
+//   256 x 256 output tile, 64-deep contraction stages (128-byte rows), 8 waves as 2 (M) x 4 (N),
+//   each wave a 128 x 64 sub-tile = 4 x 2 MFMA tiles of 32 x 32.
+//   * operands go HBM -> LDS by direct LDS-DMA (global_load_lds_dwordx4): the LDS image is
+//     lane-linear per wave instruction (8 rows x 128 B), so the bank-conflict swizzle of
+//     load_frag_row (16-byte chunk ^ ((row >> 1) & 7)) is applied to the per-lane SOURCE address;
+//   * two LDS stages (128 KiB): the DMA of stage t+1 is in flight under the MFMAs of stage t;
+//   * MFMAs are issued "swapped" (weights as the A operand) so a lane owns one output row and
+//     4 consecutive columns per accumulator group: the epilogue reads bias / residual / gelu'
+//     inputs and writes its outputs straight from registers in 8- and 16-byte pieces.
+// Requirements (checked by the launcher, otherwise gemm_nt_kernel runs): K % 64 == 0, N % 4 == 0,
+// 16-byte aligned rows on every stream.
+// ---------------------------------------------------------------------------------------------
+constexpr int BIG_BM = 256, BIG_BN = 256, BIG_BK = 64;
+constexpr int BIG_TILE = BIG_BM * BIG_BK * 2;   // 32 KiB per operand per stage
+constexpr int BIG_STAGE = 2 * BIG_TILE;
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+template <int FLAGS>
+__global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(GemmNT g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+
+  const int tiles_n = (g.N + BIG_BN - 1) / BIG_BN;
+  const int tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
+  const int tid_lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tid_lin / tiles_n, tn = tid_lin % tiles_n;
+  const int m0 = tm * BIG_BM, n0 = tn * BIG_BN;
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int h = lane >> 5, li = lane & 31;
+
+  // DMA sources: wave w moves the 1-KiB pieces w, w+8, w+16, w+24 of each operand tile
+  const bf16* pa[4];
+  const bf16* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave + 8 * i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    LdsPtr ta = smem + buf * BIG_STAGE + wave * 1024;
+    LdsPtr tb = ta + BIG_TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * 8192), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BIG_BK;
+  stage(0, 0);
+  __syncthreads();  // (carries the vmcnt(0) of the DMA)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BIG_BK);
+    const lds_char* ta = smem + cur * BIG_STAGE;
+    const lds_char* tb = ta + BIG_TILE;
+#pragma unroll
+    for (int ks = 0; ks < BIG_BK; ks += 16) {
+      Frag<bf16> fa[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, 128>(tb, wn * 64 + j * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, 128>(ta, wm * 128 + i * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue straight from the accumulators: lane = output row, 4 consecutive columns per group ----
+  constexpr int flags = FLAGS;  // compile-time: one straight-line epilogue per flag combination in use
+  const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
+  bf16* out_t = reinterpret_cast<bf16*>(g.out_t);
+  bf16* out2_t = reinterpret_cast<bf16*>(g.out2_t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = (long)m0 + wm * 128 + i * 32 + li;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
+        if (n >= g.N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
+        if (flags & EPI_BIAS) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+        if (flags & EPI_GELU_BWD) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f((float)t[e]);
+        }
+        if (flags & EPI_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
+        if (flags & EPI_OUT2_T) {
+          bf16x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x4*>(out2_t + m * g.ld_out2 + n) = t;
+        }
+        if (flags & EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        }
+        if (flags & EPI_OUT_F32) {
+          float* o = g.out_f32 + m * g.ld_out_f32 + n;
+          if (flags & EPI_ACCUM) v += *reinterpret_cast<const f32x4*>(o);
+          *reinterpret_cast<f32x4*>(o) = v;
+        }
+        if (flags & EPI_OUT_T) {
+          bf16x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x4*>(out_t + m * g.ld_out_t + n) = t;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // C[P,Q] (+)= A[M,P]^T . B[M,Q]     contraction over the (long) token axis, split across
 // workgroups in z; partial tiles are added with hardware f32 atomics.
 // ---------------------------------------------------------------------------------------------
@@ -288,9 +427,186 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_tn_big_kernel: grouped weight-gradient GEMMs  C_g[P,Q] (+)= A_g[M,P]^T . B_g[M,Q]  (bf16).
+//   One launch covers every weight gradient of the encoder stack (pfn_stack_backward keeps the
+//   per-layer output-gradient operands resident and defers the weight gradients to one grouped
+//   launch), so there are enough 256 x 256 output tiles to fill the chip WITHOUT splitting the
+//   long token axis: no atomics, a deterministic summation order, plain read-modify-write of C.
+//   (An optional split over tokens with f32 atomics stays available for small groups.)
+//   * 256 x 256 tile, 64-token stages, 8 waves as 2 (P) x 4 (Q), each 128 x 64;
+//   * both operands are token-major, so their LDS images are [token][256 columns] (512-byte rows)
+//     filled by LDS-DMA and read through ds_read_b64_tr_b16; the 64-byte-unit XOR swizzle of
+//     load_frag_tr is applied to the per-lane DMA source address;
+//   * bias gradients (column sums of A) ride along as one extra MFMA against a constant ones
+//     fragment in the workgroups of the first Q tile, split over the four Q waves.
+// Requirements: P % 256 == 0, Q % 256 == 0, 16-byte aligned rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int TNB_KT = 64;                       // tokens per stage
+constexpr int TNB_TILE = TNB_KT * 512;           // 32 KiB per operand per stage
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+
+  const int ntiles = g.tile_start[g.n];
+  const int id = xcd_remap(blockIdx.x, ntiles * g.splits);
+  const int split = id / ntiles, tile = id % ntiles;
+  int pi = 0;
+  while (tile >= g.tile_start[pi + 1]) ++pi;
+  const TnProblem& pr = g.p[pi];
+  const int tq = pr.Q / 256;
+  const int tl = tile - g.tile_start[pi];
+  const int p0 = (tl / tq) * 256, q0 = (tl % tq) * 256;
+  const long mbeg = (long)split * g.m_chunk;
+  const long mend = min((long)g.M, mbeg + g.m_chunk);
+  const int rows_total = (int)(mend - mbeg);
+  if (rows_total <= 0) return;
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wp = wave >> 2, wq = wave & 3;
+
+  // DMA sources: a 1-KiB piece is 2 token rows x 512 B; wave w moves pieces w, w+8, w+16, w+24
+  const bf16* pa[4];
+  const bf16* pb[4];
+  int prow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave + 8 * i) * 2 + (lane >> 5);
+    const int unit = ((lane & 31) >> 2) ^ (row & 3);
+    const int col = unit * 32 + (lane & 3) * 8;
+    prow[i] = row;
+    pa[i] = reinterpret_cast<const bf16*>(pr.A) + mbeg * pr.lda + p0 + col;
+    pb[i] = reinterpret_cast<const bf16*>(pr.B) + mbeg * pr.ldb + q0 + col;
+  }
+  auto stage = [&](int buf, int r0) {
+    LdsPtr ta = smem + buf * 2 * TNB_TILE + wave * 1024;
+    LdsPtr tb = ta + TNB_TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // tail rows are re-zeroed in LDS below; debug_mask is all ones except when profiling with cache-resident operands
+      const long r = min(r0 + prow[i], rows_total - 1) & g.debug_mask;
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + r * pr.lda), (lvoid_t*)(ta + i * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + r * pr.ldb), (lvoid_t*)(tb + i * 8192), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 cs;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cs[r] = 0.f;
+  const bool do_colsum = pr.colsum != nullptr && q0 == 0;
+  Frag<bf16> ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.v[e] = (bf16)1.0f;
+
+  const int nt = (rows_total + TNB_KT - 1) / TNB_KT;
+  stage(0, 0);
+  __syncthreads();
+  // the main loop exists twice (with / without the bias-gradient MFMA) so neither carries a branch
+  auto main_loop = [&](auto with_colsum) {
+    constexpr bool CS = decltype(with_colsum)::value;
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < nt) stage(cur ^ 1, (t + 1) * TNB_KT);
+      LdsPtr ta = smem + cur * 2 * TNB_TILE;
+      LdsPtr tb = ta + TNB_TILE;
+      const int valid = rows_total - t * TNB_KT;
+      if (valid < TNB_KT) {
+        // ragged last stage: the DMA clamped its source rows; clear the rows past the end (A only:
+        // a zero A row contributes nothing whatever B holds there, and B's clamped rows are finite data)
+        for (int idx = threadIdx.x; idx < (TNB_KT - valid) * 32; idx += 512) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          lds_write16(ta + (valid + idx / 32) * 512 + (idx % 32) * 16, z);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int ks = 0; ks < TNB_KT; ks += 16) {
+        Frag<bf16> fa[4], fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = load_frag_tr<bf16, 512, 1>(tb, ks, wq * 64 + j * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + i * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fa[i], fb[j], acc[i][j]);
+        // bias gradient: Q wave wq sums the columns of P sub-tile wq (one more fragment read, one more MFMA)
+        if constexpr (CS) cs = mma32(load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + wq * 32), ones, cs);
+      }
+      __syncthreads();
+    }
+  };
+  if (do_colsum) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
+
+  if (do_colsum && (lane & 31) == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) unsafeAtomicAdd(pr.colsum + p0 + wp * 128 + wq * 32 + acc_row(r, lane), cs[r]);
+  }
+  const bool atomic = g.splits > 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pp = p0 + wp * 128 + i * 32 + acc_row(r, lane);
+        const int qq = q0 + wq * 64 + j * 32 + (lane & 31);
+        float* c = pr.C + (long)pp * pr.ldc + qq;
+        if (atomic) unsafeAtomicAdd(c, acc[i][j][r]);
+        else *c += acc[i][j][r];
+      }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int g_tn_debug_wrap = 0;
+void set_gemm_tn_debug_wrap(int rows) { g_tn_debug_wrap = rows; }
+// 0: automatic, 1: never use the 256x256 kernel, 2: use it whenever the shape allows (tests)
+static int g_big_mode = 0;
+void set_gemm_nt_big_mode(int mode) { g_big_mode = mode; }
+static bool gemm_nt_use_big(const GemmNT& g) {
+  if (g_big_mode == 1 || !g.vec_ok || g.K % BIG_BK || g.N % 4) return false;
+  if (g_big_mode == 2) return true;
+  // enough 256x256 tiles to occupy most of the 256 CUs, and no mostly-empty tile columns
+  const long tiles = (long)((g.M + BIG_BM - 1) / BIG_BM) * ((g.N + BIG_BN - 1) / BIG_BN);
+  return tiles >= 192 && g.N % BIG_BN == 0;
+}
+
+template <int FLAGS> static void launch_big_t(const GemmNT& g, int tiles, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIG_STAGE);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_big_kernel<FLAGS>, dim3(tiles), dim3(512), 2 * BIG_STAGE, stream, g);
+}
+// the epilogue flag combinations the encoder stack uses; anything else takes the generic kernel
+static bool launch_big(const GemmNT& g, int tiles, hipStream_t stream) {
+  switch (g.flags) {
+#define PFN_BIG_CASE(F) case (F): launch_big_t<(F)>(g, tiles, stream); return true;
+    PFN_BIG_CASE(EPI_BIAS | EPI_OUT_T)                            // q/k/v projection
+    PFN_BIG_CASE(EPI_BIAS | EPI_RESID | EPI_OUT_F32)              // out_proj, linear2 (+ residual)
+    PFN_BIG_CASE(EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T)    // linear1 + GELU
+    PFN_BIG_CASE(EPI_GELU_BWD | EPI_OUT_T)                        // d(hpre)
+    PFN_BIG_CASE(EPI_RESID | EPI_OUT_F32)                         // dx = dgrad + residual gradient
+    PFN_BIG_CASE(EPI_OUT_T)                                       // d(ctx)
+    PFN_BIG_CASE(EPI_OUT_F32)
+    PFN_BIG_CASE(EPI_BIAS | EPI_OUT_F32)
+#undef PFN_BIG_CASE
+    default: return false;
+  }
+}
 
 int launch_gemm_nt(const GemmNT& g_in, int precision, hipStream_t stream) {
   GemmNT g = g_in;
@@ -306,6 +622,10 @@ int launch_gemm_nt(const GemmNT& g_in, int precision, hipStream_t stream) {
   if ((g.flags & EPI_GELU_BWD) && ((g.ld_aux * es) % (4 * es) || !aligned16(g.aux))) vec = false;
   if ((g.flags & EPI_BIAS) && !aligned16(g.bias)) vec = false;
   g.vec_ok = vec ? 1 : 0;
+  if (precision == PFN_PREC_BF16 && gemm_nt_use_big(g)) {
+    const int tiles_big = ((g.M + BIG_BM - 1) / BIG_BM) * ((g.N + BIG_BN - 1) / BIG_BN);
+    if (launch_big(g, tiles_big, stream)) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+  }
   const int tiles = ((g.M + GEMM_BM - 1) / GEMM_BM) * ((g.N + GEMM_BN - 1) / GEMM_BN);
   if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, dim3(tiles), dim3(256), 65536, stream, g);
   else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(tiles), dim3(256), 65536, stream, g);
@@ -329,6 +649,47 @@ int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream) {
   const size_t lds = 4 * TN_BMK * 128 * es;
   if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16>, dim3(tq, tp, splits), dim3(256), lds, stream, g);
   else hipLaunchKernelGGL(gemm_tn_kernel<float>, dim3(tq, tp, splits), dim3(256), lds, stream, g);
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+
+bool gemm_tn_group_supported(const TnProblem& p) {
+  return p.P % 256 == 0 && p.Q % 256 == 0 && (p.lda * 2) % 16 == 0 && (p.ldb * 2) % 16 == 0 && aligned16(p.A) && aligned16(p.B);
+}
+
+int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream) {
+  if (g.n <= 0 || g.M <= 0) return PFN_OK;
+  if (g.n > TN_GROUP_MAX) return PFN_ERR_ARGUMENT;
+  int tiles = 0;
+  for (int i = 0; i < g.n; ++i) {
+    if (!gemm_tn_group_supported(g.p[i])) return PFN_ERR_UNSUPPORTED;
+    g.tile_start[i] = tiles;
+    tiles += (g.p[i].P / 256) * (g.p[i].Q / 256);
+  }
+  g.tile_start[g.n] = tiles;
+  // split the token axis only when the group cannot occupy the chip by itself
+  // automatic: the smallest split count (<= 8) whose workgroup count fills whole rounds of the 256 CUs to >= 90 %
+  int splits = g.splits;
+  if (splits <= 0) {
+    splits = 8;
+    for (int sp = 1; sp <= 8; ++sp) {
+      const int blocks = tiles * sp, rounds = (blocks + 255) / 256;
+      if (blocks >= 0.9 * rounds * 256) { splits = sp; break; }
+    }
+  }
+  const int max_splits = (g.M + 4 * TNB_KT - 1) / (4 * TNB_KT);
+  if (splits > max_splits) splits = max_splits;
+  int chunk = (g.M + splits - 1) / splits;
+  chunk = (chunk + TNB_KT - 1) / TNB_KT * TNB_KT;
+  splits = (g.M + chunk - 1) / chunk;
+  g.splits = splits;
+  g.m_chunk = chunk;
+  g.debug_mask = g_tn_debug_wrap > 0 ? g_tn_debug_wrap - 1 : 0x7fffffff;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TNB_TILE);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(tiles * splits), dim3(512), 4 * TNB_TILE, stream, g);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 

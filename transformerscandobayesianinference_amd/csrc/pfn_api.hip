@@ -5,6 +5,7 @@
 // nn.TransformerEncoderLayer in post-norm form (torch nn/modules/transformer.py:952-957):
 //     x = LN1(x + out_proj(attn(in_proj(x))));  x = LN2(x + linear2(gelu(linear1(x))))
 // Backward schedule == autograd of the same graph (train.py:93), written out by hand.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -87,13 +88,17 @@ Layout make_layout(const pfn_model_desc& d) {
 }
 
 // ---- workspace ------------------------------------------------------------------------------------
-struct LayerWs { char *qkv, *ctx, *x1_t, *hpre, *h, *x2_t; float *lse, *y1, *mean1, *rstd1, *x1, *y2, *mean2, *rstd2, *x2; };
+struct LayerWs {
+  char *qkv, *ctx, *x1_t, *hpre, *h, *x2_t; float *lse, *y1, *mean1, *rstd1, *x1, *y2, *mean2, *rstd2, *x2;
+  // backward: output-gradient operands of this layer's four weight gradients, kept until the grouped launch
+  char *dy2_t, *dh_t, *dy1_t, *dqkv_t;
+};
 struct Ws {
   float* x0; char* x0_t;
   std::vector<LayerWs> layer;
   char *xt_t, *dpre, *dt;
   // backward scratch
-  char *dlog_t, *dd_t, *dy_t, *dh_t, *dctx_t, *dqkv_t;
+  char *dlog_t, *dd_t, *dctx_t;
   float *dxt, *gA, *gB, *delta;
   int64_t bytes;
 };
@@ -113,11 +118,12 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
     l.hpre = take(M * F * es); l.h = take(M * F * es);
     l.y2 = (float*)take(M * E * 4); l.mean2 = (float*)take(M * 4); l.rstd2 = (float*)take(M * 4);
     l.x2 = (float*)take(M * E * 4); l.x2_t = take(M * E * es);
+    l.dy2_t = take(M * E * es); l.dh_t = take(M * F * es); l.dy1_t = take(M * E * es); l.dqkv_t = take(M * 3 * E * es);
   }
   w.xt_t = take(M * E * es); w.dpre = take(M * F * es); w.dt = take(M * F * es);
   w.dlog_t = take(M * npad * es); w.dd_t = take(M * F * es); w.dxt = (float*)take(M * E * 4);
   w.gA = (float*)take(M * E * 4); w.gB = (float*)take(M * E * 4);
-  w.dy_t = take(M * E * es); w.dh_t = take(M * F * es); w.dctx_t = take(M * E * es); w.dqkv_t = take(M * 3 * E * es);
+  w.dctx_t = take(M * E * es);
   w.delta = (float*)take((int64_t)B * d.nhead * S * 4);
   w.bytes = cur;
   return w;
@@ -141,6 +147,13 @@ GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, 
 extern "C" {
 
 int pfn_abi_version(void) { return PFN_ABI_VERSION; }
+int pfn_set_tuning(int key, int value) {
+  switch (key) {
+    case PFN_TUNE_GEMM_NT_KERNEL: set_gemm_nt_big_mode(value); return PFN_OK;
+    case PFN_TUNE_GEMM_TN_WRAP: set_gemm_tn_debug_wrap(value); return PFN_OK;
+    default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);
+  }
+}
 const char* pfn_last_error_string(void) { return g_err; }
 
 int pfn_param_layout(const pfn_model_desc* d, int64_t* offsets, int64_t* numels, int max_tensors) {
@@ -308,43 +321,74 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
   PFN_TRY(launch_scatter_test_rows(w.dxt, w.gA, S, B, E, sep, s));
 
   // ---- encoder layers, last to first; gA holds d(loss)/d(layer output) ----
+  // Only the data-gradient chain runs here.  Each layer leaves the output-gradient operands of its four
+  // weight gradients (dy2, dh, dy1, dqkv) in its own buffers; all 4*nlayers weight (and fused bias)
+  // gradients are then computed by ONE grouped launch of 256x256 tiles (gemm_tn_big_kernel) -- enough
+  // tiles to fill the chip without splitting the token axis into hundreds of atomic partial sums.
   for (int l = d->nlayers - 1; l >= 0; --l) {
     const LayerP &p = L.layer[l], &t = L.layer_t[l];
     LayerWs& a = w.layer[l];
-    const char* xin_t = (l == 0) ? w.x0_t : w.layer[l - 1].x2_t;
     // LN2
-    PFN_TRY(launch_layernorm_bwd(w.gA, a.y2, params + p.g2, a.mean2, a.rstd2, w.gB, w.dy_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
+    PFN_TRY(launch_layernorm_bwd(w.gA, a.y2, params + p.g2, a.mean2, a.rstd2, w.gB, a.dy2_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
-      GemmNT g = nt(w.dy_t, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
-      g.aux = a.hpre; g.ld_aux = F; g.out_t = w.dh_t; g.ld_out_t = F;
+      GemmNT g = nt(a.dy2_t, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
+      g.aux = a.hpre; g.ld_aux = F; g.out_t = a.dh_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
-    PFN_TRY(launch_gemm_tn(tn(w.dy_t, E, a.h, F, grads + p.w2, F, M, E, F), prec, s));
-    PFN_TRY(launch_gemm_tn(tn(w.dh_t, F, a.x1_t, E, grads + p.w1, E, M, F, E, grads + p.b1), prec, s));
     {  // dx1 = dh . W1 + dy2
-      GemmNT g = nt(w.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID | EPI_OUT_F32);
+      GemmNT g = nt(a.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID | EPI_OUT_F32);
       g.resid = w.gB; g.ld_resid = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     // LN1
-    PFN_TRY(launch_layernorm_bwd(w.gA, a.y1, params + p.g1, a.mean1, a.rstd1, w.gB, w.dy_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
+    PFN_TRY(launch_layernorm_bwd(w.gA, a.y1, params + p.g1, a.mean1, a.rstd1, w.gB, a.dy1_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
     {  // d(ctx) = dy1 . Wo
-      GemmNT g = nt(w.dy_t, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
+      GemmNT g = nt(a.dy1_t, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
       g.out_t = w.dctx_t; g.ld_out_t = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
-    PFN_TRY(launch_gemm_tn(tn(w.dy_t, E, a.ctx, E, grads + p.w_o, E, M, E, E), prec, s));
     {
       AttnArgs at; memset(&at, 0, sizeof(at));
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
-      at.dctx = w.dctx_t; at.dqkv = w.dqkv_t; at.delta = w.delta;
+      at.dctx = w.dctx_t; at.dqkv = a.dqkv_t; at.delta = w.delta;
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
-    PFN_TRY(launch_gemm_tn(tn(w.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, M, 3 * E, E, grads + p.b_in), prec, s));
     {  // dx = dqkv . Win + dy1
-      GemmNT g = nt(w.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID | EPI_OUT_F32);
+      GemmNT g = nt(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID | EPI_OUT_F32);
       g.resid = w.gB; g.ld_resid = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+  }
+  // ---- weight gradients of every layer ----
+  {
+    std::vector<TnProblem> probs;
+    auto add = [&](const void* A, long lda, const void* Bm, long ldb, float* C, long ldc, int P, int Q, float* colsum) {
+      TnProblem t; t.A = A; t.lda = lda; t.B = Bm; t.ldb = ldb; t.C = C; t.ldc = ldc; t.P = P; t.Q = Q; t.colsum = colsum;
+      probs.push_back(t);
+    };
+    for (int l = d->nlayers - 1; l >= 0; --l) {
+      const LayerP& p = L.layer[l];
+      LayerWs& a = w.layer[l];
+      const char* xin_t = (l == 0) ? w.x0_t : w.layer[l - 1].x2_t;
+      add(a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, nullptr);
+      add(a.dh_t, F, a.x1_t, E, grads + p.w1, E, F, E, grads + p.b1);
+      add(a.dy1_t, E, a.ctx, E, grads + p.w_o, E, E, E, nullptr);
+      add(a.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, 3 * E, E, grads + p.b_in);
+    }
+    bool grouped = prec == PFN_PREC_BF16;
+    for (const TnProblem& t : probs) grouped = grouped && gemm_tn_group_supported(t);
+    if (grouped) {
+      for (size_t i0 = 0; i0 < probs.size(); i0 += TN_GROUP_MAX) {
+        GemmTNGroup g;
+        memset(&g, 0, sizeof(g));
+        g.n = (int)std::min<size_t>(TN_GROUP_MAX, probs.size() - i0);
+        g.M = M;
+        for (int i = 0; i < g.n; ++i) g.p[i] = probs[i0 + i];
+        PFN_TRY(launch_gemm_tn_group(g, s));
+      }
+    } else {  // exact-f32 parity mode and shapes outside the 256-tile kernel: one split-K launch per gradient
+      for (const TnProblem& t : probs)
+        PFN_TRY(launch_gemm_tn(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, M, t.P, t.Q, t.colsum), prec, s));
     }
   }
   // ---- embedding ----
@@ -422,6 +466,20 @@ int pfn_op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float
   GemmTN g = tn(A, lda, B, ldb, C, ldc, M, P, Q);
   g.atomic = atomic;
   PFN_TRY(launch_gemm_tn(g, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, float* const* C,
+                         const int64_t* ldc, const int32_t* P, const int32_t* Q, float* const* colsum, int M, int splits, void* stream) {
+  if (n < 1 || n > TN_GROUP_MAX || !A || !lda || !B || !ldb || !C || !ldc || !P || !Q) return fail(PFN_ERR_ARGUMENT, "bad gemm_tn_group arguments");
+  GemmTNGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n; g.M = M; g.splits = splits;
+  for (int i = 0; i < n; ++i) {
+    TnProblem& t = g.p[i];
+    t.A = A[i]; t.lda = lda[i]; t.B = B[i]; t.ldb = ldb[i]; t.C = C[i]; t.ldc = ldc[i]; t.P = P[i]; t.Q = Q[i];
+    t.colsum = colsum ? colsum[i] : nullptr;
+  }
+  PFN_TRY(launch_gemm_tn_group(g, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep, int prec, void* stream) {

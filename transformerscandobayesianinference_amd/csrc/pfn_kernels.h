@@ -33,6 +33,8 @@ struct GemmNT {
   int vec_ok;  // filled by the launcher
 };
 int launch_gemm_nt(const GemmNT& g, int precision, hipStream_t stream);
+// kernel selection knob (tests / profiling): 0 automatic, 1 only the 128x128 kernel, 2 the 256x256 kernel whenever legal
+void set_gemm_nt_big_mode(int mode);
 
 struct GemmTN {
   const void* A; long lda;  // [M,P] T
@@ -44,6 +46,25 @@ struct GemmTN {
   float* colsum;            // optional [P]: += column sums of A (bias gradient), atomically
 };
 int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream);
+
+// Grouped weight-gradient GEMMs (bf16): C_i[P_i,Q_i] (+)= A_i[M,P_i]^T . B_i[M,Q_i] for every problem of the
+// group in ONE launch of 256x256 tiles (gemm_tn_big_kernel).  splits: 0 = automatic (1 when the group has
+// enough tiles: no atomics, deterministic), > 1 = split the token axis with f32 atomics.
+constexpr int TN_GROUP_MAX = 26;
+struct TnProblem {
+  const void* A; const void* B; float* C; float* colsum;  // colsum: optional [P] += column sums of A
+  long lda, ldb, ldc;
+  int P, Q;
+};
+struct GemmTNGroup {
+  TnProblem p[TN_GROUP_MAX];
+  int tile_start[TN_GROUP_MAX + 1];  // filled by the launcher
+  int n, M, splits, m_chunk;
+  int debug_mask;                    // all ones; profiling only (pfn_set_tuning key 1): 2^k - 1 wraps the token index
+};
+void set_gemm_tn_debug_wrap(int rows);
+bool gemm_tn_group_supported(const TnProblem& p);
+int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream);
 
 // ---- attention (attention.hip) ---------------------------------------------------------------
 // qkv: [B, S, 3E] T (q | k | v, heads contiguous inside each E), ctx: [B, S, E] T,
