@@ -16,6 +16,7 @@
 // ds_read_b64_tr_b16 (bf16) in the accumulator-order slot mapping M2, so P / dS never move
 // between lanes.
 #include <algorithm>
+#include <type_traits>
 #include "pfn_device.h"
 #include "pfn_kernels.h"
 
@@ -28,6 +29,14 @@ template <typename T, int D> struct AttnCfg {
   static constexpr int NKK = D / 16;
   static constexpr int NDB = D / 32;
   static constexpr int TILE = KVB * RB;
+  static constexpr int RS = PadStride<RB>::ROW, CS = PadStride<RB>::COL;   // padded LDS row strides (pfn_device.h)
+  static constexpr int RIMG = KVB * RS, CIMG = KVB * CS;                  // bytes of one row / col image of a tile
+  // bf16 (product path): 8 waves share every K/V (or Q/dO) tile and the kernel is held to 256 registers, so
+  // two waves are resident per SIMD and one wave's MFMAs cover the other's softmax / LDS waits.  The exact-f32
+  // parity mode has twice the fragment registers and keeps 4 waves with the whole register file.
+  static constexpr int NW = sizeof(T) == 2 ? 8 : 4;
+  static constexpr int NT = NW * 64;        // threads per workgroup
+  static constexpr int QBLK = NW * 32;      // query (or key) rows per workgroup
 };
 
 template <typename T> PFN_DEV Frag<T> load_frag_global(const T* p) {
@@ -83,17 +92,18 @@ PFN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+constexpr float RESCALE_THR = 6.f;  // log2 units: lazily raised running max of the online softmax (see attn_fwd_kernel)
 
 // =============================================================================================
 // forward
 // =============================================================================================
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
-  auto Kt = [&](int buf) { return smem + buf * 2 * C::TILE; };
-  auto Vt = [&](int buf) { return smem + buf * 2 * C::TILE + C::TILE; };
+  auto Kt = [&](int buf) { return smem + buf * (C::RIMG + C::CIMG); };
+  auto Vt = [&](int buf) { return smem + buf * (C::RIMG + C::CIMG) + C::RIMG; };
 
   const int b = blockIdx.z, hd = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const T* Qp = base + hd * D;
   const T* Kp = base + a.E + hd * D;
   const T* Vp = base + 2 * a.E + hd * D;
-  const int qi = blockIdx.x * 128 + wave * 32 + li;
+  const int qi = blockIdx.x * C::QBLK + wave * 32 + li;
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
   const int sep = a.sep;
@@ -133,25 +143,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       }
   }
 
-  const int ntiles = (sep + C::KVB - 1) / C::KVB;
-  TileStage<T, C::KVB, C::RB, 256> sk, sv;
+  const int nfull = sep / C::KVB;
+  const bool has_edge = (sep % C::KVB) != 0;
+  const int ntiles = nfull + (has_edge ? 1 : 0);
+  TileStage<T, C::KVB, C::RB, C::NT> sk, sv;
   if (ntiles > 0) {
     sk.issue(Kp, rs, sep, D);
     sv.issue(Vp, rs, sep, D);
-    sk.template commit<false>(Kt(0));
-    sv.template commit<true>(Vt(0));
+    sk.template commit_p<C::RS>(Kt(0));
+    sv.template commit_p<C::CS>(Vt(0));
   }
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1, k0 = t * C::KVB;
+  // One key tile.  BUF (the LDS buffer) and EDGE (the ragged last tile, the only one that needs the
+  // key mask) are compile-time so LDS addresses fold into immediates and full tiles carry no masking.
+  // The running max is only raised -- and the accumulators only rescaled -- when some row's tile max
+  // exceeds it by more than RESCALE_THR (in log2 units): P stays below 2^THR, which neither the bf16
+  // operand rounding (relative) nor the f32 sums notice, and the O-wide rescale pass (the largest
+  // block of vector work in the loop) runs on the first tile and then almost never.
+  auto tile = [&](auto buf_c, auto edge_c, int t) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr bool EDGE = decltype(edge_c)::value;
+    const int k0 = t * C::KVB;
     if (t + 1 < ntiles) {
       const long k1 = k0 + C::KVB;
       sk.issue(Kp + k1 * rs, rs, sep - (int)k1, D);
       sv.issue(Vp + k1 * rs, rs, sep - (int)k1, D);
     }
-    const lds_char* kt = Kt(cur);
-    const lds_char* vt = Vt(cur);
+    const lds_char* kt = Kt(BUF);
+    const lds_char* vt = Vt(BUF);
     f32x16 st[C::NKB];
 #pragma unroll
     for (int kb = 0; kb < C::NKB; ++kb)
@@ -161,49 +181,65 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int kk = 0; kk < C::NKK; ++kk)
 #pragma unroll
       for (int kb = 0; kb < C::NKB; ++kb)
-        st[kb] = mma32(load_frag_row<T, C::RB>(kt, kb * 32 + li, kk * 16), qf[kk], st[kb]);
+        st[kb] = mma32(load_frag_row_p<T, C::RS>(kt, kb * 32 + li, kk * 16), qf[kk], st[kb]);
 
-    float mx = -1e30f;
-    const bool edge = k0 + C::KVB > sep;
+    float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < C::NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float tv = st[kb][r] * scale_log2;
-        if (edge && (k0 + kb * 32 + acc_row(r, lane) >= sep)) tv = -INFINITY;
-        st[kb][r] = tv;
-        mx = fmaxf(mx, tv);
+        if (EDGE && (k0 + kb * 32 + acc_row(r, lane) >= sep)) st[kb][r] = -INFINITY;
+        mx = fmaxf(mx, st[kb][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = fast_exp2(m - m_new);
-    m = m_new;
+    const float mc = mx * scale_log2;
+    if (__builtin_amdgcn_ballot_w64(mc > m + RESCALE_THR) != 0) {
+      const float m_new = fmaxf(m, mc);
+      const float alpha = fast_exp2(m - m_new);
+      m = m_new;
+      lsum *= alpha;
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
     float rsum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < C::NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(st[kb][r] - m);
+        const float p = fast_exp2(__builtin_fmaf(st[kb][r], scale_log2, -m));
         st[kb][r] = p;
         rsum += p;
       }
-    lsum = lsum * alpha + rsum;
-#pragma unroll
-    for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    lsum += rsum;
 #pragma unroll
     for (int c = 0; c < C::KVB / 16; ++c) {
       const Frag<T> pf = acc_to_frag<T>(st[c >> 1], c & 1);
 #pragma unroll
       for (int db = 0; db < C::NDB; ++db)
-        o[db] = mma32(load_frag_tr<T, C::RB, 2>(vt, c * 16, db * 32), pf, o[db]);
+        o[db] = mma32(load_frag_tr_p<T, C::CS, 2>(vt, c * 16, db * 32), pf, o[db]);
     }
     if (t + 1 < ntiles) {
-      sk.template commit<false>(Kt(cur ^ 1));
-      sv.template commit<true>(Vt(cur ^ 1));
+      sk.template commit_p<C::RS>(Kt(BUF ^ 1));
+      sv.template commit_p<C::CS>(Vt(BUF ^ 1));
     }
     __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  {
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+      tile(I0{}, std::false_type{}, t);
+      tile(I1{}, std::false_type{}, t + 1);
+    }
+    if (t < nfull) {
+      tile(I0{}, std::false_type{}, t);
+      if (has_edge) tile(I1{}, std::true_type{}, t + 1);
+    } else if (has_edge) {
+      tile(I0{}, std::true_type{}, t);
+    }
   }
 
   lsum += __shfl_xor(lsum, 32, 64);
@@ -254,14 +290,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, int D) {
 // backward, dQ (+ the self-key terms of test rows: dQ_i, dK_i, dV_i for i >= sep)
 // =============================================================================================
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
-  // per buffer: K (swz16, row frags), K (swz64, transposed frags), V (swz16)
-  auto Kr = [&](int buf) { return smem + buf * 3 * C::TILE; };
-  auto Kc = [&](int buf) { return smem + buf * 3 * C::TILE + C::TILE; };
-  auto Vr = [&](int buf) { return smem + buf * 3 * C::TILE + 2 * C::TILE; };
+  // per buffer: K (row image), K (col image, transposed frags), V (row image)
+  constexpr int DQ_BUF = 2 * C::RIMG + C::CIMG;
+  auto Kr = [&](int buf) { return smem + buf * DQ_BUF; };
+  auto Kc = [&](int buf) { return smem + buf * DQ_BUF + C::RIMG; };
+  auto Vr = [&](int buf) { return smem + buf * DQ_BUF + C::RIMG + C::CIMG; };
 
   const int b = blockIdx.z, hd = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
@@ -271,7 +308,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   const T* Kp = base + a.E + hd * D;
   const T* Vp = base + 2 * a.E + hd * D;
   T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
-  const int qi = blockIdx.x * 128 + wave * 32 + li;
+  const int qi = blockIdx.x * C::QBLK + wave * 32 + li;
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
   const int sep = a.sep;
@@ -295,60 +332,76 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
 
-  const int ntiles = (sep + C::KVB - 1) / C::KVB;
-  TileStage<T, C::KVB, C::RB, 256> sk, sv;
+  const int nfull = sep / C::KVB;
+  const bool has_edge = (sep % C::KVB) != 0;
+  const int ntiles = nfull + (has_edge ? 1 : 0);
+  TileStage<T, C::KVB, C::RB, C::NT> sk, sv;
   if (ntiles > 0) {
     sk.issue(Kp, rs, sep, D);
     sv.issue(Vp, rs, sep, D);
-    sk.template commit<false>(Kr(0));
-    sk.template commit<true>(Kc(0));
-    sv.template commit<false>(Vr(0));
+    sk.template commit_p<C::RS>(Kr(0));
+    sk.template commit_p<C::CS>(Kc(0));
+    sv.template commit_p<C::RS>(Vr(0));
   }
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1, k0 = t * C::KVB;
+  // one key tile; BUF / EDGE compile-time as in the forward kernel
+  auto tile = [&](auto buf_c, auto edge_c, int t) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr bool EDGE = decltype(edge_c)::value;
+    const int k0 = t * C::KVB;
     if (t + 1 < ntiles) {
       const long k1 = k0 + C::KVB;
       sk.issue(Kp + k1 * rs, rs, sep - (int)k1, D);
       sv.issue(Vp + k1 * rs, rs, sep - (int)k1, D);
     }
-    const lds_char* kr = Kr(cur);
-    const lds_char* kc = Kc(cur);
-    const lds_char* vr = Vr(cur);
-    f32x16 st[C::NKB], dp[C::NKB];
+    const lds_char* kr = Kr(BUF);
+    const lds_char* kc = Kc(BUF);
+    const lds_char* vr = Vr(BUF);
 #pragma unroll
-    for (int kb = 0; kb < C::NKB; ++kb)
+    for (int kb = 0; kb < C::NKB; ++kb) {   // 32 keys at a time: only one S / dP pair is live
+      f32x16 st, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int kk = 0; kk < C::NKK; ++kk)
-#pragma unroll
-      for (int kb = 0; kb < C::NKB; ++kb) {
-        st[kb] = mma32(load_frag_row<T, C::RB>(kr, kb * 32 + li, kk * 16), qf[kk], st[kb]);
-        dp[kb] = mma32(load_frag_row<T, C::RB>(vr, kb * 32 + li, kk * 16), dof[kk], dp[kb]);
+      for (int kk = 0; kk < C::NKK; ++kk) {
+        st = mma32(load_frag_row_p<T, C::RS>(kr, kb * 32 + li, kk * 16), qf[kk], st);
+        dp = mma32(load_frag_row_p<T, C::RS>(vr, kb * 32 + li, kk * 16), dof[kk], dp);
       }
-    const bool edge = k0 + C::KVB > sep;
-#pragma unroll
-    for (int kb = 0; kb < C::NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = fast_exp2(st[kb][r] * scale_log2 - lse2);
-        if (edge && (k0 + kb * 32 + acc_row(r, lane) >= sep)) p = 0.f;
-        st[kb][r] = p * (dp[kb][r] - delta);  // dS (unscaled)
+        float p = fast_exp2(__builtin_fmaf(st[r], scale_log2, -lse2));
+        if (EDGE && (k0 + kb * 32 + acc_row(r, lane) >= sep)) p = 0.f;
+        st[r] = p * (dp[r] - delta);  // dS (unscaled)
       }
 #pragma unroll
-    for (int c = 0; c < C::KVB / 16; ++c) {
-      const Frag<T> dsf = acc_to_frag<T>(st[c >> 1], c & 1);
+      for (int c = 0; c < 2; ++c) {
+        const Frag<T> dsf = acc_to_frag<T>(st, c);
 #pragma unroll
-      for (int db = 0; db < C::NDB; ++db)
-        dq[db] = mma32(load_frag_tr<T, C::RB, 2>(kc, c * 16, db * 32), dsf, dq[db]);
+        for (int db = 0; db < C::NDB; ++db)
+          dq[db] = mma32(load_frag_tr_p<T, C::CS, 2>(kc, kb * 32 + c * 16, db * 32), dsf, dq[db]);
+      }
     }
     if (t + 1 < ntiles) {
-      sk.template commit<false>(Kr(cur ^ 1));
-      sk.template commit<true>(Kc(cur ^ 1));
-      sv.template commit<false>(Vr(cur ^ 1));
+      sk.template commit_p<C::RS>(Kr(BUF ^ 1));
+      sk.template commit_p<C::CS>(Kc(BUF ^ 1));
+      sv.template commit_p<C::RS>(Vr(BUF ^ 1));
     }
     __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  {
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+      tile(I0{}, std::false_type{}, t);
+      tile(I1{}, std::false_type{}, t + 1);
+    }
+    if (t < nfull) {
+      tile(I0{}, std::false_type{}, t);
+      if (has_edge) tile(I1{}, std::true_type{}, t + 1);
+    } else if (has_edge) {
+      tile(I0{}, std::true_type{}, t);
+    }
   }
 
   // self key of test rows
@@ -400,22 +453,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // =============================================================================================
-// backward, dK and dV for the train keys [0, sep): one workgroup owns 128 keys and streams all
-// S queries.
+// backward, dK and dV for the train keys [0, sep): a workgroup owns QBLK keys (one per lane, 32 per
+// wave) and streams all S queries.  Two passes (MODE 0: dV = P^T dO, MODE 1: dK = dS^T Q) instead
+// of one fused kernel: a fused pass needs dK and dV accumulators plus the K and V fragments of
+// the wave's keys -- 240 registers before any temporary -- and would run one wave per SIMD with
+// nothing to cover its LDS waits and softmax; each split pass fits two (dK) or three (dV) waves per
+// SIMD at the price of recomputing S once.
+// Keys >= sep in the last key block run on clamped (finite or not: never stored, and a lane's key
+// column never mixes with another lane's) data instead of being masked.
 // =============================================================================================
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
+template <typename T, int D, int MODE>
+__global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dkv_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
-  constexpr int QB = 32;                     // queries per tile
-  constexpr int QT = QB * C::RB;             // bytes of one Q (or dO) tile image
-  constexpr int BUF = 4 * QT + 2 * QB * 4;   // Q row, Q col, dO row, dO col images + lse + delta
+  constexpr int QB = C::KVB;                 // queries per tile (64 for bf16 up to D = 128, else 32)
+  constexpr int NQB = QB / 32;
+  // images per buffer -- dV: Q rows, dO cols;  dK: Q rows, Q cols, dO rows;  then lse2[QB], delta[QB]
+  constexpr int IMG_BYTES = C::RIMG + C::CIMG + (MODE == 1 ? C::RIMG : 0);
+  constexpr int BUF_BYTES = IMG_BYTES + 2 * QB * 4;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
-  auto Qr = [&](int buf) { return smem + buf * BUF; };
-  auto Qc = [&](int buf) { return smem + buf * BUF + QT; };
-  auto Or = [&](int buf) { return smem + buf * BUF + 2 * QT; };
-  auto Oc = [&](int buf) { return smem + buf * BUF + 3 * QT; };
-  auto St = [&](int buf) { return smem + buf * BUF + 4 * QT; };  // [lse2 x QB][delta x QB]
+  auto Img = [&](int buf, int i) { return smem + buf * BUF_BYTES + (i == 0 ? 0 : i == 1 ? C::RIMG : C::RIMG + C::CIMG); };
+  auto St = [&](int buf) { return smem + buf * BUF_BYTES + IMG_BYTES; };  // [lse2 x QB][delta x QB]
 
   const int b = blockIdx.z, hd = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
@@ -427,7 +485,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
   const T* dOp = reinterpret_cast<const T*>(a.dctx) + (long)b * a.S * a.E + hd * D;
   T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
   const int sep = a.sep;
-  const int key = blockIdx.x * 128 + wave * 32 + li;
+  const int key = blockIdx.x * C::QBLK + wave * 32 + li;
   const bool kvalid = key < sep;
   const int kc = min(key, a.S - 1);
   const float scale = rsqrtf((float)D);
@@ -435,33 +493,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
   const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
   const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
 
-  Frag<T> kf[C::NKK], vf[C::NKK];
+  Frag<T> kf[C::NKK], vf[MODE == 1 ? C::NKK : 1];
 #pragma unroll
   for (int kk = 0; kk < C::NKK; ++kk) {
     kf[kk] = load_frag_global<T>(Kp + (long)kc * rs + kk * 16 + 8 * h);
-    vf[kk] = load_frag_global<T>(Vp + (long)kc * rs + kk * 16 + 8 * h);
+    if constexpr (MODE == 1) vf[kk] = load_frag_global<T>(Vp + (long)kc * rs + kk * 16 + 8 * h);
   }
-  f32x16 dk[C::NDB], dv[C::NDB];
+  f32x16 acc[C::NDB];
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
 
   const int ntiles = (a.S + QB - 1) / QB;
-  TileStage<T, QB, C::RB, 256> sq, so;
+  TileStage<T, QB, C::RB, C::NT> sq, so;
   float st_reg = 0.f;  // threads 0..2*QB-1 stage lse2 / delta
   auto stage_stats = [&](int q0) {
     if (threadIdx.x < 2 * QB) {
       const int q = q0 + (threadIdx.x & (QB - 1));
       if (threadIdx.x < QB) st_reg = (q < a.S) ? lse_g[q] * LOG2E : 1e30f;
-      else st_reg = (q < a.S) ? delta_g[q] : 0.f;
+      else st_reg = (MODE == 1 && q < a.S) ? delta_g[q] : 0.f;
     }
   };
   auto commit_all = [&](int buf) {
-    sq.template commit<false>(Qr(buf));
-    sq.template commit<true>(Qc(buf));
-    so.template commit<false>(Or(buf));
-    so.template commit<true>(Oc(buf));
+    sq.template commit_p<C::RS>(Img(buf, 0));
+    if constexpr (MODE == 0) {
+      so.template commit_p<C::CS>(Img(buf, 1));
+    } else {
+      sq.template commit_p<C::CS>(Img(buf, 1));
+      so.template commit_p<C::RS>(Img(buf, 2));
+    }
     if (threadIdx.x < 2 * QB) lds_write_f32(St(buf) + threadIdx.x * 4, st_reg);
   };
   sq.issue(Qp, rs, a.S, D);
@@ -470,68 +531,70 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
   commit_all(0);
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
+  auto tile = [&](auto buf_c, int t) {
+    constexpr int BUF = decltype(buf_c)::value;
     if (t + 1 < ntiles) {
       const long q1 = (long)(t + 1) * QB;
       sq.issue(Qp + q1 * rs, rs, a.S - (int)q1, D);
       so.issue(dOp + q1 * a.E, a.E, a.S - (int)q1, D);
       stage_stats((int)q1);
     }
-    const lds_char* qr = Qr(cur);
-    const lds_char* qcol = Qc(cur);
-    const lds_char* orow = Or(cur);
-    const lds_char* ocol = Oc(cur);
-    const lds_char* stt = St(cur);
-    f32x16 s, dp;
+    const lds_char* qr = Img(BUF, 0);
+    const lds_char* stt = St(BUF);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    for (int qb = 0; qb < NQB; ++qb) {
+      f32x16 s, dp;
 #pragma unroll
-    for (int kk = 0; kk < C::NKK; ++kk) {
-      s = mma32(load_frag_row<T, C::RB>(qr, li, kk * 16), kf[kk], s);
-      dp = mma32(load_frag_row<T, C::RB>(orow, li, kk * 16), vf[kk], dp);
-    }
-    // rows of s/dp are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (8 * rg + 4 * h) * 4));
-      const f32x4 dl = __builtin_bit_cast(f32x4, lds_read16(stt + (QB + 8 * rg + 4 * h) * 4));
+      for (int kk = 0; kk < C::NKK; ++kk) {
+        s = mma32(load_frag_row_p<T, C::RS>(qr, qb * 32 + li, kk * 16), kf[kk], s);
+        if constexpr (MODE == 1) dp = mma32(load_frag_row_p<T, C::RS>(Img(BUF, 2), qb * 32 + li, kk * 16), vf[kk], dp);
+      }
+      // rows of s/dp are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * rg + e;
-        float p = fast_exp2(s[r] * scale_log2 - l2[e]);
-        if (!kvalid) p = 0.f;
-        s[r] = p;
-        dp[r] = p * (dp[r] - dl[e]);
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (qb * 32 + 8 * rg + 4 * h) * 4));
+        f32x4 dl = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == 1) dl = __builtin_bit_cast(f32x4, lds_read16(stt + (QB + qb * 32 + 8 * rg + 4 * h) * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rg + e;
+          const float p = fast_exp2(__builtin_fmaf(s[r], scale_log2, -l2[e]));
+          if constexpr (MODE == 0) s[r] = p;
+          else s[r] = p * (dp[r] - dl[e]);
+        }
+      }
+      const lds_char* col = Img(BUF, 1);   // dO (dV pass) or Q (dK pass), read transposed
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const Frag<T> f = acc_to_frag<T>(s, c);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+          acc[db] = mma32(load_frag_tr_p<T, C::CS, 2>(col, qb * 32 + c * 16, db * 32), f, acc[db]);
       }
     }
-#pragma unroll
-    for (int c = 0; c < QB / 16; ++c) {
-      const Frag<T> pf = acc_to_frag<T>(s, c);
-      const Frag<T> dsf = acc_to_frag<T>(dp, c);
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) {
-        dv[db] = mma32(load_frag_tr<T, C::RB, 2>(ocol, c * 16, db * 32), pf, dv[db]);
-        dk[db] = mma32(load_frag_tr<T, C::RB, 2>(qcol, c * 16, db * 32), dsf, dk[db]);
-      }
-    }
-    if (t + 1 < ntiles) commit_all(cur ^ 1);
+    if (t + 1 < ntiles) commit_all(BUF ^ 1);
     __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(I0{}, t);
+    if (t + 1 < ntiles) tile(I1{}, t + 1);
   }
 
   if (kvalid) {
-    T* dKo = dbase + (long)key * rs + a.E + hd * D;
-    T* dVo = dbase + (long)key * rs + 2 * a.E + hd * D;
+    T* out = dbase + (long)key * rs + (MODE == 0 ? 2 * a.E : a.E) + hd * D;
+    const float f = MODE == 0 ? 1.f : scale;
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int d0 = db * 32 + 8 * rg + 4 * h;
-        f32x4 x, y;
+        f32x4 x;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { x[e] = dk[db][4 * rg + e] * scale; y[e] = dv[db][4 * rg + e]; }
-        store4<T>(dKo + d0, x);
-        store4<T>(dVo + d0, y);
+        for (int e = 0; e < 4; ++e) x[e] = acc[db][4 * rg + e] * f;
+        store4<T>(out + db * 32 + 8 * rg + 4 * h, x);
       }
   }
 }
@@ -541,10 +604,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
 // =============================================================================================
 template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
-  const size_t lds = 4 * C::TILE;
+  const size_t lds = 2 * (C::RIMG + C::CIMG);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3((a.S + C::QBLK - 1) / C::QBLK, a.H, a.B), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+template <typename T, int D, int MODE> static void launch_dkv_t(const AttnArgs& a, hipStream_t s) {
+  using C = AttnCfg<T, D>;
+  const size_t lds = 2 * (C::RIMG + C::CIMG + (MODE == 1 ? C::RIMG : 0) + 2 * C::KVB * 4);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, D, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, MODE>), dim3((a.sep + C::QBLK - 1) / C::QBLK, a.H, a.B), dim3(C::NT), lds, s, a);
 }
 template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
@@ -554,14 +623,13 @@ template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStrea
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, s, a, D);
   }
   {
-    const size_t lds = 6 * C::TILE;
+    const size_t lds = 2 * (2 * C::RIMG + C::CIMG);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3((a.S + 127) / 128, a.H, a.B), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3((a.S + C::QBLK - 1) / C::QBLK, a.H, a.B), dim3(C::NT), lds, s, a);
   }
   if (a.sep > 0) {
-    const size_t lds = 2 * (4 * 32 * C::RB + 2 * 32 * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D>), dim3((a.sep + 127) / 128, a.H, a.B), dim3(256), lds, s, a);
+    launch_dkv_t<T, D, 0>(a, s);
+    launch_dkv_t<T, D, 1>(a, s);
   }
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }

@@ -159,6 +159,60 @@ template <typename T, int RB, int MAP> PFN_DEV Frag<T> load_frag_tr(const lds_ch
 }
 
 // ---------------------------------------------------------------------------------------------
+// Padded (linear) LDS images, used by the attention kernels.  The XOR swizzles above make every
+// fragment address a different non-linear function of the lane, i.e. one address VGPR (and one
+// integer op per tile) per read; with a padded row stride the address is lane_base + constant, so
+// a whole tile is read off ONE base register with immediate offsets:
+//   row images (ds_read_b128 along the contraction): stride RB + 16 B  -> 16 consecutive rows hit 16 distinct
+//                                                   4-bank groups (stride/4 = 4 mod 64 ... an odd multiple of 4)
+//   col images (ds_read_b64_tr_b16 across rows)    : stride = 64 or 192 mod 256 -> the 4 rows of one transpose
+//                                                   read sit in 4 different 16-bank quarters
+// ---------------------------------------------------------------------------------------------
+template <int RB> struct PadStride {
+  static constexpr int ROW = RB + 16;
+  static constexpr int COL = (RB % 256 == 64 || RB % 256 == 192) ? RB : RB + 64;
+};
+
+template <typename T, int STRIDE> PFN_DEV Frag<T> load_frag_row_p(const lds_char* tile, int row, int k0) {
+  const int h = lane_id() >> 5;
+  Frag<T> f;
+  if constexpr (sizeof(T) == 2) {
+    u32x4 raw = lds_read16(tile + row * STRIDE + ((k0 >> 3) + h) * 16);
+    f.v = __builtin_bit_cast(bf16x8, raw);
+  } else {
+    const int c = (k0 >> 2) + 2 * h;
+    u32x4 r0 = lds_read16(tile + row * STRIDE + c * 16);
+    u32x4 r1 = lds_read16(tile + row * STRIDE + c * 16 + 16);
+    f32x4 a = __builtin_bit_cast(f32x4, r0), b = __builtin_bit_cast(f32x4, r1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f.v[e] = a[e]; f.v[4 + e] = b[e]; }
+  }
+  return f;
+}
+
+template <typename T, int STRIDE, int MAP> PFN_DEV Frag<T> load_frag_tr_p(const lds_char* tile, int k0, int col0) {
+  const int l = lane_id(), h = l >> 5;
+  Frag<T> f;
+  if constexpr (sizeof(T) == 2) {
+    const int i = l & 15, g = (l >> 4) & 1;
+    const int colb = (col0 + 16 * g + 4 * (i & 3)) * 2;
+    const int ra = (MAP == 1) ? (k0 + 8 * h) : (k0 + 4 * h);
+    const int rb = (MAP == 1) ? (k0 + 8 * h + 4) : (k0 + 8 + 4 * h);
+    bf16x4 lo = ds_read_tr16_b64(tile + (ra + (i >> 2)) * STRIDE + colb);
+    bf16x4 hi = ds_read_tr16_b64(tile + (rb + (i >> 2)) * STRIDE + colb);
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+    const int colb = (col0 + (l & 31)) * 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = (MAP == 1) ? (k0 + 8 * h + e) : (k0 + 8 * (e >> 2) + 4 * h + (e & 3));
+      f.v[e] = lds_read_f32(tile + row * STRIDE + colb);
+    }
+  }
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Cooperative global -> LDS tile copy in 16-byte chunks (register staged so the issue and the
 // LDS write can be split around compute).  ROWS x RB bytes, NT threads.
 // Source: row r of the tile starts at src + r*ld (elements of T); columns beyond `cols_valid`
@@ -187,6 +241,15 @@ template <typename T, int ROWS, int RB, int NT> struct TileStage {
         v = *reinterpret_cast<u32x4*>(tmp);
       }
       regs[i] = v;
+    }
+  }
+  // padded linear image (PadStride): chunk c of row r at r * STRIDE + 16 c
+  template <int STRIDE> PFN_DEV void commit_p(LdsPtr tile) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = threadIdx.x + i * NT;
+      if (TOTAL % NT != 0 && id >= TOTAL) break;
+      lds_write16(tile + (id / NCH) * STRIDE + (id % NCH) * 16, regs[i]);
     }
   }
   template <bool SWZ64> PFN_DEV void commit(LdsPtr tile) const {
