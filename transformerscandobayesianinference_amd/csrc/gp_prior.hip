@@ -9,10 +9,14 @@
 // Schedule per call (all datasets of the batch advance together, grid.y / grid.z = dataset):
 //   rng    : Philox4x32-10 -> x ~ U[0,1), z ~ N(0,1) (Box-Muller); y = 0
 //   gram   : lower-triangular 64x64 tiles of K                      (HBM-bound, 4 S^2/2 bytes written)
-//   for each 64-wide panel k:   (right-looking blocked Cholesky, S/64 panels)
-//     potrf : factor the diagonal block in LDS, y[blk] += L_kk z[blk]
-//     trsm  : one thread per row below the block: row <- row . L_kk^-T; y[row] += row . z[blk]
-//     syrk  : trailing lower tiles  C_ij -= L_ik L_jk^T  on exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+//   two-level right-looking blocked Cholesky, S/256 outer blocks of four 64-wide panels:
+//     inside the 256x256 diagonal block (narrow launches, <= 4B workgroups):
+//       potrf : factor a 64x64 diagonal block in the registers of one wave, y[blk] += L_kk z[blk]
+//       trsm  : one thread per row of the diagonal block below it: row <- row . L_kk^-T; y[row] += row . z[blk]
+//       syrk  : rank-64 update of the rest of the diagonal block (exact-f32 MFMA, v_mfma_f32_32x32x2_f32)
+//     once per outer block (wide launches):
+//       trsm_wide : every row below: X = A L_d^-T against the whole 256-wide factor (MFMA + substitution), y += X z
+//       syrk      : rank-256 update of the trailing matrix
 // so L.z (the "TRMV") costs no extra pass over the matrix.  Algorithmic work per dataset:
 // S^3/3 flop (Cholesky) + S^2 (nf+2) (Gram); the matrix (4 S^2 bytes) lives in K_ws.
 #include <algorithm>
@@ -182,11 +186,23 @@ __global__ __launch_bounds__(64) void gp_potrf_kernel(GpArgs a, int k0) {
   }
   if (live) {
     if (nb == NB) {
+      // Inverse of the block factor for the wide trsm (gp_trsm_wide_kernel multiplies by it on the MFMA instead of
+      // substituting): lane c builds column c of L^-1,  inv[r] = L^-1[r][c] = -(sum_{m<r} L[r][m] L^-1[m][c]) / L[r][r]
+      // (zero above the diagonal by construction), with L[r][m] broadcast from lane r.  Column c of L^-1 is row c
+      // of L^-T, which is exactly the strictly-upper part of the block: the block leaves as [L \ L^-T], diagonal = L.
+      float inv[NB];
+#pragma unroll
+      for (int rr = 0; rr < NB; ++rr) {
+        float acc = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < rr; ++mm) acc += lane_bcast(row[mm], rr) * inv[mm];
+        const float d = lane_bcast(row[rr], rr);
+        inv[rr] = (rr == r) ? 1.f / d : -acc / d;
+      }
 #pragma unroll
       for (int c = 0; c < NB; c += 4) {
-        // the strictly-upper part is never read again; store zeros there
-        *reinterpret_cast<f32x4*>(Kb + (long)r * S + c) = f32x4{c <= r ? row[c] : 0.f, c + 1 <= r ? row[c + 1] : 0.f,
-                                                              c + 2 <= r ? row[c + 2] : 0.f, c + 3 <= r ? row[c + 3] : 0.f};
+        *reinterpret_cast<f32x4*>(Kb + (long)r * S + c) = f32x4{c <= r ? row[c] : inv[c], c + 1 <= r ? row[c + 1] : inv[c + 1],
+                                                              c + 2 <= r ? row[c + 2] : inv[c + 2], c + 3 <= r ? row[c + 3] : inv[c + 3]};
       }
     } else {
 #pragma unroll
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(64) void gp_potrf_kernel(GpArgs a, int k0) {
 // trsm: rows below the diagonal block.  One thread per row; row . L_kk^-T by forward substitution
 // with L_kk broadcast from LDS.  Also the panel's contribution to y = L z.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0) {
+__global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0, int r_end) {
   __shared__ float L[NB][NB];  // L[j][m], m <= j
   __shared__ float zs[NB];
   const int b = blockIdx.y, S = a.S;
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0) {
   if (threadIdx.x < NB) zs[threadIdx.x] = a.z[(long)b * S + k0 + threadIdx.x];
   __syncthreads();
   const int row = k0 + NB + blockIdx.x * 256 + threadIdx.x;
-  if (row >= S) return;
+  if (row >= r_end) return;
   float* p = Kb + (long)row * S + k0;
   float v[NB];
 #pragma unroll
@@ -236,25 +252,30 @@ __global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// syrk: C_ij -= P_i P_j^T for the lower-triangular 128x128 tiles of the trailing matrix, where
-// P = the freshly solved panel (rows >= k0+NB, columns k0..k0+63).  Exact-f32 MFMA.
+// syrk: C_ij -= P_i P_j^T on 128x128 tiles of rows >= r0, columns [c0, c1), lower triangle only, where
+// P = solved panel columns [kp0, kp0 + K), K a multiple of 64 up to 256.  Exact-f32 MFMA.
+// Two uses (two-level blocking, see launch_gp_sample): K = 64 restricted to the remaining columns of the
+// current 256-wide outer block, and K = 256 over the whole trailing matrix once per outer block -- the
+// trailing matrix is then read and written S/256 times instead of S/64 times.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_syrk_kernel(GpArgs a, int k0) {
-  constexpr int RB = NB * 4;  // 256-byte panel rows
+constexpr int SYRK_KC = 32;   // panel columns per LDS chunk: 2 x 16 KiB per workgroup, so 3-4 workgroups share a CU and
+                              // one's panel loads / C read-modify-write hide under another's MFMAs
+__global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r1, int c0, int c1, int kp0, int K) {
+  constexpr int RB = SYRK_KC * 4;  // 128-byte chunk rows
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr tA = lds_cast(smem_raw);
   LdsPtr tB = tA + 128 * RB;
-  int ti, tj;
-  tri_decode(blockIdx.x, ti, tj);
-  const int b = blockIdx.y, S = a.S, t0 = k0 + NB;
+  // Hardware places workgroup n on XCD n % 8.  All tiles of one dataset share its panel rows, so datasets are
+  // dealt to XCDs (dataset b -> XCD b % 8) when the batch allows it: the panel then stays in that XCD's L2
+  // instead of being re-fetched by every tile.
+  const int S = a.S, T = gridDim.x * gridDim.y;
+  int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  int b, t;
+  if (a.B % 8 == 0) { const int xcd = lin & 7, j = lin >> 3; b = xcd + 8 * (j / T); t = j % T; }
+  else { b = lin / T; t = lin % T; }
+  const int i0 = r0 + (t / gridDim.x) * 128, j0 = c0 + (t % gridDim.x) * 128;
+  if (j0 > i0 + 127) return;          // tile entirely above the diagonal
   float* Kb = a.K + (long)b * S * S;
-  const int i0 = t0 + ti * 128, j0 = t0 + tj * 128;
-  TileStage<float, 128, RB, 256> sa, sb;
-  sa.issue(Kb + (long)i0 * S + k0, S, S - i0, NB);
-  sb.issue(Kb + (long)j0 * S + k0, S, S - j0, NB);
-  sa.template commit<false>(tA);
-  sb.template commit<false>(tB);
-  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wm = wave >> 1, wn = wave & 1;
   f32x16 acc[2][2];
 #pragma unroll
@@ -263,17 +284,30 @@ __global__ __launch_bounds__(256) void gp_syrk_kernel(GpArgs a, int k0) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  TileStage<float, 128, RB, 256> sa, sb;
+  sa.issue(Kb + (long)i0 * S + kp0, S, r1 - i0, SYRK_KC);
+  sb.issue(Kb + (long)j0 * S + kp0, S, r1 - j0, SYRK_KC);
+  for (int kc = 0; kc < K; kc += SYRK_KC) {
+    if (kc > 0) __syncthreads();      // everyone is done reading the previous chunk
+    sa.template commit<false>(tA);
+    sb.template commit<false>(tB);
+    __syncthreads();
+    if (kc + SYRK_KC < K) {           // next chunk's loads fly under this chunk's MFMAs
+      sa.issue(Kb + (long)i0 * S + kp0 + kc + SYRK_KC, S, r1 - i0, SYRK_KC);
+      sb.issue(Kb + (long)j0 * S + kp0 + kc + SYRK_KC, S, r1 - j0, SYRK_KC);
+    }
 #pragma unroll
-  for (int ks = 0; ks < NB; ks += 16) {
-    Frag<float> fa[2], fb[2];
+    for (int ks = 0; ks < SYRK_KC; ks += 16) {
+      Frag<float> fa[2], fb[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i] = load_frag_row<float, RB>(tA, wm * 64 + i * 32 + (lane & 31), ks);
+      for (int i = 0; i < 2; ++i) fa[i] = load_frag_row<float, RB>(tA, wm * 64 + i * 32 + (lane & 31), ks);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<float, RB>(tB, wn * 64 + j * 32 + (lane & 31), ks);
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<float, RB>(tB, wn * 64 + j * 32 + (lane & 31), ks);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fa[i], fb[j], acc[i][j]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -283,8 +317,104 @@ __global__ __launch_bounds__(256) void gp_syrk_kernel(GpArgs a, int k0) {
       for (int r = 0; r < 16; ++r) {
         const int gi = i0 + wm * 64 + i * 32 + acc_row(r, lane);
         const int gj = j0 + wn * 64 + j * 32 + (lane & 31);
-        if (gi < S && gj < S && gj <= gi) Kb[(long)gi * S + gj] -= acc[i][j][r];
+        if (gi < r1 && gj < c1 && gj <= gi) Kb[(long)gi * S + gj] -= acc[i][j][r];
       }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wide trsm: all rows below a finished 256-wide outer block.  X = A[rows, kout:kout+256] . L_d^-T with L_d the
+// factored 256x256 diagonal block, as a blocked forward substitution over its four 64-column blocks:
+//   V_j -= sum_{i<j} X_i L_ji^T   exact-f32 MFMA, one 32x32 tile per wave
+//   X_j  = V_j L_jj^-T            MFMA as well, with the explicit inverse of the 64x64 block factor that gp_potrf_kernel
+//                                 leaves in the block's strictly-upper triangle
+// plus the rows' contribution to y = L z.  One workgroup owns 64 rows (their 256 panel columns live in LDS).
+// This is the only pass over the rows below per OUTER block; the 64-wide panel kernels above only touch the
+// 256 rows of the diagonal block, so the chain of small launches no longer spreads over the whole chip.
+// ---------------------------------------------------------------------------------------------
+constexpr int OBW = 4 * NB;               // outer block width
+constexpr int TW_STRIDE = OBW * 4 + 16;   // padded LDS row (pfn_device.h PadStride)
+__global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr V = lds_cast(smem_raw);                     // [64][TW_STRIDE]  the workgroup's rows
+  LdsPtr Lr = V + 64 * TW_STRIDE;                    // [64][TW_STRIDE]  row block j of L_d, columns 0 .. 64(j+1)
+  float* zs = reinterpret_cast<float*>(smem_raw + 2 * 64 * TW_STRIDE);  // [256]
+  const int b = blockIdx.y, S = a.S;
+  const int row0 = kout + OBW + blockIdx.x * 64;
+  const int rows_valid = min(64, S - row0);
+  float* Kb = a.K + (long)b * S * S;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31;
+  {
+    TileStage<float, 64, OBW * 4, 256> sv;
+    sv.issue(Kb + (long)row0 * S + kout, S, rows_valid, OBW);
+    sv.template commit_p<TW_STRIDE>(V);
+    zs[threadIdx.x] = a.z[(long)b * S + kout + threadIdx.x];
+  }
+  for (int jb = 0; jb < 4; ++jb) {
+    __syncthreads();   // V current (initial load / previous block's solution), Lr free
+    {
+      TileStage<float, 64, OBW * 4, 256> sl;
+      sl.issue(Kb + (long)(kout + jb * NB) * S + kout, S, NB, (jb + 1) * NB);
+      sl.template commit_p<TW_STRIDE>(Lr);
+    }
+    __syncthreads();
+    if (jb > 0) {
+      const int rt = wave >> 1, ct = wave & 1;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int k = 0; k < jb * NB; k += 16)
+        acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, k), load_frag_row_p<float, TW_STRIDE>(Lr, ct * 32 + li, k), acc);
+      __syncthreads();  // every wave has read the X_i it needs before V_j changes (disjoint columns, but keep the phases apart)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        LdsPtr p = V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + (jb * NB + ct * 32 + li) * 4;
+        lds_write_f32(p, lds_read_f32(p) - acc[r]);
+      }
+      __syncthreads();
+    }
+    {
+      // X_j = V_j L_jj^-T on the MFMA.  The staged diagonal block holds [L \ L^-T]: L^-1[c][k] (k < c) sits at
+      // (row k, column c), the diagonal holds L[c][c], everything with k > c is masked to zero.
+      const int rt = wave >> 1, ct = wave & 1, h = lane >> 5;
+      const int c = ct * 32 + li;
+      const float rdiag = 1.f / lds_read_f32(Lr + c * TW_STRIDE + (jb * NB + c) * 4);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int kmax = ct == 0 ? 32 : NB;      // columns c < 32 only see k < 32
+      for (int k0 = 0; k0 < kmax; k0 += 16) {
+        Frag<float> fb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = k0 + 8 * h + e;
+          const float st = lds_read_f32(Lr + k * TW_STRIDE + (jb * NB + c) * 4);
+          fb.v[e] = k < c ? st : (k == c ? rdiag : 0.f);
+        }
+        acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, jb * NB + k0), fb, acc);
+      }
+      __syncthreads();   // all of V_j has been read
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        lds_write_f32(V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + (jb * NB + c) * 4, acc[r]);
+    }
+  }
+  __syncthreads();
+  {  // y[row] += X[row, :] . z   (4 threads per row, 64 columns each)
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < NB; c += 4) {
+      const f32x4 xv = __builtin_bit_cast(f32x4, lds_read16(V + r * TW_STRIDE + (q * NB + c) * 4));
+      d += xv[0] * zs[q * NB + c] + xv[1] * zs[q * NB + c + 1] + xv[2] * zs[q * NB + c + 2] + xv[3] * zs[q * NB + c + 3];
+    }
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    if (q == 0 && r < rows_valid) a.y[(long)b * S + row0 + r] += d;
+  }
+  for (int id = threadIdx.x; id < 64 * (OBW / 4); id += 256) {
+    const int r = id / (OBW / 4), c = id % (OBW / 4);
+    if (r < rows_valid) *reinterpret_cast<u32x4*>(Kb + (long)(row0 + r) * S + kout + c * 4) = lds_read16(V + r * TW_STRIDE + c * 16);
+  }
 }
 
 int launch_gp_sample(const GpArgs& a, hipStream_t s) {
@@ -301,14 +431,29 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
     if (lds > 64 * 1024) return PFN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(gp_gram_kernel, dim3(t * (t + 1) / 2, B), dim3(256), lds, s, a);
   }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_syrk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  for (int k0 = 0; k0 < S; k0 += NB) {
-    hipLaunchKernelGGL(gp_potrf_kernel, dim3(B), dim3(64), 0, s, a, k0);
-    const int below = S - k0 - NB;
-    if (below > 0) {
-      hipLaunchKernelGGL(gp_trsm_kernel, dim3((below + 255) / 256, B), dim3(256), 0, s, a, k0);
-      const int t = (below + 127) / 128;
-      hipLaunchKernelGGL(gp_syrk_kernel, dim3(t * (t + 1) / 2, B), dim3(256), 65536, s, a, k0);
+  // Two-level right-looking blocked Cholesky.  Per 256-wide outer block:
+  //   narrow chain (touches only the block's own <= 256 rows, at most B..4B workgroups, harmless to whatever
+  //   shares the GPU): 64-wide panels  potrf -> trsm -> rank-64 update, all restricted to rows < kend;
+  //   wide, once per outer block: trsm of every row below against the whole 256-wide factor, then one
+  //   rank-256 update of the trailing matrix.
+  auto syrk = [&](int r0, int r1, int c0, int c1, int kp0, int K) {
+    const int ti = (r1 - r0 + 127) / 128, tj = (c1 - c0 + 127) / 128;
+    if (ti > 0 && tj > 0) hipLaunchKernelGGL(gp_syrk_kernel, dim3(tj, ti, B), dim3(256), 2 * 128 * SYRK_KC * 4, s, a, r0, r1, c0, c1, kp0, K);
+  };
+  const size_t tw_lds = 2 * 64 * TW_STRIDE + OBW * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_trsm_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tw_lds);
+  for (int kout = 0; kout < S; kout += OBW) {
+    const int kend = std::min(kout + OBW, S);
+    for (int k0 = kout; k0 < kend; k0 += NB) {
+      hipLaunchKernelGGL(gp_potrf_kernel, dim3(B), dim3(64), 0, s, a, k0);
+      const int next = k0 + NB;
+      if (next >= kend) break;
+      hipLaunchKernelGGL(gp_trsm_kernel, dim3((kend - next + 255) / 256, B), dim3(256), 0, s, a, k0, kend);
+      syrk(next, kend, next, kend, k0, NB);
+    }
+    if (kend < S) {
+      hipLaunchKernelGGL(gp_trsm_wide_kernel, dim3((S - kend + 63) / 64, B), dim3(256), tw_lds, s, a, kout);
+      syrk(kend, S, kend, S, kout, OBW);
     }
   }
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;

@@ -139,14 +139,18 @@ int launch_embed_fwd(const EmbedArgs& a, int precision, hipStream_t s) {
   return PFN_LAUNCH_OK();
 }
 
+// One thread per embedding column e, EMBB_TOK tokens per workgroup: d(src) is read exactly once
+// (coalesced across e), every token's features come from LDS as broadcast reads, and all nf + 2
+// weight-gradient columns of the thread stay in registers until the closing atomics.
 constexpr int EMBB_TOK = 128;
+constexpr int EMBB_MAXF = 32;   // nf + 2 rounded up to 8 must fit (wider encoders take the chunked path below)
+template <int NF8>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
-  extern __shared__ float xs[];  // [EMBB_TOK][nfp] : x features, y (masked), train flag, zero pad to 8
+  extern __shared__ float xs[];  // [EMBB_TOK][NF8] : x features, y (masked), train flag, zero pad to 8
   const long ntok = (long)a.B * a.S;
   const long t0 = (long)blockIdx.x * EMBB_TOK;
-  const int nf8 = (a.nf + 2 + 7) / 8 * 8;
-  for (int i = threadIdx.x; i < EMBB_TOK * nf8; i += 256) {
-    const int tk = i / nf8, f = i % nf8;
+  for (int i = threadIdx.x; i < EMBB_TOK * NF8; i += 256) {
+    const int tk = i / NF8, f = i % NF8;
     const long tok = t0 + tk;
     float v = 0.f;
     if (tok < ntok) {
@@ -159,6 +163,52 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
   }
   __syncthreads();
   const int ntk = (int)std::min<long>(EMBB_TOK, ntok - t0);
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= a.E) return;
+  float acc[NF8];
+#pragma unroll
+  for (int j = 0; j < NF8; ++j) acc[j] = 0.f;
+  float db = 0.f;
+  const float* dcol = a.dsrc + t0 * a.E + e;
+#pragma unroll 16
+  for (int tk = 0; tk < ntk; ++tk) {   // 16 independent loads in flight per thread
+    const float d = dcol[(long)tk * a.E];
+    db += d;
+#pragma unroll
+    for (int j = 0; j < NF8; j += 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + tk * NF8 + j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[j + q] += d * xv[q];
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < NF8; ++f) {
+    if (f < a.nf) unsafeAtomicAdd(a.dwx + (long)e * a.nf + f, acc[f]);
+    else if (f == a.nf) unsafeAtomicAdd(a.dwy + e, acc[f]);
+    else if (f == a.nf + 1) unsafeAtomicAdd(a.dby + e, acc[f]);
+  }
+  unsafeAtomicAdd(a.dbx + e, db);
+}
+// wide encoders (nf + 2 > 32): features in chunks of 8, d(src) re-read per chunk
+__global__ __launch_bounds__(256) void embed_bwd_wide_kernel(EmbedBwdArgs a) {
+  extern __shared__ float xs[];
+  const long ntok = (long)a.B * a.S;
+  const long t0 = (long)blockIdx.x * 128;
+  const int nf8 = (a.nf + 2 + 7) / 8 * 8;
+  for (int i = threadIdx.x; i < 128 * nf8; i += 256) {
+    const int tk = i / nf8, f = i % nf8;
+    const long tok = t0 + tk;
+    float v = 0.f;
+    if (tok < ntok) {
+      const long b = tok / a.S, sidx = tok % a.S;
+      if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
+      else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
+      else if (f == a.nf + 1) v = (sidx < a.sep) ? 1.f : 0.f;
+    }
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int ntk = (int)std::min<long>(128, ntok - t0);
   for (int e = threadIdx.x; e < a.E; e += 256) {
     float db = 0.f;
     for (int f0 = 0; f0 < nf8; f0 += 8) {
@@ -182,10 +232,22 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
 }
 int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s) {
   const long ntok = (long)a.B * a.S;
-  const int grid = (int)((ntok + EMBB_TOK - 1) / EMBB_TOK);
-  const size_t lds = EMBB_TOK * ((a.nf + 2 + 7) / 8 * 8) * sizeof(float);
+  const int nf8 = (a.nf + 2 + 7) / 8 * 8;
+  if (nf8 <= EMBB_MAXF) {
+    const dim3 grid((unsigned)((ntok + EMBB_TOK - 1) / EMBB_TOK), (a.E + 255) / 256);
+    const size_t lds = (size_t)EMBB_TOK * nf8 * sizeof(float);
+    switch (nf8) {
+      case 8: hipLaunchKernelGGL(embed_bwd_kernel<8>, grid, dim3(256), lds, s, a); break;
+      case 16: hipLaunchKernelGGL(embed_bwd_kernel<16>, grid, dim3(256), lds, s, a); break;
+      case 24: hipLaunchKernelGGL(embed_bwd_kernel<24>, grid, dim3(256), lds, s, a); break;
+      default: hipLaunchKernelGGL(embed_bwd_kernel<32>, grid, dim3(256), lds, s, a); break;
+    }
+    return PFN_LAUNCH_OK();
+  }
+  const int grid = (int)((ntok + 127) / 128);
+  const size_t lds = 128 * (size_t)nf8 * sizeof(float);
   if (lds > 64 * 1024) return PFN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(embed_bwd_wide_kernel, dim3(grid), dim3(256), lds, s, a);
   return PFN_LAUNCH_OK();
 }
 
@@ -317,82 +379,106 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
   return PFN_LAUNCH_OK();
 }
 
+// 8 waves per workgroup, one wave per row, TWO rows in flight per wave (loads of both rows are
+// issued before either is reduced), 2 workgroups per CU: enough bytes in flight to stream at HBM
+// rate, and few enough workgroups that the column reductions (d gamma, d beta, optional bias
+// gradient) end in ~0.8 M atomics instead of several million.
+constexpr int LNB_WAVES = 8;
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                                            float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E) {
-  extern __shared__ float part[];  // [3][4 waves][E]
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                                                      float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [LNB_WAVES][E]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long wave0 = (long)blockIdx.x * 4 + wave;
+  const long wave0 = (long)blockIdx.x * LNB_WAVES + wave;
+  const long wstride = (long)gridDim.x * LNB_WAVES;
   const float invE = 1.f / (float)E;
-  f32x4 ag[NV], ab[NV], ax[NV];
-#pragma unroll
-  for (int k = 0; k < NV; ++k) { ag[k] = f32x4{0, 0, 0, 0}; ab[k] = f32x4{0, 0, 0, 0}; ax[k] = f32x4{0, 0, 0, 0}; }
-  for (long row = wave0; row < rows; row += (long)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[NV], gdy[NV];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < E) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * E + c);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * E + c);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[k][e] = (xv[e] - mu) * rs;
-          gdy[k][e] = d[e] * g[e];
-          s1 += gdy[k][e];
-          s2 += gdy[k][e] * xh[k][e];
-          ag[k][e] += d[e] * xh[k][e];
-          ab[k][e] += d[e];
-        }
-      } else { xh[k] = f32x4{0, 0, 0, 0}; gdy[k] = f32x4{0, 0, 0, 0}; }
-    }
-    s1 = wave_sum(s1) * invE;
-    s2 = wave_sum(s2) * invE;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < E) {
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = rs * (gdy[k][e] - s1 - xh[k][e] * s2); ax[k][e] += o[e]; }
-        *reinterpret_cast<f32x4*>(dx32 + row * E + c) = o;
-        if (dxt) st4<T>(dxt + row * E + c, o);
-      }
-    }
-  }
-  // block reduction of the column partials, then one atomic per column per block
+  f32x4 ag[NV], ab[NV], ax[NV], gam[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
+    ag[k] = f32x4{0, 0, 0, 0}; ab[k] = f32x4{0, 0, 0, 0}; ax[k] = f32x4{0, 0, 0, 0};
     const int c = (k * 64 + lane) * 4;
-    if (c < E) {
+    gam[k] = c < E ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0, 0, 0, 0};
+  }
+  for (long row0 = wave0; row0 < rows; row0 += 2 * wstride) {
+    const long rw[2] = {row0, row0 + wstride};
+    f32x4 xv[2][NV], dv[2][NV];
+    float mu[2], rs[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        part[(0 * 4 + wave) * E + c + e] = ag[k][e];
-        part[(1 * 4 + wave) * E + c + e] = ab[k][e];
-        part[(2 * 4 + wave) * E + c + e] = ax[k][e];
+    for (int u = 0; u < 2; ++u) {
+      const bool live = rw[u] < rows;
+      const long r = live ? rw[u] : row0;
+      mu[u] = mean[r]; rs[u] = rstd[r];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < E) {
+          xv[u][k] = *reinterpret_cast<const f32x4*>(x + r * E + c);
+          dv[u][k] = live ? *reinterpret_cast<const f32x4*>(dy + r * E + c) : f32x4{0, 0, 0, 0};
+        } else { xv[u][k] = f32x4{0, 0, 0, 0}; dv[u][k] = f32x4{0, 0, 0, 0}; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (rw[u] >= rows) break;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[u][k][e] - mu[u]) * rs[u];
+          const float g = dv[u][k][e] * gam[k][e];
+          s1 += g;
+          s2 += g * xh;
+          ag[k][e] += dv[u][k][e] * xh;
+          ab[k][e] += dv[u][k][e];
+          xv[u][k][e] = xh;
+          dv[u][k][e] = g;
+        }
+      s1 = wave_sum(s1) * invE;
+      s2 = wave_sum(s2) * invE;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < E) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2); ax[k][e] += o[e]; }
+          *reinterpret_cast<f32x4*>(dx32 + rw[u] * E + c) = o;
+          if (dxt) st4<T>(dxt + rw[u] * E + c, o);
+        }
       }
     }
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < E; c += 256) {
-    float g = 0.f, b = 0.f, xx = 0.f;
+  // block reduction of the column partials (one quantity at a time through [LNB_WAVES][E] of LDS), then one
+  // atomic per column per block
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { g += part[(0 * 4 + w) * E + c]; b += part[(1 * 4 + w) * E + c]; xx += part[(2 * 4 + w) * E + c]; }
-    unsafeAtomicAdd(dgamma + c, g);
-    unsafeAtomicAdd(dbeta + c, b);
-    if (dbias) unsafeAtomicAdd(dbias + c, xx);
+  for (int q = 0; q < 3; ++q) {
+    float* out = q == 0 ? dgamma : q == 1 ? dbeta : dbias;
+    if (out == nullptr) continue;
+    if (q > 0) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      if (c < E) *reinterpret_cast<f32x4*>(part + wave * E + c) = q == 0 ? ag[k] : q == 1 ? ab[k] : ax[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < E; c += LNB_WAVES * 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) t += part[w * E + c];
+      unsafeAtomicAdd(out + c, t);
+    }
   }
 }
 int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, void* dxt,
                          float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s) {
   if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
   if (rows == 0) return PFN_OK;
-  const int grid = grid_for(rows, 4 * 4, 2048);
-  const size_t lds = 12 * E * sizeof(float);
-#define LN_BWD(TT, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV>), dim3(grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E)
+  const int grid = grid_for(rows, LNB_WAVES * 8, 512);
+  const size_t lds = LNB_WAVES * E * sizeof(float);
+#define LN_BWD(TT, NV) do { \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_kernel<TT, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E); } while (0)
 #define LN_BWD_NV(TT) do { if (E <= 256) LN_BWD(TT, 1); else if (E <= 512) LN_BWD(TT, 2); else if (E <= 1024) LN_BWD(TT, 4); else LN_BWD(TT, 8); } while (0)
   if (precision == PFN_PREC_BF16) LN_BWD_NV(bf16); else LN_BWD_NV(float);
   return PFN_LAUNCH_OK();

@@ -75,4 +75,5 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
 
 DataLoader = get_batch_to_dataloader(get_batch)
 DataLoader.num_outputs = 1
-DataLoader.prefetch = True   # draws run one step ahead on a side stream (priors/utils.py)
+DataLoader.prefetch = True        # draws run ahead of the training steps on a side stream (priors/utils.py)
+DataLoader.prefetch_group = 4     # ... four steps' worth of datasets per sampler call

@@ -40,8 +40,21 @@ def get_batch_to_dataloader(get_batch_method_):
         def __iter__(self):
             draw = lambda: self.gbm(**self.get_batch_kwargs, fuse_x_y=self.fuse_x_y)
             if getattr(self, 'prefetch', False) and torch.cuda.is_available():
-                return prefetch_on_side_stream(draw, self.num_steps)
+                group = max(1, int(getattr(self, 'prefetch_group', 1)))
+                if group > 1 and not self.fuse_x_y and 'batch_size' in self.get_batch_kwargs:
+                    return prefetch_on_side_stream(self._draw_group, (self.num_steps + group - 1) // group, self.num_steps, group)
+                return prefetch_on_side_stream(lambda n: [draw() for _ in range(n)], self.num_steps, self.num_steps, 1)
             return iter(draw() for _ in range(self.num_steps))
+
+        def _draw_group(self, n):
+            """n steps' worth of datasets from ONE call of the prior (datasets are i.i.d., so a draw of n * batch_size
+            columns split into n batches is distributed exactly like n draws): the sampler's long chain of small
+            dependent kernels is paid once per group instead of once per step."""
+            kw = dict(self.get_batch_kwargs)
+            B = kw['batch_size']
+            kw['batch_size'] = B * n
+            (x, y), target = self.gbm(**kw, fuse_x_y=False)
+            return [((x[:, i * B:(i + 1) * B], y[:, i * B:(i + 1) * B]), target[:, i * B:(i + 1) * B]) for i in range(n)]
 
     return DL
 
@@ -54,31 +67,39 @@ def _tensors(obj):
             yield from _tensors(o)
 
 
-def prefetch_on_side_stream(draw, num_steps):
-    """Generator over `num_steps` batches whose draw for step t+1 is enqueued on a side HIP stream
-    before step t is handed out, so the (latency-bound) prior sampler overlaps the training step of
-    the previous batch instead of serialising with it (the reference samples synchronously,
-    SURVEY.md 3.3).  The consumer's stream waits on the batch's event; tensors are marked as used
-    by the consumer stream so the caching allocator cannot recycle them early."""
+def prefetch_on_side_stream(draw_group, num_groups, num_steps, group):
+    """Generator over `num_steps` batches.  `draw_group(n)` returns a list of n batches; group g + 1 is
+    enqueued on a side HIP stream before the first batch of group g is handed out, so the prior sampler -- a
+    long chain of small, latency-bound kernels (blocked Cholesky) -- overlaps the training steps of the
+    previous group instead of serialising with them (the reference samples synchronously).
+    Sharing the GPU with the training kernels stretches that chain (each of its ~100 dependent kernels waits
+    for a free CU slot), which is why a group should span several steps: measured on MI355X, one step of
+    look-ahead with one draw per step leaves every draw on the critical path.  The consumer's stream waits on
+    the group's event; tensors are marked as used by the consumer stream so the caching allocator cannot
+    recycle them early."""
     side = torch.cuda.Stream()
+    origin = torch.cuda.current_stream()
 
-    def enqueue():
+    def enqueue(g):
+        n = min(group, num_steps - g * group)
+        side.wait_stream(origin)   # anything the draw reads (hyper-parameters ...) was produced on the caller's stream
         with torch.cuda.stream(side):
-            batch = draw()
+            batches = draw_group(n)
             done = torch.cuda.Event()
             done.record(side)
-        return batch, done
+        return batches, done
 
-    pending = enqueue() if num_steps > 0 else None
-    for step in range(num_steps):
-        batch, done = pending
-        pending = enqueue() if step + 1 < num_steps else None
-        main = torch.cuda.current_stream()
-        main.wait_event(done)
-        for t in _tensors(batch):
-            if t.is_cuda:
-                t.record_stream(main)
-        yield batch
+    pending = enqueue(0) if num_groups > 0 else None
+    for g in range(num_groups):
+        batches, done = pending
+        pending = enqueue(g + 1) if g + 1 < num_groups else None
+        for batch in batches:
+            main = torch.cuda.current_stream()
+            main.wait_event(done)
+            for t in _tensors(batch):
+                if t.is_cuda:
+                    t.record_stream(main)
+            yield batch
 
 
 def trunc_norm_sampler_f(mu, sigma):
