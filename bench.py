@@ -98,11 +98,14 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
         t = time_kernel(lambda: hipops.gemm_nt(A, B_, _hip.EPI_OUT_T, _hip.PREC_BF16, out_t=o))
         out.append(dict(kernel=f'gemm_nt[{name} {m}x{n}x{k}]', launches_per_step=count, seconds=t, flops=2.0 * m * n * k))
 
-    def gemm_t(name, m, p, q, count):
-        A, B_ = r(m, p), r(m, q)
-        C = torch.zeros(p, q, device=dev)
-        t = time_kernel(lambda: hipops.gemm_tn(A, B_, C, _hip.PREC_BF16))
-        out.append(dict(kernel=f'gemm_tn[{name} {p}x{q}x{m}]', launches_per_step=count, seconds=t, flops=2.0 * m * p * q))
+    def wgrad_group():
+        # every weight gradient of the stack in ONE grouped launch (pfn_stack_backward defers them)
+        probs = []
+        for _ in range(L):
+            probs += [(r(M, E), r(M, F), torch.zeros(E, F, device=dev), None), (r(M, F), r(M, E), torch.zeros(F, E, device=dev), torch.zeros(F, device=dev)),
+                      (r(M, E), r(M, E), torch.zeros(E, E, device=dev), None), (r(M, 3 * E), r(M, E), torch.zeros(3 * E, E, device=dev), torch.zeros(3 * E, device=dev))]
+        t = time_kernel(lambda: hipops.gemm_tn_group(probs, 0), iters=5, warm=2)
+        out.append(dict(kernel=f'gemm_tn_group[{4 * L} weight gradients, {M} tokens]', launches_per_step=1, seconds=t, flops=2.0 * M * L * (2 * E * F + 4 * E * E)))
 
     gemm('qkv', M, 3 * E, E, L)
     gemm('out_proj / dctx', M, E, E, 2 * L)
@@ -110,9 +113,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     gemm('linear2 / d(linear1)', M, E, F, 2 * L)
     gemm('d(linear2)', M, F, E, L)
     gemm('d(qkv)', M, E, 3 * E, L)
-    gemm_t('dW qkv', M, 3 * E, E, L)
-    gemm_t('dW out_proj', M, E, E, L)
-    gemm_t('dW linear1/2', M, F, E, 2 * L)
+    wgrad_group()
     qkv = r(batch, S, 3 * E)
     t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16))
     attn_fl = 4.0 * E * pairs(S, sep) * batch
@@ -120,7 +121,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     ctx, lse = hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16)
     dctx = r(batch, S, E)
     t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16))
-    out.append(dict(kernel='attn_bwd (delta + dq + dkdv)', launches_per_step=L, seconds=t, flops=2.0 * attn_fl))
+    out.append(dict(kernel='attn_bwd (delta + dq + dv + dk kernels)', launches_per_step=L, seconds=t, flops=2.0 * attn_fl))
     for k in out:
         k['tflops'] = k['flops'] / k['seconds'] / 1e12
         k['step_seconds'] = k['seconds'] * k['launches_per_step']

@@ -1,0 +1,53 @@
+"""Condense the outputs of tools/profile_bench.sh: the rocprofv3 kernel stats table plus per-kernel
+PMC averages (FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3; FETCH_SIZE is doubled for the
+gfx950 under-count documented in MI355X_MICROARCH.md 'HBM')."""
+import csv
+import glob
+import os
+import sys
+
+
+def find(root, pattern):
+    hits = glob.glob(os.path.join(root, '**', pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(n):
+    return n.replace('void ', '').replace('pfn::', '')[:64]
+
+
+def main():
+    out = sys.argv[1]
+    st = find(os.path.join(out, 'stats'), '*kernel_stats.csv')
+    if st:
+        print('== rocprofv3 --kernel-trace --stats: bench.py --steps 10 --warmup 3 ==')
+        rows = list(csv.DictReader(open(st)))
+        print(f'{"kernel":66s} {"calls":>7s} {"total_ms":>10s} {"avg_us":>10s} {"pct":>6s}')
+        for r in rows[:28]:
+            print(f'{short(r["Name"]):66s} {int(r["Calls"]):7d} {float(r["TotalDurationNs"]) / 1e6:10.3f} {float(r["AverageNs"]) / 1e3:10.2f} {float(r["Percentage"]):6.2f}')
+    for d in sorted(glob.glob(os.path.join(out, 'pmc_*'))):
+        if not os.path.isdir(d):
+            continue
+        cc = find(d, '*counter_collection.csv')
+        if not cc:
+            print('no counter csv under', d)
+            continue
+        agg = {}
+        for r in csv.DictReader(open(cc)):
+            k = (short(r['Kernel_Name']), r['Counter_Name'])
+            a = agg.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r['Counter_Value'])
+        print(f'== PMC pass {os.path.basename(d)} (average per launch) ==')
+        for (k, c), (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+            avg = v / n
+            extra = ''
+            if c == 'FETCH_SIZE':
+                extra = f'  -> {2 * avg / 1024:10.1f} MB/launch read (x2 gfx950 correction)'
+            if c == 'WRITE_SIZE':
+                extra = f'  -> {avg / 1024:10.1f} MB/launch written (uncalibrated)'
+            print(f'{k:66s} {c:28s} n={n:5d} avg={avg:16.1f}{extra}')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Profiles of the bench command on the GPU box (writes under gpurun_out/$1):
+#   1. rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3` (per-kernel durations)
+#   2. separate PMC passes (FETCH_SIZE; WRITE_SIZE; MFMA busy) of a shorter run, kernel trace only
+# usage: tools/profile_bench.sh <tag>
+set -u
+TAG=${1:-prof}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_stats_run.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+  name=$(echo $c | tr ' ' '_')
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$name -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-breakdown > $OUT/pmc_$name.log 2>&1
+done
+cd $ROOT
+python tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+tail -5 $OUT/bench_stats_run.log | grep '^{' > $OUT/bench.json
+cat $OUT/summary.txt | head -60

@@ -90,6 +90,24 @@ template <typename T> PFN_DEV void store4(T* p, f32x4 x) {
 }
 PFN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Workgroup -> (row block, head, dataset) for a 1-D launch of nblk * H * B workgroups.  Hardware deals
+// consecutive workgroup ids round-robin over the 8 XCDs (each with a private L2); every row block of one
+// (dataset, head) streams the SAME K/V (or Q/dO) rows, so the ids are remapped (bijectively, as in gemm.hip) to
+// give each XCD whole (dataset, head) groups: the operand rows are then fetched into one L2 once instead of
+// into all eight.
+struct AttnBlock { int blk, hd, b; };
+PFN_DEV AttnBlock attn_block(int nblk, int H) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  AttnBlock o;
+  o.blk = id % nblk;
+  const int bh = id / nblk;
+  o.hd = bh % H;
+  o.b = bh / H;
+  return o;
+}
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float RESCALE_THR = 6.f;  // log2 units: lazily raised running max of the online softmax (see attn_fwd_kernel)
@@ -105,14 +123,15 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   auto Kt = [&](int buf) { return smem + buf * (C::RIMG + C::CIMG); };
   auto Vt = [&](int buf) { return smem + buf * (C::RIMG + C::CIMG) + C::RIMG; };
 
-  const int b = blockIdx.z, hd = blockIdx.y;
+  const AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
+  const int b = wg.b, hd = wg.hd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
   const long rs = 3L * a.E;
   const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
   const T* Qp = base + hd * D;
   const T* Kp = base + a.E + hd * D;
   const T* Vp = base + 2 * a.E + hd * D;
-  const int qi = blockIdx.x * C::QBLK + wave * 32 + li;
+  const int qi = wg.blk * C::QBLK + wave * 32 + li;
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
   const int sep = a.sep;
@@ -300,7 +319,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   auto Kc = [&](int buf) { return smem + buf * DQ_BUF + C::RIMG; };
   auto Vr = [&](int buf) { return smem + buf * DQ_BUF + C::RIMG + C::CIMG; };
 
-  const int b = blockIdx.z, hd = blockIdx.y;
+  const AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
+  const int b = wg.b, hd = wg.hd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
   const long rs = 3L * a.E;
   const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
@@ -308,7 +328,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   const T* Kp = base + a.E + hd * D;
   const T* Vp = base + 2 * a.E + hd * D;
   T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
-  const int qi = blockIdx.x * C::QBLK + wave * 32 + li;
+  const int qi = wg.blk * C::QBLK + wave * 32 + li;
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
   const int sep = a.sep;
@@ -475,7 +495,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dkv_kernel(AttnA
   auto Img = [&](int buf, int i) { return smem + buf * BUF_BYTES + (i == 0 ? 0 : i == 1 ? C::RIMG : C::RIMG + C::CIMG); };
   auto St = [&](int buf) { return smem + buf * BUF_BYTES + IMG_BYTES; };  // [lse2 x QB][delta x QB]
 
-  const int b = blockIdx.z, hd = blockIdx.y;
+  const AttnBlock wg = attn_block((a.sep + C::QBLK - 1) / C::QBLK, a.H);
+  const int b = wg.b, hd = wg.hd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
   const long rs = 3L * a.E;
   const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
@@ -485,7 +506,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dkv_kernel(AttnA
   const T* dOp = reinterpret_cast<const T*>(a.dctx) + (long)b * a.S * a.E + hd * D;
   T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
   const int sep = a.sep;
-  const int key = blockIdx.x * C::QBLK + wave * 32 + li;
+  const int key = wg.blk * C::QBLK + wave * 32 + li;
   const bool kvalid = key < sep;
   const int kc = min(key, a.S - 1);
   const float scale = rsqrtf((float)D);
@@ -606,14 +627,14 @@ template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStrea
   using C = AttnCfg<T, D>;
   const size_t lds = 2 * (C::RIMG + C::CIMG);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3((a.S + C::QBLK - 1) / C::QBLK, a.H, a.B), dim3(C::NT), lds, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 template <typename T, int D, int MODE> static void launch_dkv_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
   const size_t lds = 2 * (C::RIMG + C::CIMG + (MODE == 1 ? C::RIMG : 0) + 2 * C::KVB * 4);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, D, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, MODE>), dim3((a.sep + C::QBLK - 1) / C::QBLK, a.H, a.B), dim3(C::NT), lds, s, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, MODE>), dim3(((a.sep + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
 }
 template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
@@ -625,7 +646,7 @@ template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStrea
   {
     const size_t lds = 2 * (2 * C::RIMG + C::CIMG);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3((a.S + C::QBLK - 1) / C::QBLK, a.H, a.B), dim3(C::NT), lds, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
   }
   if (a.sep > 0) {
     launch_dkv_t<T, D, 0>(a, s);

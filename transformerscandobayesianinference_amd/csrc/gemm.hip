@@ -175,46 +175,66 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 // Requirements (checked by the launcher, otherwise gemm_nt_kernel runs): K % 64 == 0, N % 4 == 0,
 // 16-byte aligned rows on every stream.
 // ---------------------------------------------------------------------------------------------
-constexpr int BIG_BM = 256, BIG_BN = 256, BIG_BK = 64;
-constexpr int BIG_TILE = BIG_BM * BIG_BK * 2;   // 32 KiB per operand per stage
-constexpr int BIG_STAGE = 2 * BIG_TILE;
+// Two shapes of the same kernel (template NWM = waves along M, BK = contraction depth per stage):
+//   NWM 2, BK 64 : 256 x 256 tile, 8 waves, 128 KiB LDS, one workgroup per CU  -- best per-tile rate, long K
+//   NWM 1, BK 32 : 128 x 256 tile, 4 waves,  48 KiB LDS, three workgroups per CU -- the encoder's K = 512..1536
+//                  GEMMs spend as long in their prologue + epilogue (first DMA, bias / GELU / residual, 64..256 MB of
+//                  output) as in the MFMA loop; with three independent workgroups per CU one's stores and first
+//                  loads run under another's MFMAs instead of the whole chip alternating between the two phases.
+constexpr int BIG_BN = 256;
+template <int NWM, int BK> struct BigCfg {
+  static constexpr int BM = NWM * 128, BN = BIG_BN, NW = NWM * 4, NT = NW * 64;
+  static constexpr int RB = BK * 2;                 // bytes per tile row
+  static constexpr int CPR = RB / 16;               // 16-byte chunks per row
+  static constexpr int RPP = 1024 / RB;             // rows per 1-KiB DMA piece
+  static constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;   // pieces per wave per operand
+  static constexpr int TILE_A = BM * RB, TILE_B = BN * RB, STAGE = TILE_A + TILE_B;
+  static constexpr int MIN_BLOCKS = NWM == 1 ? 3 : 1;
+};
+constexpr int BIG_BM = 256, BIG_BK = 64;            // the large shape (launcher heuristics, tests)
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-template <int FLAGS>
-__global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(GemmNT g) {
+template <int FLAGS, int NWM, int BK>
+__global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS)) void gemm_nt_big_kernel(GemmNT g) {
+  using C = BigCfg<NWM, BK>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
 
-  const int tiles_n = (g.N + BIG_BN - 1) / BIG_BN;
-  const int tiles_m = (g.M + BIG_BM - 1) / BIG_BM;
+  const int tiles_n = (g.N + C::BN - 1) / C::BN;
+  const int tiles_m = (g.M + C::BM - 1) / C::BM;
   const int tid_lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = tid_lin / tiles_n, tn = tid_lin % tiles_n;
-  const int m0 = tm * BIG_BM, n0 = tn * BIG_BN;
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wm = wave >> 2, wn = wave & 3;
   const int h = lane >> 5, li = lane & 31;
 
-  // DMA sources: wave w moves the 1-KiB pieces w, w+8, w+16, w+24 of each operand tile
-  const bf16* pa[4];
-  const bf16* pb[4];
+  // DMA sources: wave w moves the 1-KiB pieces w, w + NW, ... of each operand tile; the bank-conflict swizzle
+  // of load_frag_row goes on the source chunk (the LDS image of a piece is lane-linear)
+  const bf16* pa[C::PA];
+  const bf16* pb[C::PB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave + 8 * i) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+  for (int i = 0; i < C::PA; ++i) {
+    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
+    const int chunk = swz16<C::RB>(row, lane % C::CPR);
     pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < C::PB; ++i) {
+    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
+    const int chunk = swz16<C::RB>(row, lane % C::CPR);
     pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
   }
   auto stage = [&](int buf, int k0) {
-    LdsPtr ta = smem + buf * BIG_STAGE + wave * 1024;
-    LdsPtr tb = ta + BIG_TILE;
+    LdsPtr ta = smem + buf * C::STAGE + wave * 1024;
+    LdsPtr tb = smem + buf * C::STAGE + C::TILE_A + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * 8192), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * 8192), 16, 0, 0);
-    }
+    for (int i = 0; i < C::PA; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * C::NW * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C::PB; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * C::NW * 1024), 16, 0, 0);
   };
 
   f32x16 acc[4][2];
@@ -225,21 +245,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(GemmNT g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = g.K / BIG_BK;
+  const int nk = g.K / BK;
   stage(0, 0);
   __syncthreads();  // (carries the vmcnt(0) of the DMA)
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BIG_BK);
-    const lds_char* ta = smem + cur * BIG_STAGE;
-    const lds_char* tb = ta + BIG_TILE;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * C::STAGE;
+    const lds_char* tb = ta + C::TILE_A;
 #pragma unroll
-    for (int ks = 0; ks < BIG_BK; ks += 16) {
+    for (int ks = 0; ks < BK; ks += 16) {
       Frag<bf16> fa[4], fb[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, 128>(tb, wn * 64 + j * 32 + li, ks);
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, C::RB>(tb, wn * 64 + j * 32 + li, ks);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, 128>(ta, wm * 128 + i * 32 + li, ks);
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, C::RB>(ta, wm * 128 + i * 32 + li, ks);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -572,29 +592,36 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 static int g_tn_debug_wrap = 0;
 void set_gemm_tn_debug_wrap(int rows) { g_tn_debug_wrap = rows; }
-// 0: automatic, 1: never use the 256x256 kernel, 2: use it whenever the shape allows (tests)
+// 0: automatic, 1: only the generic 128x128 kernel, 2: the 256x256 LDS-DMA kernel whenever legal,
+// 3: the 128x256 LDS-DMA kernel whenever legal (tests / profiling)
 static int g_big_mode = 0;
 void set_gemm_nt_big_mode(int mode) { g_big_mode = mode; }
-static bool gemm_nt_use_big(const GemmNT& g) {
-  if (g_big_mode == 1 || !g.vec_ok || g.K % BIG_BK || g.N % 4) return false;
-  if (g_big_mode == 2) return true;
-  // enough 256x256 tiles to occupy most of the 256 CUs, and no mostly-empty tile columns
-  const long tiles = (long)((g.M + BIG_BM - 1) / BIG_BM) * ((g.N + BIG_BN - 1) / BIG_BN);
-  return tiles >= 192 && g.N % BIG_BN == 0;
+// returns 0 (generic kernel), 1 (256x256) or 2 (128x256)
+static int gemm_nt_pick(const GemmNT& g) {
+  if (g_big_mode == 1 || !g.vec_ok || g.K % 64 || g.N % 4) return 0;
+  if (g_big_mode == 2) return 1;
+  if (g_big_mode == 3) return 2;
+  if (g.N % BIG_BN) return 0;                       // no mostly-empty tile columns
+  // measured at the north-star shape with the real epilogues (tools/bench_gemm_epi.py): the 256x256 tile wins
+  // whenever it can occupy the chip (3.07 vs 3.53 ms per step); the 128x256 tile covers smaller token counts
+  const long tiles256 = (long)((g.M + 255) / 256) * (g.N / BIG_BN), tiles128 = (long)((g.M + 127) / 128) * (g.N / BIG_BN);
+  return tiles256 >= 192 ? 1 : (tiles128 >= 192 ? 2 : 0);
 }
 
-template <int FLAGS> static void launch_big_t(const GemmNT& g, int tiles, hipStream_t stream) {
+template <int FLAGS, int NWM, int BK> static void launch_big_t(const GemmNT& g, hipStream_t stream) {
+  using C = BigCfg<NWM, BK>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BIG_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<FLAGS, NWM, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::STAGE);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_nt_big_kernel<FLAGS>, dim3(tiles), dim3(512), 2 * BIG_STAGE, stream, g);
+  const int tiles = ((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
+  hipLaunchKernelGGL((gemm_nt_big_kernel<FLAGS, NWM, BK>), dim3(tiles), dim3(C::NT), 2 * C::STAGE, stream, g);
 }
 // the epilogue flag combinations the encoder stack uses; anything else takes the generic kernel
-static bool launch_big(const GemmNT& g, int tiles, hipStream_t stream) {
+static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
   switch (g.flags) {
-#define PFN_BIG_CASE(F) case (F): launch_big_t<(F)>(g, tiles, stream); return true;
+#define PFN_BIG_CASE(F) case (F): if (small_tile) launch_big_t<(F), 1, 32>(g, stream); else launch_big_t<(F), 2, 64>(g, stream); return true;
     PFN_BIG_CASE(EPI_BIAS | EPI_OUT_T)                            // q/k/v projection
     PFN_BIG_CASE(EPI_BIAS | EPI_RESID | EPI_OUT_F32)              // out_proj, linear2 (+ residual)
     PFN_BIG_CASE(EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T)    // linear1 + GELU
@@ -622,9 +649,9 @@ int launch_gemm_nt(const GemmNT& g_in, int precision, hipStream_t stream) {
   if ((g.flags & EPI_GELU_BWD) && ((g.ld_aux * es) % (4 * es) || !aligned16(g.aux))) vec = false;
   if ((g.flags & EPI_BIAS) && !aligned16(g.bias)) vec = false;
   g.vec_ok = vec ? 1 : 0;
-  if (precision == PFN_PREC_BF16 && gemm_nt_use_big(g)) {
-    const int tiles_big = ((g.M + BIG_BM - 1) / BIG_BM) * ((g.N + BIG_BN - 1) / BIG_BN);
-    if (launch_big(g, tiles_big, stream)) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+  if (precision == PFN_PREC_BF16) {
+    const int pick = gemm_nt_pick(g);
+    if (pick && launch_big(g, pick == 2, stream)) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
   }
   const int tiles = ((g.M + GEMM_BM - 1) / GEMM_BM) * ((g.N + GEMM_BN - 1) / GEMM_BN);
   if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, dim3(tiles), dim3(256), 65536, stream, g);
