@@ -140,6 +140,8 @@ def test_gemm_nt_big_epilogues(big_gemm):
     assert relerr(out, pre + resid.double()) < 1e-5
     hipops.gemm_nt(A, B, _hip.EPI_RESID | _hip.EPI_OUT_F32, BF, resid=resid, out_f32=out)
     assert relerr(out, base + resid.double()) < 1e-5
+    hipops.gemm_nt(A, B, _hip.EPI_RESID_T | _hip.EPI_OUT_F32, BF, aux=aux, out_f32=out)
+    assert relerr(out, base + aux.double()) < 1e-5
     hipops.gemm_nt(A, B, _hip.EPI_BIAS | _hip.EPI_OUT_T, BF, bias=bias, out_t=out_t)
     assert relerr(out_t, pre) < tol_t
     hipops.gemm_nt(A, B, _hip.EPI_OUT_T, BF, out_t=out_t)

@@ -19,7 +19,7 @@ PREC_BF16 = 0
 PREC_F32 = 1
 
 # GEMM epilogue flags (csrc/pfn_kernels.h)
-EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_OUT_F32, EPI_OUT_T, EPI_OUT2_T, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_OUT_F32, EPI_OUT_T, EPI_OUT2_T, EPI_ACCUM, EPI_RESID_T = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class HipExtensionError(RuntimeError):

@@ -128,6 +128,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
         for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
       }
       if (flags & EPI_RESID) { f32x4 r = *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + ncol); v += r; }
+      if (flags & EPI_RESID_T) {
+        if constexpr (sizeof(T) == 2) { bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) v[e] += (float)t[e]; }
+        else { f32x4 t = *reinterpret_cast<const f32x4*>(aux + m * g.ld_aux + ncol); v += t; }
+      }
       if (flags & EPI_OUT2_T) {
         if constexpr (sizeof(T) == 2) { bf16x4 t; for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e]; *reinterpret_cast<bf16x4*>(out2_t + m * g.ld_out2 + ncol) = t; }
         else *reinterpret_cast<f32x4*>(out2_t + m * g.ld_out2 + ncol) = v;
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
         if (flags & EPI_BIAS) x += bias[n];
         if (flags & EPI_GELU_BWD) x *= gelu_grad_f((float)aux[m * g.ld_aux + n]);
         if (flags & EPI_RESID) x += g.resid[m * g.ld_resid + n];
+        if (flags & EPI_RESID_T) x += (float)aux[m * g.ld_aux + n];
         if (flags & EPI_OUT2_T) out2_t[m * g.ld_out2 + n] = (T)x;
         if (flags & EPI_GELU) x = gelu_f(x);
         if (flags & EPI_OUT_F32) { float* o = g.out_f32 + m * g.ld_out_f32 + n; *o = (flags & EPI_ACCUM) ? (*o + x) : x; }
@@ -293,6 +298,11 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
           for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f((float)t[e]);
         }
         if (flags & EPI_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
+        if (flags & EPI_RESID_T) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
+        }
         if (flags & EPI_OUT2_T) {
           bf16x4 t;
 #pragma unroll
@@ -626,7 +636,8 @@ static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
     PFN_BIG_CASE(EPI_BIAS | EPI_RESID | EPI_OUT_F32)              // out_proj, linear2 (+ residual)
     PFN_BIG_CASE(EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T)    // linear1 + GELU
     PFN_BIG_CASE(EPI_GELU_BWD | EPI_OUT_T)                        // d(hpre)
-    PFN_BIG_CASE(EPI_RESID | EPI_OUT_F32)                         // dx = dgrad + residual gradient
+    PFN_BIG_CASE(EPI_RESID | EPI_OUT_F32)
+    PFN_BIG_CASE(EPI_RESID_T | EPI_OUT_F32)                       // dx = dgrad + residual gradient (kept in operand precision)
     PFN_BIG_CASE(EPI_OUT_T)                                       // d(ctx)
     PFN_BIG_CASE(EPI_OUT_F32)
     PFN_BIG_CASE(EPI_BIAS | EPI_OUT_F32)
@@ -646,7 +657,7 @@ int launch_gemm_nt(const GemmNT& g_in, int precision, hipStream_t stream) {
   if ((g.flags & EPI_OUT_T) && ((g.ld_out_t * es) % (4 * es) || !aligned16(g.out_t))) vec = false;
   if ((g.flags & EPI_OUT2_T) && ((g.ld_out2 * es) % (4 * es) || !aligned16(g.out2_t))) vec = false;
   if ((g.flags & EPI_RESID) && (g.ld_resid % 4 || !aligned16(g.resid))) vec = false;
-  if ((g.flags & EPI_GELU_BWD) && ((g.ld_aux * es) % (4 * es) || !aligned16(g.aux))) vec = false;
+  if ((g.flags & (EPI_GELU_BWD | EPI_RESID_T)) && ((g.ld_aux * es) % (4 * es) || !aligned16(g.aux))) vec = false;
   if ((g.flags & EPI_BIAS) && !aligned16(g.bias)) vec = false;
   g.vec_ok = vec ? 1 : 0;
   if (precision == PFN_PREC_BF16) {

@@ -99,7 +99,7 @@ struct Ws {
   char *xt_t, *dpre, *dt;
   // backward scratch
   char *dlog_t, *dd_t, *dctx_t;
-  float *dxt, *gA, *gB, *delta;
+  float *dxt, *gA, *delta;
   int64_t bytes;
 };
 
@@ -122,7 +122,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   }
   w.xt_t = take(M * E * es); w.dpre = take(M * F * es); w.dt = take(M * F * es);
   w.dlog_t = take(M * npad * es); w.dd_t = take(M * F * es); w.dxt = (float*)take(M * E * 4);
-  w.gA = (float*)take(M * E * 4); w.gB = (float*)take(M * E * 4);
+  w.gA = (float*)take(M * E * 4);
   w.dctx_t = take(M * E * es);
   w.delta = (float*)take((int64_t)B * d.nhead * S * 4);
   w.bytes = cur;
@@ -329,19 +329,21 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
     const LayerP &p = L.layer[l], &t = L.layer_t[l];
     LayerWs& a = w.layer[l];
     // LN2
-    PFN_TRY(launch_layernorm_bwd(w.gA, a.y2, params + p.g2, a.mean2, a.rstd2, w.gB, a.dy2_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
+    // LN2: the input gradient leaves only in operand precision (dy2_t); it is both the GEMM operand below and the
+    // residual-branch gradient that the dx1 GEMM adds back, so no f32 copy is written or re-read
+    PFN_TRY(launch_layernorm_bwd(w.gA, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
       GemmNT g = nt(a.dy2_t, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = a.hpre; g.ld_aux = F; g.out_t = a.dh_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     {  // dx1 = dh . W1 + dy2
-      GemmNT g = nt(a.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID | EPI_OUT_F32);
-      g.resid = w.gB; g.ld_resid = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
+      GemmNT g = nt(a.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID_T | EPI_OUT_F32);
+      g.aux = a.dy2_t; g.ld_aux = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     // LN1
-    PFN_TRY(launch_layernorm_bwd(w.gA, a.y1, params + p.g1, a.mean1, a.rstd1, w.gB, a.dy1_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
+    PFN_TRY(launch_layernorm_bwd(w.gA, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, a.dy1_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
     {  // d(ctx) = dy1 . Wo
       GemmNT g = nt(a.dy1_t, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
       g.out_t = w.dctx_t; g.ld_out_t = E;
@@ -354,8 +356,8 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     {  // dx = dqkv . Win + dy1
-      GemmNT g = nt(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID | EPI_OUT_F32);
-      g.resid = w.gB; g.ld_resid = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
+      GemmNT g = nt(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID_T | EPI_OUT_F32);
+      g.aux = a.dy1_t; g.ld_aux = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
   }

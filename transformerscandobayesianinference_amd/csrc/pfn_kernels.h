@@ -17,6 +17,7 @@ enum : int {
   EPI_OUT_T = 32,    // store operand type T
   EPI_OUT2_T = 64,   // store pre-activation (before GELU) as T
   EPI_ACCUM = 128,   // out_f32 += v
+  EPI_RESID_T = 256, // + aux[m,n] (T): residual taken from an operand-precision tensor (not with EPI_GELU_BWD)
 };
 
 struct GemmNT {

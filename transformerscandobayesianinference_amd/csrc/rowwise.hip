@@ -148,39 +148,43 @@ template <int NF8>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
   extern __shared__ float xs[];  // [EMBB_TOK][NF8] : x features, y (masked), train flag, zero pad to 8
   const long ntok = (long)a.B * a.S;
-  const long t0 = (long)blockIdx.x * EMBB_TOK;
-  for (int i = threadIdx.x; i < EMBB_TOK * NF8; i += 256) {
-    const int tk = i / NF8, f = i % NF8;
-    const long tok = t0 + tk;
-    float v = 0.f;
-    if (tok < ntok) {
-      const long b = tok / a.S, sidx = tok % a.S;
-      if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
-      else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
-      else if (f == a.nf + 1) v = (sidx < a.sep) ? 1.f : 0.f;
-    }
-    xs[i] = v;
-  }
-  __syncthreads();
-  const int ntk = (int)std::min<long>(EMBB_TOK, ntok - t0);
   const int e = blockIdx.y * 256 + threadIdx.x;
-  if (e >= a.E) return;
   float acc[NF8];
 #pragma unroll
   for (int j = 0; j < NF8; ++j) acc[j] = 0.f;
   float db = 0.f;
-  const float* dcol = a.dsrc + t0 * a.E + e;
+  // each workgroup walks several token chunks (grid.x is capped) so the closing atomics stay few
+  for (long t0 = (long)blockIdx.x * EMBB_TOK; t0 < ntok; t0 += (long)gridDim.x * EMBB_TOK) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < EMBB_TOK * NF8; i += 256) {
+      const int tk = i / NF8, f = i % NF8;
+      const long tok = t0 + tk;
+      float v = 0.f;
+      if (tok < ntok) {
+        const long b = tok / a.S, sidx = tok % a.S;
+        if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
+        else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
+        else if (f == a.nf + 1) v = (sidx < a.sep) ? 1.f : 0.f;
+      }
+      xs[i] = v;
+    }
+    __syncthreads();
+    if (e >= a.E) continue;
+    const int ntk = (int)std::min<long>(EMBB_TOK, ntok - t0);
+    const float* dcol = a.dsrc + t0 * a.E + e;
 #pragma unroll 16
-  for (int tk = 0; tk < ntk; ++tk) {   // 16 independent loads in flight per thread
-    const float d = dcol[(long)tk * a.E];
-    db += d;
+    for (int tk = 0; tk < ntk; ++tk) {   // 16 independent loads in flight per thread
+      const float d = dcol[(long)tk * a.E];
+      db += d;
 #pragma unroll
-    for (int j = 0; j < NF8; j += 4) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + tk * NF8 + j);
+      for (int j = 0; j < NF8; j += 4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + tk * NF8 + j);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[j + q] += d * xv[q];
+        for (int q = 0; q < 4; ++q) acc[j + q] += d * xv[q];
+      }
     }
   }
+  if (e >= a.E) return;
 #pragma unroll
   for (int f = 0; f < NF8; ++f) {
     if (f < a.nf) unsafeAtomicAdd(a.dwx + (long)e * a.nf + f, acc[f]);
@@ -234,7 +238,8 @@ int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s) {
   const long ntok = (long)a.B * a.S;
   const int nf8 = (a.nf + 2 + 7) / 8 * 8;
   if (nf8 <= EMBB_MAXF) {
-    const dim3 grid((unsigned)((ntok + EMBB_TOK - 1) / EMBB_TOK), (a.E + 255) / 256);
+    const int ey = (a.E + 255) / 256;
+    const dim3 grid((unsigned)std::min<long>((ntok + EMBB_TOK - 1) / EMBB_TOK, std::max(1, 256 / ey)), ey);
     const size_t lds = (size_t)EMBB_TOK * nf8 * sizeof(float);
     switch (nf8) {
       case 8: hipLaunchKernelGGL(embed_bwd_kernel<8>, grid, dim3(256), lds, s, a); break;
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const flo
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2); ax[k][e] += o[e]; }
-          *reinterpret_cast<f32x4*>(dx32 + rw[u] * E + c) = o;
+          if (dx32) *reinterpret_cast<f32x4*>(dx32 + rw[u] * E + c) = o;
           if (dxt) st4<T>(dxt + rw[u] * E + c, o);
         }
       }
