@@ -120,8 +120,9 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   using C = AttnCfg<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
-  auto Kt = [&](int buf) { return smem + buf * (C::RIMG + C::CIMG); };
-  auto Vt = [&](int buf) { return smem + buf * (C::RIMG + C::CIMG) + C::RIMG; };
+  // two K buffers (row images) followed by three V buffers (col images): P.V runs one tile behind Q.K (below)
+  auto Kt = [&](int buf) { return smem + buf * C::RIMG; };
+  auto Vt = [&](int buf) { return smem + 2 * C::RIMG + buf * C::CIMG; };
 
   const AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
   const int b = wg.b, hd = wg.hd;
@@ -163,8 +164,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   }
 
   const int nfull = sep / C::KVB;
-  const bool has_edge = (sep % C::KVB) != 0;
-  const int ntiles = nfull + (has_edge ? 1 : 0);
+  const int ntiles = (sep + C::KVB - 1) / C::KVB;
   TileStage<T, C::KVB, C::RB, C::NT> sk, sv;
   if (ntiles > 0) {
     sk.issue(Kp, rs, sep, D);
@@ -174,23 +174,35 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   }
   __syncthreads();
 
-  // One key tile.  BUF (the LDS buffer) and EDGE (the ragged last tile, the only one that needs the
-  // key mask) are compile-time so LDS addresses fold into immediates and full tiles carry no masking.
-  // The running max is only raised -- and the accumulators only rescaled -- when some row's tile max
-  // exceeds it by more than RESCALE_THR (in log2 units): P stays below 2^THR, which neither the bf16
-  // operand rounding (relative) nor the f32 sums notice, and the O-wide rescale pass (the largest
-  // block of vector work in the loop) runs on the first tile and then almost never.
-  auto tile = [&](auto buf_c, auto edge_c, int t) {
-    constexpr int BUF = decltype(buf_c)::value;
-    constexpr bool EDGE = decltype(edge_c)::value;
+  // Software pipeline over key tiles, P.V ONE TILE BEHIND Q.K:
+  //   iteration t :  S = K_t Q^T (MFMA)  |  running-max check (rare rescale)  |  { P_t = exp2(S - m)  +  O += V_{t-1} P_{t-1} }
+  // The exponentials of tile t (the bulk of the vector work: fma, exp, row sums, bf16 packing) and the 16 P.V
+  // MFMAs of tile t-1 are independent and sit in one basic block, so the matrix pipe runs under the vector ALU
+  // instead of after it.  P_{t-1} waits in registers as packed operand fragments; V needs three LDS buffers
+  // (tile t-1 is read while tile t+1 is written), K two.
+  // The running max is only raised -- and O, the row sums and the pending P_{t-1} only rescaled -- when some row's
+  // tile max exceeds it by more than RESCALE_THR (log2 units): P stays below 2^THR, which neither the bf16
+  // operand rounding (relative) nor the f32 sums notice, and the O-wide rescale runs on the first tile and then
+  // almost never.  The key mask only runs on the ragged last tile.
+  constexpr int NPF = C::KVB / 16;
+  Frag<T> pf[NPF];                       // P_{t-1}, in the slot order the P.V MFMA consumes
+  auto pv_prev = [&](int vb) __attribute__((always_inline)) {
+    const lds_char* vt = Vt(vb);
+#pragma unroll
+    for (int c = 0; c < NPF; ++c)
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db)
+        o[db] = mma32(load_frag_tr_p<T, C::CS, 2>(vt, c * 16, db * 32), pf[c], o[db]);
+  };
+  int vb_prev = 0, vb_cur = 0;           // V buffer of tile t-1 / tile t
+  for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * C::KVB;
     if (t + 1 < ntiles) {
       const long k1 = k0 + C::KVB;
       sk.issue(Kp + k1 * rs, rs, sep - (int)k1, D);
       sv.issue(Vp + k1 * rs, rs, sep - (int)k1, D);
     }
-    const lds_char* kt = Kt(BUF);
-    const lds_char* vt = Vt(BUF);
+    const lds_char* kt = Kt(t & 1);
     f32x16 st[C::NKB];
 #pragma unroll
     for (int kb = 0; kb < C::NKB; ++kb)
@@ -201,15 +213,18 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
 #pragma unroll
       for (int kb = 0; kb < C::NKB; ++kb)
         st[kb] = mma32(load_frag_row_p<T, C::RS>(kt, kb * 32 + li, kk * 16), qf[kk], st[kb]);
-
+    if (t == nfull) {   // ragged last tile: keys >= sep do not exist
+#pragma unroll
+      for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + kb * 32 + acc_row(r, lane) >= sep) st[kb][r] = -INFINITY;
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < C::NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (EDGE && (k0 + kb * 32 + acc_row(r, lane) >= sep)) st[kb][r] = -INFINITY;
-        mx = fmaxf(mx, st[kb][r]);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mc = mx * scale_log2;
     if (__builtin_amdgcn_ballot_w64(mc > m + RESCALE_THR) != 0) {
@@ -221,45 +236,49 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
       for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-    float rsum = 0.f;
+      if (t > 0) {     // P_{t-1} is still at the old maximum
 #pragma unroll
-    for (int kb = 0; kb < C::NKB; ++kb)
+        for (int c = 0; c < NPF; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(__builtin_fmaf(st[kb][r], scale_log2, -m));
-        st[kb][r] = p;
-        rsum += p;
+          for (int e = 0; e < 8; ++e) pf[c].set(e, frag_get(pf[c], e) * alpha);
       }
-    lsum += rsum;
-#pragma unroll
-    for (int c = 0; c < C::KVB / 16; ++c) {
-      const Frag<T> pf = acc_to_frag<T>(st[c >> 1], c & 1);
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db)
-        o[db] = mma32(load_frag_tr_p<T, C::CS, 2>(vt, c * 16, db * 32), pf, o[db]);
     }
+    if (t > 0) {
+      // one basic block: exponentials of tile t + P.V MFMAs of tile t-1
+      float rsum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(__builtin_fmaf(st[kb][r], scale_log2, -m));
+          st[kb][r] = p;
+          rsum += p;
+        }
+      lsum += rsum;
+      pv_prev(vb_prev);
+    } else {
+      float rsum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(__builtin_fmaf(st[kb][r], scale_log2, -m));
+          st[kb][r] = p;
+          rsum += p;
+        }
+      lsum += rsum;
+    }
+#pragma unroll
+    for (int c = 0; c < NPF; ++c) pf[c] = acc_to_frag<T>(st[c >> 1], c & 1);
+    vb_prev = vb_cur;
+    vb_cur = vb_cur == 2 ? 0 : vb_cur + 1;
     if (t + 1 < ntiles) {
-      sk.template commit_p<C::RS>(Kt(BUF ^ 1));
-      sv.template commit_p<C::CS>(Vt(BUF ^ 1));
+      sk.template commit_p<C::RS>(Kt((t + 1) & 1));
+      sv.template commit_p<C::CS>(Vt(vb_cur));
     }
     __syncthreads();
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  {
-    int t = 0;
-    for (; t + 2 <= nfull; t += 2) {
-      tile(I0{}, std::false_type{}, t);
-      tile(I1{}, std::false_type{}, t + 1);
-    }
-    if (t < nfull) {
-      tile(I0{}, std::false_type{}, t);
-      if (has_edge) tile(I1{}, std::true_type{}, t + 1);
-    } else if (has_edge) {
-      tile(I0{}, std::true_type{}, t);
-    }
   }
+  if (ntiles > 0) pv_prev(vb_prev);
 
   lsum += __shfl_xor(lsum, 32, 64);
   const float inv = 1.f / lsum;
@@ -625,7 +644,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dkv_kernel(AttnA
 // =============================================================================================
 template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
-  const size_t lds = 2 * (C::RIMG + C::CIMG);
+  const size_t lds = 2 * C::RIMG + 3 * C::CIMG;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
