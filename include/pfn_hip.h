@@ -137,6 +137,20 @@ int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws,
                         int B, int S, int nf, int kernel, int gen_x, int gen_z,
                         uint64_t seed, uint64_t offset, int32_t* info, void* stream);
 
+/* ---- BNN prior sampler: replaces the per-dataset module forwards of priors.mlp.get_batch (priors/mlp.py:116-124
+ * network, :150-157 forward of the non-causal branch, :195-197 Python loop over datasets).  For dataset b with model
+ * m = model_of[b]:  h_0 = causes W_0^T + b_0;  h_l = act(h_{l-1}) W_l^T + b_l + noise_std[m] * eps_l  (1 <= l < L_m);
+ * y[b,t] = h_{L-1}[t, 0].
+ * weights [num_models][Lmax][HP][HP] f32: layer l stored TRANSPOSED ([in][out]) and zero padded to HP (a multiple of 4,
+ * <= 152); biases [num_models][Lmax][HP]; dims [num_models][3] = (num_causes, hidden, num_layers); noise_std [num_models].
+ * causes [B][T][HP]: filled with N(0,1) in the first num_causes columns when gen_causes != 0 (the x of the dataset),
+ * else taken as input.  noise: NULL (generated, Philox) or [B][Lmax-1][T][HP] standard normals.
+ * activation: 0 identity, 1 relu, 2 tanh, 3 sigmoid. */
+int pfn_mlp_prior_forward(const float* weights, const float* biases, const int32_t* model_of, const int32_t* dims,
+                          const float* noise_std, float* causes, const float* noise, float* y,
+                          int B, int T, int HP, int Lmax, int activation, int gen_causes,
+                          uint64_t seed, uint64_t offset, void* stream);
+
 /* ---- single-op entry points (unit tests / profiling of individual kernels) --------------------
  * prec selects operand element type T: bf16 (2 bytes) or f32. */
 int pfn_op_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

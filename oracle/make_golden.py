@@ -146,6 +146,46 @@ def utils_case(ref):
     print('utils ok')
 
 
+def mlp_prior_case(ref):
+    """Runs the reference's priors.mlp.get_batch (non-causal tabular configuration) and records,
+    by intercepting the torch calls it makes, every tensor a restatement needs to reproduce its output: the initialised
+    parameters of each model, the cause / noise draws of each dataset in call order, the order_by_y coin flips."""
+    import numpy as np
+    from priors import mlp as ref_mlp
+    from priors import utils as ref_putils
+    T, B, NF, PER = 48, 6, 7, 3
+    hps = (lambda: 3, ref_putils.scaled_beta_sampler_f(2., 4., 20, 2), torch.nn.Tanh,
+           ref_putils.gamma_sampler_f(3.6187797729244253, 0.06773738681062867), ref_putils.gamma_sampler_f(1.8663049257557085, 0.05275478076173361),
+           lambda: 0.0, True, ref_putils.scaled_beta_sampler_f(1., 1.6, NF, 2), None, False, None, None, None, True, False, lambda n: ([], []), 0.0)
+    torch.manual_seed(21); random.seed(21); np.random.seed(21)
+    rec = dict(config=dict(T=T, B=B, NF=NF, PER=PER, activation='tanh'), params=[], normals=[], coins=[])
+    orig_init, orig_normal, orig_randint = torch.nn.init.normal_, torch.normal, random.randint
+
+    def init_normal(p, mean=0., std=1.):
+        out = orig_init(p, mean=mean, std=std)
+        rec['params'].append(p.detach().clone())
+        return out
+
+    def normal(*a, **k):
+        out = orig_normal(*a, **k)
+        rec['normals'].append(out.detach().clone())
+        return out
+
+    def randint(a, b):
+        v = orig_randint(a, b)
+        rec['coins'].append(v)
+        return v
+
+    torch.nn.init.normal_, torch.normal, random.randint = init_normal, normal, randint
+    try:
+        x, y, _ = ref_mlp.get_batch(B, T, NF, device='cpu', hyperparameters=hps, batch_size_per_gp_sample=PER)
+    finally:
+        torch.nn.init.normal_, torch.normal, random.randint = orig_init, orig_normal, orig_randint
+    rec['x'], rec['y'] = x.clone(), y.clone()
+    torch.save(rec, os.path.join(OUT, 'mlp_prior.pt'))
+    print('mlp prior', x.shape, y.shape, 'params', len(rec['params']), 'normals', len(rec['normals']), 'coins', rec['coins'], 'y mean', float(y.mean()))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -154,3 +194,4 @@ if __name__ == '__main__':
     model_case(ref, 'model_small_h64', T=100, B=4, F=5, E=128, H=2, nhid=72, L=1, nbars=100, seps=[70, 33], seed=12)
     bar_case(ref)
     utils_case(ref)
+    mlp_prior_case(ref)

@@ -186,3 +186,39 @@ def get_batch_fast_gp(batch_size, seq_len, num_features, hyperparameters=None, g
     y = gp_sample(x, z, hyperparameters["lengthscale"], hyperparameters["outputscale"], max(hyperparameters["noise"], 1e-9), 'rbf', dtype)
     y = y.float()
     return x.transpose(0, 1), y.transpose(0, 1), y.transpose(0, 1)
+
+
+# ---- BNN prior (priors.mlp) ----------------------------------------------------------------------------
+def _activation(name):
+    return {'tanh': torch.tanh, 'relu': torch.relu, 'identity': (lambda v: v), 'sigmoid': torch.sigmoid}[name]
+
+
+def mlp_prior_forward(weights, biases, causes, noises, activation='tanh'):
+    """One dataset of the non-causal BNN prior (reference priors/mlp.py:116-157): `causes` [T, nc] feed
+    Linear(nc, h); every further layer is activation -> Linear -> additive Gaussian noise (:117-124, GaussianNoise
+    :32-38).  weights[l] is [out_l, in_l] (torch Linear layout), noises[l-1] the already drawn noise of layer l >= 1.
+    Returns the last layer's output [T] (y before normalisation; x is `causes`)."""
+    act = _activation(activation)
+    h = causes @ weights[0].t() + biases[0]
+    for l in range(1, len(weights)):
+        h = act(h) @ weights[l].t() + biases[l] + noises[l - 1]
+    return h.squeeze(-1)
+
+
+def mlp_prior_postprocess(x, y, num_features, binary=True, order_sign=None, nfu_scale=None):
+    """x [T, nfu], y [T] of one dataset -> (x [T, num_features], y [T]) as the reference's MLP.forward does after the
+    network (:185-201): normalize_data over the sequence axis (unbiased std, + 1e-6; priors/utils.py:73-78), median
+    binarisation (Binarize :85-91, torch.median = lower median), optional division by the used-feature share (:191-192),
+    order_by_y (:94-100; order_sign = +1 sorts by y, -1 by -y) and zero padding of the unused features (:198)."""
+    norm = lambda d: (d - d.mean(0)) / (d.std(0) + .000001)
+    x, y = norm(x), norm(y)
+    if binary:
+        y = (y > torch.median(y)).to(x.dtype)
+    if nfu_scale is not None:
+        x = x / nfu_scale
+    if binary and order_sign is not None:
+        order = torch.argsort(y * order_sign, dim=0, stable=False)
+        order = order.reshape(2, -1).transpose(0, 1).reshape(-1)
+        x, y = x[order], y[order]
+    pad = torch.zeros(x.shape[0], num_features - x.shape[1], dtype=x.dtype)
+    return torch.cat([x, pad], -1), y

@@ -234,3 +234,140 @@ def test_gp_prior_sampler_statistics():
     assert (emp - K).abs().max().item() < 0.12
     ys2 = fast_gp.get_batch(64, 24, 3, device=DEV, hyperparameters=(0.05, 1.0, 0.8))[1]
     assert not torch.equal(ys, ys2)
+
+
+def test_gp_mix_sampler_per_dataset_hyperparameters_vs_oracle():
+    """priors.fast_gp_mix path of the sampler: Matern-5/2, ARD lengthscales and per-dataset outputscale / noise,
+    against the f64 restatement on injected (x, z) (reference priors/fast_gp_mix.py:28-47, 96-99)."""
+    from transformerscandobayesianinference_amd.priors import fast_gp, fast_gp_mix
+    g = torch.Generator().manual_seed(5)
+    for (B, T, F) in [(4, 130, 3), (3, 516, 18)]:
+        x = torch.rand(B, T, F, generator=g)
+        z = torch.randn(B, T, generator=g)
+        ls, osc, nz = fast_gp_mix.sample_hyperparameters(B, F, None, 'cpu', generator=g)
+        ls = ls.clamp_min(0.05)   # keep cond(K) where an f32 Cholesky is meaningful for the comparison
+        want = pfn_oracle.gp_sample(x, z, ls, osc, nz, 'matern')
+        _, got, _, info = fast_gp.gp_sample(B, T, F, DEV, ls, osc, nz, fast_gp.KERNEL_MATERN52, x=x, z=z)
+        assert int(info.abs().sum()) == 0
+        assert relerr(got, want) < 2e-3, (B, T, F, relerr(got, want))
+
+
+def test_gp_mix_get_batch_and_validate():
+    from transformerscandobayesianinference_amd.priors import fast_gp_mix
+    torch.manual_seed(11)
+    x, y, t = fast_gp_mix.get_batch(20, 64, 4, device=DEV)
+    assert x.shape == (64, 20, 4) and y.shape == (64, 20) and t is y
+    assert torch.isfinite(y).all() and 0 <= x.min() and x.max() < 1
+    # the default hyper-prior has E[noise] = 22 and E[outputscale] = 3.3: marginal std of y is sqrt(os + noise)
+    _, ybig, _ = fast_gp_mix.get_batch(400, 32, 2, device=DEV)
+    assert 3.0 < ybig.std().item() < 8.0
+    xn, yn, _ = fast_gp_mix.get_batch(10, 50, 2, device=DEV, hyperparameters={'y_minmax_norm': True})
+    assert yn.min().item() == 0.0 and yn.max().item() == 1.0
+    hp = {'outputscale_concentration': 2.0, 'outputscale_rate': 40.0, 'noise_concentration': 1.1, 'noise_rate': 400.0}
+    xr, yr, _ = fast_gp_mix.get_batch(16, 40, 2, device=DEV, hyperparameters=hp, fix_to_range=(-1.0, 1.0))
+    assert yr.shape == (40, 16) and yr.min() >= -1.0 and yr.max() < 1.0
+    # DataLoader.validate: forward-only sweeps over the evaluation positions through the HIP stack
+    dl = fast_gp_mix.DataLoader(num_steps=1, batch_size=4, seq_len=24, num_features=3, device=DEV, hyperparameters=hp)
+    borders = bar_distribution.get_bucket_limits(20, ys=yr.flatten().cpu())
+    model = TransformerModel(encoders.Linear(3, 64), 20, 64, 2, 128, 1, 0.0, y_encoder=encoders.Linear(1, 64), precision='bf16')
+    model.criterion = bar_distribution.FullSupportBarDistribution(borders)
+    model.to(DEV)
+    scores = dl.validate(model, step_size=6, start_pos=3)
+    assert scores.shape == (4,) and torch.isfinite(scores).all()
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_mlp_prior_kernel_vs_reference_golden():
+    """The BNN-prior kernel on the very tensors the reference drew (tests/golden/mlp_prior.pt): injected parameters,
+    causes and layer noise must reproduce the reference's priors.mlp.get_batch output."""
+    from transformerscandobayesianinference_amd.priors import mlp
+    rec = torch.load(os.path.join(GOLD, 'mlp_prior.pt'))
+    cfg = rec['config']
+    T, B, NF, PER = cfg['T'], cfg['B'], cfg['NF'], cfg['PER']
+    M = B // PER
+    weights = [[rec['params'][6 * m + 2 * l] for l in range(3)] for m in range(M)]
+    biases = [[rec['params'][6 * m + 2 * l + 1] for l in range(3)] for m in range(M)]
+    W, b, dims, HP = mlp.pack_networks(weights, biases, DEV)
+    causes = torch.zeros(B, T, HP)
+    noise = torch.zeros(B, 2, T, HP)
+    for i in range(B):
+        c, n1, n2 = [t[:, 0, :] for t in rec['normals'][3 * i: 3 * i + 3]]
+        causes[i, :, :c.shape[1]] = c
+        noise[i, 0, :, :n1.shape[1]] = n1
+        noise[i, 1, :, :n2.shape[1]] = n2
+    model_of = (torch.arange(B, dtype=torch.int32) // PER).to(DEV)
+    ones = torch.ones(M, device=DEV)   # the recorded noise tensors already carry their std
+    got_c, y_raw = mlp.forward_networks(W, b, dims, ones, model_of, T, 2, causes=causes.to(DEV), noise=noise.to(DEV))
+    nfu = dims[:, 0][model_of.long()]
+    for i in range(B):
+        m = i // PER
+        want = pfn_oracle.mlp_prior_forward([w_.double() for w_ in weights[m]], [b_.double() for b_ in biases[m]], causes[i, :, :weights[m][0].shape[1]].double(),
+                                            [noise[i, 0, :, :weights[m][1].shape[0]].double(), noise[i, 1, :, :1].double()], 'tanh')
+        assert relerr(y_raw[i], want) < 1e-5, (i, relerr(y_raw[i], want))
+    sign = torch.tensor([1.0 if c else -1.0 for c in rec['coins']], device=DEV)
+    x, y = mlp.postprocess(got_c, y_raw, nfu, NF, True, sign)
+    assert torch.equal(y.cpu().t(), rec['y'])            # class pattern after order_by_y
+    xr = rec['x'].transpose(0, 1)                        # [B,T,NF]; ties inside a class may be ordered differently:
+    for i in range(B):                                   # compare each class's rows as sorted sets
+        for cls in (0.0, 1.0):
+            a_ = x[i][y[i] == cls].cpu()
+            b_ = xr[i][rec['y'][:, i] == cls]
+            assert torch.allclose(a_[a_[:, 0].argsort()], b_[b_[:, 0].argsort()], atol=2e-5, rtol=2e-5), (i, cls)
+
+
+def test_mlp_prior_get_batch():
+    from transformerscandobayesianinference_amd.priors import mlp
+    from transformerscandobayesianinference_amd.priors.utils import gamma_sampler_f, scaled_beta_sampler_f
+    import numpy as np
+    torch.manual_seed(3); random.seed(3); np.random.seed(3)
+    hps = (lambda: 3, scaled_beta_sampler_f(2., 4., 150, 2), torch.nn.Tanh, gamma_sampler_f(3.6187797729244253, 0.06773738681062867),
+           gamma_sampler_f(1.8663049257557085, 0.05275478076173361), lambda: 0.0, True, scaled_beta_sampler_f(1., 1.6, 60, 2),
+           None, False, None, None, None, True, False, lambda n: ([], []), 0.0)
+    x, y, t = mlp.get_batch(64, 1000, 60, device=DEV, hyperparameters=hps, batch_size_per_gp_sample=8)
+    assert x.shape == (1000, 64, 60) and y.shape == (1000, 64) and t is y
+    assert set(y.unique().tolist()) <= {0.0, 1.0}
+    assert (y.mean(0) - 0.5).abs().max() <= 0.002             # median split of 1000 rows
+    assert torch.equal(y[0::2].sum(0) + y[1::2].sum(0), y.sum(0))
+    used = (x.abs().sum(0) > 0)                                 # [B, F]
+    assert (used.sum(1) >= 2).all() and (used.sum(1) <= 60).all()
+    xm, xs = x.mean(0)[used], x.std(0)[used]
+    assert xm.abs().max() < 1e-3 and (xs - 1).abs().max() < 1e-3
+    # order_by_y interleaves the sorted halves: row 2k comes from the first half, row 2k+1 from the second
+    d = (y[1::2] - y[0::2])
+    assert (d.abs().sum(0) > 0).all() and ((d >= 0).all(0) | (d <= 0).all(0)).all()
+    # the DataLoader protocol (prefetching iterator) and a second, different draw
+    dl = mlp.DataLoader(num_steps=2, batch_size=16, seq_len=100, num_features=60, device=DEV, hyperparameters=hps, batch_size_per_gp_sample=8)
+    batches = list(dl)
+    assert len(batches) == 2 and batches[0][0][0].shape == (100, 16, 60)
+    assert not torch.equal(batches[0][0][0], batches[1][0][0])
+
+
+def test_train_entry_point_with_every_prior():
+    """train() (reference train.py:22-135 call surface) drives all three priors through the HIP stack: GP + adaptive
+    full-support bar NLL (configs 1-3), BNN prior + BCE (config 4, tabular.py:129), GP mixture + bar NLL with its
+    validate() sweep (config 5)."""
+    import numpy as np
+    from transformerscandobayesianinference_amd import train as train_mod, utils as u
+    from transformerscandobayesianinference_amd.priors import fast_gp, fast_gp_mix, mlp
+    from transformerscandobayesianinference_amd.priors.utils import gamma_sampler_f, scaled_beta_sampler_f
+    torch.manual_seed(1); random.seed(1); np.random.seed(1)
+    common = dict(emsize=64, nhid=128, nlayers=2, nhead=2, dropout=0.0, epochs=2, steps_per_epoch=2, batch_size=8, lr=1e-3, warmup_epochs=1,
+                  y_encoder_generator=encoders.Linear, gpu_device=DEV, verbose=False)
+    ys = fast_gp.get_batch(64, 20, 3, device=DEV, hyperparameters=(1e-4, 1., .6))[1].cpu()
+    crit = bar_distribution.FullSupportBarDistribution(bar_distribution.get_bucket_limits(20, ys=ys))
+    loss, pos, model = train_mod.train(fast_gp.DataLoader, crit, encoders.Linear, bptt=40, single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(40),
+                                       extra_prior_kwargs_dict={'num_features': 3, 'hyperparameters': (1e-4, 1., .6), 'device': DEV}, **common)
+    assert math.isfinite(loss) and next(model.parameters()).device.type == 'cpu'
+    hps = (lambda: 3, scaled_beta_sampler_f(2., 4., 30, 2), torch.nn.Tanh, gamma_sampler_f(3.6, 0.07), gamma_sampler_f(1.9, 0.05), lambda: 0.0, True,
+           scaled_beta_sampler_f(1., 1.6, 12, 2), None, False, None, None, None, True, False, lambda n: ([], []), 0.0)
+    loss, pos, model = train_mod.train(mlp.DataLoader, train_mod.Losses.bce, encoders.Linear, bptt=40, single_eval_pos_gen=u.get_uniform_single_eval_pos_sampler(40),
+                                       extra_prior_kwargs_dict={'num_features': 12, 'hyperparameters': hps, 'batch_size_per_gp_sample': 4, 'device': DEV}, **common)
+    assert math.isfinite(loss) and 0.3 < loss < 1.5          # BCE of a barely trained classifier on balanced labels
+    mix_hp = {'outputscale_concentration': 2.0, 'outputscale_rate': 40.0, 'noise_concentration': 1.1, 'noise_rate': 400.0}
+    ys = fast_gp_mix.get_batch(64, 20, 3, device=DEV, hyperparameters=mix_hp)[1].cpu()
+    crit = bar_distribution.FullSupportBarDistribution(bar_distribution.get_bucket_limits(20, ys=ys))
+    loss, pos, model = train_mod.train(fast_gp_mix.DataLoader, crit, encoders.Linear, bptt=40, single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(40),
+                                       validation_period=1, extra_prior_kwargs_dict={'num_features': 3, 'hyperparameters': mix_hp, 'device': DEV}, **common)
+    assert math.isfinite(loss)

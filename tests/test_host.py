@@ -238,3 +238,16 @@ def test_data_parallel_helpers_over_gloo(tmp_path):
                           '--master-port', '29533', str(script), ROOT], capture_output=True, text=True, env=env, timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count('ok') == 2
+
+
+def test_gp_mix_hyperprior_moments():
+    """Gamma hyper-priors of priors.fast_gp_mix (reference :26,33,37): E[lengthscale] = 3/6, E[outputscale] = .5/.15,
+    noise ~ Gamma(1.1, .05) floored at 1e-4."""
+    from transformerscandobayesianinference_amd.priors import fast_gp_mix
+    g = torch.Generator().manual_seed(0)
+    ls, osc, nz = fast_gp_mix.sample_hyperparameters(40000, 2, None, 'cpu', generator=g)
+    assert ls.shape == (40000, 2) and abs(ls.mean().item() - 0.5) < 0.01 and abs(ls.var().item() - 3 / 36) < 0.005
+    assert abs(osc.mean().item() - 0.5 / 0.15) < 0.1
+    assert abs(nz.mean().item() - 22.0) < 0.5 and nz.min().item() >= 1e-4
+    ls2, _, nz2 = fast_gp_mix.sample_hyperparameters(1000, 3, {'lengthscale_concentration': 2.0, 'lengthscale_rate': 4.0, 'noise_concentration': 0.01, 'noise_rate': 100.0}, 'cpu', generator=g)
+    assert abs(ls2.mean().item() - 0.5) < 0.05 and (nz2 >= 1e-4).all() and (nz2 == 1e-4).any()

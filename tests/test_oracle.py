@@ -117,3 +117,22 @@ def test_gp_oracle_covariance():
     assert abs(K[0, 0].item() - 1.5) < 1e-6
     xs, ys, ts = pfn_oracle.get_batch_fast_gp(4, 10, 3, (0.1, 0.1, 0.1), g)
     assert xs.shape == (10, 4, 3) and ys.shape == (10, 4) and ts.shape == (10, 4)
+
+
+def test_oracle_mlp_prior_matches_reference():
+    """priors.mlp.get_batch of the reference (non-causal tabular BNN prior) re-built by the oracle from the tensors the
+    reference itself drew (tests/golden/mlp_prior.pt, recorded by oracle/make_golden.py::mlp_prior_case)."""
+    rec = torch.load(os.path.join(GOLD, 'mlp_prior.pt'))
+    cfg = rec['config']
+    T, B, NF, PER = cfg['T'], cfg['B'], cfg['NF'], cfg['PER']
+    for i in range(B):
+        m = i // PER
+        W = [rec['params'][6 * m + 2 * l] for l in range(3)]
+        b = [rec['params'][6 * m + 2 * l + 1] for l in range(3)]
+        causes, n1, n2 = [t[:, 0, :] for t in rec['normals'][3 * i: 3 * i + 3]]
+        y_raw = pfn_oracle.mlp_prior_forward(W, b, causes, [n1, n2], cfg['activation'])
+        sign = 1.0 if rec['coins'][i] else -1.0
+        x, y = pfn_oracle.mlp_prior_postprocess(causes, y_raw, NF, binary=True, order_sign=sign)
+        assert torch.equal(y, rec['y'][:, i]), i
+        assert torch.allclose(x, rec['x'][:, i, :], atol=1e-5, rtol=1e-5), i
+        assert x[:, causes.shape[1]:].abs().max() == 0

@@ -27,26 +27,6 @@ namespace pfn {
 
 constexpr int NB = 64;  // panel width
 
-// ---------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011), counter = (index, stream), key = seed
-// ---------------------------------------------------------------------------------------------
-struct U4 { unsigned x, y, z, w; };
-PFN_DEV U4 philox4x32_10(unsigned long long idx, unsigned long long stream, unsigned long long seed) {
-  unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)stream, c3 = (unsigned)(stream >> 32);
-  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return U4{c0, c1, c2, c3};
-}
-PFN_DEV float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }             // [0,1)
-PFN_DEV float u01_open(unsigned r) { return ((float)(r >> 8) + 1.f) * 5.9604644775390625e-8f; }  // (0,1]
-
 __global__ __launch_bounds__(256) void gp_rng_kernel(GpArgs a) {
   const long nx = (long)a.B * a.S * a.nf, nz = (long)a.B * a.S;
   const long nx4 = (nx + 3) / 4, nz4 = (nz + 3) / 4;

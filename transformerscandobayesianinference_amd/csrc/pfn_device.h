@@ -298,4 +298,33 @@ PFN_DEV float wave_max(float v) {
 }
 template <typename T> PFN_DEV float to_f(T x) { return (float)x; }
 
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter = (index, stream), key = seed
+// ---------------------------------------------------------------------------------------------
+struct U4 { unsigned x, y, z, w; };
+PFN_DEV U4 philox4x32_10(unsigned long long idx, unsigned long long stream, unsigned long long seed) {
+  unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)stream, c3 = (unsigned)(stream >> 32);
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+PFN_DEV float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }             // [0,1)
+PFN_DEV float u01_open(unsigned r) { return ((float)(r >> 8) + 1.f) * 5.9604644775390625e-8f; }  // (0,1]
+
+// four standard normals from one Philox block (Box-Muller)
+PFN_DEV void normal4(const U4& r, float (&n)[4]) {
+  const float r0 = sqrtf(-2.f * __logf(u01_open(r.x))), r1 = sqrtf(-2.f * __logf(u01_open(r.z)));
+  float s0, c0, s1, c1;
+  __sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+  __sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+  n[0] = r0 * c0; n[1] = r0 * s0; n[2] = r1 * c1; n[3] = r1 * s1;
+}
+
 }  // namespace pfn

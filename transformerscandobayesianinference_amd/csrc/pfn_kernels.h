@@ -168,4 +168,19 @@ struct GpArgs {
 };
 int launch_gp_sample(const GpArgs& a, hipStream_t s);
 
+// ---- BNN prior sampler (mlp_prior.hip) -----------------------------------------------------------
+struct MlpPriorArgs {
+  const float* weights;   // [num_models][Lmax][HP][HP]: layer l transposed ([in][out]), zero padded
+  const float* biases;    // [num_models][Lmax][HP], zero padded
+  const int* model_of;    // [B] model index of each dataset
+  const int* dims;        // [num_models][3] = (num_causes, hidden, num_layers)
+  const float* noise_std; // [num_models]
+  float* causes;          // [B][T][HP]: N(0,1) in the first num_causes columns, written when gen_causes != 0, else input
+  const float* noise;     // optional [B][Lmax-1][T][HP] injected standard normals (else generated)
+  float* y;               // [B][T] last layer, column 0
+  int B, T, HP, Lmax, activation, gen_causes;
+  unsigned long long seed, offset;
+};
+int launch_mlp_prior(const MlpPriorArgs& a, hipStream_t s);
+
 }  // namespace pfn

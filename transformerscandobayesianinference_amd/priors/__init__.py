@@ -1,3 +1,3 @@
-"""Priors on the hot path: fast_gp (GP, RBF), with prior / utils plumbing.  Unlike the reference
+"""Priors on the hot path: fast_gp (GP, RBF), fast_gp_mix (Matern-5/2 ARD with Gamma hyper-priors), mlp (BNN prior), with prior / utils plumbing.  Unlike the reference
 package (priors/__init__.py:1) nothing here depends on gpytorch / botorch / pyro."""
-from transformerscandobayesianinference_amd.priors import prior, utils, fast_gp  # noqa: F401
+from transformerscandobayesianinference_amd.priors import prior, utils, fast_gp, fast_gp_mix, mlp  # noqa: F401

@@ -41,17 +41,27 @@ def gp_sample(batch_size, seq_len, num_features, device, lengthscale, outputscal
     osc = per_dataset(outputscale, (B,))
     nz = per_dataset(noise, (B,))
     gen_x, gen_z = x is None, z is None
-    x = torch.empty(B, T, F, dtype=torch.float32, device=dev) if gen_x else x.to(dev).float().contiguous()
-    z = torch.empty(B, T, dtype=torch.float32, device=dev) if gen_z else z.to(dev).float().contiguous()
-    y = torch.empty(B, T, dtype=torch.float32, device=dev)
-    K = torch.empty(B, T, T, dtype=torch.float32, device=dev)
+    # the kernels want 16-byte aligned matrix rows (T % 4 == 0): draw the GP at up to 3 extra points and drop them --
+    # the marginal of a GP on the first T points is unchanged, and with L lower triangular (L z)[:T] only sees z[:T]
+    Tp = (T + 3) // 4 * 4
+    if Tp != T:
+        if not gen_x:
+            x = torch.cat([x.to(dev).float(), torch.rand(B, Tp - T, F, device=dev)], 1)
+        if not gen_z:
+            z = torch.cat([z.to(dev).float(), torch.zeros(B, Tp - T, device=dev)], 1)
+    x = torch.empty(B, Tp, F, dtype=torch.float32, device=dev) if gen_x else x.to(dev).float().contiguous()
+    z = torch.empty(B, Tp, dtype=torch.float32, device=dev) if gen_z else z.to(dev).float().contiguous()
+    y = torch.empty(B, Tp, dtype=torch.float32, device=dev)
+    K = torch.empty(B, Tp, Tp, dtype=torch.float32, device=dev)
     info = torch.zeros(B, dtype=torch.int32, device=dev)
     if seed is None:
         seed = torch.initial_seed()
     _call_counter[0] += 1
     _hip.check(lib.pfn_gp_prior_sample(x.data_ptr(), z.data_ptr(), y.data_ptr(), K.data_ptr(), ls.data_ptr(), osc.data_ptr(),
-                                       nz.data_ptr(), B, T, F, kernel, int(gen_x), int(gen_z), seed & (2 ** 64 - 1),
+                                       nz.data_ptr(), B, Tp, F, kernel, int(gen_x), int(gen_z), seed & (2 ** 64 - 1),
                                        _call_counter[0], info.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_prior_sample')
+    if Tp != T:
+        x, y, z = x[:, :T].contiguous(), y[:, :T].contiguous(), z[:, :T].contiguous()
     return x, y, z, info
 
 
