@@ -92,11 +92,22 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(bf)
     out = []
 
-    def gemm(name, m, n, k, count):
-        A, B_ = r(m, k), r(n, k)
-        o = torch.empty(m, n, dtype=bf, device=dev)
-        t = time_kernel(lambda: hipops.gemm_nt(A, B_, _hip.EPI_OUT_T, _hip.PREC_BF16, out_t=o))
-        out.append(dict(kernel=f'gemm_nt[{name} {m}x{n}x{k}]', launches_per_step=count, seconds=t, flops=2.0 * m * n * k))
+    f32 = lambda *s: torch.randn(*s, device=dev)
+    Hh = _hip
+
+    def gemm(name, n, k, flags, count):
+        """One encoder GEMM with its REAL epilogue (bias / GELU / residual / output streams), M = batch * bptt rows."""
+        A, B_ = r(M, k), r(n, k)
+        kw = {}
+        if flags & Hh.EPI_BIAS: kw['bias'] = f32(n)
+        if flags & Hh.EPI_RESID: kw['resid'] = f32(M, n)
+        if flags & (Hh.EPI_GELU_BWD | Hh.EPI_RESID_T): kw['aux'] = r(M, n)
+        if flags & Hh.EPI_OUT_F32: kw['out_f32'] = torch.empty(M, n, device=dev)
+        if flags & Hh.EPI_OUT_T: kw['out_t'] = torch.empty(M, n, dtype=bf, device=dev)
+        if flags & Hh.EPI_OUT2_T: kw['out2_t'] = torch.empty(M, n, dtype=bf, device=dev)
+        t = time_kernel(lambda: hipops.gemm_nt(A, B_, flags, Hh.PREC_BF16, **kw))
+        out.append(dict(kernel=f'gemm_nt[{name} {M}x{n}x{k}]', rocprof_name=f'gemm_nt_big_kernel<{flags}, 2, 64>', single=True,
+                        launches_per_step=count, seconds=t, flops=2.0 * M * n * k))
 
     def wgrad_group():
         # every weight gradient of the stack in ONE grouped launch (pfn_stack_backward defers them)
@@ -105,23 +116,26 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
             probs += [(r(M, E), r(M, F), torch.zeros(E, F, device=dev), None), (r(M, F), r(M, E), torch.zeros(F, E, device=dev), torch.zeros(F, device=dev)),
                       (r(M, E), r(M, E), torch.zeros(E, E, device=dev), None), (r(M, 3 * E), r(M, E), torch.zeros(3 * E, E, device=dev), torch.zeros(3 * E, device=dev))]
         t = time_kernel(lambda: hipops.gemm_tn_group(probs, 0), iters=5, warm=2)
-        out.append(dict(kernel=f'gemm_tn_group[{4 * L} weight gradients, {M} tokens]', launches_per_step=1, seconds=t, flops=2.0 * M * L * (2 * E * F + 4 * E * E)))
+        out.append(dict(kernel=f'gemm_tn_group[{4 * L} weight gradients, {M} tokens]', rocprof_name='gemm_tn_big_kernel', single=True,
+                        launches_per_step=1, seconds=t, flops=2.0 * M * L * (2 * E * F + 4 * E * E)))
 
-    gemm('qkv', M, 3 * E, E, L)
-    gemm('out_proj / dctx', M, E, E, 2 * L)
-    gemm('linear1', M, F, E, L)
-    gemm('linear2 / d(linear1)', M, E, F, 2 * L)
-    gemm('d(linear2)', M, F, E, L)
-    gemm('d(qkv)', M, E, 3 * E, L)
+    gemm('qkv', 3 * E, E, Hh.EPI_BIAS | Hh.EPI_OUT_T, L)
+    gemm('out_proj + residual', E, E, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
+    gemm('linear1 + GELU', F, E, Hh.EPI_BIAS | Hh.EPI_GELU | Hh.EPI_OUT_T | Hh.EPI_OUT2_T, L)
+    gemm('linear2 + residual', E, F, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
+    gemm('d(hpre) = dy2.W2 * gelu\'', F, E, Hh.EPI_GELU_BWD | Hh.EPI_OUT_T, L)
+    gemm('dx1 = dh.W1 + dy2', E, F, Hh.EPI_RESID_T | Hh.EPI_OUT_F32, L)
+    gemm('d(ctx) = dy1.Wo', E, E, Hh.EPI_OUT_T, L)
+    gemm('dx = dqkv.Win + dy1', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_F32, L)
     wgrad_group()
     qkv = r(batch, S, 3 * E)
     t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16))
     attn_fl = 4.0 * E * pairs(S, sep) * batch
-    out.append(dict(kernel='attn_fwd', launches_per_step=L, seconds=t, flops=attn_fl))
+    out.append(dict(kernel='attn_fwd', rocprof_name='attn_fwd_kernel', single=True, launches_per_step=L, seconds=t, flops=attn_fl))
     ctx, lse = hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16)
     dctx = r(batch, S, E)
     t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16))
-    out.append(dict(kernel='attn_bwd (delta + dq + dv + dk kernels)', launches_per_step=L, seconds=t, flops=2.0 * attn_fl))
+    out.append(dict(kernel='attn_bwd (delta + dq + dv + dk kernels)', rocprof_name='attn_bwd_*', single=False, launches_per_step=L, seconds=t, flops=2.0 * attn_fl))
     for k in out:
         k['tflops'] = k['flops'] / k['seconds'] / 1e12
         k['step_seconds'] = k['seconds'] * k['launches_per_step']
@@ -210,8 +224,7 @@ def main():
     seps = []
 
     def loader(num_steps):
-        # the reference's DataLoader protocol (priors/utils.py); draws are prefetched one step ahead on a
-        # side stream, every draw of a loader happens after iter() is called (inside the timed region)
+        # the reference's DataLoader protocol (priors/utils.py); draws run a group of steps ahead on a side stream
         return iter(fast_gp.DataLoader(num_steps=num_steps, batch_size=args.batch, seq_len=S, num_features=nf,
                                        hyperparameters=w['hyperparameters'], device=device))
 
@@ -233,15 +246,19 @@ def main():
         torch.cuda.synchronize()
 
     import contextlib, io
+    # ONE loader across warm-up and timed steps: a continuous training run.  The sampler works a group of steps
+    # ahead on a side stream (priors/utils.py), so the draws consumed by the first timed steps were produced during
+    # the warm-up -- and an equal amount of draw work, for the steps after the window, happens inside it (the loader
+    # is one look-ahead group longer than warm-up + steps): the timed region carries exactly `steps` steps' worth of
+    # prior sampling, forward, loss, backward and optimizer work in steady state.
+    group = getattr(fast_gp.DataLoader, 'prefetch_group', 1)
     with contextlib.redirect_stdout(io.StringIO()):   # DataLoader.__init__ prints its kwargs (reference behaviour)
-        warm_batches = loader(args.warmup)
+        batches = loader(args.warmup + args.steps + group)
     for _ in range(args.warmup):
-        step(warm_batches)
+        step(batches)
     barrier()
     seps.clear()
     t0 = time.time()
-    with contextlib.redirect_stdout(io.StringIO()):
-        batches = loader(args.steps)
     for _ in range(args.steps):
         loss = step(batches)
     barrier()
@@ -270,9 +287,18 @@ def main():
     }
     if world == 1 and not args.no_kernel_breakdown:
         ks = kernel_breakdown(args.batch, int(round(sum(seps) / len(seps))))
-        dom = max(ks, key=lambda k: k['step_seconds'])
-        result['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                              'frac': dom['tflops'] * 1e12 / MFMA_BF16_PEAK, 'traffic': None,
+        dom = max((k for k in ks if k['single']), key=lambda k: k['step_seconds'])   # the dominant single kernel of the step
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(pmc_path) and args.batch == 16:       # PMC passes of this command, collected by tools/profile_bench.sh
+            pmc = json.load(open(pmc_path))
+            hit = [v for k, v in pmc.get('kernels', {}).items() if dom['rocprof_name'].split('<')[0] in k and (('<' not in dom['rocprof_name']) or dom['rocprof_name'].split('<')[1].split(',')[0] + ',' in k or dom['rocprof_name'].split('<')[1].split(',')[0] + '>' in k)]
+            if hit:
+                traffic = hit[0].get('read_bytes', 0) + hit[0].get('write_bytes', 0)
+                traffic_src = f"profiles/r01_pmc_traffic.json ({pmc.get('note', '')})"
+        result['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'rocprof_kernel': dom['rocprof_name'], 'achieved': dom['tflops'],
+                              'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': dom['tflops'] * 1e12 / MFMA_BF16_PEAK,
+                              'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_flops_per_launch': dom['flops'],
                               'avg_launch_us': dom['seconds'] * 1e6, 'launches_per_step': dom['launches_per_step']}
         result['kernels'] = [{k: (round(v, 6) if isinstance(v, float) else v) for k, v in kk.items()} for kk in ks]
     if world == 1 and not args.no_cpu_baseline:

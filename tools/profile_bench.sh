@@ -16,5 +16,5 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
 done
 cd $ROOT
 python tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
-tail -5 $OUT/bench_stats_run.log | grep '^{' > $OUT/bench.json
+grep '^{"metric"' $OUT/bench_stats_run.log > $OUT/bench.json
 cat $OUT/summary.txt | head -60

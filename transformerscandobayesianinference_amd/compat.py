@@ -13,5 +13,5 @@ def install():
     pkg = 'transformerscandobayesianinference_amd'
     for name in _NAMES:
         sys.modules[name] = importlib.import_module(f'{pkg}.{name}')
-    for sub in ['prior', 'utils', 'fast_gp']:
+    for sub in ['prior', 'utils', 'fast_gp', 'fast_gp_mix', 'mlp']:
         sys.modules[f'priors.{sub}'] = importlib.import_module(f'{pkg}.priors.{sub}')
