@@ -166,6 +166,15 @@ int pfn_op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float
 int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb,
                          float* const* C, const int64_t* ldc, const int32_t* P, const int32_t* Q,
                          float* const* colsum, int M, int splits, void* stream);
+/* fused linear + bias + residual + LayerNorm (bf16 operands, N in {128, 256, 512}, K % 32 == 0):
+ *   v = A[M,K] . B[N,K]^T + bias + r;  y = v (f32);  mean / rstd of v per row;  x_t = bf16((v - mean) rstd gamma + beta)
+ * r = resid[M,N] (f32) when resid != NULL, else the previous LayerNorm's output recomputed as
+ * (ry - rmean) rrstd rgamma + rbeta.  Replaces `x = norm(x + dropout(sublayer(x)))` of torch's TransformerEncoderLayer
+ * (nn/modules/transformer.py:952-957) for the out_proj and linear2 sublayers. */
+int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
+                   const float* resid, const float* ry, const float* rmean, const float* rrstd,
+                   const float* rgamma, const float* rbeta, const float* gamma, const float* beta, float eps,
+                   float* y, float* mean, float* rstd, void* x_t, void* stream);
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep,
                          int prec, void* stream);
 int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx,

@@ -41,6 +41,27 @@ def gemm_tn_group(problems, splits=0):
     _hip.check(_hip.lib().pfn_op_gemm_tn_group(n, A, lda, B, ldb, C, ldc, P, Q, cs, M, splits, sp()), 'pfn_op_gemm_tn_group')
 
 
+def gemm_ln(A, B, bias, gamma, beta, eps, resid=None, prev=None, out=None):
+    """prev = (ry, rmean, rrstd, rgamma, rbeta) when the residual is the previous LayerNorm's (recomputed) output.
+    out = (y[M+2,N], x_t, mean, rstd) pre-allocated buffers (timing loops)."""
+    M, K = A.shape
+    N = B.shape[0]
+    dev = A.device
+    if out is None:
+        y = torch.full((M + 2, N), float('nan'), device=dev)
+        x_t = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    else:
+        y, x_t, mean, rstd = out
+    p = _hip.ptr
+    pv = prev if prev is not None else (None,) * 5
+    _hip.check(_hip.lib().pfn_op_gemm_ln(p(A), A.stride(0), p(B), B.stride(0), M, N, K, p(bias), p(resid), p(pv[0]), p(pv[1]), p(pv[2]), p(pv[3]), p(pv[4]),
+                                         p(gamma), p(beta), eps, p(y), p(mean), p(rstd), p(x_t), sp()), 'pfn_op_gemm_ln')
+    if out is None:
+        assert torch.isnan(y[M:]).all()
+    return y[:M], x_t, mean, rstd
+
+
 def attention_fwd(qkv, H, sep, prec):
     B, S, E3 = qkv.shape
     E = E3 // 3

@@ -168,6 +168,30 @@ def test_gemm_tn(M, P, Q, prec):
     assert relerr(C, ref) < 3e-6, relerr(C, ref)
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (77, 512, 32)])
+def test_gemm_ln_fused(M, N, K):
+    """linear + bias + residual + LayerNorm in one kernel, both residual forms, against f64 PyTorch."""
+    dt = torch.bfloat16
+    A, B = rnd(M, K, dtype=dt, seed=40), rnd(N, K, dtype=dt, seed=41, scale=0.1)
+    bias, gamma, beta = rnd(N, seed=42), rnd(N, seed=43) + 1, rnd(N, seed=44)
+    resid = rnd(M, N, seed=45)
+    v = A.double() @ B.double().t() + bias.double() + resid.double()
+    y, x_t, mean, rstd = hipops.gemm_ln(A, B, bias, gamma, beta, 1e-5, resid=resid)
+    ref = torch.nn.functional.layer_norm(v, (N,), gamma.double(), beta.double(), 1e-5)
+    assert relerr(y, v) < 1e-5 and relerr(x_t, ref) < 4e-3
+    assert maxerr(mean, v.mean(1)) < 1e-5 and relerr(rstd, 1 / torch.sqrt(v.var(1, unbiased=False) + 1e-5)) < 1e-5
+    # residual = previous LayerNorm output, recomputed from its pre-LN sums and statistics
+    ry = rnd(M, N, seed=46) * 2 + 0.3
+    rg, rb = rnd(N, seed=47) + 1, rnd(N, seed=48)
+    rmean, rvar = ry.double().mean(1), ry.double().var(1, unbiased=False)
+    rrstd = 1 / torch.sqrt(rvar + 1e-5)
+    r2 = (ry.double() - rmean[:, None]) * rrstd[:, None] * rg.double() + rb.double()
+    v2 = A.double() @ B.double().t() + bias.double() + r2
+    y2, x2, _, _ = hipops.gemm_ln(A, B, bias, gamma, beta, 1e-5, prev=(ry, rmean.float(), rrstd.float(), rg, rb))
+    assert relerr(y2, v2) < 1e-5
+    assert relerr(x2, torch.nn.functional.layer_norm(v2, (N,), gamma.double(), beta.double(), 1e-5)) < 4e-3
+
+
 @pytest.mark.parametrize('M,splits', [(64, 1), (1000, 1), (1000, 0), (4100, 3), (37, 1)])
 def test_gemm_tn_group(M, splits):
     """Grouped 256x256 weight-gradient kernel: several problems in one launch, ragged token tail, fused bias gradient."""

@@ -63,6 +63,7 @@ SIGNATURES = {
     'pfn_op_gemm_nt': (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _P]),
     'pfn_op_gemm_tn': (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
     'pfn_op_gemm_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'pfn_op_gemm_ln': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
     'pfn_op_attention_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_attention_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_layernorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),

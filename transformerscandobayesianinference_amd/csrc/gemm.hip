@@ -330,6 +330,175 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_nt_ln_kernel: out_proj / linear2 with the residual add AND the following LayerNorm fused (GemmLN in
+// pfn_kernels.h).  Tile = 128 rows x ALL N = 64 NWN columns (NWN = 2, 4 or 8 waves side by side, each 128 x 64 like
+// the big kernel's waves), 32-deep LDS-DMA stages.  After the MFMA loop a lane holds 32 values of each of its 4
+// rows; row sums go lane -> half-wave partner -> the NWN waves through LDS (two-pass mean / variance, like the
+// standalone kernel), then the pre-LN sum (f32), the normalised operand copy (bf16) and the statistics are written
+// once.  Saves, per LayerNorm, the f32 round trip of the pre-LN sum and the f32 LayerNorm output entirely.
+// ---------------------------------------------------------------------------------------------
+template <int NWN, bool RESID_LN, int BK>
+__global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
+  constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
+  constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
+  constexpr int TILE_A = BM * RB, STAGE = TILE_A + BN * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  const int m0 = blockIdx.x * BM;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int h = lane >> 5, li = lane & 31;
+
+  const bf16* pa[PA];
+  const bf16* pb[PB];
+  constexpr int APIECES = BM / RPP;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int piece = wave + NWN * i;
+    const int row = piece * RPP + lane / CPR;
+    const int chunk = swz16<RB>(row, lane % CPR);
+    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = (wave + NWN * i) * RPP + lane / CPR;
+    const int chunk = swz16<RB>(row, lane % CPR);
+    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)row * g.ldb + chunk * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    LdsPtr ta = smem + buf * STAGE + wave * 1024;
+    LdsPtr tb = smem + buf * STAGE + TILE_A + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      if (wave + NWN * i < APIECES) __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * NWN * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * NWN * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * STAGE;
+    const lds_char* tb = ta + TILE_A;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      Frag<bf16> fa[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, RB>(tb, wave * 64 + j * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, RB>(ta, i * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: v = acc + bias + residual (kept in the accumulator registers), row statistics, outputs ----
+  float* red = reinterpret_cast<float*>(smem_raw);          // [128 rows][NWN] partial sums; the stage buffers are dead
+  float mean[4], rstd[4];
+  const float invN = 1.f / (float)BN;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = min((long)m0 + i * 32 + li, (long)g.M - 1);
+    float rm = 0.f, rr = 0.f;
+    if constexpr (RESID_LN) { rm = g.rmean[m]; rr = g.rrstd[m]; }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
+        f32x4 r;
+        if constexpr (RESID_LN) {
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(g.ry + m * BN + n);
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(g.rgamma + n), be = *reinterpret_cast<const f32x4*>(g.rbeta + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = (yv[e] - rm) * rr * ga[e] + be[e];
+        } else {
+          r = *reinterpret_cast<const f32x4*>(g.resid + m * BN + n);
+        }
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[i][j][4 * gq + e] + bi[e] + r[e];
+          acc[i][j][4 * gq + e] = v;
+          s += v;
+        }
+      }
+    s += __shfl_xor(s, 32, 64);
+    if (h == 0) red[(i * 32 + li) * NWN + wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWN; ++w) t += red[(i * 32 + li) * NWN + w];
+    mean[i] = t * invN;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float d = acc[i][j][r] - mean[i]; s += d * d; }
+    s += __shfl_xor(s, 32, 64);
+    if (h == 0) red[(i * 32 + li) * NWN + wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWN; ++w) t += red[(i * 32 + li) * NWN + w];
+    rstd[i] = rsqrtf(t * invN + g.eps);
+  }
+  bf16* x_t = reinterpret_cast<bf16*>(g.x_t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = (long)m0 + i * 32 + li;
+    if (m >= g.M) continue;
+    if (wave == 0 && h == 0) { g.mean[m] = mean[i]; g.rstd[m] = rstd[i]; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(g.gamma + n), be = *reinterpret_cast<const f32x4*>(g.beta + n);
+        f32x4 v;
+        bf16x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][j][4 * gq + e];
+          t[e] = (bf16)((v[e] - mean[i]) * rstd[i] * ga[e] + be[e]);
+        }
+        *reinterpret_cast<f32x4*>(g.y + m * BN + n) = v;
+        *reinterpret_cast<bf16x4*>(x_t + m * BN + n) = t;
+        if (g.x_f32) {
+          f32x4 xo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
+          *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // C[P,Q] (+)= A[M,P]^T . B[M,Q]     contraction over the (long) token axis, split across
 // workgroups in z; partial tiles are added with hardware f32 atomics.
 // ---------------------------------------------------------------------------------------------
@@ -687,6 +856,37 @@ int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream) {
   const size_t lds = 4 * TN_BMK * 128 * es;
   if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16>, dim3(tq, tp, splits), dim3(256), lds, stream, g);
   else hipLaunchKernelGGL(gemm_tn_kernel<float>, dim3(tq, tp, splits), dim3(256), lds, stream, g);
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+
+bool gemm_ln_supported(const GemmLN& g) {
+  return (g.N == 128 || g.N == 256 || g.N == 512) && g.K % 32 == 0 && g.K >= 32 && (g.lda * 2) % 16 == 0 && (g.ldb * 2) % 16 == 0 &&
+         aligned16(g.A) && aligned16(g.B) && aligned16(g.bias) && aligned16(g.gamma) && aligned16(g.beta) && aligned16(g.y) && aligned16(g.x_t) &&
+         (g.resid ? aligned16(g.resid) : (aligned16(g.ry) && aligned16(g.rgamma) && aligned16(g.rbeta)));
+}
+template <int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g, hipStream_t stream) {
+  const size_t lds = 2 * (128 + NWN * 64) * (BK * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ln_kernel<NWN, RL, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_ln_kernel<NWN, RL, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
+}
+int launch_gemm_ln(const GemmLN& g, hipStream_t stream) {
+  if (g.M <= 0) return PFN_OK;
+  if (!gemm_ln_supported(g)) return PFN_ERR_UNSUPPORTED;
+  const bool rl = g.resid == nullptr;
+  // 64-deep stages (two of them fill the CU's 160 KiB of LDS at N = 512) whenever K allows, else 32-deep
+#define PFN_LN_CASE(NWN) \
+  if (g.K % 64 == 0) { if (rl) launch_gemm_ln_t<NWN, true, 64>(g, stream); else launch_gemm_ln_t<NWN, false, 64>(g, stream); } \
+  else { if (rl) launch_gemm_ln_t<NWN, true, 32>(g, stream); else launch_gemm_ln_t<NWN, false, 32>(g, stream); }
+  switch (g.N / 64) {
+    case 2: PFN_LN_CASE(2) break;
+    case 4: PFN_LN_CASE(4) break;
+    default: PFN_LN_CASE(8) break;
+  }
+#undef PFN_LN_CASE
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 

@@ -233,6 +233,18 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
   }
   const float* xin = w.x0;
   const char* xin_t = w.x0_t;
+  // out_proj and linear2 run fused with their residual add and LayerNorm (gemm_nt_ln_kernel) when the shape allows:
+  // the f32 LayerNorm output is then never stored -- the next residual add recomputes it from the pre-LN sum and the
+  // row statistics -- except after the last layer, whose f32 output feeds the decoder gather.
+  GemmLN probe; memset(&probe, 0, sizeof(probe));
+  probe.A = w.x0_t; probe.lda = E; probe.B = sh; probe.ldb = E; probe.M = M; probe.N = E; probe.K = E;
+  probe.bias = params; probe.gamma = params; probe.beta = params; probe.resid = w.x0; probe.y = w.x0; probe.x_t = w.x0_t;
+  const bool fuse_ln = prec == PFN_PREC_BF16 && gemm_ln_supported(probe) && F % 32 == 0;
+  struct Resid { const float* plain; const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; };
+  Resid res = {w.x0, nullptr, nullptr, nullptr, nullptr, nullptr};   // where the layer input lives in f32
+  auto set_resid = [](GemmLN& g, const Resid& r) {
+    g.resid = r.plain; g.ry = r.y; g.rmean = r.mean; g.rrstd = r.rstd; g.rgamma = r.gamma; g.rbeta = r.beta;
+  };
   for (int l = 0; l < d->nlayers; ++l) {
     const LayerP& p = L.layer[l];
     LayerWs& a = w.layer[l];
@@ -246,23 +258,44 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
       PFN_TRY(launch_attn_fwd(at, prec, s));
     }
-    {  // out_proj + residual
-      GemmNT g = nt(a.ctx, E, W(p.w_o), E, M, E, E, EPI_BIAS | EPI_RESID | EPI_OUT_F32);
-      g.bias = params + p.b_o; g.resid = xin; g.ld_resid = E; g.out_f32 = a.y1; g.ld_out_f32 = E;
-      PFN_TRY(launch_gemm_nt(g, prec, s));
+    if (fuse_ln) {  // x1 = LN1(x + out_proj(ctx))
+      GemmLN g; memset(&g, 0, sizeof(g));
+      g.A = a.ctx; g.lda = E; g.B = W(p.w_o); g.ldb = E; g.M = M; g.N = E; g.K = E; g.bias = params + p.b_o;
+      set_resid(g, res);
+      g.gamma = params + p.g1; g.beta = params + p.be1; g.eps = d->ln_eps;
+      g.y = a.y1; g.mean = a.mean1; g.rstd = a.rstd1; g.x_t = a.x1_t;
+      PFN_TRY(launch_gemm_ln(g, s));
+      res = Resid{nullptr, a.y1, a.mean1, a.rstd1, params + p.g1, params + p.be1};
+    } else {
+      {  // out_proj + residual
+        GemmNT g = nt(a.ctx, E, W(p.w_o), E, M, E, E, EPI_BIAS | EPI_RESID | EPI_OUT_F32);
+        g.bias = params + p.b_o; g.resid = xin; g.ld_resid = E; g.out_f32 = a.y1; g.ld_out_f32 = E;
+        PFN_TRY(launch_gemm_nt(g, prec, s));
+      }
+      PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, a.x1, a.x1_t, a.mean1, a.rstd1, M, E, d->ln_eps, prec, s));
     }
-    PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, a.x1, a.x1_t, a.mean1, a.rstd1, M, E, d->ln_eps, prec, s));
     {  // linear1 + GELU (pre-activation kept for the backward)
       GemmNT g = nt(a.x1_t, E, W(p.w1), E, M, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
       g.bias = params + p.b1; g.out_t = a.h; g.ld_out_t = F; g.out2_t = a.hpre; g.ld_out2 = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
-    {  // linear2 + residual
-      GemmNT g = nt(a.h, F, W(p.w2), F, M, E, F, EPI_BIAS | EPI_RESID | EPI_OUT_F32);
-      g.bias = params + p.b2; g.resid = a.x1; g.ld_resid = E; g.out_f32 = a.y2; g.ld_out_f32 = E;
-      PFN_TRY(launch_gemm_nt(g, prec, s));
+    if (fuse_ln) {  // x2 = LN2(x1 + linear2(h))
+      GemmLN g; memset(&g, 0, sizeof(g));
+      g.A = a.h; g.lda = F; g.B = W(p.w2); g.ldb = F; g.M = M; g.N = E; g.K = F; g.bias = params + p.b2;
+      set_resid(g, res);
+      g.gamma = params + p.g2; g.beta = params + p.be2; g.eps = d->ln_eps;
+      g.y = a.y2; g.mean = a.mean2; g.rstd = a.rstd2; g.x_t = a.x2_t;
+      g.x_f32 = (l == d->nlayers - 1) ? a.x2 : nullptr;
+      PFN_TRY(launch_gemm_ln(g, s));
+      res = Resid{nullptr, a.y2, a.mean2, a.rstd2, params + p.g2, params + p.be2};
+    } else {
+      {  // linear2 + residual
+        GemmNT g = nt(a.h, F, W(p.w2), F, M, E, F, EPI_BIAS | EPI_RESID | EPI_OUT_F32);
+        g.bias = params + p.b2; g.resid = a.x1; g.ld_resid = E; g.out_f32 = a.y2; g.ld_out_f32 = E;
+        PFN_TRY(launch_gemm_nt(g, prec, s));
+      }
+      PFN_TRY(launch_layernorm_fwd(a.y2, params + p.g2, params + p.be2, a.x2, a.x2_t, a.mean2, a.rstd2, M, E, d->ln_eps, prec, s));
     }
-    PFN_TRY(launch_layernorm_fwd(a.y2, params + p.g2, params + p.be2, a.x2, a.x2_t, a.mean2, a.rstd2, M, E, d->ln_eps, prec, s));
     xin = a.x2; xin_t = a.x2_t;
   }
   // decoder on the test rows only (the reference decodes all rows, then slices: transformer.py:85,91)
@@ -494,6 +527,17 @@ int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const 
     t.colsum = colsum ? colsum[i] : nullptr;
   }
   PFN_TRY(launch_gemm_tn_group(g, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
+                   const float* resid, const float* ry, const float* rmean, const float* rrstd, const float* rgamma, const float* rbeta,
+                   const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd, void* x_t, void* stream) {
+  GemmLN g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.bias = bias; g.resid = resid;
+  g.ry = ry; g.rmean = rmean; g.rrstd = rrstd; g.rgamma = rgamma; g.rbeta = rbeta; g.gamma = gamma; g.beta = beta; g.eps = eps;
+  g.y = y; g.mean = mean; g.rstd = rstd; g.x_t = x_t;
+  PFN_TRY(launch_gemm_ln(g, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep, int prec, void* stream) {

@@ -64,6 +64,25 @@ struct GemmTNGroup {
   int debug_mask;                    // all ones; profiling only (pfn_set_tuning key 1): 2^k - 1 wraps the token index
 };
 void set_gemm_tn_debug_wrap(int rows);
+// GEMM + bias + residual + LayerNorm in one kernel (gemm_nt_ln_kernel): one workgroup owns 128 full rows of the
+// N = emsize columns, so the row statistics are taken straight from the accumulators:
+//     v = A . B^T + bias + r,   y = v (f32, kept for the LayerNorm backward),   x_t = (T) ((v - mean) rstd gamma + beta)
+// The residual r is either a plain f32 tensor (resid) or the PREVIOUS LayerNorm's output recomputed on the fly from
+// its pre-LN sums and statistics (r = (ry - rmean) rrstd rgamma + rbeta): the f32 LayerNorm output is never stored.
+struct GemmLN {
+  const void* A; long lda;      // [M,K] bf16
+  const void* B; long ldb;      // [N,K] bf16
+  int M, N, K;
+  const float* bias;            // [N]
+  const float* resid;           // [M,N] f32, or nullptr to use the recomputed form below
+  const float* ry; const float* rmean; const float* rrstd; const float* rgamma; const float* rbeta;
+  const float* gamma; const float* beta; float eps;
+  float* y; float* mean; float* rstd; void* x_t;   // outputs
+  float* x_f32;                                    // optional: the LayerNorm output in f32 as well (last layer -> decoder)
+};
+bool gemm_ln_supported(const GemmLN& g);
+int launch_gemm_ln(const GemmLN& g, hipStream_t stream);
+
 bool gemm_tn_group_supported(const TnProblem& p);
 int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream);
 
