@@ -290,8 +290,8 @@ def main():
         dom = max((k for k in ks if k['single']), key=lambda k: k['step_seconds'])   # the dominant single kernel of the step
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(pmc_path) and args.batch == 16:       # PMC passes of this command, collected by tools/profile_bench.sh
-            pmc = json.load(open(pmc_path))
+        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+        if pmc.get('batch') == args.batch:                       # PMC passes of this command, collected by tools/profile_bench.sh
             hit = [v for k, v in pmc.get('kernels', {}).items() if dom['rocprof_name'].split('<')[0] in k and (('<' not in dom['rocprof_name']) or dom['rocprof_name'].split('<')[1].split(',')[0] + ',' in k or dom['rocprof_name'].split('<')[1].split(',')[0] + '>' in k)]
             if hit:
                 traffic = hit[0].get('read_bytes', 0) + hit[0].get('write_bytes', 0)

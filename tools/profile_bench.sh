@@ -15,6 +15,6 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$name -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-breakdown > $OUT/pmc_$name.log 2>&1
 done
 cd $ROOT
-python tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+python tools/pmc_summary.py $OUT 32 > $OUT/summary.txt 2>&1
 grep '^{"metric"' $OUT/bench_stats_run.log > $OUT/bench.json
 cat $OUT/summary.txt | head -60
