@@ -195,6 +195,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='datasets per GPU per step')
+    ap.add_argument('--streams', type=int, default=2, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-breakdown', action='store_true')
@@ -204,6 +205,7 @@ def main():
     from transformerscandobayesianinference_amd import dp
     from transformerscandobayesianinference_amd.optim import FusedClipAdam
     from transformerscandobayesianinference_amd.priors import fast_gp
+    from transformerscandobayesianinference_amd.streams import MicroBatchStreams
     from transformerscandobayesianinference_amd.utils import get_weighted_single_eval_pos_sampler
     rank, world, local = dp.init_from_env()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -228,17 +230,19 @@ def main():
         return iter(fast_gp.DataLoader(num_steps=num_steps, batch_size=args.batch, seq_len=S, num_features=nf,
                                        hyperparameters=w['hyperparameters'], device=device))
 
+    micro = MicroBatchStreams(args.streams)
+
     def step(batches):
         sep = args.fixed_sep if args.fixed_sep is not None else sampler()
         seps.append(sep)
         (x, y), target = next(batches)
-        logits = model((x, y), single_eval_pos=sep)
-        loss = model.criterion(logits.reshape(-1, O), target[sep:].reshape(-1)).mean()
-        loss.backward()
+        # forward + bar NLL + backward of the batch, as `--streams` concurrent column groups (streams.py)
+        losses = micro.forward_backward(model, (x, y), target, sep,
+                                        lambda out, tg: model.criterion(out.reshape(-1, O), tg[sep:].reshape(-1)).view(out.shape[0], -1))
         if world > 1:
             dp.all_reduce_gradients(model.flat_parameters()[1])
         opt.step(zero_grad=True)
-        return loss
+        return losses.mean()
 
     def barrier():
         if world > 1:
@@ -279,7 +283,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
         'config': {'workload': 'priors.fast_gp, bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, 1000 bars (BASELINE.json configs[1])',
-                   'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'seq_len': S, 'parallelism': f'dp{world}',
+                   'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'seq_len': S, 'parallelism': f'dp{world}', 'micro_batch_streams': args.streams,
                    'eval_pos': 'weighted sampler(2000)' if args.fixed_sep is None else args.fixed_sep, 'mean_sep': sum(seps) / len(seps),
                    'final_loss': final_loss},
         'step_roofline': {'bound': 'mfma', 'achieved': step_flops / elapsed / 1e12 / world, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',

@@ -371,3 +371,31 @@ def test_train_entry_point_with_every_prior():
     loss, pos, model = train_mod.train(fast_gp_mix.DataLoader, crit, encoders.Linear, bptt=40, single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(40),
                                        validation_period=1, extra_prior_kwargs_dict={'num_features': 3, 'hyperparameters': mix_hp, 'device': DEV}, **common)
     assert math.isfinite(loss)
+
+
+def test_micro_batch_streams_match_single_stream():
+    """Two concurrent half-batches on two HIP streams (streams.py) give the full-batch loss and gradients."""
+    from transformerscandobayesianinference_amd.priors import fast_gp
+    from transformerscandobayesianinference_amd.streams import MicroBatchStreams
+    torch.manual_seed(2)
+    T, B, F, E, nb, sep = 120, 8, 4, 128, 30, 77
+    x, y, target = fast_gp.get_batch(B, T, F, device=DEV, hyperparameters=(1e-4, 1., .6))
+    borders = bar_distribution.get_bucket_limits(nb, ys=y.flatten().cpu())
+    model = TransformerModel(encoders.Linear(F, E), nb, E, 2, 256, 2, 0.0, y_encoder=encoders.Linear(1, E), precision='bf16')
+    model.criterion = bar_distribution.FullSupportBarDistribution(borders)
+    with torch.no_grad():
+        for layer in model.transformer_encoder.layers:
+            layer.linear2.weight.normal_(0, 0.05)
+            layer.self_attn.out_proj.weight.normal_(0, 0.05)
+    model.to(DEV).train()
+    loss_fn = lambda out, tg: model.criterion(out.reshape(-1, nb), tg[sep:].reshape(-1)).view(out.shape[0], -1)
+    grads = []
+    for n in (1, 2, 4):
+        flat, g = model.flat_parameters()
+        g.zero_()
+        losses = MicroBatchStreams(n).forward_backward(model, (x, y), target, sep, loss_fn)
+        torch.cuda.synchronize()
+        grads.append((losses.mean().item(), model.flat_parameters()[1].clone()))
+    for loss_n, g_n in grads[1:]:
+        assert abs(loss_n - grads[0][0]) < 1e-5 * abs(grads[0][0])
+        assert relerr(g_n, grads[0][1]) < 1e-4, relerr(g_n, grads[0][1])

@@ -749,7 +749,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) unsafeAtomicAdd(pr.colsum + p0 + wp * 128 + wq * 32 + acc_row(r, lane), cs[r]);
   }
-  const bool atomic = g.splits > 1;
+  // always atomic: token splits add into the same tile, and concurrent backward passes (micro-batches on several
+  // HIP streams, streams.py) accumulate into the same gradient buffer
+  const bool atomic = true;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll

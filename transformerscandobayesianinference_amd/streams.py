@@ -1,0 +1,52 @@
+"""Concurrent micro-batches: one optimizer step's batch is split into `n` equal column groups whose forward +
+loss + backward run on `n` HIP streams at the same time.
+
+Every kernel of the encoder stack alternates a memory-bound phase (operand prologue, bias / GELU / residual /
+LayerNorm epilogue, attention row loads and stores) with a matrix-core phase, and one launch occupies the whole
+chip in lock-step; two independent launches in flight fill each other's phases and tails (measured on MI355X at the
+north-star shape: 32 datasets as 2 x 16 on two streams 17.6 ms vs 18.9 ms on one).  Datasets are independent columns
+(SURVEY.md 8(e)), every group uses the same `single_eval_pos`, and the loss of the step is the mean over equally
+sized groups, so the summed gradients are those of the full batch; all gradient kernels accumulate with atomics
+into the shared flat gradient buffer.  The reference has no counterpart (single stream, train.py:66-97)."""
+import torch
+
+from transformerscandobayesianinference_amd import _hip
+
+
+class MicroBatchStreams:
+    def __init__(self, n):
+        self.n = max(1, int(n))
+        self.streams = [torch.cuda.Stream() for _ in range(self.n)] if self.n > 1 and torch.cuda.is_available() else []
+
+    def forward_backward(self, model, data, targets, single_eval_pos, loss_fn):
+        """data = (x[T,B,F], y[T,B]); targets [T,B] (already sliced to the test rows by the caller's loss_fn if needed).
+        loss_fn(output, targets_group) -> per-(position, dataset) losses [T - sep, b].  Runs backward of the mean loss
+        (over all groups) and returns the detached losses [T - sep, B]."""
+        x, y = data
+        B = x.shape[1]
+        n = self.n if (self.streams and B % self.n == 0 and B >= 2 * self.n) else 1
+        if n == 1:
+            output = model(data, single_eval_pos=single_eval_pos)
+            losses = loss_fn(output, targets)
+            losses.mean().backward()
+            return losses.detach()
+        main = torch.cuda.current_stream()
+        model.flat_parameters()
+        model._refresh_shadow(_hip.stream_ptr(x.device))      # operand copies of the weights: once, before the fork
+        h = B // n
+        outs = []
+        for i, s in enumerate(self.streams[:n]):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                sl = slice(i * h, (i + 1) * h)
+                output = model((x[:, sl], y[:, sl]), single_eval_pos=single_eval_pos)
+                losses = loss_fn(output, targets[:, sl])
+                (losses.mean() / n).backward()
+                outs.append(losses.detach())
+            for t in (x, y, targets):
+                t.record_stream(s)
+        for s in self.streams[:n]:
+            main.wait_stream(s)
+        for o in outs:
+            o.record_stream(main)
+        return torch.cat(outs, 1)

@@ -22,6 +22,7 @@ from torch import nn
 from transformerscandobayesianinference_amd import dp, encoders, positional_encodings, priors
 from transformerscandobayesianinference_amd.bar_distribution import BarDistribution, FullSupportBarDistribution, get_bucket_limits
 from transformerscandobayesianinference_amd.optim import FusedClipAdam
+from transformerscandobayesianinference_amd.streams import MicroBatchStreams
 from transformerscandobayesianinference_amd.transformer import TransformerModel
 from transformerscandobayesianinference_amd.utils import (StoreDictKeyPair, get_cosine_schedule_with_warmup, get_openai_lr,
                                                           get_uniform_single_eval_pos_sampler, get_weighted_single_eval_pos_sampler)
@@ -55,7 +56,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
           epochs=10, steps_per_epoch=100, batch_size=200, bptt=10, lr=None, warmup_epochs=10, input_normalization=False,
           y_encoder_generator=None, pos_encoder_generator=None, decoder=None, extra_prior_kwargs_dict={},
           scheduler=get_cosine_schedule_with_warmup, load_weights_from_this_state_dict=None, validation_period=10,
-          single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16'):
+          single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16', micro_streams=2):
     device = gpu_device if torch.cuda.is_available() else 'cpu:0'
     print(f'Using {device} device')
     world = dp.world_size()
@@ -89,6 +90,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     optimizer = FusedClipAdam(model, lr=lr, max_grad_norm=1.)
     optimizer.grad_multiplier = 1.0 / world
     scheduler = scheduler(optimizer, warmup_epochs, epochs)
+    micro = MicroBatchStreams(micro_streams if str(device).startswith('cuda') else 1)   # concurrent half-batches (streams.py)
 
     def train_epoch():
         model.train()
@@ -103,14 +105,20 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
             before_forward = time.time()
             single_eval_pos = single_eval_pos_gen() if callable(single_eval_pos_gen) else single_eval_pos_gen
             data = tuple(e.to(device) for e in data) if isinstance(data, tuple) else data.to(device)
-            output = model(data, single_eval_pos=single_eval_pos)
-            forward_time = time.time() - before_forward
-
-            if single_eval_pos is not None:
-                targets = targets[single_eval_pos:]
-            losses = compute_losses(criterion, output, targets.to(device), n_out)
-            loss = losses.mean()
-            loss.backward()
+            if isinstance(data, tuple) and single_eval_pos is not None:
+                targets = targets.to(device)
+                losses = micro.forward_backward(model, data, targets, single_eval_pos,
+                                                lambda out, tg: compute_losses(criterion, out, tg[single_eval_pos:], n_out))
+                loss = losses.mean()
+                forward_time = time.time() - before_forward
+            else:
+                output = model(data, single_eval_pos=single_eval_pos)
+                forward_time = time.time() - before_forward
+                if single_eval_pos is not None:
+                    targets = targets[single_eval_pos:]
+                losses = compute_losses(criterion, output, targets.to(device), n_out)
+                loss = losses.mean()
+                loss.backward()
             if batch % aggregate_k_gradients == aggregate_k_gradients - 1:
                 if world > 1:
                     dp.all_reduce_gradients(model.flat_parameters()[1])
