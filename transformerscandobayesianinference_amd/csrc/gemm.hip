@@ -809,6 +809,7 @@ static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
     PFN_BIG_CASE(EPI_GELU_BWD | EPI_OUT_T)                        // d(hpre)
     PFN_BIG_CASE(EPI_RESID | EPI_OUT_F32)
     PFN_BIG_CASE(EPI_RESID_T | EPI_OUT_F32)                       // dx = dgrad + residual gradient (kept in operand precision)
+    PFN_BIG_CASE(EPI_RESID_T | EPI_OUT_T)                         // ... between layers the sum stays in operand precision too
     PFN_BIG_CASE(EPI_OUT_T)                                       // d(ctx)
     PFN_BIG_CASE(EPI_OUT_F32)
     PFN_BIG_CASE(EPI_BIAS | EPI_OUT_F32)

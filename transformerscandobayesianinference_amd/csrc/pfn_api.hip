@@ -99,7 +99,8 @@ struct Ws {
   char *xt_t, *dpre, *dt;
   // backward scratch
   char *dlog_t, *dd_t, *dctx_t;
-  float *dxt, *gA, *delta;
+  float *dxt, *gA, *delta;   // gA: f32 gradient of the embedding output (the last dx of the backward)
+  char* gA_t;                // gradient w.r.t. a layer's output between layers, operand precision
   int64_t bytes;
 };
 
@@ -122,7 +123,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   }
   w.xt_t = take(M * E * es); w.dpre = take(M * F * es); w.dt = take(M * F * es);
   w.dlog_t = take(M * npad * es); w.dd_t = take(M * F * es); w.dxt = (float*)take(M * E * 4);
-  w.gA = (float*)take(M * E * 4);
+  w.gA = (float*)take(M * E * 4); w.gA_t = take(M * E * es);
   w.dctx_t = take(M * E * es);
   w.delta = (float*)take((int64_t)B * d.nhead * S * 4);
   w.bytes = cur;
@@ -351,7 +352,7 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
   }
-  PFN_TRY(launch_scatter_test_rows(w.dxt, w.gA, S, B, E, sep, s));
+  PFN_TRY(launch_scatter_test_rows(w.dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
 
   // ---- encoder layers, last to first; gA holds d(loss)/d(layer output) ----
   // Only the data-gradient chain runs here.  Each layer leaves the output-gradient operands of its four
@@ -364,19 +365,19 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
     // LN2
     // LN2: the input gradient leaves only in operand precision (dy2_t); it is both the GEMM operand below and the
     // residual-branch gradient that the dx1 GEMM adds back, so no f32 copy is written or re-read
-    PFN_TRY(launch_layernorm_bwd(w.gA, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
+    PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
       GemmNT g = nt(a.dy2_t, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = a.hpre; g.ld_aux = F; g.out_t = a.dh_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     {  // dx1 = dh . W1 + dy2
-      GemmNT g = nt(a.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID_T | EPI_OUT_F32);
-      g.aux = a.dy2_t; g.ld_aux = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
+      GemmNT g = nt(a.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID_T | EPI_OUT_T);
+      g.aux = a.dy2_t; g.ld_aux = E; g.out_t = w.gA_t; g.ld_out_t = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     // LN1
-    PFN_TRY(launch_layernorm_bwd(w.gA, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, a.dy1_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
+    PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, a.dy1_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
     {  // d(ctx) = dy1 . Wo
       GemmNT g = nt(a.dy1_t, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
       g.out_t = w.dctx_t; g.ld_out_t = E;
@@ -389,8 +390,9 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     {  // dx = dqkv . Win + dy1
-      GemmNT g = nt(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID_T | EPI_OUT_F32);
-      g.aux = a.dy1_t; g.ld_aux = E; g.out_f32 = w.gA; g.ld_out_f32 = E;
+      // the gradient stays in operand precision between layers; the embedding's gradient (layer 0) leaves in f32
+      GemmNT g = nt(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID_T | (l == 0 ? EPI_OUT_F32 : EPI_OUT_T));
+      g.aux = a.dy1_t; g.ld_aux = E; g.out_f32 = w.gA; g.ld_out_f32 = E; g.out_t = w.gA_t; g.ld_out_t = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
   }
@@ -561,7 +563,7 @@ int pfn_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 }
 int pfn_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx_f32,
                          void* dx_t, float* dgamma, float* dbeta, float* dbias_extra, int64_t rows, int E, int prec, void* stream) {
-  PFN_TRY(launch_layernorm_bwd(dy, x, gamma, mean, rstd, dx_f32, dx_t, dgamma, dbeta, dbias_extra, rows, E, prec, (hipStream_t)stream));
+  PFN_TRY(launch_layernorm_bwd(dy, 0, x, gamma, mean, rstd, dx_f32, dx_t, dgamma, dbeta, dbias_extra, rows, E, prec, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_cast(const float* src, void* dst, int64_t n, int prec, void* stream) {

@@ -130,9 +130,9 @@ int launch_bse_to_sbe(const float* src_bse, float* dst_sbe, int S, int B, int E,
 // y = LN(x) * gamma + beta over E; writes f32 and T copies, mean/rstd per row
 int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
                          float* mean, float* rstd, long rows, int E, float eps, int precision, hipStream_t s);
-// dx = LN'(dy); dx written f32 + T; dgamma/dbeta accumulated with atomics; optional dbias_extra
+// dx = LN'(dy) (dy f32, or T when dy_is_t); dx written f32 + T; dgamma/dbeta accumulated with atomics; optional dbias_extra
 // accumulates colsum(dx) (the bias gradient of the linear that produced x's pre-LN sum).
-int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd,
                          float* dx_f32, void* dx_t, float* dgamma, float* dbeta, float* dbias_extra,
                          long rows, int E, int precision, hipStream_t s);
 // out[n] += sum_m a[m,n]
@@ -141,7 +141,7 @@ int launch_colsum(const void* a_t, long lda, long rows, int cols, float* out, in
 // gather test rows: dst[(s-sep)*B + b, :] = src[b, s, :]  (f32 in, T out)  and its transpose
 int launch_gather_test_rows(const float* src_bse, void* dst_t, int S, int B, int E, int sep, int precision, hipStream_t s);
 // dst[b, s, :] = (s >= sep) ? src[(s-sep)*B + b, :] : 0
-int launch_scatter_test_rows(const float* src, float* dst_bse, int S, int B, int E, int sep, hipStream_t s);
+int launch_scatter_test_rows(const float* src, void* dst_bse_t, int S, int B, int E, int sep, int precision, hipStream_t s);
 
 // ---- bar distribution (bar.hip) ----------------------------------------------------------------
 struct BarArgs {

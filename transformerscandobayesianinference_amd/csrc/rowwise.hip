@@ -311,7 +311,7 @@ int launch_gather_test_rows(const float* src, void* dst, int S, int B, int E, in
   else hipLaunchKernelGGL(gather_test_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep);
   return PFN_LAUNCH_OK();
 }
-__global__ __launch_bounds__(256) void scatter_test_kernel(const float* src, float* dst, int S, int B, int E, int sep) {
+template <typename T> __global__ __launch_bounds__(256) void scatter_test_kernel(const float* src, T* dst, int S, int B, int E, int sep) {
   const int e4 = E / 4;
   const long n4 = (long)S * B * e4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -319,13 +319,14 @@ __global__ __launch_bounds__(256) void scatter_test_kernel(const float* src, flo
     const long b = tok / S, sidx = tok % S;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (sidx >= sep) v = *reinterpret_cast<const f32x4*>(src + ((sidx - sep) * B + b) * E + c);
-    *reinterpret_cast<f32x4*>(dst + tok * E + c) = v;
+    st4<T>(dst + tok * E + c, v);
   }
 }
-int launch_scatter_test_rows(const float* src, float* dst, int S, int B, int E, int sep, hipStream_t s) {
+int launch_scatter_test_rows(const float* src, void* dst, int S, int B, int E, int sep, int precision, hipStream_t s) {
   if (E % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = (long)S * B * E / 4;
-  hipLaunchKernelGGL(scatter_test_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, dst, S, B, E, sep);
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(scatter_test_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep);
+  else hipLaunchKernelGGL(scatter_test_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep);
   return PFN_LAUNCH_OK();
 }
 
@@ -389,10 +390,12 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 // rate, and few enough workgroups that the column reductions (d gamma, d beta, optional bias
 // gradient) end in ~0.8 M atomics instead of several million.
 constexpr int LNB_WAVES = 8;
-template <typename T, int NV>
-__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+template <typename T, int NV, bool DY_T>
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const void* dy_any, const float* x, const float* gamma, const float* mean, const float* rstd,
                                                                       float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E) {
   extern __shared__ __attribute__((aligned(16))) float part[];  // [LNB_WAVES][E]
+  const float* dy = reinterpret_cast<const float*>(dy_any);     // upstream gradient: f32, or operand precision when DY_T
+  const T* dy_t = reinterpret_cast<const T*>(dy_any);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wave0 = (long)blockIdx.x * LNB_WAVES + wave;
   const long wstride = (long)gridDim.x * LNB_WAVES;
@@ -418,7 +421,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const flo
         const int c = (k * 64 + lane) * 4;
         if (c < E) {
           xv[u][k] = *reinterpret_cast<const f32x4*>(x + r * E + c);
-          dv[u][k] = live ? *reinterpret_cast<const f32x4*>(dy + r * E + c) : f32x4{0, 0, 0, 0};
+          if constexpr (DY_T) dv[u][k] = live ? ld4<T>(dy_t + r * E + c) : f32x4{0, 0, 0, 0};
+          else dv[u][k] = live ? *reinterpret_cast<const f32x4*>(dy + r * E + c) : f32x4{0, 0, 0, 0};
         } else { xv[u][k] = f32x4{0, 0, 0, 0}; dv[u][k] = f32x4{0, 0, 0, 0}; }
       }
     }
@@ -475,15 +479,16 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const flo
     }
   }
 }
-int launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, void* dxt,
+int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, void* dxt,
                          float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s) {
   if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
   if (rows == 0) return PFN_OK;
   const int grid = grid_for(rows, LNB_WAVES * 8, 512);
   const size_t lds = LNB_WAVES * E * sizeof(float);
-#define LN_BWD(TT, NV) do { \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_kernel<TT, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E); } while (0)
+#define LN_BWD_K(TT, NV, DT) do { \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_kernel<TT, NV, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E); } while (0)
+#define LN_BWD(TT, NV) do { if (dy_is_t) LN_BWD_K(TT, NV, true); else LN_BWD_K(TT, NV, false); } while (0)
 #define LN_BWD_NV(TT) do { if (E <= 256) LN_BWD(TT, 1); else if (E <= 512) LN_BWD(TT, 2); else if (E <= 1024) LN_BWD(TT, 4); else LN_BWD(TT, 8); } while (0)
   if (precision == PFN_PREC_BF16) LN_BWD_NV(bf16); else LN_BWD_NV(float);
   return PFN_LAUNCH_OK();
