@@ -286,19 +286,34 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);   // swapped: a lane owns one ROW of the tile
     }
   }
+  // read-modify-write of C in 16-byte pieces: lane = row, accumulator group g = 4 consecutive columns
+  const int h = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    const int gi = i0 + wm * 64 + i * 32 + (lane & 31);
+    if (gi >= r1) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gi = i0 + wm * 64 + i * 32 + acc_row(r, lane);
-        const int gj = j0 + wn * 64 + j * 32 + (lane & 31);
-        if (gi < r1 && gj < c1 && gj <= gi) Kb[(long)gi * S + gj] -= acc[i][j][r];
+      for (int gq = 0; gq < 4; ++gq) {
+        const int gj = j0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
+        if (gj > gi || gj >= c1) continue;
+        float* cp = Kb + (long)gi * S + gj;
+        if (gj + 3 <= gi && gj + 3 < c1) {
+          f32x4 c = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c[e] -= acc[i][j][4 * gq + e];
+          *reinterpret_cast<f32x4*>(cp) = c;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gj + e <= gi && gj + e < c1) cp[e] -= acc[i][j][4 * gq + e];
+        }
       }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
