@@ -290,12 +290,17 @@ def main():
                           'frac': step_flops / elapsed / world / MFMA_BF16_PEAK, 'note': 'whole step per GPU, algorithmic mask-aware FLOPs 3*fwd(S,sep)'},
     }
     if world == 1 and not args.no_kernel_breakdown:
-        ks = kernel_breakdown(args.batch, int(round(sum(seps) / len(seps))))
+        # kernels are launched per micro-batch (column group of the batch, streams.py): time them at THAT shape
+        groups = args.streams if (args.streams > 1 and args.batch % args.streams == 0 and args.batch >= 2 * args.streams) else 1
+        ks = kernel_breakdown(args.batch // groups, int(round(sum(seps) / len(seps))))
+        for k in ks:
+            k['launches_per_step'] *= groups
+            k['step_seconds'] *= groups
         dom = max((k for k in ks if k['single']), key=lambda k: k['step_seconds'])   # the dominant single kernel of the step
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
         pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-        if pmc.get('batch') == args.batch:                       # PMC passes of this command, collected by tools/profile_bench.sh
+        if pmc.get('batch') == args.batch and pmc.get('streams', 1) == args.streams:   # PMC passes of this command (tools/profile_bench.sh)
             hit = [v for k, v in pmc.get('kernels', {}).items() if dom['rocprof_name'].split('<')[0] in k and (('<' not in dom['rocprof_name']) or dom['rocprof_name'].split('<')[1].split(',')[0] + ',' in k or dom['rocprof_name'].split('<')[1].split(',')[0] + '>' in k)]
             if hit:
                 traffic = hit[0].get('read_bytes', 0) + hit[0].get('write_bytes', 0)
@@ -303,7 +308,10 @@ def main():
         result['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'rocprof_kernel': dom['rocprof_name'], 'achieved': dom['tflops'],
                               'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': dom['tflops'] * 1e12 / MFMA_BF16_PEAK,
                               'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_flops_per_launch': dom['flops'],
-                              'avg_launch_us': dom['seconds'] * 1e6, 'launches_per_step': dom['launches_per_step']}
+                              'avg_launch_us': dom['seconds'] * 1e6, 'launches_per_step': dom['launches_per_step'],
+                              'note': 'launch timed alone with HIP events on its stream; inside the step two micro-batch streams and the sampler stream share the GPU, so a '
+                                      'rocprofv3 trace of the default command shows this kernel stretched by its co-runners -- profiles/r01_bench_streams1_kernel_stats.csv '
+                                      '(same command with --streams 1) is the trace whose average duration matches'}
         result['kernels'] = [{k: (round(v, 6) if isinstance(v, float) else v) for k, v in kk.items()} for kk in ks]
     if world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline()
