@@ -139,28 +139,32 @@ int launch_embed_fwd(const EmbedArgs& a, int precision, hipStream_t s) {
   return PFN_LAUNCH_OK();
 }
 
-// One thread per embedding column e, EMBB_TOK tokens per workgroup: d(src) is read exactly once
-// (coalesced across e), every token's features come from LDS as broadcast reads, and all nf + 2
-// weight-gradient columns of the thread stay in registers until the closing atomics.
-constexpr int EMBB_TOK = 128;
+// Workgroup = 64 embedding columns x one slice of the tokens; thread = (column, one of 4 token lanes).  d(src) is
+// read exactly once (a wave reads 256 contiguous bytes per token), the token's features come from LDS as broadcast
+// reads, all nf + 2 weight-gradient columns of a thread stay in registers; the 4 token lanes are reduced through LDS
+// and every gradient element receives one atomic per workgroup -- gridDim.x (<= 32) of them in total instead of
+// one per 128-token chunk.
+constexpr int EMBB_TOK = 128;   // tokens staged per pass
 constexpr int EMBB_MAXF = 32;   // nf + 2 rounded up to 8 must fit (wider encoders take the chunked path below)
 template <int NF8>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
-  extern __shared__ float xs[];  // [EMBB_TOK][NF8] : x features, y (masked), train flag, zero pad to 8
+  extern __shared__ float xs[];  // [EMBB_TOK][NF8] : x features, y (masked), train flag, zero pad to 8;  later [4][64][NF8 + 1] partials
   const long ntok = (long)a.B * a.S;
-  const int e = blockIdx.y * 256 + threadIdx.x;
+  const int col = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int e = blockIdx.y * 64 + col;
+  const long per = (ntok + gridDim.x - 1) / gridDim.x;
+  const long tbeg = (long)blockIdx.x * per, tend = std::min(ntok, tbeg + per);
   float acc[NF8];
 #pragma unroll
   for (int j = 0; j < NF8; ++j) acc[j] = 0.f;
   float db = 0.f;
-  // each workgroup walks several token chunks (grid.x is capped) so the closing atomics stay few
-  for (long t0 = (long)blockIdx.x * EMBB_TOK; t0 < ntok; t0 += (long)gridDim.x * EMBB_TOK) {
+  for (long t0 = tbeg; t0 < tend; t0 += EMBB_TOK) {
     __syncthreads();
     for (int i = threadIdx.x; i < EMBB_TOK * NF8; i += 256) {
       const int tk = i / NF8, f = i % NF8;
       const long tok = t0 + tk;
       float v = 0.f;
-      if (tok < ntok) {
+      if (tok < tend) {
         const long b = tok / a.S, sidx = tok % a.S;
         if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
         else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
@@ -170,10 +174,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
     }
     __syncthreads();
     if (e >= a.E) continue;
-    const int ntk = (int)std::min<long>(EMBB_TOK, ntok - t0);
+    const int ntk = (int)std::min<long>(EMBB_TOK, tend - t0);
     const float* dcol = a.dsrc + t0 * a.E + e;
-#pragma unroll 16
-    for (int tk = 0; tk < ntk; ++tk) {   // 16 independent loads in flight per thread
+#pragma unroll 8
+    for (int tk = tl; tk < ntk; tk += 4) {   // independent loads in flight per thread
       const float d = dcol[(long)tk * a.E];
       db += d;
 #pragma unroll
@@ -184,14 +188,24 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
       }
     }
   }
-  if (e >= a.E) return;
+  __syncthreads();
+  float* red = xs;   // [4 token lanes][64 columns][NF8 + 1]
 #pragma unroll
-  for (int f = 0; f < NF8; ++f) {
-    if (f < a.nf) unsafeAtomicAdd(a.dwx + (long)e * a.nf + f, acc[f]);
-    else if (f == a.nf) unsafeAtomicAdd(a.dwy + e, acc[f]);
-    else if (f == a.nf + 1) unsafeAtomicAdd(a.dby + e, acc[f]);
+  for (int j = 0; j < NF8; ++j) red[(tl * 64 + col) * (NF8 + 1) + j] = acc[j];
+  red[(tl * 64 + col) * (NF8 + 1) + NF8] = db;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * (NF8 + 1); i += 256) {
+    const int c = i / (NF8 + 1), f = i % (NF8 + 1);
+    const int ee = blockIdx.y * 64 + c;
+    if (ee >= a.E) continue;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t += red[(q * 64 + c) * (NF8 + 1) + f];
+    if (f < a.nf) unsafeAtomicAdd(a.dwx + (long)ee * a.nf + f, t);
+    else if (f == a.nf) unsafeAtomicAdd(a.dwy + ee, t);
+    else if (f == a.nf + 1) unsafeAtomicAdd(a.dby + ee, t);
+    else if (f == NF8) unsafeAtomicAdd(a.dbx + ee, t);
   }
-  unsafeAtomicAdd(a.dbx + e, db);
 }
 // wide encoders (nf + 2 > 32): features in chunks of 8, d(src) re-read per chunk
 __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(EmbedBwdArgs a) {
@@ -238,9 +252,9 @@ int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s) {
   const long ntok = (long)a.B * a.S;
   const int nf8 = (a.nf + 2 + 7) / 8 * 8;
   if (nf8 <= EMBB_MAXF) {
-    const int ey = (a.E + 255) / 256;
-    const dim3 grid((unsigned)std::min<long>((ntok + EMBB_TOK - 1) / EMBB_TOK, std::max(1, 256 / ey)), ey);
-    const size_t lds = (size_t)EMBB_TOK * nf8 * sizeof(float);
+    const int ey = (a.E + 63) / 64;
+    const dim3 grid((unsigned)std::max<long>(1, std::min<long>((ntok + EMBB_TOK - 1) / EMBB_TOK, std::max(1, 512 / ey))), ey);
+    const size_t lds = std::max((size_t)EMBB_TOK * nf8, (size_t)4 * 64 * (nf8 + 1)) * sizeof(float);
     switch (nf8) {
       case 8: hipLaunchKernelGGL(embed_bwd_kernel<8>, grid, dim3(256), lds, s, a); break;
       case 16: hipLaunchKernelGGL(embed_bwd_kernel<16>, grid, dim3(256), lds, s, a); break;
