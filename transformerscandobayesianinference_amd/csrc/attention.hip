@@ -31,10 +31,11 @@ template <typename T, int D> struct AttnCfg {
   static constexpr int TILE = KVB * RB;
   static constexpr int RS = PadStride<RB>::ROW, CS = PadStride<RB>::COL;   // padded LDS row strides (pfn_device.h)
   static constexpr int RIMG = KVB * RS, CIMG = KVB * CS;                  // bytes of one row / col image of a tile
-  // bf16 (product path): 8 waves share every K/V (or Q/dO) tile and the kernel is held to 256 registers, so
-  // two waves are resident per SIMD and one wave's MFMAs cover the other's softmax / LDS waits.  The exact-f32
-  // parity mode has twice the fragment registers and keeps 4 waves with the whole register file.
-  static constexpr int NW = sizeof(T) == 2 ? 8 : 4;
+  // bf16 up to head dim 128 (product path): 8 waves share every K/V (or Q/dO) tile and the kernel is held to 256
+  // registers, so two waves are resident per SIMD and one wave's MFMAs cover the other's softmax / LDS waits.
+  // Head dim 256 and the exact-f32 parity mode have twice the accumulator / fragment registers and keep 4 waves
+  // with the whole register file (at 256 registers they spill into scratch inside the tile loop).
+  static constexpr int NW = (sizeof(T) == 2 && D <= 128) ? 8 : 4;
   static constexpr int NT = NW * 64;        // threads per workgroup
   static constexpr int QBLK = NW * 32;      // query (or key) rows per workgroup
 };
