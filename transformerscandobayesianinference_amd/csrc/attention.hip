@@ -143,11 +143,17 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
 #pragma unroll
   for (int kk = 0; kk < C::NKK; ++kk) qf[kk] = load_frag_global<T>(Qp + (long)qc * rs + kk * 16 + 8 * h);
 
-  // initial state: the self key for test rows, empty for train rows
+  // initial state: the self key for test rows, empty for train rows.  The self K / V rows are only fetched by waves
+  // that hold a test row at all (wave-uniform branch): 7 of 8 waves at the north star skip 24 loads per lane.
   const bool is_test = qc >= sep;
-  float m, lsum;
+  const bool wave_has_test = wg.blk * C::QBLK + wave * 32 + 31 >= sep;
+  float m = -1e30f, lsum = 0.f;
   f32x16 o[C::NDB];
-  {
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  if (wave_has_test) {
     float part = 0.f;
 #pragma unroll
     for (int kk = 0; kk < C::NKK; ++kk) part += dot8(qf[kk], load_frag_global<T>(Kp + (long)qc * rs + kk * 16 + 8 * h));
@@ -447,7 +453,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   // self key of test rows
   const bool is_test = qc >= sep;
   float ds_self = 0.f, p_self = 0.f;
-  {
+  const bool wave_has_test = wg.blk * C::QBLK + wave * 32 + 31 >= sep;
+  if (wave_has_test) {   // only waves that hold a test row fetch the self K / V rows
     float tq = 0.f, dpv = 0.f;
 #pragma unroll
     for (int kk = 0; kk < C::NKK; ++kk) {
@@ -468,7 +475,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int d0 = db * 32 + 8 * rg + 4 * h;
-        f32x4 kv = load4<T>(Kp + (long)qc * rs + d0);
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f};
+        if (wave_has_test) kv = load4<T>(Kp + (long)qc * rs + d0);
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (dq[db][4 * rg + e] + ds_self * kv[e]) * scale;
