@@ -89,6 +89,28 @@ template <typename T> PFN_DEV void store4(T* p, f32x4 x) {
     *reinterpret_cast<bf16x4*>(p) = v;
   } else *reinterpret_cast<f32x4*>(p) = x;
 }
+// One 32-column block of a row-per-lane accumulator tile (lane = row, half-wave h holds columns 8g + 4h .. +3 of group g)
+// to global memory.  bf16: neighbouring groups are exchanged between the half-waves (v_permlane32_swap) so every lane
+// owns 8 contiguous columns and the block leaves as two 16-byte stores per lane instead of four 8-byte ones (the store
+// tail of these kernels is instruction-issue bound).  All lanes must call it (the exchange is wave-wide); `valid`
+// guards the stores.  v[4 g + e] = column 8 g + 4 h + e.
+template <typename T> PFN_DEV void store_row_block(T* row_block, const float (&v)[16], int h, bool valid) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      bf16x2 a0 = {(bf16)v[8 * p + 0], (bf16)v[8 * p + 1]}, a1 = {(bf16)v[8 * p + 2], (bf16)v[8 * p + 3]};
+      bf16x2 b0 = {(bf16)v[8 * p + 4], (bf16)v[8 * p + 5]}, b1 = {(bf16)v[8 * p + 6], (bf16)v[8 * p + 7]};
+      const auto r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
+      const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+      if (valid) *reinterpret_cast<u32x4*>(row_block + 16 * p + 8 * h) = w;
+    }
+  } else {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      if (valid) *reinterpret_cast<f32x4*>(row_block + 8 * rg + 4 * h) = f32x4{v[4 * rg], v[4 * rg + 1], v[4 * rg + 2], v[4 * rg + 3]};
+  }
+}
 PFN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Workgroup -> (row block, head, dataset) for a 1-D launch of nblk * H * B workgroups.  Hardware deals
@@ -289,18 +311,16 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
 
   lsum += __shfl_xor(lsum, 32, 64);
   const float inv = 1.f / lsum;
-  if (qvalid) {
-    T* out = reinterpret_cast<T*>(a.ctx) + ((long)b * a.S + qi) * a.E + hd * D;
+  {
+    T* out = reinterpret_cast<T*>(a.ctx) + ((long)b * a.S + qc) * a.E + hd * D;
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db)
+    for (int db = 0; db < C::NDB; ++db) {
+      float v[16];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = o[db][4 * rg + e] * inv;
-        store4<T>(out + db * 32 + 8 * rg + 4 * h, v);
-      }
-    if (h == 0) a.lse[((long)b * a.H + hd) * a.S + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;
+      for (int r = 0; r < 16; ++r) v[r] = o[db][r] * inv;
+      store_row_block<T>(out + db * 32, v, h, qvalid);
+    }
+    if (qvalid && h == 0) a.lse[((long)b * a.H + hd) * a.S + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;
   }
 }
 
@@ -468,20 +488,23 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
       ds_self = p_self * (dpv - delta);
     }
   }
-  if (qvalid) {
-    T* dQo = dbase + (long)qi * rs + hd * D;
+  {
+    T* dQo = dbase + (long)qc * rs + hd * D;
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db)
+    for (int db = 0; db < C::NDB; ++db) {
+      float v[16];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int d0 = db * 32 + 8 * rg + 4 * h;
         f32x4 kv = {0.f, 0.f, 0.f, 0.f};
         if (wave_has_test) kv = load4<T>(Kp + (long)qc * rs + d0);
-        f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (dq[db][4 * rg + e] + ds_self * kv[e]) * scale;
-        store4<T>(dQo + d0, v);
+        for (int e = 0; e < 4; ++e) v[4 * rg + e] = (dq[db][4 * rg + e] + ds_self * kv[e]) * scale;
       }
+      store_row_block<T>(dQo + db * 32, v, h, qvalid);
+    }
+  }
+  if (qvalid) {
     if (is_test) {
       T* dKo = dbase + (long)qi * rs + a.E + hd * D;
       T* dVo = dbase + (long)qi * rs + 2 * a.E + hd * D;
@@ -633,18 +656,16 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dkv_kernel(AttnA
     if (t + 1 < ntiles) tile(I1{}, t + 1);
   }
 
-  if (kvalid) {
-    T* out = dbase + (long)key * rs + (MODE == 0 ? 2 * a.E : a.E) + hd * D;
+  {
+    T* out = dbase + (long)kc * rs + (MODE == 0 ? 2 * a.E : a.E) + hd * D;
     const float f = MODE == 0 ? 1.f : scale;
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db)
+    for (int db = 0; db < C::NDB; ++db) {
+      float v[16];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        f32x4 x;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = acc[db][4 * rg + e] * f;
-        store4<T>(out + db * 32 + 8 * rg + 4 * h, x);
-      }
+      for (int r = 0; r < 16; ++r) v[r] = acc[db][r] * f;
+      store_row_block<T>(out + db * 32, v, h, kvalid);
+    }
   }
 }
 
