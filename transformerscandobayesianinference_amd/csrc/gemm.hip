@@ -280,14 +280,16 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
   bf16* out2_t = reinterpret_cast<bf16*>(g.out2_t);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long m = (long)m0 + wm * 128 + i * 32 + li;
-    if (m >= g.M) continue;
+    const long m_row = (long)m0 + wm * 128 + i * 32 + li;
+    const bool mvalid = m_row < g.M;
+    const long m = mvalid ? m_row : (long)g.M - 1;     // clamped for the loads; stores are guarded
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      const int nb = n0 + wn * 64 + j * 32;            // first column of this 32-column block (wave-uniform)
+      float pre[16], post[16];
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
-        if (n >= g.N) continue;
+        const int n = min(nb + 8 * gq + 4 * h, g.N - 4);
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
@@ -303,26 +305,47 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
         }
-        if (flags & EPI_OUT2_T) {
-          bf16x4 t;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x4*>(out2_t + m * g.ld_out2 + n) = t;
-        }
+        for (int e = 0; e < 4; ++e) pre[4 * gq + e] = v[e];
         if (flags & EPI_GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
         }
-        if (flags & EPI_OUT_F32) {
-          float* o = g.out_f32 + m * g.ld_out_f32 + n;
-          if (flags & EPI_ACCUM) v += *reinterpret_cast<const f32x4*>(o);
-          *reinterpret_cast<f32x4*>(o) = v;
-        }
-        if (flags & EPI_OUT_T) {
-          bf16x4 t;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x4*>(out_t + m * g.ld_out_t + n) = t;
+        for (int e = 0; e < 4; ++e) post[4 * gq + e] = v[e];
+        if (flags & EPI_OUT_F32) {
+          if (mvalid && nb + 8 * gq + 4 * h < g.N) {
+            float* o = g.out_f32 + m * g.ld_out_f32 + n;
+            if (flags & EPI_ACCUM) v += *reinterpret_cast<const f32x4*>(o);
+            *reinterpret_cast<f32x4*>(o) = v;
+          }
+        }
+      }
+      // operand-precision outputs: 16-byte stores after a half-wave exchange when the whole block is inside N
+      // (wave-uniform test) and the row pitch keeps them aligned, else 8-byte stores per group
+      if (flags & (EPI_OUT_T | EPI_OUT2_T)) {
+        const bool wide = nb + 32 <= g.N && g.wide_t;
+        if (wide) {
+          if (flags & EPI_OUT2_T) store_row_block<bf16>(out2_t + m * g.ld_out2 + nb, pre, h, mvalid);
+          if (flags & EPI_OUT_T) store_row_block<bf16>(out_t + m * g.ld_out_t + nb, post, h, mvalid);
+        } else {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int n = nb + 8 * gq + 4 * h;
+            if (!mvalid || n >= g.N) continue;
+            if (flags & EPI_OUT2_T) {
+              bf16x4 t;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t[e] = (bf16)pre[4 * gq + e];
+              *reinterpret_cast<bf16x4*>(out2_t + m * g.ld_out2 + n) = t;
+            }
+            if (flags & EPI_OUT_T) {
+              bf16x4 t;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t[e] = (bf16)post[4 * gq + e];
+              *reinterpret_cast<bf16x4*>(out_t + m * g.ld_out_t + n) = t;
+            }
+          }
         }
       }
     }
@@ -470,31 +493,32 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   bf16* x_t = reinterpret_cast<bf16*>(g.x_t);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long m = (long)m0 + i * 32 + li;
-    if (m >= g.M) continue;
-    if (wave == 0 && h == 0) { g.mean[m] = mean[i]; g.rstd[m] = rstd[i]; }
+    const long m_row = (long)m0 + i * 32 + li;
+    const bool mvalid = m_row < g.M;
+    const long m = mvalid ? m_row : (long)g.M - 1;
+    if (mvalid && wave == 0 && h == 0) { g.mean[m] = mean[i]; g.rstd[m] = rstd[i]; }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      const int nb = wave * 64 + j * 32;
+      float xn[16];
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
+        const int n = nb + 8 * gq + 4 * h;
         const f32x4 ga = *reinterpret_cast<const f32x4*>(g.gamma + n), be = *reinterpret_cast<const f32x4*>(g.beta + n);
-        f32x4 v;
-        bf16x4 t;
+        f32x4 v, xo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[i][j][4 * gq + e];
-          t[e] = (bf16)((v[e] - mean[i]) * rstd[i] * ga[e] + be[e]);
+          xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
+          xn[4 * gq + e] = xo[e];
         }
-        *reinterpret_cast<f32x4*>(g.y + m * BN + n) = v;
-        *reinterpret_cast<bf16x4*>(x_t + m * BN + n) = t;
-        if (g.x_f32) {
-          f32x4 xo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
-          *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;
+        if (mvalid) {
+          *reinterpret_cast<f32x4*>(g.y + m * BN + n) = v;
+          if (g.x_f32) *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;
         }
       }
+      store_row_block<bf16>(x_t + m * BN + nb, xn, h, mvalid);   // 16-byte stores after a half-wave exchange
+    }
   }
 }
 
@@ -832,6 +856,7 @@ int launch_gemm_nt(const GemmNT& g_in, int precision, hipStream_t stream) {
   if ((g.flags & (EPI_GELU_BWD | EPI_RESID_T)) && ((g.ld_aux * es) % (4 * es) || !aligned16(g.aux))) vec = false;
   if ((g.flags & EPI_BIAS) && !aligned16(g.bias)) vec = false;
   g.vec_ok = vec ? 1 : 0;
+  g.wide_t = (!(g.flags & EPI_OUT_T) || g.ld_out_t % 8 == 0) && (!(g.flags & EPI_OUT2_T) || g.ld_out2 % 8 == 0) ? 1 : 0;   // 16-byte rows
   if (precision == PFN_PREC_BF16) {
     const int pick = gemm_nt_pick(g);
     if (pick && launch_big(g, pick == 2, stream)) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;

@@ -212,6 +212,29 @@ template <typename T, int STRIDE, int MAP> PFN_DEV Frag<T> load_frag_tr_p(const 
   return f;
 }
 
+// One 32-column block of a row-per-lane accumulator tile (lane = row, half-wave h holds columns 8g + 4h .. +3 of group g)
+// to global memory.  bf16: neighbouring groups are exchanged between the half-waves (v_permlane32_swap) so every lane
+// owns 8 contiguous columns and the block leaves as two 16-byte stores per lane instead of four 8-byte ones (the store
+// tail of these kernels is instruction-issue bound).  All lanes must call it (the exchange is wave-wide); `valid`
+// guards the stores.  v[4 g + e] = column 8 g + 4 h + e.
+template <typename T> PFN_DEV void store_row_block(T* row_block, const float (&v)[16], int h, bool valid) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      bf16x2 a0 = {(bf16)v[8 * p + 0], (bf16)v[8 * p + 1]}, a1 = {(bf16)v[8 * p + 2], (bf16)v[8 * p + 3]};
+      bf16x2 b0 = {(bf16)v[8 * p + 4], (bf16)v[8 * p + 5]}, b1 = {(bf16)v[8 * p + 6], (bf16)v[8 * p + 7]};
+      const auto r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
+      const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+      if (valid) *reinterpret_cast<u32x4*>(row_block + 16 * p + 8 * h) = w;
+    }
+  } else {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      if (valid) *reinterpret_cast<f32x4*>(row_block + 8 * rg + 4 * h) = f32x4{v[4 * rg], v[4 * rg + 1], v[4 * rg + 2], v[4 * rg + 3]};
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Cooperative global -> LDS tile copy in 16-byte chunks (register staged so the issue and the
 // LDS write can be split around compute).  ROWS x RB bytes, NT threads.

@@ -32,6 +32,7 @@ struct GemmNT {
   void* out_t; long ld_out_t;
   void* out2_t; long ld_out2;
   int vec_ok;  // filled by the launcher
+  int wide_t;  // filled by the launcher: operand-precision outputs may be stored 16 bytes at a time
 };
 int launch_gemm_nt(const GemmNT& g, int precision, hipStream_t stream);
 // kernel selection knob (tests / profiling): 0 automatic, 1 only the 128x128 kernel, 2 the 256x256 kernel whenever legal
