@@ -109,6 +109,13 @@ PFN_DEV AttnBlock attn_block(int nblk, int H) {
   return o;
 }
 
+// Profiling builds only (tools/exp_attn_variants.py): -DPFN_ATTN_ABLATE=<bits> drops, in every main loop, the
+// global tile requests (1), the LDS tile writes (2), the barrier (4).  Results are then garbage; the timing
+// differences price the three parts (MI355X, north-star shape: requests 9-14 %, writes 6-7 %, barrier 4 %).
+#ifndef PFN_ATTN_ABLATE
+#define PFN_ATTN_ABLATE 0
+#endif
+constexpr int ABL = PFN_ATTN_ABLATE;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float RESCALE_THR = 6.f;  // log2 units: lazily raised running max of the online softmax (see attn_fwd_kernel)
@@ -178,6 +185,10 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
     sv.issue(Vp, rs, sep, D);
     sk.template commit_p<C::RS>(Kt(0));
     sv.template commit_p<C::CS>(Vt(0));
+    if (ntiles > 1) {   // tile 1 stays in flight across the barrier (see the loop)
+      sk.issue(Kp + (long)C::KVB * rs, rs, sep - C::KVB, D);
+      sv.issue(Vp + (long)C::KVB * rs, rs, sep - C::KVB, D);
+    }
   }
   __syncthreads();
 
@@ -204,12 +215,15 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   int vb_prev = 0, vb_cur = 0;           // V buffer of tile t-1 / tile t
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * C::KVB;
-    if (t + 1 < ntiles) {
-      const long k1 = k0 + C::KVB;
-      sk.issue(Kp + k1 * rs, rs, sep - (int)k1, D);
-      sv.issue(Vp + k1 * rs, rs, sep - (int)k1, D);
-    }
+    // all K fragments of the tile are requested before anything else: the LDS round trip (>100 cycles under load)
+    // then overlaps the global-load issue below and the first MFMAs instead of stalling each one
     const lds_char* kt = Kt(t & 1);
+    Frag<T> kfr[C::NKK][C::NKB];
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk)
+#pragma unroll
+      for (int kb = 0; kb < C::NKB; ++kb) kfr[kk][kb] = load_frag_row_p<T, C::RS>(kt, kb * 32 + li, kk * 16);
+    PFN_PIN_LDS_MFMA();
     f32x16 st[C::NKB];
 #pragma unroll
     for (int kb = 0; kb < C::NKB; ++kb)
@@ -218,8 +232,23 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
 #pragma unroll
     for (int kk = 0; kk < C::NKK; ++kk)
 #pragma unroll
-      for (int kb = 0; kb < C::NKB; ++kb)
-        st[kb] = mma32(load_frag_row_p<T, C::RS>(kt, kb * 32 + li, kk * 16), qf[kk], st[kb]);
+      for (int kb = 0; kb < C::NKB; ++kb) st[kb] = mma32(kfr[kk][kb], qf[kk], st[kb]);
+    PFN_PIN_LDS_MFMA();
+    // Global -> LDS staging, one tile ahead with the loads in flight across the barrier: the staged registers hold
+    // tile t+1 (requested one iteration ago); they are written to the buffers tile t-1 has released -- the wait for
+    // them sits behind the queued Q.K MFMAs -- and at once re-used for the request of tile t+2.  On the last tile the
+    // registers are stale and go to buffers nobody reads again (a branch here would split the block and strand the
+    // exponentials behind the P.V MFMAs).
+    const int vb_next = vb_cur == 2 ? 0 : vb_cur + 1;   // the slot tile t-2 has released
+    if (!(ABL & 2)) {
+      sk.template commit_p<C::RS>(Kt((t + 1) & 1));
+      sv.template commit_p<C::CS>(Vt(vb_next));
+    }
+    if (!(ABL & 1) && t + 2 < ntiles) {
+      const long k2 = k0 + 2 * C::KVB;
+      sk.issue(Kp + k2 * rs, rs, sep - (int)k2, D);
+      sv.issue(Vp + k2 * rs, rs, sep - (int)k2, D);
+    }
     if (t == nfull) {   // ragged last tile: keys >= sep do not exist
 #pragma unroll
       for (int kb = 0; kb < C::NKB; ++kb)
@@ -278,12 +307,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
 #pragma unroll
     for (int c = 0; c < NPF; ++c) pf[c] = acc_to_frag<T>(st[c >> 1], c & 1);
     vb_prev = vb_cur;
-    vb_cur = vb_cur == 2 ? 0 : vb_cur + 1;
-    if (t + 1 < ntiles) {
-      sk.template commit_p<C::RS>(Kt((t + 1) & 1));
-      sv.template commit_p<C::CS>(Vt(vb_cur));
-    }
-    __syncthreads();
+    vb_cur = vb_next;
+    if (!(ABL & 4)) __syncthreads();
   }
   if (ntiles > 0) pv_prev(vb_prev);
 
@@ -386,6 +411,10 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
     sk.template commit_p<C::RS>(Kr(0));
     sk.template commit_p<C::CS>(Kc(0));
     sv.template commit_p<C::RS>(Vr(0));
+    if (ntiles > 1) {   // tile 1 stays in flight across the barrier (staging as in attn_fwd_kernel)
+      sk.issue(Kp + (long)C::KVB * rs, rs, sep - C::KVB, D);
+      sv.issue(Vp + (long)C::KVB * rs, rs, sep - C::KVB, D);
+    }
   }
   __syncthreads();
   // one key tile; BUF / EDGE compile-time as in the forward kernel
@@ -393,24 +422,51 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
     constexpr int BUF = decltype(buf_c)::value;
     constexpr bool EDGE = decltype(edge_c)::value;
     const int k0 = t * C::KVB;
-    if (t + 1 < ntiles) {
-      const long k1 = k0 + C::KVB;
-      sk.issue(Kp + k1 * rs, rs, sep - (int)k1, D);
-      sv.issue(Vp + k1 * rs, rs, sep - (int)k1, D);
-    }
     const lds_char* kr = Kr(BUF);
     const lds_char* kc = Kc(BUF);
     const lds_char* vr = Vr(BUF);
 #pragma unroll
     for (int kb = 0; kb < C::NKB; ++kb) {   // 32 keys at a time: only one S / dP pair is live
+      // operand fragments of the S / dP products run PD k-steps ahead of the MFMAs that consume them
+      constexpr int PD = C::NKK < 4 ? C::NKK : 4;
+      Frag<T> kfr[C::NKK], vfr[C::NKK];
+#pragma unroll
+      for (int kk = 0; kk < PD; ++kk) {
+        kfr[kk] = load_frag_row_p<T, C::RS>(kr, kb * 32 + li, kk * 16);
+        vfr[kk] = load_frag_row_p<T, C::RS>(vr, kb * 32 + li, kk * 16);
+      }
+      PFN_PIN_LDS_MFMA();
       f32x16 st, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < C::NKK; ++kk) {
-        st = mma32(load_frag_row_p<T, C::RS>(kr, kb * 32 + li, kk * 16), qf[kk], st);
-        dp = mma32(load_frag_row_p<T, C::RS>(vr, kb * 32 + li, kk * 16), dof[kk], dp);
+        if (kk + PD < C::NKK) {
+          kfr[kk + PD] = load_frag_row_p<T, C::RS>(kr, kb * 32 + li, (kk + PD) * 16);
+          vfr[kk + PD] = load_frag_row_p<T, C::RS>(vr, kb * 32 + li, (kk + PD) * 16);
+        }
+        st = mma32(kfr[kk], qf[kk], st);
+        dp = mma32(vfr[kk], dof[kk], dp);
+        PFN_PIN_LDS_MFMA();
       }
+      if (kb == 0) {   // staged tile t+1 -> the other buffer (stale and unread after the last tile), then request t+2
+        if (!(ABL & 2)) {
+          sk.template commit_p<C::RS>(Kr(BUF ^ 1));
+          sk.template commit_p<C::CS>(Kc(BUF ^ 1));
+          sv.template commit_p<C::RS>(Vr(BUF ^ 1));
+        }
+        if (!(ABL & 1) && t + 2 < ntiles) {
+          const long k2 = k0 + 2 * C::KVB;
+          sk.issue(Kp + k2 * rs, rs, sep - (int)k2, D);
+          sv.issue(Vp + k2 * rs, rs, sep - (int)k2, D);
+        }
+      }
+      // transposed K fragments of the dQ products: the first half is requested before the softmax arithmetic, the
+      // second before the first half's MFMAs
+      Frag<T> cf[2][C::NDB];
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) cf[0][db] = load_frag_tr_p<T, C::CS, 2>(kc, kb * 32, db * 32);
+      PFN_PIN_LDS_MFMA();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float p = fast_exp2(__builtin_fmaf(st[r], scale_log2, -lse2));
@@ -420,17 +476,16 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const Frag<T> dsf = acc_to_frag<T>(st, c);
+        if (c == 0) {
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-          dq[db] = mma32(load_frag_tr_p<T, C::CS, 2>(kc, kb * 32 + c * 16, db * 32), dsf, dq[db]);
+          for (int db = 0; db < C::NDB; ++db) cf[1][db] = load_frag_tr_p<T, C::CS, 2>(kc, kb * 32 + 16, db * 32);
+        }
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) dq[db] = mma32(cf[c][db], dsf, dq[db]);
+        PFN_PIN_LDS_MFMA();
       }
     }
-    if (t + 1 < ntiles) {
-      sk.template commit_p<C::RS>(Kr(BUF ^ 1));
-      sk.template commit_p<C::CS>(Kc(BUF ^ 1));
-      sv.template commit_p<C::RS>(Vr(BUF ^ 1));
-    }
-    __syncthreads();
+    if (!(ABL & 4)) __syncthreads();
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -579,28 +634,53 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dkv_kernel(AttnA
   so.issue(dOp, a.E, a.S, D);
   stage_stats(0);
   commit_all(0);
+  auto request = [&](int t) {   // tile t -> staging registers
+    const long q1 = (long)t * QB;
+    sq.issue(Qp + q1 * rs, rs, a.S - (int)q1, D);
+    so.issue(dOp + q1 * a.E, a.E, a.S - (int)q1, D);
+    stage_stats((int)q1);
+  };
+  if (ntiles > 1) request(1);   // stays in flight across the barrier (staging as in attn_fwd_kernel)
   __syncthreads();
 
   auto tile = [&](auto buf_c, int t) {
     constexpr int BUF = decltype(buf_c)::value;
-    if (t + 1 < ntiles) {
-      const long q1 = (long)(t + 1) * QB;
-      sq.issue(Qp + q1 * rs, rs, a.S - (int)q1, D);
-      so.issue(dOp + q1 * a.E, a.E, a.S - (int)q1, D);
-      stage_stats((int)q1);
-    }
     const lds_char* qr = Img(BUF, 0);
     const lds_char* stt = St(BUF);
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
+      // operand fragments run PD k-steps ahead of the MFMAs that consume them (see attn_bwd_dq_kernel)
+      constexpr int PD = C::NKK < 4 ? C::NKK : 4;
+      Frag<T> qfr[C::NKK], ofr[MODE == 1 ? C::NKK : 1];
+#pragma unroll
+      for (int kk = 0; kk < PD; ++kk) {
+        qfr[kk] = load_frag_row_p<T, C::RS>(qr, qb * 32 + li, kk * 16);
+        if constexpr (MODE == 1) ofr[kk] = load_frag_row_p<T, C::RS>(Img(BUF, 2), qb * 32 + li, kk * 16);
+      }
+      PFN_PIN_LDS_MFMA();
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < C::NKK; ++kk) {
-        s = mma32(load_frag_row_p<T, C::RS>(qr, qb * 32 + li, kk * 16), kf[kk], s);
-        if constexpr (MODE == 1) dp = mma32(load_frag_row_p<T, C::RS>(Img(BUF, 2), qb * 32 + li, kk * 16), vf[kk], dp);
+        if (kk + PD < C::NKK) {
+          qfr[kk + PD] = load_frag_row_p<T, C::RS>(qr, qb * 32 + li, (kk + PD) * 16);
+          if constexpr (MODE == 1) ofr[kk + PD] = load_frag_row_p<T, C::RS>(Img(BUF, 2), qb * 32 + li, (kk + PD) * 16);
+        }
+        s = mma32(qfr[kk], kf[kk], s);
+        if constexpr (MODE == 1) dp = mma32(ofr[kk], vf[kk], dp);
+        PFN_PIN_LDS_MFMA();
       }
+      if (qb == 0) {   // staged tile t+1 -> the other buffer (stale and unread after the last tile), then request t+2
+        if (!(ABL & 2)) commit_all(BUF ^ 1);
+        if (!(ABL & 1) && t + 2 < ntiles) request(t + 2);
+      }
+      // transposed dO / Q fragments of the second product: first half requested before the softmax arithmetic
+      const lds_char* col = Img(BUF, 1);   // dO (dV pass) or Q (dK pass), read transposed
+      Frag<T> cf[2][C::NDB];
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) cf[0][db] = load_frag_tr_p<T, C::CS, 2>(col, qb * 32, db * 32);
+      PFN_PIN_LDS_MFMA();
       // rows of s/dp are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
@@ -615,17 +695,19 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dkv_kernel(AttnA
           else s[r] = p * (dp[r] - dl[e]);
         }
       }
-      const lds_char* col = Img(BUF, 1);   // dO (dV pass) or Q (dK pass), read transposed
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const Frag<T> f = acc_to_frag<T>(s, c);
+        if (c == 0) {
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-          acc[db] = mma32(load_frag_tr_p<T, C::CS, 2>(col, qb * 32 + c * 16, db * 32), f, acc[db]);
+          for (int db = 0; db < C::NDB; ++db) cf[1][db] = load_frag_tr_p<T, C::CS, 2>(col, qb * 32 + 16, db * 32);
+        }
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) acc[db] = mma32(cf[c][db], f, acc[db]);
+        PFN_PIN_LDS_MFMA();
       }
     }
-    if (t + 1 < ntiles) commit_all(BUF ^ 1);
-    __syncthreads();
+    if (!(ABL & 4)) __syncthreads();
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;

@@ -9,7 +9,10 @@ pids=()
 for f in $SRCS; do
   o=../_build/${f%.hip}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ pfn_device.h -nt "$o" ] || [ pfn_kernels.h -nt "$o" ] || [ ../../include/pfn_hip.h -nt "$o" ]; then
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result "$@" -c "$f" -o "$o" &
+    extra=""
+    # attention.hip: no SLP packing -- v_pk_add/mul_f32 beside MFMAs issue slower than the scalar ops they replace
+    [ "$f" = attention.hip ] && extra="-fno-slp-vectorize"
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $extra "$@" -c "$f" -o "$o" &
     pids+=($!)
   fi
 done

@@ -34,6 +34,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define PFN_DEV __device__ __forceinline__
+// Scheduling fence for LDS and MFMA instructions only (vector / scalar ALU and global memory instructions may still
+// cross it): the machine scheduler otherwise sinks every LDS fragment load to just before the MFMA that consumes it
+// -- minimal register pressure, but each MFMA then waits out a full LDS round trip.
+#define PFN_PIN_LDS_MFMA() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x20 | 0x40)
 
 PFN_DEV int lane_id() { return threadIdx.x & 63; }
 
