@@ -137,6 +137,18 @@ int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws,
                         int B, int S, int nf, int kernel, int gen_x, int gen_z,
                         uint64_t seed, uint64_t offset, int32_t* info, void* stream);
 
+/* ---- Exact-GP sequential predictions: replaces priors.fast_gp.evaluate (priors/fast_gp.py:88-120), which refits a
+ * gpytorch ExactGP on points 0..t-1 and predicts point t for every t (one Cholesky per t).  Here ONE factorisation of
+ * the full covariance gives all of them (gp_prior.hip): for every dataset b and position t, the posterior at x[b,t]
+ * given (x[b,:t], y[b,:t]) under the GP with the given hyper-parameters:
+ *   mean[b,t], var[b,t] (predictive, observation noise included), nll[b,t] = -log N(y[b,t]; mean, var).
+ * Position 0 is the prior.  x [B,S,nf], y [B,S]; K_ws [B,S,S], resid_ws / w_ws [B,S] scratch; nll / mean / var may be
+ * null.  S % 4 == 0.  info as in pfn_gp_prior_sample. */
+int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_ws, float* w_ws,
+                     const float* lengthscale, const float* outputscale, const float* noise,
+                     int B, int S, int nf, int kernel, float* nll, float* mean, float* var,
+                     int32_t* info, void* stream);
+
 /* ---- BNN prior sampler: replaces the per-dataset module forwards of priors.mlp.get_batch (priors/mlp.py:116-124
  * network, :150-157 forward of the non-causal branch, :195-197 Python loop over datasets).  For dataset b with model
  * m = model_of[b]:  h_0 = causes W_0^T + b_0;  h_l = act(h_{l-1}) W_l^T + b_l + noise_std[m] * eps_l  (1 <= l < L_m);

@@ -12,6 +12,8 @@ Explicit-math restatement, in plain PyTorch on CPU tensors (f64 by default), of
   * priors.fast_gp.get_batch                      reference priors/fast_gp.py:13-58 (gpytorch
     semantics restated: K = outputscale * exp(-0.5 |dx/l|^2) + noise I, y = chol(K) z)
   * priors.fast_gp_mix kernel                     reference priors/fast_gp_mix.py:28-47 (Matern-5/2 ARD)
+  * priors.fast_gp.evaluate                       reference priors/fast_gp.py:88-120 (one exact GP per position;
+    gpytorch's ExactGP prediction equations restated -- parity unpinned like the GP prior)
 Nothing here calls nn.TransformerEncoder: the layer math is written out, and is pinned against the
 real reference modules by tests/golden (oracle/make_golden.py).
 """
@@ -186,6 +188,43 @@ def get_batch_fast_gp(batch_size, seq_len, num_features, hyperparameters=None, g
     y = gp_sample(x, z, hyperparameters["lengthscale"], hyperparameters["outputscale"], max(hyperparameters["noise"], 1e-9), 'rbf', dtype)
     y = y.float()
     return x.transpose(0, 1), y.transpose(0, 1), y.transpose(0, 1)
+
+
+def gp_evaluate(x, y, use_mse=False, hyperparameters=None, step_size=1, start_pos=0, kernel='rbf', dtype=torch.float64):
+    """CPU statement of priors.fast_gp.evaluate (fast_gp.py:88-120), literally: for every t a NEW exact GP is
+    conditioned on (x[:t], y[:t]) (train covariance = outputscale k + noise I, zero mean, fast_gp.py:13-32) and asked
+    for the noisy predictive at x[t] (`likelihood(model(x[t]))`, :101-104); loss = -log N(y[t]; mean, var) (:115) or
+    (mean - y[t])^2 (:112).  x [T,B,F], y [T,B].  Returns (losses [n_t,B], means [n_t,B], variances [n_t,B]).
+    gpytorch itself is not installed here: this restates its ExactGP prediction equations,
+    mean = k_t^T C_t^-1 y_t, var = k(x_t,x_t) + noise - k_t^T C_t^-1 k_t, with one Cholesky PER t -- on purpose a
+    different algorithm from the product's single factorisation."""
+    if isinstance(hyperparameters, (tuple, list)):
+        hyperparameters = {"noise": hyperparameters[0], "outputscale": hyperparameters[1], "lengthscale": hyperparameters[2]}
+    elif hyperparameters is None:
+        hyperparameters = {"noise": .1, "outputscale": .1, "lengthscale": .1}
+    xb, yb = x.transpose(0, 1).to(dtype), y.transpose(0, 1).to(dtype)
+    B, T, F = xb.shape
+    as_t = lambda v: torch.as_tensor(v, dtype=dtype)
+    ls = as_t(hyperparameters["lengthscale"])
+    ls = ls.reshape(B, 1, -1) if ls.dim() > 0 and ls.numel() > 1 else ls.reshape(1, 1, 1)
+    os_ = as_t(hyperparameters["outputscale"]).reshape(-1, 1, 1)
+    nz = as_t(hyperparameters["noise"]).clamp_min(1e-9).reshape(-1, 1, 1)
+    C = gp_gram(xb, ls, os_, nz, kernel)                      # [B,T,T], noise on the diagonal
+    losses, means, varis = [], [], []
+    for t in range(max(start_pos, 1), T, step_size):
+        L = torch.linalg.cholesky(C[:, :t, :t])
+        k = C[:, :t, t].unsqueeze(-1)                         # cross covariance (no noise: off-diagonal)
+        alpha = torch.cholesky_solve(yb[:, :t].unsqueeze(-1), L)
+        v = torch.linalg.solve_triangular(L, k, upper=False)
+        mean = (k * alpha).sum((1, 2))
+        var = C[:, t, t] - (v * v).sum((1, 2))                # C[t,t] = outputscale k(x_t,x_t) + noise
+        means.append(mean)
+        varis.append(var)
+        if use_mse:
+            losses.append((mean - yb[:, t]) ** 2)
+        else:
+            losses.append(0.5 * (math.log(2 * math.pi) + torch.log(var) + (yb[:, t] - mean) ** 2 / var))
+    return torch.stack(losses), torch.stack(means), torch.stack(varis)
 
 
 # ---- BNN prior (priors.mlp) ----------------------------------------------------------------------------

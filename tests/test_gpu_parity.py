@@ -236,6 +236,49 @@ def test_gp_prior_sampler_statistics():
     assert not torch.equal(ys, ys2)
 
 
+def test_gp_posterior_vs_oracle():
+    """priors.fast_gp.evaluate: every sequential exact-GP prediction from ONE batched factorisation on the GPU against
+    the oracle's one-Cholesky-per-position restatement of the reference loop (fast_gp.py:88-120).  f32 factorisation
+    vs f64: 1e-3 relative on the losses the paper's baseline curve is drawn from (their mean per position)."""
+    from transformerscandobayesianinference_amd.priors import fast_gp
+    g = torch.Generator().manual_seed(11)
+    for (B, T, F, hps) in [(4, 64, 3, (0.1, 0.1, 0.1)), (3, 201, 5, (0.05, 1.0, 0.6)), (2, 330, 18, (0.1, 0.1, 0.1))]:
+        x, y, _ = pfn_oracle.get_batch_fast_gp(B, T, F, hps, g)
+        want_nll, want_mean, want_var = pfn_oracle.gp_evaluate(x, y, hyperparameters=hps)
+        losses, per_t, secs = fast_gp.evaluate(x, y, y, hyperparameters=hps, device=DEV)
+        assert losses.shape == (T - 1, B) and per_t.shape == (T,) and per_t[0].item() == 0.0 and secs > 0
+        assert (losses.double() - want_nll).abs().max().item() < 2e-3 * want_nll.abs().max().item(), (B, T, F)
+        assert relerr(per_t[1:], want_nll.mean(1)) < 1e-3
+        mean, var, nll, info = fast_gp.gp_posterior(x.transpose(0, 1).contiguous().to(DEV), y.transpose(0, 1).contiguous().to(DEV),
+                                                    hps[2], hps[1], hps[0])
+        assert int(info.abs().sum()) == 0
+        # means relative to the range of y (far from every earlier point the true mean is ~0: no relative error there)
+        assert (mean[:, 1:].t().double().cpu() - want_mean).abs().max().item() < 1e-3 * y.abs().max().item()
+        assert relerr(var[:, 1:].t(), want_var) < 1e-3
+        # position 0 is the prior: mean 0, variance outputscale + noise
+        assert mean[:, 0].abs().max().item() < 1e-6 and torch.allclose(var[:, 0].cpu(), torch.full((B,), hps[1] + hps[0]), rtol=1e-5)
+        mse, per_t2, _ = fast_gp.evaluate(x, y, y, use_mse=True, hyperparameters=hps, device=DEV, step_size=5, start_pos=2)
+        want_mse, _, _ = pfn_oracle.gp_evaluate(x, y, use_mse=True, hyperparameters=hps, step_size=5, start_pos=2)
+        assert mse.shape == want_mse.shape and per_t2.shape == (want_mse.shape[0],)
+        assert (mse.double() - want_mse).abs().max().item() < 1e-3 * want_mse.abs().max().item()
+
+
+def test_gp_posterior_full_size_chain_rule():
+    """bptt = 2000 (north-star size), where the per-position oracle loop is too slow: the per-position negative log
+    densities plus the prior term of position 0 must add up to the joint -log N(y; 0, C), computed in f64 on the CPU."""
+    from transformerscandobayesianinference_amd.priors import fast_gp
+    g = torch.Generator().manual_seed(12)
+    B, T, F, hps = 2, 2000, 18, (0.1, 0.1, 0.1)
+    x, y, _ = pfn_oracle.get_batch_fast_gp(B, T, F, hps, g)
+    mean, var, nll, info = fast_gp.gp_posterior(x.transpose(0, 1).contiguous().to(DEV), y.transpose(0, 1).contiguous().to(DEV), hps[2], hps[1], hps[0])
+    assert int(info.abs().sum()) == 0
+    t64 = lambda v: torch.tensor(v, dtype=torch.float64).reshape(1, 1, 1)
+    C = pfn_oracle.gp_gram(x.transpose(0, 1).double(), t64(hps[2]), t64(hps[1]), t64(hps[0]))
+    joint = -torch.distributions.MultivariateNormal(torch.zeros(B, T, dtype=torch.float64), covariance_matrix=C).log_prob(y.transpose(0, 1).double())
+    assert relerr(nll.double().sum(1), joint) < 1e-4
+    assert (var > 0).all() and (var.cpu() <= hps[1] + hps[0] + 1e-5).all()   # conditioning never adds variance
+
+
 def test_gp_mix_sampler_per_dataset_hyperparameters_vs_oracle():
     """priors.fast_gp_mix path of the sampler: Matern-5/2, ARD lengthscales and per-dataset outputscale / noise,
     against the f64 restatement on injected (x, z) (reference priors/fast_gp_mix.py:28-47, 96-99)."""

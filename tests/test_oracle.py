@@ -119,6 +119,30 @@ def test_gp_oracle_covariance():
     assert xs.shape == (10, 4, 3) and ys.shape == (10, 4) and ts.shape == (10, 4)
 
 
+def test_gp_evaluate_oracle_chain_rule_and_noise_limit():
+    """The restated priors.fast_gp.evaluate (one exact GP per position): its per-position negative log densities are
+    the chain-rule factors of the joint Gaussian, so with the prior term of position 0 they add up to
+    -log N(y; 0, outputscale k + noise I); and with a huge lengthscale-free noise the prediction is the prior."""
+    g = torch.Generator().manual_seed(5)
+    T, B, F = 40, 3, 2
+    hps = (0.05, 0.9, 0.4)
+    x, y, _ = pfn_oracle.get_batch_fast_gp(B, T, F, hps, g, dtype=torch.float64)
+    nll, mean, var = pfn_oracle.gp_evaluate(x, y, hyperparameters=hps)
+    assert nll.shape == (T - 1, B) and (var > 0).all()
+    t64 = lambda v: torch.tensor(v, dtype=torch.float64).reshape(1, 1, 1)
+    C = pfn_oracle.gp_gram(x.transpose(0, 1).double(), t64(0.4), t64(0.9), t64(0.05))
+    yb = y.transpose(0, 1).double()
+    joint = -torch.distributions.MultivariateNormal(torch.zeros(B, T, dtype=torch.float64), covariance_matrix=C).log_prob(yb)
+    first = 0.5 * (math.log(2 * math.pi) + torch.log(C[:, 0, 0]) + yb[:, 0] ** 2 / C[:, 0, 0])
+    assert torch.allclose(nll.sum(0) + first, joint, rtol=1e-9, atol=1e-9)
+    mse, _, _ = pfn_oracle.gp_evaluate(x, y, use_mse=True, hyperparameters=hps, step_size=7, start_pos=3)
+    assert mse.shape == (len(range(3, T, 7)), B)
+    assert torch.allclose(mse[0], (mean[2] - yb[:, 3]) ** 2)
+    # observation noise >> signal: the posterior mean collapses to the prior mean 0, the variance to outputscale + noise
+    _, m2, v2 = pfn_oracle.gp_evaluate(x, y, hyperparameters=(1e6, 0.9, 0.4))
+    assert m2.abs().max().item() < 1e-4 and torch.allclose(v2, torch.full_like(v2, 1e6 + 0.9), rtol=1e-6)
+
+
 def test_oracle_mlp_prior_matches_reference():
     """priors.mlp.get_batch of the reference (non-causal tabular BNN prior) re-built by the oracle from the tensors the
     reference itself drew (tests/golden/mlp_prior.pt, recorded by oracle/make_golden.py::mlp_prior_case)."""

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(64) void gp_potrf_kernel(GpArgs a, int k0) {
     if (c > r) row[c] = 0.f;                    // only the lower triangle is defined
     if (c == r && !live) row[c] = 1.f;          // padding rows of the last (partial) panel: identity
   }
-  const float zr = live ? a.z[(long)b * S + k0 + r] : 0.f;
+  const bool solve = a.w != nullptr;
+  const float zr = (live && !solve) ? a.z[(long)b * S + k0 + r] : 0.f;
   int bad = 0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -159,10 +160,22 @@ __global__ __launch_bounds__(64) void gp_potrf_kernel(GpArgs a, int k0) {
   }
   if (r == 0 && bad && a.info[b] == 0) a.info[b] = bad;
   float acc = 0.f;
+  if (!solve) {
 #pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    const float zc = lane_bcast(zr, c);
-    if (c <= r) acc += row[c] * zc;
+    for (int c = 0; c < NB; ++c) {
+      const float zc = lane_bcast(zr, c);
+      if (c <= r) acc += row[c] * zc;
+    }
+  } else {
+    // posterior mode: w[blk] = L_kk^-1 residual[blk] by forward substitution along the lanes (lane j's quotient is
+    // the only one read in step j; padding rows of a partial panel carry a zero residual and an identity row)
+    float res = live ? a.y[(long)b * S + k0 + r] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float wj = lane_bcast(res / row[j], j);
+      if (r == j) acc = wj;
+      if (r > j) res -= row[j] * wj;
+    }
   }
   if (live) {
     if (nb == NB) {
@@ -188,7 +201,8 @@ __global__ __launch_bounds__(64) void gp_potrf_kernel(GpArgs a, int k0) {
 #pragma unroll
       for (int c = 0; c < NB; ++c) if (c <= r) Kb[(long)r * S + c] = row[c];
     }
-    a.y[(long)b * S + k0 + r] += acc;
+    if (solve) a.w[(long)b * S + k0 + r] = acc;
+    else a.y[(long)b * S + k0 + r] += acc;
   }
 }
 
@@ -205,7 +219,8 @@ __global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0, int r_en
     const int r = i / NB, c = i % NB;
     L[r][c] = (c <= r) ? Kb[(long)(k0 + r) * S + k0 + c] : 0.f;
   }
-  if (threadIdx.x < NB) zs[threadIdx.x] = a.z[(long)b * S + k0 + threadIdx.x];
+  const float* zsrc = a.w ? a.w : a.z;   // posterior mode: the panel's solution takes the place of the base normals
+  if (threadIdx.x < NB) zs[threadIdx.x] = zsrc[(long)b * S + k0 + threadIdx.x];
   __syncthreads();
   const int row = k0 + NB + blockIdx.x * 256 + threadIdx.x;
   if (row >= r_end) return;
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0, int r_en
   }
 #pragma unroll
   for (int c = 0; c < NB; c += 4) *reinterpret_cast<f32x4*>(p + c) = f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]};
-  a.y[(long)b * S + row] += ydot;
+  a.y[(long)b * S + row] += a.w ? -ydot : ydot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
     TileStage<float, 64, OBW * 4, 256> sv;
     sv.issue(Kb + (long)row0 * S + kout, S, rows_valid, OBW);
     sv.template commit_p<TW_STRIDE>(V);
-    zs[threadIdx.x] = a.z[(long)b * S + kout + threadIdx.x];
+    zs[threadIdx.x] = (a.w ? a.w : a.z)[(long)b * S + kout + threadIdx.x];
   }
   for (int jb = 0; jb < 4; ++jb) {
     __syncthreads();   // V current (initial load / previous block's solution), Lr free
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
     }
     d += __shfl_xor(d, 1, 64);
     d += __shfl_xor(d, 2, 64);
-    if (q == 0 && r < rows_valid) a.y[(long)b * S + row0 + r] += d;
+    if (q == 0 && r < rows_valid) a.y[(long)b * S + row0 + r] += a.w ? -d : d;
   }
   for (int id = threadIdx.x; id < 64 * (OBW / 4); id += 256) {
     const int r = id / (OBW / 4), c = id % (OBW / 4);
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
 int launch_gp_sample(const GpArgs& a, hipStream_t s) {
   const int S = a.S, B = a.B;
   if (S % 4) return PFN_ERR_UNSUPPORTED;  // 16-byte aligned matrix rows
-  {
+  if (!a.w) {
     const long work = ((long)B * S * a.nf + 3) / 4 + ((long)B * S + 3) / 4;
     const int grid = (int)std::max<long>(1, std::min<long>((work + 255) / 256, 4096));
     hipLaunchKernelGGL(gp_rng_kernel, dim3(grid), dim3(256), 0, s, a);
@@ -451,6 +466,35 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
       syrk(kend, S, kend, S, kout, OBW);
     }
   }
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sequential exact-GP predictions (reference priors/fast_gp.py:88-120 `evaluate`: for every t it refits
+// an ExactGP on points 0..t-1 and predicts point t -- one Cholesky per t).  All of them fall out of ONE
+// factorisation of the full covariance C = outputscale k(x,x) + noise I = L L^T: the leading t x t block of L
+// is the factor of the first t points, row t of L is L_t^-1 k_t, and the forward solve w = L^-1 y is causal, so
+//   mean_t = sum_{j<t} L[t,j] w[j] = y_t - L[t,t] w[t],   var_t (with noise) = L[t,t]^2,
+//   -log N(y_t; mean_t, var_t) = log L[t,t] + w[t]^2 / 2 + log(2 pi) / 2.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_posterior_kernel(GpArgs a, const float* y_data, float* nll, float* mean, float* var) {
+  const long n = (long)a.B * a.S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / a.S, t = i % a.S;
+    const float d = a.K[(b * a.S + t) * a.S + t], w = a.w[i];
+    if (nll) nll[i] = __logf(d) + 0.5f * w * w + 0.9189385332046727f;
+    if (mean) mean[i] = y_data[i] - d * w;
+    if (var) var[i] = d * d;
+  }
+}
+
+int launch_gp_posterior(const GpArgs& a, const float* y_data, float* nll, float* mean, float* var, hipStream_t s) {
+  if (!a.w || !a.y || !y_data) return PFN_ERR_ARGUMENT;
+  if (hipMemcpyAsync(a.y, y_data, sizeof(float) * a.B * a.S, hipMemcpyDeviceToDevice, s) != hipSuccess) return PFN_ERR_LAUNCH;
+  const int rc = launch_gp_sample(a, s);
+  if (rc != PFN_OK) return rc;
+  const long n = (long)a.B * a.S;
+  hipLaunchKernelGGL(gp_posterior_kernel, dim3((int)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, s, a, y_data, nll, mean, var);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 

@@ -185,8 +185,15 @@ struct GpArgs {
   unsigned long long seed, offset;
   int gen_x, gen_z;
   int* info;                 // [B] 0 ok, else index+1 of the first non-positive pivot
+  // posterior mode (launch_gp_posterior): the same factorisation run as a forward solve  w = L^-1 y_data  -- y holds the
+  // running residual (y_data on entry), w the solution, and every panel subtracts L[rows, panel] w[panel] from the
+  // residual below it where the sampler adds L[rows, panel] z[panel] to the draw
+  float* w;                  // [B,S]; null = sampler mode
 };
 int launch_gp_sample(const GpArgs& a, hipStream_t s);
+// Sequential exact-GP predictions from ONE factorisation: for every t, the posterior at x_t given points 0..t-1.
+//   mean[b,t], var[b,t] (with observation noise), nll[b,t] = -log N(y_t; mean, var);  resid_ws / w_ws: [B,S] scratch
+int launch_gp_posterior(const GpArgs& a, const float* y_data, float* nll, float* mean, float* var, hipStream_t s);
 
 // ---- BNN prior sampler (mlp_prior.hip) -----------------------------------------------------------
 struct MlpPriorArgs {

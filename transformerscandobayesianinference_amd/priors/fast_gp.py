@@ -85,5 +85,77 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
 
 DataLoader = get_batch_to_dataloader(get_batch)
 DataLoader.num_outputs = 1
+
+
+@torch.no_grad()
+def gp_posterior(x, y, lengthscale, outputscale, noise, kernel=KERNEL_RBF):
+    """Sequential exact-GP predictions through the C ABI (`pfn_gp_posterior`): for every dataset b and position t the
+    posterior at x[b,t] given (x[b,:t], y[b,:t]).  x [B,T,F], y [B,T] on the GPU; hyper-parameters as in `gp_sample`.
+    Returns (mean[B,T], var[B,T] with observation noise, nll[B,T], info[B])."""
+    dev = x.device
+    if dev.type != 'cuda':
+        raise _hip.HipExtensionError(f'the GP posterior runs on the GPU only (got device {dev}); no CPU fallback')
+    lib = _hip.lib()
+    B, T, F = x.shape
+
+    def per_dataset(v, cols):
+        t = torch.as_tensor(v, dtype=torch.float32, device=dev)
+        if t.dim() == 0:
+            return t.expand(B, cols).contiguous()
+        return t.reshape(B, -1).expand(B, cols).contiguous()
+
+    ls, osc, nz = per_dataset(lengthscale, F), per_dataset(outputscale, 1), per_dataset(noise, 1)
+    # 16-byte aligned matrix rows: append up to 3 points AFTER the real ones -- a prediction only sees earlier points
+    Tp = (T + 3) // 4 * 4
+    xp, yp = x.float(), y.float()
+    if Tp != T:
+        xp = torch.cat([xp, torch.rand(B, Tp - T, F, device=dev)], 1)
+        yp = torch.cat([yp, torch.zeros(B, Tp - T, device=dev)], 1)
+    xp, yp = xp.contiguous(), yp.contiguous()
+    K = torch.empty(B, Tp, Tp, dtype=torch.float32, device=dev)
+    resid, w = torch.empty_like(yp), torch.empty_like(yp)
+    mean, var, nll = torch.empty_like(yp), torch.empty_like(yp), torch.empty_like(yp)
+    info = torch.zeros(B, dtype=torch.int32, device=dev)
+    _hip.check(lib.pfn_gp_posterior(xp.data_ptr(), yp.data_ptr(), K.data_ptr(), resid.data_ptr(), w.data_ptr(), ls.data_ptr(),
+                                    osc.data_ptr(), nz.data_ptr(), B, Tp, F, kernel, nll.data_ptr(), mean.data_ptr(),
+                                    var.data_ptr(), info.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_posterior')
+    return mean[:, :T], var[:, :T], nll[:, :T], info
+
+
+def _hyperparameters_dict(hyperparameters):
+    if isinstance(hyperparameters, (tuple, list)):
+        return {"noise": hyperparameters[0], "outputscale": hyperparameters[1], "lengthscale": hyperparameters[2]}
+    hps = dict(_DEFAULT_HPS)
+    hps.update(hyperparameters or {})
+    return hps
+
+
+@torch.no_grad()
+def evaluate(x, y, y_non_noisy, use_mse=False, hyperparameters={}, get_model_on_device=None, device=default_device,
+             step_size=1, start_pos=0):
+    """The exact-GP baseline of the reference (priors/fast_gp.py:88-120): for t in range(max(start_pos, 1), T, step_size)
+    the loss of the GP posterior given the first t points at point t -- negative log density of y[t] under the noisy
+    predictive, or squared error of its mean.  Same arguments (x [T,B,F], y [T,B]) and the same return value
+    (losses [n_t, B] on the CPU, their means per t with the reference's leading 0. when start_pos == 0, seconds).
+    The reference refits a gpytorch model per t; here every t comes from one batched factorisation on the GPU
+    (`gp_posterior`), with the exact Cholesky the notebook selects (`fast_computations` off).  `get_model_on_device`
+    exists for signature compatibility; a fitted-hyper-parameter model has no meaning here and is rejected."""
+    import time
+    if get_model_on_device is not None:
+        raise NotImplementedError('evaluate() runs the fixed-hyper-parameter GP of priors.fast_gp; pass hyperparameters instead')
+    start_time = time.time()
+    hps = _hyperparameters_dict(hyperparameters)
+    xb = x.to(device).transpose(0, 1).contiguous()
+    yb = y.to(device).transpose(0, 1).contiguous()
+    mean, var, nll, _ = gp_posterior(xb, yb, hps["lengthscale"], hps["outputscale"], max(float(hps["noise"]), 1e-9))
+    ts = list(range(max(start_pos, 1), x.shape[0], step_size))
+    idx = torch.as_tensor(ts, dtype=torch.long, device=mean.device)
+    ls = ((mean - yb) ** 2 if use_mse else nll).index_select(1, idx).transpose(0, 1)     # [n_t, B]
+    per_t = ls.mean(1)
+    if start_pos == 0:
+        per_t = torch.cat([per_t.new_zeros(1), per_t])
+    if mean.is_cuda:
+        torch.cuda.synchronize(mean.device)
+    return ls.to('cpu'), per_t.to('cpu'), time.time() - start_time
 DataLoader.prefetch = True        # draws run ahead of the training steps on a side stream (priors/utils.py)
 DataLoader.prefetch_group = 4     # ... four steps' worth of datasets per sampler call
