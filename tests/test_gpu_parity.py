@@ -442,3 +442,51 @@ def test_micro_batch_streams_match_single_stream():
     for loss_n, g_n in grads[1:]:
         assert abs(loss_n - grads[0][0]) < 1e-5 * abs(grads[0][0])
         assert relerr(g_n, grads[0][1]) < 1e-4, relerr(g_n, grads[0][1])
+
+
+def test_tabular_get_model_and_checkpoint_roundtrip(tmp_path):
+    """tabular.get_model (reference tabular.py:109-155) trains a tiny BNN-prior classifier through the HIP path; the
+    notebooks' `(state_dict, None)` checkpoint tuple (BayesianModels...ipynb cells 14/16, TabularEvalSimple cell 12)
+    written from it loads into a freshly built (`should_train=False`) model with identical predictions, and its keys
+    are the reference's state-dict keys."""
+    import numpy as np
+    from test_host import _tabular_config
+    from transformerscandobayesianinference_amd import tabular
+    from transformerscandobayesianinference_amd.priors import mlp
+    torch.manual_seed(4); random.seed(4); np.random.seed(4)
+    cfg = _tabular_config('mlp')
+    loss, pos, model = tabular.get_model(cfg, DEV, eval_positions=[10, 20, 30], should_train=True, steps_per_epoch=3)
+    assert math.isfinite(loss) and len(pos) == cfg['bptt']
+    path = str(tmp_path / 'pfn.cpkt')
+    tabular.save_checkpoint(model, path)
+    state, opt = torch.load(path)
+    assert opt is None
+    keys = set(state)
+    for k in ['encoder.weight', 'y_encoder.bias', 'transformer_encoder.layers.0.self_attn.in_proj_weight',
+              'transformer_encoder.layers.1.self_attn.out_proj.bias', 'transformer_encoder.layers.0.linear1.weight',
+              'transformer_encoder.layers.1.linear2.bias', 'transformer_encoder.layers.0.norm1.weight',
+              'transformer_encoder.layers.1.norm2.bias', 'decoder.0.weight', 'decoder.2.bias']:
+        assert k in keys, k
+    assert state['transformer_encoder.layers.0.self_attn.in_proj_weight'].shape == (3 * cfg['emsize'], cfg['emsize'])
+    assert state['decoder.2.weight'].shape == (1, cfg['emsize'] * cfg['nhid_factor'])
+    _, _, fresh = tabular.get_model(cfg, DEV, eval_positions=[10, 20, 30], should_train=False)
+    assert tabular.load_checkpoint(fresh, path) is None
+    x, y, _ = mlp.get_batch(4, cfg['bptt'], cfg['num_features'], device=DEV, hyperparameters=tabular.get_mlp_prior_hyperparameters(cfg),
+                            batch_size_per_gp_sample=4)
+    model.to(DEV).eval(); fresh.to(DEV).eval()
+    with torch.no_grad():
+        a = model((x, y), single_eval_pos=25)
+        b = fresh((x, y), single_eval_pos=25)
+    assert a.shape == (cfg['bptt'] - 25, 4, 1) and torch.equal(a, b)
+
+
+def test_binarized_regression_priors():
+    """priors.binarized_regression (reference :4-21): labels ~ Bernoulli(sigmoid(y)) of a HIP GP draw."""
+    from transformerscandobayesianinference_amd.priors import binarized_regression as br
+    torch.manual_seed(0)
+    for cls, kw in [(br.Binarized_fast_gp_dataloader, {'hyperparameters': (1e-4, 1., .6)}), (br.Binarized_fast_gp_mix_dataloader, {})]:
+        dl = cls(num_steps=1, batch_size=64, seq_len=32, num_features=3, device=DEV, **kw)
+        (x, y), target = next(iter(dl))
+        assert x.shape == (32, 64, 3) and y.shape == (32, 64) and target is y and x.is_cuda
+        assert set(y.unique().tolist()) <= {0., 1.} and 0.25 < y.mean().item() < 0.75
+    assert cls.num_outputs == 1

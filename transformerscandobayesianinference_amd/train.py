@@ -177,7 +177,7 @@ def main(argv=None):
     config_parser = argparse.ArgumentParser(description='Only used as a first parser for the config file path.')
     config_parser.add_argument('--config')
     parser = argparse.ArgumentParser()
-    parser.add_argument('prior', choices=['gp'])
+    parser.add_argument('prior', choices=['gp', 'mix_gp', 'ridge'])   # the reference's 'stroke' prior needs its image data (out of scope)
     parser.add_argument('--loss_function', default='barnll')
     parser.add_argument('--min_y', type=float, help='barnll can only model y in strict ranges, this is the minimum y can take.')
     parser.add_argument('--max_y', type=float, help='barnll can only model y in strict ranges, this is the maximum y can take.')
@@ -209,7 +209,7 @@ def main(argv=None):
         cfg['nhid'] = 2 * cfg['emsize']
 
     dp.init_from_env()
-    prior = {'gp': priors.fast_gp.DataLoader}[cfg.pop('prior')]
+    prior = {'gp': priors.fast_gp.DataLoader, 'mix_gp': priors.fast_gp_mix.DataLoader, 'ridge': priors.ridge.DataLoader}[cfg.pop('prior')]
     loss_function, num_buckets = cfg.pop('loss_function'), cfg.pop('num_buckets')
     max_y, min_y = cfg.pop('max_y'), cfg.pop('min_y')
 
