@@ -490,3 +490,33 @@ def test_binarized_regression_priors():
         assert x.shape == (32, 64, 3) and y.shape == (32, 64) and target is y and x.is_cuda
         assert set(y.unique().tolist()) <= {0., 1.} and 0.25 < y.mean().item() < 0.75
     assert cls.num_outputs == 1
+
+
+def test_evaluation_sweeps():
+    """evaluation.run_test (notebook SetupForGPFittingExperiments.ipynb cell 6) and the exact-GP curve it is compared
+    with: shapes / finiteness of the 5-tuple on a barely trained PFN, and the baseline's sanity -- more training points
+    never hurt an exact GP on its own prior, and no PFN beats it on average."""
+    import numpy as np
+    from transformerscandobayesianinference_amd import evaluation, train as train_mod, utils as u
+    from transformerscandobayesianinference_amd.priors import fast_gp
+    torch.manual_seed(5); random.seed(5); np.random.seed(5)
+    hps = (1e-2, 1., .6)
+    ys = fast_gp.get_batch(256, 20, 2, device=DEV, hyperparameters=hps)[1].cpu()
+    crit = bar_distribution.FullSupportBarDistribution(bar_distribution.get_bucket_limits(50, ys=ys))
+    _, _, model = train_mod.train(fast_gp.DataLoader, crit, encoders.Linear, emsize=64, nhid=128, nlayers=2, nhead=2, dropout=0.0, epochs=2,
+                                  steps_per_epoch=4, batch_size=16, lr=1e-3, warmup_epochs=1, y_encoder_generator=encoders.Linear, gpu_device=DEV,
+                                  verbose=False, bptt=40, single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(40),
+                                  extra_prior_kwargs_dict={'num_features': 2, 'hyperparameters': hps, 'device': DEV})
+    pos, mse, mode_mse, nll, conf = evaluation.run_test(model, DEV, step_size=12, start_pos=1, batch_size=64, sub_batch_size=32, seq_len=40,
+                                                        num_features=2, hyperparameters=hps)
+    assert pos == [1, 13, 25, 37]
+    for t in (mse, mode_mse, nll, conf):
+        assert t.shape == (4,) and torch.isfinite(t).all()
+    assert (mse > 0).all() and (conf > 0).all()
+    gpos, gmse, gnll, gconf = evaluation.gp_baseline(DEV, step_size=12, start_pos=1, batch_size=256, sub_batch_size=128, seq_len=40,
+                                                     num_features=2, hyperparameters=hps)
+    assert gpos == pos and gmse.shape == gnll.shape == gconf.shape == (4,)
+    assert gnll[-1] < gnll[0] - 0.3 and gmse[-1] < 0.5 * gmse[0]          # 37 training points vs 1
+    assert (gnll < nll + 3 * (conf + gconf)).all()                        # the Bayes-optimal predictor is not beaten
+    m, h = evaluation.compute_mean_and_conf_interval([1., 2., 3., 4.])
+    assert m == 2.5 and abs(h - 2.0541) < 1e-3
