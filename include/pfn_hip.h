@@ -194,7 +194,9 @@ int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, con
                          int prec, void* stream);
 int pfn_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
                          float* mean, float* rstd, int64_t rows, int E, float eps, int prec, void* stream);
-int pfn_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+/* dy: f32 when dy_is_t == 0, operand precision (prec) otherwise -- the form the backward schedule feeds it;
+ * dx_f32 / dx_t may each be null. */
+int pfn_op_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean,
                          const float* rstd, float* dx_f32, void* dx_t, float* dgamma, float* dbeta,
                          float* dbias_extra, int64_t rows, int E, int prec, void* stream);
 int pfn_op_cast(const float* src, void* dst, int64_t n, int prec, void* stream);

@@ -92,14 +92,16 @@ def layernorm_fwd(x, gamma, beta, eps, prec):
     return y32, yt, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, prec):
+def layernorm_bwd(dy, x, gamma, mean, rstd, prec, want_f32=True):
+    """dy: f32, or the operand dtype of `prec` (the form the backward schedule uses; then usually want_f32=False)."""
     rows, E = x.shape
-    dx32 = torch.empty_like(x)
+    dy_is_t = int(dy.dtype != torch.float32)
+    dx32 = torch.empty_like(x) if want_f32 else None
     dxt = torch.empty(rows, E, dtype=TDT[prec], device=x.device)
     dg = torch.zeros(E, device=x.device)
     db = torch.zeros(E, device=x.device)
     dbias = torch.zeros(E, device=x.device)
-    _hip.check(_hip.lib().pfn_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                               dx32.data_ptr(), dxt.data_ptr(), dg.data_ptr(), db.data_ptr(), dbias.data_ptr(),
+    _hip.check(_hip.lib().pfn_op_layernorm_bwd(dy.data_ptr(), dy_is_t, x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               dx32.data_ptr() if want_f32 else 0, dxt.data_ptr(), dg.data_ptr(), db.data_ptr(), dbias.data_ptr(),
                                                rows, E, prec, sp()), 'ln bwd')
     return dx32, dxt, dg, db, dbias

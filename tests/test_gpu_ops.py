@@ -246,6 +246,13 @@ def test_layernorm(rows, E, prec):
     assert relerr(dx32, xd.grad) < 1e-5
     assert relerr(dg, gd.grad) < 1e-5 and relerr(db, bd.grad) < 1e-5
     assert relerr(dbias, xd.grad.sum(0)) < 1e-4
+    # the form the backward schedule uses: upstream gradient in operand precision, operand-precision dx only
+    dy_t = dy.to(hipops.TDT[prec])
+    xd2 = x.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd2, (E,), gamma.double(), beta.double(), 1e-5).backward(dy_t.double())
+    none32, dxt2, dg2, db2, _ = hipops.layernorm_bwd(dy_t, x, gamma, mean, rstd, prec, want_f32=False)
+    assert none32 is None and relerr(dxt2, xd2.grad) < (4e-3 if prec == BF else 1e-5)
+    assert relerr(db2, dy_t.double().sum(0)) < 1e-5
 
 
 def attention_reference(qkv, H, sep):

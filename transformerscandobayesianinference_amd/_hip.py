@@ -68,7 +68,7 @@ SIGNATURES = {
     'pfn_op_attention_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_attention_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_layernorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
-    'pfn_op_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'pfn_op_layernorm_bwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'pfn_op_cast': (_I, [_P, _P, _L, _I, _P]),
 }
 

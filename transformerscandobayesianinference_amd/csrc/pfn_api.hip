@@ -576,9 +576,9 @@ int pfn_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
   PFN_TRY(launch_layernorm_fwd(x, gamma, beta, y_f32, y_t, mean, rstd, rows, E, eps, prec, (hipStream_t)stream));
   return PFN_OK;
 }
-int pfn_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx_f32,
+int pfn_op_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx_f32,
                          void* dx_t, float* dgamma, float* dbeta, float* dbias_extra, int64_t rows, int E, int prec, void* stream) {
-  PFN_TRY(launch_layernorm_bwd(dy, 0, x, gamma, mean, rstd, dx_f32, dx_t, dgamma, dbeta, dbias_extra, rows, E, prec, (hipStream_t)stream));
+  PFN_TRY(launch_layernorm_bwd(dy, dy_is_t, x, gamma, mean, rstd, dx_f32, dx_t, dgamma, dbeta, dbias_extra, rows, E, prec, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_cast(const float* src, void* dst, int64_t n, int prec, void* stream) {

@@ -404,7 +404,34 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 // rate, and few enough workgroups that the column reductions (d gamma, d beta, optional bias
 // gradient) end in ~0.8 M atomics instead of several million.
 constexpr int LNB_WAVES = 8;
-template <typename T, int NV, bool DY_T>
+// EV contiguous elements per lane and 64 EV-element chunks per wave pass: EV = 8 makes every operand-precision access a
+// 16-byte one (bf16 dY loads and dX stores of 8 bytes per lane stream at little more than half the rate).
+template <typename T, int EV> PFN_DEV void ln_load(const T* p, float (&v)[EV]) {
+  if constexpr (sizeof(T) == 2 && EV == 8) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  } else {
+#pragma unroll
+    for (int j = 0; j < EV; j += 4) {
+      const f32x4 t = ld4<T>(p + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[j + e] = t[e];
+    }
+  }
+}
+template <typename T, int EV> PFN_DEV void ln_store(T* p, const float (&v)[EV]) {
+  if constexpr (sizeof(T) == 2 && EV == 8) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  } else {
+#pragma unroll
+    for (int j = 0; j < EV; j += 4) st4<T>(p + j, f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]});
+  }
+}
+template <typename T, int NV, int EV, bool DY_T>
 __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const void* dy_any, const float* x, const float* gamma, const float* mean, const float* rstd,
                                                                       float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E) {
   extern __shared__ __attribute__((aligned(16))) float part[];  // [LNB_WAVES][E]
@@ -414,16 +441,17 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const voi
   const long wave0 = (long)blockIdx.x * LNB_WAVES + wave;
   const long wstride = (long)gridDim.x * LNB_WAVES;
   const float invE = 1.f / (float)E;
-  f32x4 ag[NV], ab[NV], ax[NV], gam[NV];
+  float ag[NV][EV], ab[NV][EV], ax[NV][EV], gam[NV][EV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    ag[k] = f32x4{0, 0, 0, 0}; ab[k] = f32x4{0, 0, 0, 0}; ax[k] = f32x4{0, 0, 0, 0};
-    const int c = (k * 64 + lane) * 4;
-    gam[k] = c < E ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0, 0, 0, 0};
+    const int c = (k * 64 + lane) * EV;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; ax[k][e] = 0.f; gam[k][e] = 0.f; }
+    if (c < E) ln_load<float, EV>(gamma + c, gam[k]);
   }
   for (long row0 = wave0; row0 < rows; row0 += 2 * wstride) {
     const long rw[2] = {row0, row0 + wstride};
-    f32x4 xv[2][NV], dv[2][NV];
+    float xv[2][NV][EV], dv[2][NV][EV];
     float mu[2], rs[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -432,12 +460,17 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const voi
       mu[u] = mean[r]; rs[u] = rstd[r];
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
-        const int c = (k * 64 + lane) * 4;
+        const int c = (k * 64 + lane) * EV;
         if (c < E) {
-          xv[u][k] = *reinterpret_cast<const f32x4*>(x + r * E + c);
-          if constexpr (DY_T) dv[u][k] = live ? ld4<T>(dy_t + r * E + c) : f32x4{0, 0, 0, 0};
-          else dv[u][k] = live ? *reinterpret_cast<const f32x4*>(dy + r * E + c) : f32x4{0, 0, 0, 0};
-        } else { xv[u][k] = f32x4{0, 0, 0, 0}; dv[u][k] = f32x4{0, 0, 0, 0}; }
+          ln_load<float, EV>(x + r * E + c, xv[u][k]);
+          if constexpr (DY_T) ln_load<T, EV>(dy_t + r * E + c, dv[u][k]);
+          else ln_load<float, EV>(dy + r * E + c, dv[u][k]);
+        }
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+          if (c >= E) xv[u][k][e] = 0.f;
+          if (c >= E || !live) dv[u][k][e] = 0.f;
+        }
       }
     }
 #pragma unroll
@@ -447,7 +480,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const voi
 #pragma unroll
       for (int k = 0; k < NV; ++k)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < EV; ++e) {
           const float xh = (xv[u][k][e] - mu[u]) * rs[u];
           const float g = dv[u][k][e] * gam[k][e];
           s1 += g;
@@ -461,13 +494,13 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const voi
       s2 = wave_sum(s2) * invE;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
-        const int c = (k * 64 + lane) * 4;
+        const int c = (k * 64 + lane) * EV;
         if (c < E) {
-          f32x4 o;
+          float o[EV];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2); ax[k][e] += o[e]; }
-          if (dx32) *reinterpret_cast<f32x4*>(dx32 + rw[u] * E + c) = o;
-          if (dxt) st4<T>(dxt + rw[u] * E + c, o);
+          for (int e = 0; e < EV; ++e) { o[e] = rs[u] * (dv[u][k][e] - s1 - xv[u][k][e] * s2); ax[k][e] += o[e]; }
+          if (dx32) ln_store<float, EV>(dx32 + rw[u] * E + c, o);
+          if (dxt) ln_store<T, EV>(dxt + rw[u] * E + c, o);
         }
       }
     }
@@ -481,8 +514,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const voi
     if (q > 0) __syncthreads();
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int c = (k * 64 + lane) * 4;
-      if (c < E) *reinterpret_cast<f32x4*>(part + wave * E + c) = q == 0 ? ag[k] : q == 1 ? ab[k] : ax[k];
+      const int c = (k * 64 + lane) * EV;
+      if (c < E) ln_store<float, EV>(part + wave * E + c, q == 0 ? ag[k] : q == 1 ? ab[k] : ax[k]);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += LNB_WAVES * 64) {
@@ -499,11 +532,14 @@ int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const floa
   if (rows == 0) return PFN_OK;
   const int grid = grid_for(rows, LNB_WAVES * 8, 512);
   const size_t lds = LNB_WAVES * E * sizeof(float);
-#define LN_BWD_K(TT, NV, DT) do { \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_kernel<TT, NV, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E); } while (0)
-#define LN_BWD(TT, NV) do { if (dy_is_t) LN_BWD_K(TT, NV, true); else LN_BWD_K(TT, NV, false); } while (0)
-#define LN_BWD_NV(TT) do { if (E <= 256) LN_BWD(TT, 1); else if (E <= 512) LN_BWD(TT, 2); else if (E <= 1024) LN_BWD(TT, 4); else LN_BWD(TT, 8); } while (0)
+#define LN_BWD_K(TT, NV, EV, DT) do { \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_kernel<TT, NV, EV, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, EV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E); } while (0)
+#define LN_BWD(TT, NV, EV) do { if (dy_is_t) LN_BWD_K(TT, NV, EV, true); else LN_BWD_K(TT, NV, EV, false); } while (0)
+  // rows of >= 512 elements in 8-element lane chunks (16-byte operand-precision accesses), narrower rows in 4-element ones
+#define LN_BWD_NV(TT) do { \
+    if (E % 8 == 0 && E >= 512) { if (E <= 512) LN_BWD(TT, 1, 8); else if (E <= 1024) LN_BWD(TT, 2, 8); else LN_BWD(TT, 4, 8); } \
+    else if (E <= 256) LN_BWD(TT, 1, 4); else if (E <= 512) LN_BWD(TT, 2, 4); else if (E <= 1024) LN_BWD(TT, 4, 4); else LN_BWD(TT, 8, 4); } while (0)
   if (precision == PFN_PREC_BF16) LN_BWD_NV(bf16); else LN_BWD_NV(float);
   return PFN_LAUNCH_OK();
 }
