@@ -310,8 +310,8 @@ def main():
                               'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_flops_per_launch': dom['flops'],
                               'avg_launch_us': dom['seconds'] * 1e6, 'launches_per_step': dom['launches_per_step'],
                               'note': 'launch timed alone with HIP events on its stream; inside the step two micro-batch streams and the sampler stream share the GPU, so a '
-                                      'rocprofv3 trace of the default command shows this kernel stretched by its co-runners -- profiles/r01_bench_streams1_kernel_stats.csv '
-                                      '(same command with --streams 1) is the trace whose average duration matches'}
+                                      'rocprofv3 trace of the default command (profiles/r01_bench_kernel_stats.csv) shows this kernel stretched by its co-runners by a few percent -- '
+                                      'profiles/r01_bench_streams1_kernel_stats.csv (--batch 16 --streams 1: the same launch shape on one stream) is the trace whose average duration matches'}
         result['kernels'] = [{k: (round(v, 6) if isinstance(v, float) else v) for k, v in kk.items()} for kk in ks]
     if world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline()
