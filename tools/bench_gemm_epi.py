@@ -8,7 +8,10 @@ import bench, hipops
 from transformerscandobayesianinference_amd import _hip
 H = _hip
 ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=16); ap.add_argument('--modes', default='2,3')
+ap.add_argument('--lib', default=None, help='alternative build of libpfn_hip.so (experiment variants under _build/exp)')
 a = ap.parse_args()
+if a.lib:
+    _hip.LIB_PATH = os.path.abspath(a.lib)
 w = bench.WORKLOAD
 E, F, L = w['emsize'], w['nhid'], w['nlayers']
 M = a.batch * w['bptt']

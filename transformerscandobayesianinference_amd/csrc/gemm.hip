@@ -125,20 +125,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
         if constexpr (sizeof(T) == 2) { bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) a[e] = (float)t[e]; }
         else { f32x4 t = *reinterpret_cast<const f32x4*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) a[e] = t[e]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(a[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= a[e];
       }
       if (flags & EPI_RESID) { f32x4 r = *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + ncol); v += r; }
       if (flags & EPI_RESID_T) {
         if constexpr (sizeof(T) == 2) { bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) v[e] += (float)t[e]; }
         else { f32x4 t = *reinterpret_cast<const f32x4*>(aux + m * g.ld_aux + ncol); v += t; }
       }
-      if (flags & EPI_OUT2_T) {
-        if constexpr (sizeof(T) == 2) { bf16x4 t; for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e]; *reinterpret_cast<bf16x4*>(out2_t + m * g.ld_out2 + ncol) = t; }
-        else *reinterpret_cast<f32x4*>(out2_t + m * g.ld_out2 + ncol) = v;
-      }
+      f32x4 second = v;          // EPI_OUT2_T: the value before the activation, or with EPI_GELU the activation's derivative there
       if (flags & EPI_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        for (int e = 0; e < 4; ++e) { float y, dy; gelu_and_grad(v[e], y, dy); v[e] = y; second[e] = dy; }
+      }
+      if (flags & EPI_OUT2_T) {
+        if constexpr (sizeof(T) == 2) { bf16x4 t; for (int e = 0; e < 4; ++e) t[e] = (bf16)second[e]; *reinterpret_cast<bf16x4*>(out2_t + m * g.ld_out2 + ncol) = t; }
+        else *reinterpret_cast<f32x4*>(out2_t + m * g.ld_out2 + ncol) = second;
       }
       if (flags & EPI_OUT_F32) {
         float* o = g.out_f32 + m * g.ld_out_f32 + ncol;
@@ -154,11 +155,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
         float x = v[e];
         const int n = ncol + e;
         if (flags & EPI_BIAS) x += bias[n];
-        if (flags & EPI_GELU_BWD) x *= gelu_grad_f((float)aux[m * g.ld_aux + n]);
+        if (flags & EPI_GELU_BWD) x *= (float)aux[m * g.ld_aux + n];
         if (flags & EPI_RESID) x += g.resid[m * g.ld_resid + n];
         if (flags & EPI_RESID_T) x += (float)aux[m * g.ld_aux + n];
-        if (flags & EPI_OUT2_T) out2_t[m * g.ld_out2 + n] = (T)x;
-        if (flags & EPI_GELU) x = gelu_f(x);
+        float second = x;
+        if (flags & EPI_GELU) gelu_and_grad(x, x, second);
+        if (flags & EPI_OUT2_T) out2_t[m * g.ld_out2 + n] = (T)second;
         if (flags & EPI_OUT_F32) { float* o = g.out_f32 + m * g.ld_out_f32 + n; *o = (flags & EPI_ACCUM) ? (*o + x) : x; }
         if (flags & EPI_OUT_T) out_t[m * g.ld_out_t + n] = (T)x;
       }
@@ -297,7 +299,7 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
         if (flags & EPI_GELU_BWD) {
           const bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f((float)t[e]);
+          for (int e = 0; e < 4; ++e) v[e] *= (float)t[e];
         }
         if (flags & EPI_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
         if (flags & EPI_RESID_T) {
@@ -306,10 +308,10 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
           for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pre[4 * gq + e] = v[e];
+        for (int e = 0; e < 4; ++e) pre[4 * gq + e] = v[e];   // second output: value before the activation ...
         if (flags & EPI_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+          for (int e = 0; e < 4; ++e) { float y; gelu_and_grad(v[e], y, pre[4 * gq + e]); v[e] = y; }   // ... or the GELU derivative there
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) post[4 * gq + e] = v[e];

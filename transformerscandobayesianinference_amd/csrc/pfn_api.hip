@@ -89,6 +89,7 @@ Layout make_layout(const pfn_model_desc& d) {
 
 // ---- workspace ------------------------------------------------------------------------------------
 struct LayerWs {
+  // hpre: gelu'(pre-activation of linear1) -- what the backward multiplies by
   char *qkv, *ctx, *x1_t, *hpre, *h, *x2_t; float *lse, *y1, *mean1, *rstd1, *x1, *y2, *mean2, *rstd2, *x2;
   // backward: output-gradient operands of this layer's four weight gradients, kept until the grouped launch
   char *dy2_t, *dh_t, *dy1_t, *dqkv_t;

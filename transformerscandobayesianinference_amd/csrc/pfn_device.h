@@ -313,6 +313,20 @@ PFN_DEV float gelu_grad_f(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// GELU and its derivative together (one erf evaluation: its exp(-x^2/2) is the Gaussian density the derivative needs):
+// the forward epilogue stores gelu'(pre-activation) instead of the pre-activation, the backward one only multiplies.
+PFN_DEV void gelu_and_grad(float x, float& y, float& dy) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float ex = __expf(-ax * ax);                       // exp(-x^2 / 2)
+  const float cdf = 0.5f * (1.f + copysignf(1.f - p * t * ex, x));
+  y = x * cdf;
+  dy = cdf + x * 0.39894228040143267794f * ex;
+}
 PFN_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

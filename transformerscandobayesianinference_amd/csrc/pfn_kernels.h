@@ -11,11 +11,11 @@ namespace pfn {
 enum : int {
   EPI_BIAS = 1,      // + bias[n] (f32)
   EPI_GELU = 2,      // out = gelu(v)   (exact erf GELU, torch nn.GELU default)
-  EPI_GELU_BWD = 4,  // v *= gelu'(aux[m,n])
+  EPI_GELU_BWD = 4,  // v *= aux[m,n] (T): the GELU derivative the forward GEMM stored (EPI_GELU | EPI_OUT2_T)
   EPI_RESID = 8,     // + resid[m,n] (f32)
   EPI_OUT_F32 = 16,  // store f32
   EPI_OUT_T = 32,    // store operand type T
-  EPI_OUT2_T = 64,   // store pre-activation (before GELU) as T
+  EPI_OUT2_T = 64,   // second T output: with EPI_GELU the GELU DERIVATIVE at the pre-activation, else the value before the activation
   EPI_ACCUM = 128,   // out_f32 += v
   EPI_RESID_T = 256, // + aux[m,n] (T): residual taken from an operand-precision tensor (not with EPI_GELU_BWD)
 };
