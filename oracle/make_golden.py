@@ -115,6 +115,12 @@ def bar_case(ref):
         rec[(nb, full)] = dict(borders=borders, logits=logits.detach().clone(), y=y, nll=nll.detach().clone(), w=w,
                                dlogits=logits.grad.clone(), mean=crit.mean(logits.detach()).clone(),
                                bucket=crit.map_to_bucket_idx(y).clamp(0, nb - 1))
+        # the evaluation-side methods (bar_distribution.py:40-80), from the same logits (no further random draws)
+        lg = logits.detach()
+        best_f = borders[nb // 3].item()
+        rec[(nb, full)].update(quantile=crit.quantile(lg).clone(), quantile90=crit.quantile(lg, center_prob=.9).clone(),
+                               mode=crit.mode(lg).clone(), best_f=best_f, ei_max=crit.ei(lg, best_f, maximize=True).clone(),
+                               ei_min=crit.ei(lg, best_f, maximize=False).clone())
     rec['bucket_limits_uniform'] = ref['bar_distribution'].get_bucket_limits(8, full_range=(-2., 6.))
     torch.save(rec, os.path.join(OUT, 'bar_distribution.pt'))
     print('bar cases', list(k for k in rec if isinstance(k, tuple)))

@@ -312,3 +312,27 @@ def test_ridge_prior_and_baseline_vs_sklearn():
     dl = ridge.DataLoader(num_steps=2, batch_size=4, seq_len=10, num_features=3, device='cpu')
     (xx, yy), tt = next(iter(dl))
     assert xx.shape == (10, 4, 3) and yy.shape == tt.shape == (10, 4) and dl.num_outputs == 1
+
+
+def test_bar_distribution_eval_methods_match_reference_golden():
+    """quantile / mode / ei (reference bar_distribution.py:40-80) against values recorded from the
+    reference classes themselves (tests/golden/bar_distribution.pt, oracle/make_golden.py::bar_case).  These are host
+    tensor arithmetic in both code bases (vectorised here, Python loops there): bit-exact."""
+    import os
+    from transformerscandobayesianinference_amd import bar_distribution as bd
+    rec = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bar_distribution.pt'))
+    seen = 0
+    for key, c in rec.items():
+        if not isinstance(key, tuple):
+            continue
+        nb, full = key
+        crit = (bd.FullSupportBarDistribution if full else bd.BarDistribution)(c['borders'].clone())
+        lg = c['logits']
+        assert torch.equal(crit.quantile(lg), c['quantile']) and torch.equal(crit.quantile(lg, center_prob=.9), c['quantile90'])
+        assert torch.equal(crit.mode(lg), c['mode'])
+        assert torch.equal(crit.ei(lg, c['best_f'], maximize=True), c['ei_max'])
+        assert torch.equal(crit.ei(lg, c['best_f'], maximize=False), c['ei_min'])
+        assert torch.equal(crit.quantile(lg.view(8, 8, nb)), c['quantile'].view(8, 8, 2))      # leading dims are kept
+        seen += 1
+    assert seen == 5
+    assert torch.equal(bd.get_bucket_limits(8, full_range=(-2., 6.)), rec['bucket_limits_uniform'])

@@ -110,7 +110,9 @@ class BarDistribution(nn.Module):
         return torch.stack([lo, hi], -1).reshape(*shape[:-1], 2).cpu()
 
     def mode(self, logits):
-        return self.bucket_means()[logits.argmax(-1)]
+        """Centre of the most likely bucket (reference :64-67).  The plain centre also for the two half-normal tail
+        buckets of the full-support variant -- the reference does not override `mode` there."""
+        return BarDistribution.bucket_means(self)[logits.argmax(-1)]
 
     def ei(self, logits, best_f, maximize=True):
         """Expected improvement over `best_f` under the bar density (reference :69-80)."""
