@@ -36,6 +36,18 @@ class Losses():
     get_BarDistribution = BarDistribution
 
 
+def _accepts_kwarg(fn, name):
+    """True if `fn` can be called with keyword `name` (named parameter or **kwargs)."""
+    import inspect
+    if fn is None:
+        return False
+    try:
+        params = inspect.signature(fn).parameters.values()
+    except (TypeError, ValueError):
+        return False
+    return any(p.name == name or p.kind is inspect.Parameter.VAR_KEYWORD for p in params)
+
+
 def _is_bar(criterion):
     return isinstance(criterion, BarDistribution) or "BarDistribution" in criterion.__class__.__name__
 
@@ -62,8 +74,13 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     world = dp.world_size()
     if world > 1:
         dp.seed_ranks()
+    if str(device).startswith('cuda'):
+        torch.cuda.set_device(torch.device(device))     # side streams and scratch allocations follow the current device
+    prior_kwargs = dict(extra_prior_kwargs_dict)
+    if 'device' not in prior_kwargs and _accepts_kwarg(getattr(priordataloader_class, 'get_batch_method', None), 'device'):
+        prior_kwargs['device'] = device                   # draw where the model lives (the priors default to cuda:0)
     dl = priordataloader_class(num_steps=steps_per_epoch, batch_size=dp.local_batch_size(batch_size), seq_len=bptt,
-                               **extra_prior_kwargs_dict)
+                               **prior_kwargs)
 
     encoder = encoder_generator(dl.num_features + 1 if dl.fuse_x_y else dl.num_features, emsize)
     n_out = dl.num_outputs
@@ -208,7 +225,10 @@ def main(argv=None):
     if cfg['nhid'] is None:
         cfg['nhid'] = 2 * cfg['emsize']
 
-    dp.init_from_env()
+    _, world, local = dp.init_from_env()
+    if world > 1:
+        cfg['gpu_device'] = f'cuda:{local}'               # one process per GPU (torchrun sets LOCAL_RANK)
+        cfg['extra_prior_kwargs_dict'] = {**cfg['extra_prior_kwargs_dict'], 'device': cfg['gpu_device']}   # also for get_y_sample below
     prior = {'gp': priors.fast_gp.DataLoader, 'mix_gp': priors.fast_gp_mix.DataLoader, 'ridge': priors.ridge.DataLoader}[cfg.pop('prior')]
     loss_function, num_buckets = cfg.pop('loss_function'), cfg.pop('num_buckets')
     max_y, min_y = cfg.pop('max_y'), cfg.pop('min_y')
