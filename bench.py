@@ -55,7 +55,9 @@ def build_model(device, precision, w=WORKLOAD):
     from transformerscandobayesianinference_amd.transformer import TransformerModel
     torch.manual_seed(0)
     ys = fast_gp.get_batch(5000, 20, w['num_features'], device=device, hyperparameters=w['hyperparameters'])[1]
-    borders = bar_distribution.get_bucket_limits(w['num_bars'], ys=ys.cpu())
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):   # get_bucket_limits prints (reference behaviour); stdout carries the JSON line only
+        borders = bar_distribution.get_bucket_limits(w['num_bars'], ys=ys.cpu())
     criterion = bar_distribution.FullSupportBarDistribution(borders)
     model = TransformerModel(encoders.Linear(w['num_features'], w['emsize']), w['num_bars'], w['emsize'], w['nhead'], w['nhid'],
                              w['nlayers'], 0.0, y_encoder=encoders.Linear(1, w['emsize']), precision=precision)

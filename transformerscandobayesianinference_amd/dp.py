@@ -35,6 +35,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rk = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hooks for a one-GPU box: PFN_DP_BACKEND=gloo with PFN_DP_SINGLE_DEVICE=1 runs every rank on device 0 (RCCL
+    # refuses two ranks on one GPU), which exercises the whole multi-rank control path of bench.py / train()
+    backend = backend or os.environ.get('PFN_DP_BACKEND')
+    if os.environ.get('PFN_DP_SINGLE_DEVICE') == '1':
+        local = 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
