@@ -1,14 +1,26 @@
-"""Positional encodings (reference positional_encodings.py).
+"""Positional encodings (the module surface of the reference's positional_encodings.py).
 
-Protocol: __init__(d_model, max_len=...), forward(x[S,B,E]) -> x + pe.  The permutation-invariant
-PFN setup of every BASELINE config uses NoPositionalEncoding (train.py:42); that case is a no-op and
-the HIP embedding kernel feeds the stack directly.  The others are PyTorch plumbing applied to
-the embedding before it enters the HIP stack.
+Contract shared by all four: `cls(d_model, max_len)` and `module(x[S, B, E]) -> x + table[:S, None, :]`.
+Every BASELINE configuration is permutation invariant and uses `NoPositionalEncoding` (train.py:42) -- a no-op, so
+the HIP embedding kernel feeds the encoder stack directly.  The other three add a [S, 1, E] table to the embedding
+with one broadcast add before it enters the HIP stack.  Buffer / parameter names (`pe`, `positional_embeddings`) and
+the order in which the random generator is consumed (one normal draw at construction, one `randperm` per scrambled
+forward) are those of the reference, so its checkpoints and seeds carry over.
 """
 import math
 
 import torch
 from torch import nn
+
+
+class _AdditiveTable(nn.Module):
+    """x + rows(S)[:, None, :] for a subclass-defined [S, E] table."""
+
+    def rows(self, seq_len):
+        raise NotImplementedError
+
+    def forward(self, x):
+        return self.rows(x.shape[0]).unsqueeze(1) + x
 
 
 class NoPositionalEncoding(nn.Module):
@@ -19,49 +31,43 @@ class NoPositionalEncoding(nn.Module):
         return x
 
 
-class PositionalEncoding(nn.Module):
-    """Fixed sinusoids (reference positional_encodings.py:21-34)."""
+class PositionalEncoding(_AdditiveTable):
+    """The fixed sinusoid table of 'Attention is all you need' (reference :21-34): even columns sin, odd columns cos
+    of position / 10000^(column / d_model).  Stored as buffer `pe` of shape [max_len, 1, d_model]."""
 
     def __init__(self, d_model, max_len=5000):
         super().__init__()
-        pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
-        freq = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
-        table = torch.zeros(max_len, d_model)
-        table[:, 0::2] = torch.sin(pos * freq)
-        table[:, 1::2] = torch.cos(pos * freq)
-        self.register_buffer('pe', table.unsqueeze(1))  # [max_len, 1, d_model]
+        inv_wavelength = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        angle = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1) * inv_wavelength       # [max_len, d_model / 2]
+        table = torch.stack([torch.sin(angle), torch.cos(angle)], dim=-1).reshape(max_len, -1)   # interleave sin / cos
+        self.register_buffer('pe', table[:, :d_model].unsqueeze(1).contiguous())
 
-    def forward(self, x):
-        return self.pe[:x.size(0), :] + x
+    def rows(self, seq_len):
+        return self.pe[:seq_len, 0]
 
 
-class LearnedPositionalEncoding(nn.Module):
-    """One learned vector per position (reference positional_encodings.py:37-49)."""
+class LearnedPositionalEncoding(_AdditiveTable):
+    """One trainable vector per position, N(0, 1 / d_model) at construction (reference :37-49)."""
 
     def __init__(self, d_model, max_len=5000):
         super().__init__()
         self.max_seq_len = max_len
-        self.positional_embeddings = nn.Parameter(torch.empty(max_len, d_model))
-        nn.init.normal_(self.positional_embeddings, mean=0, std=d_model ** -0.5)
+        self.positional_embeddings = nn.Parameter(torch.empty(max_len, d_model).normal_(mean=0, std=d_model ** -0.5))
 
-    def _table(self, seq_len):
-        assert seq_len <= len(self.positional_embeddings), 'seq_len can be at most max_len.'
+    def rows(self, seq_len):
+        assert seq_len <= self.positional_embeddings.shape[0], 'seq_len can be at most max_len.'
         return self.positional_embeddings[:seq_len]
-
-    def forward(self, x):
-        seq_len, bs, d_model = x.shape
-        return self._table(seq_len).unsqueeze(1).expand(seq_len, bs, d_model) + x
 
 
 class PairedScrambledPositionalEncodings(LearnedPositionalEncoding):
-    """Learned table whose consecutive pairs are randomly permuted on every call (reference
-    positional_encodings.py:52-62)."""
+    """The learned table read through a fresh random permutation on every call (reference :52-62).  What is permuted
+    are the rows of the table viewed as [max_len, d_model / 2, 2] -- the reference's "pairs" -- so whole position
+    vectors move; one permutation serves the full batch."""
 
-    def forward(self, x):
-        seq_len, bs, d_model = x.shape
+    def rows(self, seq_len):
         table = self.positional_embeddings
-        assert seq_len <= len(table), 'seq_len can be at most max_len.'
-        assert len(table) % 2 == 0, 'Please specify an even max_len.'
-        pairs = table.view(len(table), -1, 2)
-        scrambled = pairs[torch.randperm(len(pairs))].view(*table.shape)[:seq_len]
-        return scrambled.unsqueeze(1).expand(seq_len, bs, d_model) + x
+        assert seq_len <= table.shape[0], 'seq_len can be at most max_len.'
+        assert table.shape[0] % 2 == 0, 'Please specify an even max_len.'
+        grouped = table.view(table.shape[0], -1, 2)
+        order = torch.randperm(grouped.shape[0])
+        return grouped[order].view_as(table)[:seq_len]

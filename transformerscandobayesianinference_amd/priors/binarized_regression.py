@@ -1,6 +1,7 @@
-"""Regression priors turned into binary-classification priors (reference priors/binarized_regression.py):
-label ~ Bernoulli(sigmoid(y)) of a regression draw.  The draw itself is the HIP GP sampler of `fast_gp` /
-`fast_gp_mix`; the squashing and the coin flips are two elementwise launches on the same device.
+"""Binary-classification priors made from regression priors (the module surface of the reference's
+priors/binarized_regression.py): every target becomes a coin flip with success probability sigmoid(y).
+The regression draw is the HIP GP sampler of `fast_gp` / `fast_gp_mix`; squashing and coin flips are two elementwise
+launches on the same device.
 """
 import torch
 
@@ -8,20 +9,30 @@ from transformerscandobayesianinference_amd.priors import fast_gp, fast_gp_mix
 from transformerscandobayesianinference_amd.priors.utils import get_batch_to_dataloader
 
 
-def regression_prior_to_binary(get_batch_function):
-    """Wrap a `get_batch` returning (x, y, target_y) with y real-valued into one whose y (and target) are {0, 1} labels
-    (reference :4-14).  `assert_on` checks the assumption that the wrapped prior has no separate noise-free target."""
-    def binarized_get_batch_function(*args, assert_on=False, **kwargs):
-        x, y, target_y = get_batch_function(*args, **kwargs)
-        if assert_on:
-            assert y is target_y, "y == target_y is assumed by this function"
-        labels = torch.bernoulli(torch.sigmoid(y))
+class _Binarized:
+    """`get_batch` of a regression prior with labels ~ Bernoulli(sigmoid(y)) in place of y -- and of the target, which
+    these priors do not distinguish from y (`assert_on=True` verifies that assumption, reference :8-10)."""
+
+    def __init__(self, regression_get_batch):
+        self.regression_get_batch = regression_get_batch
+
+    def __call__(self, *args, assert_on=False, **kwargs):
+        x, y, target_y = self.regression_get_batch(*args, **kwargs)
+        if assert_on and y is not target_y:
+            raise AssertionError('y == target_y is assumed by this function')
+        labels = torch.sigmoid(y).bernoulli()
         return x, labels, labels
-    return binarized_get_batch_function
 
 
-Binarized_fast_gp_dataloader = get_batch_to_dataloader(regression_prior_to_binary(fast_gp.get_batch))
-Binarized_fast_gp_dataloader.num_outputs = 1
+def regression_prior_to_binary(get_batch_function):
+    return _Binarized(get_batch_function)
 
-Binarized_fast_gp_mix_dataloader = get_batch_to_dataloader(regression_prior_to_binary(fast_gp_mix.get_batch))
-Binarized_fast_gp_mix_dataloader.num_outputs = 1
+
+def _loader(get_batch_function):
+    cls = get_batch_to_dataloader(regression_prior_to_binary(get_batch_function))
+    cls.num_outputs = 1
+    return cls
+
+
+Binarized_fast_gp_dataloader = _loader(fast_gp.get_batch)
+Binarized_fast_gp_mix_dataloader = _loader(fast_gp_mix.get_batch)

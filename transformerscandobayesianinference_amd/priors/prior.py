@@ -10,4 +10,8 @@ from torch.utils.data import DataLoader
 
 
 class PriorDataLoader(DataLoader):
-    pass
+    # protocol attributes; a prior module sets them on its loader class (`DataLoader.num_outputs = 1`) or the loader
+    # instance takes them from its constructor keywords (priors/utils.py)
+    num_features = None
+    num_outputs = None
+    fuse_x_y = False
