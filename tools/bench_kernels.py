@@ -21,7 +21,10 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--sep', type=int, default=1755)
     ap.add_argument('--gemm-modes', default='1,2')
+    ap.add_argument('--lib', default=None, help='alternative build of libpfn_hip.so (experiment variants)')
     args = ap.parse_args()
+    if args.lib:
+        _hip.LIB_PATH = os.path.abspath(args.lib)
     for mode in [int(m) for m in args.gemm_modes.split(',')]:
         _hip.check(_hip.lib().pfn_set_tuning(0, mode), 'tuning')
         for k in bench.kernel_breakdown(args.batch, args.sep):
