@@ -17,7 +17,6 @@ The JSON line also carries
 """
 import argparse
 import json
-import math
 import os
 import random
 import sys

@@ -2,7 +2,6 @@
     python tools/bench_kernels.py [--batch 16] [--only gemm|attn|all]
 Prints one line per kernel: average launch duration (HIP events on the launch stream) and TFLOP/s."""
 import argparse
-import json
 import os
 import sys
 

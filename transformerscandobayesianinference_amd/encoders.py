@@ -5,7 +5,6 @@ handed to the stack as a pre-embedded [S,B,E] tensor.
 """
 import math
 
-import torch
 from torch import nn
 
 Linear = nn.Linear  # reference encoders.py:8

@@ -18,7 +18,6 @@ kept.  Always exact Cholesky; only nu = 2.5 (the reference defa
 Model fitting / MCMC comparison code of the reference file (get_fitted_model, get_mcmc_model, evaluate_, :156-287)
 needs gpytorch / botorch / pyro and is out of scope.
 """
-import random
 
 import torch
 from torch import nn

@@ -11,7 +11,6 @@ buffer) so the optimizer and the data-parallel all-reduce touch a single contigu
 There is no PyTorch fallback: CPU tensors or a missing library raise `HipExtensionError`.
 """
 import ctypes
-import math
 
 import torch
 from torch import nn
