@@ -552,3 +552,33 @@ def test_evaluation_sweeps():
     assert (gnll < nll + 3 * (conf + gconf)).all()                        # the Bayes-optimal predictor is not beaten
     m, h = evaluation.compute_mean_and_conf_interval([1., 2., 3., 4.])
     assert m == 2.5 and abs(h - 2.0541) < 1e-3
+
+
+def test_train_option_matrix():
+    """The less travelled arguments of train() (reference train.py:22-27): gradient aggregation over k batches, Gaussian
+    NLL head (two outputs per point), sinusoidal / learned positional encodings, input normalisation (SeqBN), MSE loss.
+    Each runs a few optimizer steps through the HIP stack and must produce a finite loss."""
+    import numpy as np
+    from torch import nn
+    from transformerscandobayesianinference_amd import positional_encodings as pe, train as train_mod, utils as u
+    from transformerscandobayesianinference_amd.priors import fast_gp
+    torch.manual_seed(6); random.seed(6); np.random.seed(6)
+    base = dict(emsize=64, nhid=128, nlayers=2, nhead=2, dropout=0.0, epochs=1, steps_per_epoch=4, batch_size=8, lr=1e-3, warmup_epochs=0,
+                y_encoder_generator=encoders.Linear, gpu_device=DEV, verbose=False, bptt=32,
+                extra_prior_kwargs_dict={'num_features': 3, 'hyperparameters': (1e-2, 1., .6), 'device': DEV})
+    ys = fast_gp.get_batch(64, 20, 3, device=DEV, hyperparameters=(1e-2, 1., .6))[1].cpu()
+    bars = lambda: bar_distribution.FullSupportBarDistribution(bar_distribution.get_bucket_limits(20, ys=ys))
+    cases = [
+        dict(criterion=bars(), aggregate_k_gradients=2, single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(32)),
+        dict(criterion=nn.GaussianNLLLoss(reduction='none', full=True), single_eval_pos_gen=u.get_uniform_single_eval_pos_sampler(32)),
+        dict(criterion=nn.MSELoss(reduction='none'), single_eval_pos_gen=20, pos_encoder_generator=pe.PositionalEncoding),
+        dict(criterion=bars(), single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(32), pos_encoder_generator=pe.LearnedPositionalEncoding),
+        dict(criterion=bars(), single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(32), input_normalization=True),
+        dict(criterion=bars(), single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(32), micro_streams=1),
+    ]
+    for extra in cases:
+        kw = dict(base); kw.update(extra)
+        crit = kw.pop('criterion')
+        loss, pos, model = train_mod.train(fast_gp.DataLoader, crit, encoders.Linear, **kw)
+        assert math.isfinite(loss), extra
+        assert len(pos) == 32
