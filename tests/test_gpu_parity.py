@@ -209,6 +209,16 @@ def test_full_size_properties_bf16():
         nll16 = model.criterion(base.reshape(-1, 1000), y[sep:].flatten()).mean().item()
         nll32 = model32.criterion(ref.reshape(-1, 1000), y[sep:].flatten()).mean().item()
     assert abs(nll16 - nll32) < 1e-3 * abs(nll32), (nll16, nll32)
+    # ... and of the backward: the global gradient of the product precision against the exact-f32 kernels at full size
+    grads = {}
+    for name, mdl in (('bf16', model), ('f32', model32)):
+        mdl.train()
+        mdl.flat_parameters()[1].zero_()
+        out = mdl((x, y), single_eval_pos=sep)
+        mdl.criterion(out.reshape(-1, 1000), y[sep:].flatten()).mean().backward()
+        grads[name] = mdl.flat_parameters()[1].double().clone()
+    assert torch.isfinite(grads['bf16']).all()
+    assert ((grads['bf16'] - grads['f32']).norm() / grads['f32'].norm()).item() < 5e-2
 
 
 def test_negative_and_edge_eval_positions():
