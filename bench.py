@@ -1,24 +1,36 @@
 """Benchmark of the PFN training hot path on MI355X (contract: see the task statement / DESIGN.md).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py [--config 2|4|5] --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one full training step of BASELINE.json configs[1] on every rank: draw `batch` synthetic
-datasets from priors.fast_gp (HIP sampler), forward through the 6-layer PFN (HIP), bar-distribution
-NLL (HIP), backward (HIP), [RCCL all-reduce of the flat gradient], clip + Adam (HIP).  The metric is
-synthetic datasets / second over all ranks (weak scaling: per-GPU batch fixed).
+`--gpus N` with N > 1 and no torchrun environment spawns the N ranks itself (same torch.distributed.run command line).
+
+One "step" = one full training step of the selected BASELINE.json configuration on every rank: draw `batch` synthetic
+datasets from the prior (HIP sampler), forward through the PFN (HIP), loss (HIP bar NLL / BCE), backward (HIP), [RCCL
+all-reduce of the flat gradient], clip + Adam (HIP).  The metric is synthetic datasets / second over all ranks (weak
+scaling: per-GPU batch fixed).  The default is configs[1] (the configuration the metric is quoted on).
 
 The JSON line also carries
-  roofline     : the dominant kernel of the step, timed live with HIP events on the launch stream,
-                 algorithmic FLOPs (mask-aware) / duration vs the dense bf16 MFMA peak;
+  roofline     : the step's dominant kernel BY IN-STEP TIME (launches x duration; every kernel symbol timed on its own
+                 with HIP events on the launch stream), algorithmic FLOPs (mask-aware) / duration vs
+                 the dense bf16 MFMA peak, and the FLOPs it executes when that differs (recomputation);
   step_roofline: the same accounting for the whole step (train(S,sep) = 3 * fwd(S,sep) per dataset);
-  cpu_baseline : the CPU oracle (a port of the reference math, torch f32 on the host cores) timed on a
-                 bounded sample of the same workload (rank 0, N=1 only).
+  parity       : the benchmarked model (its weights after the timed steps) in the benchmarked precision against the
+                 f64 CPU oracle on the SAME fixed-seed draw, weights and eval position: loss and posterior-predictive
+                 means (rank 0, N = 1);
+  val_bar_nll  : the loss of the benchmarked model on a fixed-seed validation draw (second half of BASELINE.json's metric);
+  cpu_baseline : the CPU oracle (a port of the reference math, torch f32 on the host cores) timed on a bounded sample of
+                 the same workload starting from the same weights and inputs (rank 0, N = 1 only).
 """
 import argparse
+import contextlib
+import io
 import json
+import math
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +40,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK = 2.5e15     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-WORKLOAD = dict(prior='fast_gp', bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, num_bars=1000,
-                hyperparameters=dict(noise=1e-4, outputscale=1.0, lengthscale=0.6))
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+
+# BASELINE.json configs (index = position in the list; 3 is configs[1] on 8 GPUs)
+CONFIGS = {
+    2: dict(prior='fast_gp', bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, criterion='bar', num_bars=1000,
+            hyperparameters=dict(noise=1e-4, outputscale=1.0, lengthscale=0.6), batch=32, streams=2, eval_pos='weighted', parity_batch=2, parity_sep=1755,
+            metric='synthetic datasets/sec (GP prior, bptt=2000)',
+            workload='priors.fast_gp, bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, 1000 bars (BASELINE.json configs[1])'),
+    4: dict(prior='mlp', bptt=1000, num_features=60, emsize=512, nhead=4, nhid=1024, nlayers=6, criterion='bce', num_bars=1,
+            hyperparameters=None, batch=64, streams=2, eval_pos='uniform', parity_batch=2, parity_sep=500,
+            metric='synthetic datasets/sec (BNN prior, bptt=1000)',
+            workload='priors.mlp (tabular_model_bnn BNN prior, batch_size_per_gp_sample=8), bptt=1000, num_features=60, emsize=512, nhead=4, nhid=1024, '
+                     'nlayers=6, BCE head (BASELINE.json configs[3])'),
+    5: dict(prior='fast_gp_mix', bptt=4000, num_features=18, emsize=1024, nhead=4, nhid=2048, nlayers=12, criterion='bar', num_bars=1000,
+            hyperparameters={}, batch=8, streams=2, eval_pos='weighted', parity_batch=1, parity_sep=3549,
+            metric='synthetic datasets/sec (GP-mixture prior, bptt=4000)',
+            workload='priors.fast_gp_mix default hyper-prior, bptt=4000, num_features=18, emsize=1024, nhead=4 (head dim 256), nhid=2048, nlayers=12, '
+                     '1000 bars (BASELINE.json configs[4])'),
+}
+CONFIGS[3] = CONFIGS[2]
+WORKLOAD = CONFIGS[2]   # tools/ import this name
+
+
+def bnn_hyperparameters():
+    """The 17-tuple of the tabular_model_bnn configuration (reference tabular.py:47-70)."""
+    from transformerscandobayesianinference_amd.priors.utils import gamma_sampler_f, scaled_beta_sampler_f
+    return (lambda: 3, scaled_beta_sampler_f(2., 4., 150, 2), torch.nn.Tanh, gamma_sampler_f(3.6187797729244253, 0.06773738681062867),
+            gamma_sampler_f(1.8663049257557085, 0.05275478076173361), lambda: 0.0, True, scaled_beta_sampler_f(1., 1.6, 60, 2),
+            None, False, None, None, None, True, False, lambda n: ([], []), 0.0)
 
 
 def pairs(S, sep):
@@ -48,16 +87,48 @@ def train_flops(S, sep, nf, E, F, L, n_out):
     return 3 * fwd_flops(S, sep, nf, E, F, L, n_out)
 
 
-def build_model(device, precision, w=WORKLOAD):
-    from transformerscandobayesianinference_amd import bar_distribution, encoders
-    from transformerscandobayesianinference_amd.priors import fast_gp
+def quiet():
+    """The reference's loaders / get_bucket_limits print; stdout carries the JSON line only."""
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def prior_module(w):
+    from transformerscandobayesianinference_amd.priors import fast_gp, fast_gp_mix, mlp
+    return {'fast_gp': fast_gp, 'fast_gp_mix': fast_gp_mix, 'mlp': mlp}[w['prior']]
+
+
+def prior_kwargs(w):
+    kw = dict(num_features=w['num_features'])
+    if w['prior'] == 'mlp':
+        kw.update(hyperparameters=bnn_hyperparameters(), batch_size_per_gp_sample=8)
+    else:
+        kw.update(hyperparameters=w['hyperparameters'])
+    return kw
+
+
+def make_criterion(w, device):
+    from transformerscandobayesianinference_amd import bar_distribution
+    if w['criterion'] == 'bce':
+        return torch.nn.BCEWithLogitsLoss(reduction='none')
+    ys = prior_module(w).get_batch(5000 if w['prior'] == 'fast_gp' else 1000, 20, w['num_features'], device=device, hyperparameters=w['hyperparameters'])[1]
+    with quiet():
+        borders = bar_distribution.get_bucket_limits(w['num_bars'], ys=ys.cpu())
+    return bar_distribution.FullSupportBarDistribution(borders)
+
+
+def loss_of(w, criterion):
+    """per-(position, dataset) losses of the test rows, as train.py's compute_losses does"""
+    O = w['num_bars']
+    if w['criterion'] == 'bce':
+        return lambda out, tg: criterion(out.squeeze(-1), tg)
+    return lambda out, tg: criterion(out.reshape(-1, O), tg.reshape(-1)).view(out.shape[0], -1)
+
+
+def build_model(device, precision, w=WORKLOAD, criterion=None):
+    from transformerscandobayesianinference_amd import encoders
     from transformerscandobayesianinference_amd.transformer import TransformerModel
     torch.manual_seed(0)
-    ys = fast_gp.get_batch(5000, 20, w['num_features'], device=device, hyperparameters=w['hyperparameters'])[1]
-    import contextlib, io
-    with contextlib.redirect_stdout(io.StringIO()):   # get_bucket_limits prints (reference behaviour); stdout carries the JSON line only
-        borders = bar_distribution.get_bucket_limits(w['num_bars'], ys=ys.cpu())
-    criterion = bar_distribution.FullSupportBarDistribution(borders)
+    criterion = criterion if criterion is not None else make_criterion(w, device)
     model = TransformerModel(encoders.Linear(w['num_features'], w['emsize']), w['num_bars'], w['emsize'], w['nhead'], w['nhid'],
                              w['nlayers'], 0.0, y_encoder=encoders.Linear(1, w['emsize']), precision=precision)
     model.criterion = criterion
@@ -82,19 +153,23 @@ def time_kernel(fn, iters=10, warm=3):
 
 
 def kernel_breakdown(batch, sep, w=WORKLOAD):
-    """Isolated timings of the step's kernel classes at the workload shape (through the single-op C ABI)."""
+    """Isolated timings of the step's kernels at the workload shape (through the single-op C ABI): one entry per kernel
+    symbol, with the number of launches per step, so the dominant one can be picked by in-step time."""
     from transformerscandobayesianinference_amd import _hip
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import hipops
     dev = torch.device('cuda')
-    S, E, F, H, L, O = w['bptt'], w['emsize'], w['nhid'], w['nhead'], w['nlayers'], w['num_bars']
-    M, Mt = batch * S, batch * (S - sep)
+    S, E, F, H, L = w['bptt'], w['emsize'], w['nhid'], w['nhead'], w['nlayers']
+    M = batch * S
     bf = torch.bfloat16
     r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(bf)
-    out = []
-
     f32 = lambda *s: torch.randn(*s, device=dev)
     Hh = _hip
+    out = []
+
+    def add(kernel, rocprof, seconds, flops, count, executed=None):
+        out.append(dict(kernel=kernel, rocprof_name=rocprof, launches_per_step=count, seconds=seconds, flops=flops,
+                        executed_flops=executed if executed is not None else flops))
 
     def gemm(name, n, k, flags, count):
         """One encoder GEMM with its REAL epilogue (bias / GELU / residual / output streams), M = batch * bptt rows."""
@@ -107,8 +182,19 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
         if flags & Hh.EPI_OUT_T: kw['out_t'] = torch.empty(M, n, dtype=bf, device=dev)
         if flags & Hh.EPI_OUT2_T: kw['out2_t'] = torch.empty(M, n, dtype=bf, device=dev)
         t = time_kernel(lambda: hipops.gemm_nt(A, B_, flags, Hh.PREC_BF16, **kw))
-        out.append(dict(kernel=f'gemm_nt[{name} {M}x{n}x{k}]', rocprof_name=f'gemm_nt_big_kernel<{flags}, 2, 64>', single=True,
-                        launches_per_step=count, seconds=t, flops=2.0 * M * n * k))
+        add(f'gemm_nt[{name} {M}x{n}x{k}]', f'gemm_nt_big_kernel<{flags}, ', t, 2.0 * M * n * k, count)
+
+    def gemm_ln(name, k, count):
+        """out_proj / linear2 with bias + residual + LayerNorm in the epilogue (the kernel the step runs when emsize allows)."""
+        A, B_ = r(M, k), r(E, k)
+        bias, gamma, beta, resid = f32(E), f32(E), f32(E), f32(M, E)
+        bufs = (torch.empty(M + 2, E, device=dev), torch.empty(M, E, dtype=bf, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev))
+        try:
+            t = time_kernel(lambda: hipops.gemm_ln(A, B_, bias, gamma, beta, 1e-5, resid=resid, out=bufs))
+        except _hip.HipExtensionError:   # shape outside the fused kernel (emsize 1024): the step runs GEMM + LayerNorm kernels there
+            return False
+        add(f'gemm_nt_ln[{name} + residual + LayerNorm {M}x{E}x{k}]', 'gemm_nt_ln_kernel', t, 2.0 * M * E * k, count)
+        return True
 
     def wgrad_group():
         # every weight gradient of the stack in ONE grouped launch (pfn_stack_backward defers them)
@@ -116,29 +202,40 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
         for _ in range(L):
             probs += [(r(M, E), r(M, F), torch.zeros(E, F, device=dev), None), (r(M, F), r(M, E), torch.zeros(F, E, device=dev), torch.zeros(F, device=dev)),
                       (r(M, E), r(M, E), torch.zeros(E, E, device=dev), None), (r(M, 3 * E), r(M, E), torch.zeros(3 * E, E, device=dev), torch.zeros(3 * E, device=dev))]
-        t = time_kernel(lambda: hipops.gemm_tn_group(probs, 0), iters=5, warm=2)
-        out.append(dict(kernel=f'gemm_tn_group[{4 * L} weight gradients, {M} tokens]', rocprof_name='gemm_tn_big_kernel', single=True,
-                        launches_per_step=1, seconds=t, flops=2.0 * M * L * (2 * E * F + 4 * E * E)))
+        nmax = 26
+        launches = [probs[i:i + nmax] for i in range(0, len(probs), nmax)]
+        t = time_kernel(lambda: [hipops.gemm_tn_group(g, 0) for g in launches], iters=5, warm=2)
+        add(f'gemm_tn_group[{4 * L} weight gradients, {M} tokens, {len(launches)} launch(es)]', 'gemm_tn_big_kernel', t / len(launches),
+            2.0 * M * L * (2 * E * F + 4 * E * E) / len(launches), len(launches))
 
     gemm('qkv', 3 * E, E, Hh.EPI_BIAS | Hh.EPI_OUT_T, L)
-    gemm('out_proj + residual', E, E, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
+    if not gemm_ln('out_proj', E, L):
+        gemm('out_proj + residual', E, E, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
     gemm('linear1 + GELU', F, E, Hh.EPI_BIAS | Hh.EPI_GELU | Hh.EPI_OUT_T | Hh.EPI_OUT2_T, L)
-    gemm('linear2 + residual', E, F, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
+    if not gemm_ln('linear2', F, L):
+        gemm('linear2 + residual', E, F, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
     gemm('d(hpre) = dy2.W2 * gelu\'', F, E, Hh.EPI_GELU_BWD | Hh.EPI_OUT_T, L)
-    gemm('dx1 = dh.W1 + dy2', E, F, Hh.EPI_RESID_T | Hh.EPI_OUT_F32, L)
+    gemm('dx1 = dh.W1 + dy2', E, F, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
     gemm('d(ctx) = dy1.Wo', E, E, Hh.EPI_OUT_T, L)
-    gemm('dx = dqkv.Win + dy1', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_F32, L)
+    gemm('dx = dqkv.Win + dy1', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
     wgrad_group()
     qkv = r(batch, S, 3 * E)
+    D = E // H
     t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16))
-    attn_fl = 4.0 * E * pairs(S, sep) * batch
-    out.append(dict(kernel='attn_fwd', rocprof_name='attn_fwd_kernel', single=True, launches_per_step=L, seconds=t, flops=attn_fl))
+    unit = 2.0 * E * pairs(S, sep) * batch          # one S x keys x head-dim product over all heads
+    add('attn_fwd', f'attn_fwd_kernel<__bf16, {D}>', t, 2 * unit, L)
     ctx, lse = hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16)
     dctx = r(batch, S, E)
+    for name, rocprof, part, alg_units, exec_units in hipops.ATTENTION_BWD_PARTS:
+        rocprof = rocprof.format(D=D)
+        t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=part))
+        add(name, rocprof, t, alg_units * unit, L, exec_units * unit)
     t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16))
-    out.append(dict(kernel='attn_bwd (delta + dq + dv + dk kernels)', rocprof_name='attn_bwd_*', single=False, launches_per_step=L, seconds=t, flops=2.0 * attn_fl))
+    out.append(dict(kernel='attn_bwd (whole launch set, for reference)', rocprof_name='attn_bwd_* + attn_delta_kernel', launches_per_step=0,
+                    seconds=t, flops=4 * unit, executed_flops=sum(p[4] for p in hipops.ATTENTION_BWD_PARTS) * unit))
     for k in out:
         k['tflops'] = k['flops'] / k['seconds'] / 1e12
+        k['executed_tflops'] = k['executed_flops'] / k['seconds'] / 1e12
         k['step_seconds'] = k['seconds'] * k['launches_per_step']
     return out
 
@@ -156,28 +253,116 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(w=WORKLOAD, batch=2, steps=3, warm=1):
-    """The CPU oracle (port of the reference math, f32) on the host cores: GP draw + forward + bar NLL +
-    backward + clip + Adam at the workload shape, bounded to a few steps."""
+# ---- parity + CPU baseline (rank 0, N = 1): both paths on the same fixed-seed inputs and the same weights -------------------
+def parity_inputs(w, device, seed=1234):
+    """(x[T,B,F], y[T,B]) on the CPU in f64: a fixed-seed draw of the configuration's prior.  GP priors: the oracle's own
+    sampler (f64 Cholesky on the host).  BNN prior: no host port of the sampler exists, the fixed-seed draw comes from the HIP
+    sampler and both paths then read the same tensors."""
     from oracle import pfn_oracle
-    from transformerscandobayesianinference_amd import bar_distribution, encoders
-    from transformerscandobayesianinference_amd.transformer import TransformerModel
+    B, S, nf = w['parity_batch'], w['bptt'], w['num_features']
+    gen = torch.Generator().manual_seed(seed)
+    if w['prior'] == 'fast_gp':
+        x, y, _ = pfn_oracle.get_batch_fast_gp(B, S, nf, w['hyperparameters'], gen, dtype=torch.float64)
+        return x.double(), y.double()
+    if w['prior'] == 'fast_gp_mix':
+        from transformerscandobayesianinference_amd.priors import fast_gp_mix
+        ls, osc, nz = fast_gp_mix.sample_hyperparameters(B, nf, w['hyperparameters'], 'cpu', generator=gen)
+        x = torch.rand(B, S, nf, generator=gen)
+        z = torch.randn(B, S, generator=gen)
+        y = pfn_oracle.gp_sample(x, z, ls.double(), osc.double(), nz.double(), 'matern', torch.float64)
+        return x.transpose(0, 1).double(), y.transpose(0, 1).double()
+    import numpy as np
+    from transformerscandobayesianinference_amd.priors import mlp
+    state = (torch.random.get_rng_state(), random.getstate(), np.random.get_state())
+    torch.manual_seed(seed); random.seed(seed); np.random.seed(seed)
+    x, y, _ = mlp.get_batch(8, S, nf, device=device, **{k: v for k, v in prior_kwargs(w).items() if k != 'num_features'})
+    torch.random.set_rng_state(state[0]); random.setstate(state[1]); np.random.set_state(state[2])
+    return x[:, :B].double().cpu(), y[:, :B].double().cpu()
+
+
+def oracle_loss_and_means(w, sd, logits, y_test):
+    from oracle import pfn_oracle
+    if w['criterion'] == 'bce':
+        z = logits.squeeze(-1)
+        return torch.nn.functional.binary_cross_entropy_with_logits(z, y_test.to(z.dtype), reduction='none'), torch.sigmoid(z)
+    borders = sd['criterion.borders'].to(logits.dtype)
+    return (pfn_oracle.bar_nll(logits.reshape(-1, w['num_bars']), y_test.reshape(-1), borders).view(logits.shape[:2]),
+            pfn_oracle.bar_mean(logits, borders))
+
+
+def hip_loss_and_means(w, model, logits, y_test):
+    if w['criterion'] == 'bce':
+        z = logits.squeeze(-1)
+        return model.criterion(z, y_test), torch.sigmoid(z)
+    return model.criterion(logits.reshape(-1, w['num_bars']), y_test.reshape(-1)).view(logits.shape[:2]), model.criterion.mean(logits)
+
+
+def parity_check(model, w, device, precision):
+    """HIP path (benchmarked precision, benchmarked weights) vs the f64 oracle on the same inputs."""
+    from oracle import pfn_oracle
+    x, y = parity_inputs(w, device)
+    sep = w['parity_sep']
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        xd, yd = x.float().to(device), y.float().to(device)
+        lg = model((xd, yd), single_eval_pos=sep)
+        loss_h, mean_h = hip_loss_and_means(w, model, lg, yd[sep:])
+    model.train(was_training)
+    t0 = time.time()
+    with torch.no_grad():
+        lo = pfn_oracle.forward({k: v for k, v in sd.items() if not k.startswith('criterion.')}, x, y, sep, w['nhead'], dtype=torch.float64)
+        loss_o, mean_o = oracle_loss_and_means(w, sd, lo, y[sep:])
+    oracle_s = time.time() - t0
+    lg, loss_h, mean_h = lg.double().cpu(), loss_h.double().cpu(), mean_h.double().cpu()
+    d = mean_h - mean_o
+    nll_h, nll_o = loss_h.mean().item(), loss_o.mean().item()
+    y_test = y[sep:]
+    return dict(
+        against='oracle/pfn_oracle.py forward + loss in f64 on the host (pinned to the reference modules by tests/golden)',
+        inputs=f"fixed-seed draw of the configuration's prior (seed 1234), {w['parity_batch']} dataset(s), bptt {w['bptt']}, eval position {sep}; "
+               f"weights = the benchmarked model's after the timed steps",
+        precision=precision,
+        nll_hip=nll_h, nll_oracle=nll_o, nll_rel=abs(nll_h - nll_o) / abs(nll_o),
+        logits_rel_l2=((lg - lo).norm() / lo.norm()).item(),
+        mean_rel_l2=(d.norm() / mean_o.norm()).item(),                                   # relative to the means' own norm
+        mean_max_over_range=(d.abs().max() / (mean_o.max() - mean_o.min())).item(),       # ... to the spread of the reference means
+        mean_rel_l2_vs_targets=(d.norm() / y_test.norm()).item(),                        # ... to the scale of the predicted quantity
+        mean_max_over_y_range=(d.abs().max() / (y.max() - y.min())).item(),
+        mean_abs_max=d.abs().max().item(), mean_ref_rms=mean_o.pow(2).mean().sqrt().item(), y_test_rms=y_test.pow(2).mean().sqrt().item(),
+        oracle_forward_s=oracle_s), (x, y, sd)
+
+
+def cpu_baseline(w, inputs, steps=3, warm=1):
+    """The CPU oracle (port of the reference math, f32) on the host cores: [prior draw +] forward + loss + backward + clip +
+    Adam at the workload shape, bounded to a few steps, starting from the benchmarked weights and the parity inputs."""
+    from oracle import pfn_oracle
+    x0, y0, sd = inputs
     threads = usable_cores()
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    S, nf = w['bptt'], w['num_features']
-    model = TransformerModel(encoders.Linear(nf, w['emsize']), w['num_bars'], w['emsize'], w['nhead'], w['nhid'], w['nlayers'], 0.0,
-                             y_encoder=encoders.Linear(1, w['emsize']))
-    borders = torch.sort(torch.randn(w['num_bars'] + 1))[0] * 2
-    params = {k: v.detach().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    S, nf, B = w['bptt'], w['num_features'], x0.shape[1]
+    if w['prior'] == 'fast_gp_mix':
+        steps, warm = 1, 0
+    params = {k: v.detach().float().clone().requires_grad_(True) for k, v in sd.items() if not k.startswith('criterion.')}
     opt = torch.optim.Adam(list(params.values()), lr=1e-4)
-    sep = 1755
-    times = []
+    sep = w['parity_sep']
+    times, draws = [], []
     for it in range(warm + steps):
         t0 = time.time()
-        x, y, _ = pfn_oracle.get_batch_fast_gp(batch, S, nf, w['hyperparameters'], dtype=torch.float32)
+        if it == 0 or w['prior'] == 'mlp':
+            x, y = x0.float(), y0.float()            # the parity inputs (BNN prior: no host port of the sampler -- draw time not included)
+        elif w['prior'] == 'fast_gp':
+            x, y, _ = pfn_oracle.get_batch_fast_gp(B, S, nf, w['hyperparameters'], dtype=torch.float32)
+        else:
+            from transformerscandobayesianinference_amd.priors import fast_gp_mix
+            ls, osc, nz = fast_gp_mix.sample_hyperparameters(B, nf, w['hyperparameters'], 'cpu', generator=torch.Generator().manual_seed(it))
+            y = pfn_oracle.gp_sample(torch.rand(B, S, nf), torch.randn(B, S), ls, osc, nz, 'matern', torch.float32).float().transpose(0, 1)
+            x = x0.float()
+        draws.append(time.time() - t0)
         logits = pfn_oracle.forward(params, x, y, sep, w['nhead'], dtype=torch.float32)
-        loss = pfn_oracle.bar_nll(logits.reshape(-1, w['num_bars']), y[sep:].reshape(-1), borders).mean()
+        loss = oracle_loss_and_means(w, sd, logits, y[sep:])[0].mean()
         opt.zero_grad()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
@@ -185,9 +370,44 @@ def cpu_baseline(w=WORKLOAD, batch=2, steps=3, warm=1):
         if it >= warm:
             times.append(time.time() - t0)
     per_step = sum(times) / len(times)
-    return dict(value=batch / per_step, unit='datasets/s', cores=threads, kind='port',
-                sample=f'{steps} full training steps (GP draw + fwd + bar NLL + bwd + clip + Adam), batch {batch}, bptt {S}, sep {sep}, torch f32 CPU oracle',
+    note = ' (BNN prior draw not included: the reference sampler is per-dataset Python, 57 datasets/s in BASELINE.md)' if w['prior'] == 'mlp' else ''
+    return dict(value=B / per_step, unit='datasets/s', cores=threads, kind='port',
+                sample=f'{steps} full training step(s) (prior draw + fwd + loss + bwd + clip + Adam), batch {B}, bptt {S}, eval position {sep}, torch f32 CPU '
+                       f'oracle from the benchmarked weights; step 0 reads the parity inputs' + note,
                 seconds_per_step=per_step)
+
+
+def validation_loss(model, w, device, n=8, seed=4321):
+    """Loss of the benchmarked model on a fixed-seed validation draw at the configuration's typical eval position."""
+    w2 = dict(w, parity_batch=n if w['prior'] != 'fast_gp_mix' else 4)
+    x, y = parity_inputs(w2, device, seed=seed)
+    sep = w['parity_sep']
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        xd, yd = x.float().to(device), y.float().to(device)
+        loss = hip_loss_and_means(w, model, model((xd, yd), single_eval_pos=sep), yd[sep:])[0].mean().item()
+    model.train(was_training)
+    return dict(value=loss, datasets=x.shape[1], eval_position=sep, seed=seed,
+                note='bar NLL (BCE for the BNN configuration) of the benchmarked model -- random initialisation plus the few optimizer steps of this '
+                     'run -- on a fixed-seed draw; it is a regression value for the step, not a trained model\'s score')
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: spawn the N ranks (one per GPU, RCCL) and relay rank 0's line."""
+    visible = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if visible < args.gpus and env.get('PFN_DP_SINGLE_DEVICE') != '1':
+        raise SystemExit(f'bench.py --gpus {args.gpus}: only {visible} GPU(s) visible.  (Test hook for a one-GPU box: PFN_DP_SINGLE_DEVICE=1 '
+                         f'PFN_DP_BACKEND=gloo runs every rank on device 0; the line then says so.)')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, env=env)
+    raise SystemExit(res.returncode)
 
 
 def main():
@@ -195,51 +415,57 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='datasets per GPU per step')
-    ap.add_argument('--streams', type=int, default=2, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='BASELINE.json configuration (2 = configs[1], the metric\'s; 4 = BNN prior; 5 = GP mixture, bptt 4000)')
+    ap.add_argument('--batch', type=int, default=None, help='datasets per GPU per step (default: per configuration)')
+    ap.add_argument('--streams', type=int, default=None, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-kernel-breakdown', action='store_true')
-    ap.add_argument('--fixed-sep', type=int, default=None, help='use one eval position instead of the weighted sampler')
+    ap.add_argument('--fixed-sep', type=int, default=None, help='use one eval position instead of the sampler')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
 
     from transformerscandobayesianinference_amd import dp
     from transformerscandobayesianinference_amd.optim import FusedClipAdam
-    from transformerscandobayesianinference_amd.priors import fast_gp
     from transformerscandobayesianinference_amd.streams import MicroBatchStreams
-    from transformerscandobayesianinference_amd.utils import get_weighted_single_eval_pos_sampler
+    from transformerscandobayesianinference_amd.utils import get_uniform_single_eval_pos_sampler, get_weighted_single_eval_pos_sampler
     rank, world, local = dp.init_from_env()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
-    w = WORKLOAD
+    w = CONFIGS[args.config]
+    batch = args.batch or w['batch']
+    streams = args.streams or w['streams']
     S, nf, E, F, L, O = w['bptt'], w['num_features'], w['emsize'], w['nhid'], w['nlayers'], w['num_bars']
 
-    model = build_model(device, args.precision)
+    import numpy as np
+    torch.manual_seed(0); np.random.seed(0)
+    criterion = make_criterion(w, device)
+    model = build_model(device, args.precision, w, criterion)
     if world > 1:
         torch.distributed.broadcast(model.flat_parameters()[0], 0)
+        if criterion is not None and hasattr(criterion, 'borders'):
+            criterion.to(device)
+            torch.distributed.broadcast(criterion.borders, 0)
     model.train()
     opt = FusedClipAdam(model, lr=1e-4, max_grad_norm=1.0)
     opt.grad_multiplier = 1.0 / world
     random.seed(1234)                      # rank-shared eval-position stream
     torch.manual_seed(1234 + rank)         # rank-distinct prior draws
-    sampler = get_weighted_single_eval_pos_sampler(S)
+    np.random.seed(1234 + rank)
+    sampler = (get_weighted_single_eval_pos_sampler if w['eval_pos'] == 'weighted' else get_uniform_single_eval_pos_sampler)(S)
     seps = []
-
-    def loader(num_steps):
-        # the reference's DataLoader protocol (priors/utils.py); draws run a group of steps ahead on a side stream
-        return iter(fast_gp.DataLoader(num_steps=num_steps, batch_size=args.batch, seq_len=S, num_features=nf,
-                                       hyperparameters=w['hyperparameters'], device=device))
-
-    micro = MicroBatchStreams(args.streams)
+    loss_fn = loss_of(w, criterion)
+    micro = MicroBatchStreams(streams)
 
     def step(batches):
         sep = args.fixed_sep if args.fixed_sep is not None else sampler()
         seps.append(sep)
         (x, y), target = next(batches)
-        # forward + bar NLL + backward of the batch, as `--streams` concurrent column groups (streams.py)
-        losses = micro.forward_backward(model, (x, y), target, sep,
-                                        lambda out, tg: model.criterion(out.reshape(-1, O), tg[sep:].reshape(-1)).view(out.shape[0], -1))
+        # forward + loss + backward of the batch, as `--streams` concurrent column groups (streams.py)
+        losses = micro.forward_backward(model, (x, y), target, sep, lambda out, tg: loss_fn(out, tg[sep:]))
         if world > 1:
             dp.all_reduce_gradients(model.flat_parameters()[1])
         opt.step(zero_grad=True)
@@ -250,15 +476,20 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    import contextlib, io
-    # ONE loader across warm-up and timed steps: a continuous training run.  The sampler works a group of steps
-    # ahead on a side stream (priors/utils.py), so the draws consumed by the first timed steps were produced during
-    # the warm-up -- and an equal amount of draw work, for the steps after the window, happens inside it (the loader
-    # is one look-ahead group longer than warm-up + steps): the timed region carries exactly `steps` steps' worth of
-    # prior sampling, forward, loss, backward and optimizer work in steady state.
-    group = getattr(fast_gp.DataLoader, 'prefetch_group', 1)
-    with contextlib.redirect_stdout(io.StringIO()):   # DataLoader.__init__ prints its kwargs (reference behaviour)
-        batches = loader(args.warmup + args.steps + group)
+    # ONE loader across warm-up and timed steps: a continuous training run.  The sampler works one look-ahead group of G steps
+    # ahead on a side stream (priors/utils.py): the draw for group g + 1 is enqueued when the first batch of group g is handed
+    # out.  With G dividing `steps` the groups enqueued inside the timed window are exactly steps / G full groups wherever the
+    # window starts (one per multiple of G among the window's step indices) -- as much sampler work as the window's steps
+    # consume -- and the synchronisations on both sides of the window make the executed work equal the enqueued work.  The
+    # loader is a whole number of groups long and extends one group past the window so that every one of those groups exists
+    # and is full.
+    loader_cls = prior_module(w).DataLoader
+    group = math.gcd(args.steps, int(getattr(loader_cls, 'prefetch_group', 1))) if getattr(loader_cls, 'prefetch', False) else 1
+    num_steps = (args.warmup + args.steps + group + group - 1) // group * group
+    with quiet():   # DataLoader.__init__ prints its kwargs (reference behaviour)
+        dl = loader_cls(num_steps=num_steps, batch_size=batch, seq_len=S, device=device, **prior_kwargs(w))
+    dl.prefetch_group = group
+    batches = iter(dl)
     for _ in range(args.warmup):
         step(batches)
     barrier()
@@ -269,53 +500,75 @@ def main():
     barrier()
     elapsed = time.time() - t0
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    ranks_seen = torch.ones(1, device=device, dtype=torch.float64)
+    allreduce_ms = None
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(ranks_seen)
+        grad = model.flat_parameters()[1]
+        barrier()
+        t1 = time.time()
+        for _ in range(5):
+            dp.all_reduce_gradients(grad)
+        torch.cuda.synchronize()
+        allreduce_ms = (time.time() - t1) / 5 * 1e3
+        grad.zero_()
     elapsed = t.item()
     final_loss = loss.item()
 
     if rank != 0:
         return
-    total = args.batch * world * args.steps
-    step_flops = sum(train_flops(S, s, nf, E, F, L, O) for s in seps) * args.batch * world
+    total = batch * world * args.steps
+    step_flops = sum(train_flops(S, s, nf, E, F, L, O) for s in seps) * batch * world
     result = {
-        'metric': 'synthetic datasets/sec (GP prior, bptt=2000)', 'value': total / elapsed, 'unit': 'datasets/s',
+        'metric': w['metric'], 'value': total / elapsed, 'unit': 'datasets/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
-        'config': {'workload': 'priors.fast_gp, bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, 1000 bars (BASELINE.json configs[1])',
-                   'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'seq_len': S, 'parallelism': f'dp{world}', 'micro_batch_streams': args.streams,
-                   'eval_pos': 'weighted sampler(2000)' if args.fixed_sep is None else args.fixed_sep, 'mean_sep': sum(seps) / len(seps),
-                   'final_loss': final_loss},
+        'config': {'workload': w['workload'], 'baseline_config': args.config,
+                   'per_gpu_batch': batch, 'global_batch': batch * world, 'seq_len': S, 'parallelism': f'dp{world}', 'micro_batch_streams': streams,
+                   'eval_pos': f"{w['eval_pos']} sampler({S})" if args.fixed_sep is None else args.fixed_sep, 'mean_sep': sum(seps) / len(seps),
+                   'sampler_group_steps': group, 'final_loss': final_loss},
         'step_roofline': {'bound': 'mfma', 'achieved': step_flops / elapsed / 1e12 / world, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
                           'frac': step_flops / elapsed / world / MFMA_BF16_PEAK, 'note': 'whole step per GPU, algorithmic mask-aware FLOPs 3*fwd(S,sep)'},
     }
+    if world > 1:
+        result['ranks_seen'] = int(ranks_seen.item())
+        result['allreduce_ms'] = allreduce_ms
+        result['allreduce_bytes'] = model.flat_parameters()[1].numel() * 4
+        result['collective_backend'] = torch.distributed.get_backend()
+        result['devices_visible'] = torch.cuda.device_count()
+        if os.environ.get('PFN_DP_SINGLE_DEVICE') == '1':
+            result['ranks_share_device'] = True    # one-GPU test hook: NOT a scaling measurement
     if world == 1 and not args.no_kernel_breakdown:
         # kernels are launched per micro-batch (column group of the batch, streams.py): time them at THAT shape
-        groups = args.streams if (args.streams > 1 and args.batch % args.streams == 0 and args.batch >= 2 * args.streams) else 1
-        ks = kernel_breakdown(args.batch // groups, int(round(sum(seps) / len(seps))))
+        groups = streams if (streams > 1 and batch % streams == 0 and batch >= 2 * streams) else 1
+        ks = kernel_breakdown(batch // groups, int(round(sum(seps) / len(seps))), w)
         for k in ks:
             k['launches_per_step'] *= groups
             k['step_seconds'] *= groups
-        dom = max((k for k in ks if k['single']), key=lambda k: k['step_seconds'])   # the dominant single kernel of the step
+        dom = max(ks, key=lambda k: k['step_seconds'])   # the kernel the step spends most time in
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-        if pmc.get('batch') == args.batch and pmc.get('streams', 1) == args.streams:   # PMC passes of this command (tools/profile_bench.sh)
-            hit = [v for k, v in pmc.get('kernels', {}).items() if dom['rocprof_name'].split('<')[0] in k and (('<' not in dom['rocprof_name']) or dom['rocprof_name'].split('<')[1].split(',')[0] + ',' in k or dom['rocprof_name'].split('<')[1].split(',')[0] + '>' in k)]
+        pmc = json.load(open(PMC_TRAFFIC)) if os.path.exists(PMC_TRAFFIC) else {}
+        if pmc.get('config', 2) == args.config and pmc.get('batch') == batch and pmc.get('streams', 1) == streams:   # PMC passes of this command
+            hit = [v for name, v in pmc.get('kernels', {}).items() if name.startswith(dom['rocprof_name'])]
             if hit:
                 traffic = hit[0].get('read_bytes', 0) + hit[0].get('write_bytes', 0)
-                traffic_src = f"profiles/r01_pmc_traffic.json ({pmc.get('note', '')})"
+                traffic_src = f"profiles/{os.path.basename(PMC_TRAFFIC)} ({pmc.get('note', '')})"
         result['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'rocprof_kernel': dom['rocprof_name'], 'achieved': dom['tflops'],
                               'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': dom['tflops'] * 1e12 / MFMA_BF16_PEAK,
                               'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_flops_per_launch': dom['flops'],
+                              'executed_flops_per_launch': dom['executed_flops'], 'executed_frac': dom['executed_tflops'] * 1e12 / MFMA_BF16_PEAK,
                               'avg_launch_us': dom['seconds'] * 1e6, 'launches_per_step': dom['launches_per_step'],
-                              'note': 'launch timed alone with HIP events on its stream; inside the step two micro-batch streams and the sampler stream share the GPU, so a '
-                                      'rocprofv3 trace of the default command (profiles/r01_bench_kernel_stats.csv) shows this kernel stretched by its co-runners by a few percent -- '
-                                      'profiles/r01_bench_streams1_kernel_stats.csv (--batch 16 --streams 1: the same launch shape on one stream) is the trace whose average duration matches'}
+                              'in_step_ms': dom['step_seconds'] * 1e3,
+                              'note': 'dominant kernel by launches x duration; each launch timed alone with HIP events on its stream (inside the step the '
+                                      'micro-batch streams and the sampler stream share the GPU and stretch it by a few percent)'}
         result['kernels'] = [{k: (round(v, 6) if isinstance(v, float) else v) for k, v in kk.items()} for kk in ks]
-    if world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline()
+    if world == 1 and not args.no_parity:
+        result['parity'], inputs = parity_check(model, w, device, args.precision)
+        result['val_bar_nll'] = validation_loss(model, w, device)
+        if not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(w, inputs)
     print(json.dumps(result))
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 1
+#define PFN_ABI_VERSION 2
 
 enum {
   PFN_OK = 0,
@@ -189,9 +189,14 @@ int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M
                    float* y, float* mean, float* rstd, void* x_t, void* stream);
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep,
                          int prec, void* stream);
+/* Attention backward = three launches: delta = rowsum(dO * O); the key-block pass (dK, dV and dS^T into ds_ws); the
+ * query-block pass (dQ from ds_ws, plus the self-key terms of the test rows).  ds_ws: pfn_op_attention_bwd_ws_bytes(B, S, H,
+ * prec) bytes of scratch.  parts: 0 = all, else a bit mask (1 delta, 2 key-block pass, 4 query-block pass) that lets bench.py
+ * time every launch on its own; a partial run leaves the outputs of the skipped launches untouched. */
+int64_t pfn_op_attention_bwd_ws_bytes(int B, int S, int H, int prec);
 int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx,
-                         void* dqkv, float* delta_ws, int B, int S, int E, int H, int sep,
-                         int prec, void* stream);
+                         void* dqkv, float* delta_ws, void* ds_ws, int B, int S, int E, int H, int sep,
+                         int prec, int parts, void* stream);
 int pfn_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
                          float* mean, float* rstd, int64_t rows, int E, float eps, int prec, void* stream);
 /* dy: f32 when dy_is_t == 0, operand precision (prec) otherwise -- the form the backward schedule feeds it;

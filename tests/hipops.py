@@ -71,13 +71,35 @@ def attention_fwd(qkv, H, sep, prec):
     return ctx, lse
 
 
-def attention_bwd(qkv, ctx, lse, dctx, H, sep, prec):
+# (name, rocprofv3 kernel name, `parts` bit, algorithmic product units, executed product units) of every launch of the attention
+# backward; one unit = one [S x keys x head-dim] product over all heads (the backward's algorithmic work is 4: dV, dP, dK, dQ;
+# it executes 5, the forward's S being recomputed once)
+ATTENTION_BWD_PARTS = [
+    ('attn_bwd: delta = rowsum(dO * O)', 'attn_delta_kernel<__bf16>', 1, 0.0, 0.0),
+    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', 'attn_bwd_kv_kernel<__bf16, {D}>', 2, 3.0, 4.0),
+    ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', 'attn_bwd_dq_kernel<__bf16, {D}>', 4, 1.0, 1.0),
+]
+_bwd_scratch = {}
+
+
+def attention_bwd(qkv, ctx, lse, dctx, H, sep, prec, parts=0):
+    """parts = 0: the whole backward (outputs start as NaN so a skipped element shows).  parts != 0 (timing): only the selected
+    launches, into cached scratch buffers (the skipped launches' products must exist from an earlier full call with the same
+    shapes for the numbers to mean anything)."""
     B, S, E3 = qkv.shape
     E = E3 // 3
-    dqkv = torch.full_like(qkv, float('nan'))
-    delta = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
+    key = (tuple(qkv.shape), qkv.dtype, qkv.device, H)
+    if key not in _bwd_scratch:
+        _bwd_scratch.clear()
+        ws = _hip.check(_hip.lib().pfn_op_attention_bwd_ws_bytes(B, S, H, prec), 'attn bwd ws')
+        _bwd_scratch[key] = (torch.zeros_like(qkv), torch.zeros(B, H, S, dtype=torch.float32, device=qkv.device),
+                             torch.empty(ws, dtype=torch.uint8, device=qkv.device))
+    dqkv, delta, ds = _bwd_scratch[key]
+    if not parts:
+        dqkv = torch.full_like(qkv, float('nan'))
+        ds.fill_(0xff)                                 # NaN patterns: a dS^T element the key-block pass skipped would show in dQ
     _hip.check(_hip.lib().pfn_op_attention_bwd(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(),
-                                               delta.data_ptr(), B, S, E, H, sep, prec, sp()), 'attn bwd')
+                                               delta.data_ptr(), ds.data_ptr(), B, S, E, H, sep, prec, parts, sp()), 'attn bwd')
     return dqkv
 
 

@@ -275,6 +275,7 @@ def attention_reference(qkv, H, sep):
 ATTN_CASES = [  # B, S, E, H, sep
     (2, 100, 128, 4, 70), (1, 256, 256, 2, 256), (2, 130, 128, 2, 0), (1, 333, 512, 4, 301), (2, 200, 128, 2, 1),
     (1, 2000, 512, 4, 1755), (1, 257, 64, 2, 64), (1, 300, 512, 2, 129),
+    (1, 4000, 1024, 4, 3549), (1, 4000, 1024, 16, 3549),     # BASELINE config 5 length: head dim 256 (nhead 4) and 64 (nhead 16)
 ]
 
 

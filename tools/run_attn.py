@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import hipops
 from transformerscandobayesianinference_amd import _hip
-B, S, E, H, sep = 16, 2000, 512, 4, 1755
+B, S, E, H, sep = 16, 2000, 512, 4, 1604
 qkv = (torch.randn(B, S, 3 * E, device='cuda') * 0.5).to(torch.bfloat16)
 dctx = (torch.randn(B, S, E, device='cuda') * 0.5).to(torch.bfloat16)
 for _ in range(3):

@@ -20,7 +20,7 @@ class _BarNLL(torch.autograd.Function):
         lib = _hip.lib()
         logits = logits.contiguous().float()
         y = y.contiguous().float().to(logits.device)
-        borders = borders.contiguous().float()
+        borders = borders.contiguous().float().to(logits.device)   # a criterion left on the CPU must not hand a host pointer to the kernel
         R, nbars = logits.shape
         nll = torch.empty(R, device=logits.device, dtype=torch.float32)
         lse = torch.empty_like(nll)
@@ -48,7 +48,8 @@ def _bar_mean(logits, borders, full_support):
     shape = logits.shape[:-1]
     flat = logits.detach().reshape(-1, logits.shape[-1]).contiguous().float()
     out = torch.empty(flat.shape[0], device=flat.device, dtype=torch.float32)
-    _hip.check(_hip.lib().pfn_bar_mean(flat.data_ptr(), flat.shape[1], borders.contiguous().float().data_ptr(),
+    borders = borders.contiguous().float().to(flat.device)
+    _hip.check(_hip.lib().pfn_bar_mean(flat.data_ptr(), flat.shape[1], borders.data_ptr(),
                                        flat.shape[0], flat.shape[1], int(full_support), out.data_ptr(),
                                        _hip.stream_ptr(flat.device)), 'pfn_bar_mean')
     return out.view(shape)

@@ -10,8 +10,9 @@
 // as a row-wise correction term (backward).
 //
 // Formulation (all MFMAs are 32x32, "swapped" so softmax statistics are lane-local):
-//   fwd / dQ kernels : lane <-> query.   S^T = K.Q^T, O^T = V^T.P^T, dP^T = V.dO^T, dQ^T = K^T.dS^T
-//   dK/dV kernel     : lane <-> key.     S = Q.K^T, dP = dO.V^T, dV^T = dO^T.P, dK^T = Q^T.dS
+//   fwd kernel       : lane <-> query.   S^T = K.Q^T, O^T = V^T.P^T
+//   bwd key pass     : lane <-> key.     S = Q.K^T, dP = dO.V^T, dV^T = dO^T.P, dK^T = Q^T.dS;  stores dS^T
+//   bwd query pass   : lane <-> query.   dQ^T = K^T.dS^T  (dS^T read back)
 // Operands that are k-major in memory (V, K^T, Q^T, dO^T) come from LDS through
 // ds_read_b64_tr_b16 (bf16) in the accumulator-order slot mapping M2, so P / dS never move
 // between lanes.
@@ -116,6 +117,13 @@ PFN_DEV AttnBlock attn_block(int nblk, int H) {
 #define PFN_ATTN_ABLATE 0
 #endif
 constexpr int ABL = PFN_ATTN_ABLATE;
+// ... and -DPFN_KV_ABLATE=<bits> in the backward key-block pass: no dS^T store (1), the transposed fragments of the dV / dK
+// products read once instead of four times (2), V row fragments not read (4), exponentials replaced by a multiply (8)
+#ifndef PFN_KV_ABLATE
+#define PFN_KV_ABLATE 0
+#endif
+constexpr int KVABL = PFN_KV_ABLATE;
+typedef __attribute__((address_space(3))) void lvoid_t;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float RESCALE_THR = 6.f;  // log2 units: lazily raised running max of the online softmax (see attn_fwd_kernel)
@@ -355,20 +363,342 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, int D) {
 }
 
 // =============================================================================================
-// backward, dQ (+ the self-key terms of test rows: dQ_i, dK_i, dV_i for i >= sep)
+// backward, key-block pass: dK and dV for the train keys [0, sep), and dS^T for the dQ pass.
+//
+// A workgroup owns QBLK keys (one per lane, 32 per wave) and streams all S queries in tiles of 32.  Per tile and
+// wave:   S = Q K^T,  dP = dO V^T   (lane <-> key, rows <-> queries; 8 + 8 MFMAs at head dim 128)
+//         P = exp2(S scale - lse),  dS = P (dP - delta)
+//         dV^T += dO^T P,  dK^T += Q^T dS   (P and dS go from the accumulator straight into the operand slots)
+//         dS^T[key][query] -> global, in operand precision -- the exact values the dK product consumed.
+// S and dP are computed ONCE for the whole backward (round 1 recomputed S three times and dP twice: 8 product
+// units for 4 algorithmic ones; now 5 with the dQ pass below).  Register budget at head dim 128, bf16: K fragments
+// of the wave's keys 32 + dK and dV accumulators 128 stay for the whole kernel; the V fragments (B operand of the dP
+// product) would be another 32 and push the kernel out of the 256 registers that two waves per SIMD allow, so the
+// workgroup's V rows live in LDS as a row image (69 KB, loaded once) and are read per tile like the Q / dO rows.
+// The 4-wave configurations (exact-f32 mode, head dim 256) have the whole register file and keep V in registers.
+// Keys >= sep in the last key block run on clamped data: never stored (dK, dV) and never read (the dQ pass
+// zero-fills dS^T rows >= sep when it stages them).
 // =============================================================================================
+template <typename T, int D> struct BwdKvCfg {
+  using C = AttnCfg<T, D>;
+  static constexpr int QB = 32;                         // queries per tile
+  static constexpr bool VLDS = C::NW == 8;              // V rows of the workgroup's keys in LDS instead of registers
+  static constexpr int VIMG = VLDS ? C::QBLK * C::RS : 0;
+  // Q / dO tiles go global -> LDS by LDS-DMA in 1-KiB pieces (64 lanes x 16 bytes, lane-linear in LDS): every image is
+  // allocated in whole pieces; piece p of an image holds its bytes [1024 p, 1024 p + 1024)
+  static constexpr int NPR = (QB * C::RS + 1023) / 1024, NPC = (QB * C::CS + 1023) / 1024;   // pieces of a row / col image
+  static constexpr int RIMG = NPR * 1024, CIMG = NPC * 1024;
+  static constexpr int NP = 2 * (NPR + NPC);                  // Q rows, Q cols, dO rows, dO cols
+  static constexpr int NI = (NP + C::NW - 1) / C::NW;         // pieces per wave
+  static constexpr int IMG = 2 * (RIMG + CIMG);
+  static constexpr int BUF = IMG + 2 * QB * 4;                // + lse2[QB], delta[QB]
+  // the lanes' DMA source offsets (one per piece of the wave) live in an LDS table when there is room (8-wave configurations):
+  // recomputing them per tile costs ~20 vector instructions per piece, keeping them in registers costs registers this kernel
+  // does not have
+  static constexpr bool PVLDS = C::NW == 8;
+  static constexpr int PVTAB = PVLDS ? NI * C::NT * 4 : 0;
+  static constexpr int LDS = VIMG + 2 * BUF + PVTAB;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnArgs a) {
+  using C = AttnCfg<T, D>;
+  using K = BwdKvCfg<T, D>;
+  constexpr int QB = K::QB;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  auto Vimg = [&]() { return smem; };
+  auto Qr = [&](int buf) { return smem + K::VIMG + buf * K::BUF; };
+  auto Qc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::RIMG; };
+  auto Or = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::RIMG + K::CIMG; };
+  auto Oc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + 2 * K::RIMG + K::CIMG; };
+  auto St = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::IMG; };   // [lse2 x QB][delta x QB]
+
+  const AttnBlock wg = attn_block((a.sep + C::QBLK - 1) / C::QBLK, a.H);
+  const int b = wg.b, hd = wg.hd;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
+  const long rs = 3L * a.E;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
+  const T* Qp = base + hd * D;
+  const T* Kp = base + a.E + hd * D;
+  const T* Vp = base + 2 * a.E + hd * D;
+  const T* dOp = reinterpret_cast<const T*>(a.dctx) + (long)b * a.S * a.E + hd * D;
+  T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
+  const int sep = a.sep;
+  const int key0 = wg.blk * C::QBLK;
+  const int key = key0 + wave * 32 + li;
+  const bool kvalid = key < sep;
+  const int kc = min(key, a.S - 1);
+  const float scale = rsqrtf((float)D);
+  const float scale_log2 = scale * LOG2E;
+  const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
+  const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
+  // dS^T of this (dataset, head): 32 x 32 blocks, block (key / 32, query / 32) at ((key / 32) * (ds_ld / 32) + query / 32) blocks
+  // (store_frag_pair_blocked); the wave owns block row key / 32
+  constexpr int DSBLK = 32 * 32;   // elements per block
+  T* dsT = reinterpret_cast<T*>(a.ds) + ((long)b * a.H + hd) * a.ds_rows * a.ds_ld + (long)(key0 / 32 + wave) * (a.ds_ld / 32) * DSBLK;
+
+  Frag<T> kf[C::NKK], vf[K::VLDS ? 1 : C::NKK];
+#pragma unroll
+  for (int kk = 0; kk < C::NKK; ++kk) {
+    kf[kk] = load_frag_global<T>(Kp + (long)kc * rs + kk * 16 + 8 * h);
+    if constexpr (!K::VLDS) vf[kk] = load_frag_global<T>(Vp + (long)kc * rs + kk * 16 + 8 * h);
+  }
+  if constexpr (K::VLDS) {   // the workgroup's V rows -> LDS row image (rows >= S read as zero)
+    TileStageBuf<T, C::QBLK, C::RB, C::NT> sv;
+    sv.init((int)(rs * sizeof(T)));
+    sv.issue(make_rsrc(Vp, ((long)(a.S - 1) * rs + D) * (long)sizeof(T)), key0 * (int)(rs * sizeof(T)));
+    sv.template commit_p<C::RS>(Vimg());
+  }
+  f32x16 dk[C::NDB], dv[C::NDB];
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+  const int ntiles = (a.S + QB - 1) / QB;
+  // Q / dO tiles: global -> LDS by LDS-DMA through buffer descriptors (rows >= S are out of the descriptor's range and
+  // arrive as zeros), issued from assembly (pfn_device.h dma16: why).  No staging registers: the pieces of tile t+1 are issued at the top of tile t into the other buffer and
+  // waited for at its end.  Wave w moves pieces w, w + NW, ... of the list [Q rows | Q cols | dO rows | dO cols]; lane l of
+  // piece p supplies the 16 bytes at image offset 1024 p + 16 l (a padded row's pad chunk, or the tail past the image, is
+  // pointed out of range).
+  const DmaRsrc rq = make_dma_rsrc(Qp, ((long)(a.S - 1) * rs + D) * (long)sizeof(T));
+  const DmaRsrc ro = make_dma_rsrc(dOp, ((long)(a.S - 1) * a.E + D) * (long)sizeof(T));
+  const int tq_bytes = QB * (int)rs * (int)sizeof(T), to_bytes = QB * a.E * (int)sizeof(T);
+  const int ldq = (int)rs * (int)sizeof(T), ldo = a.E * (int)sizeof(T);
+  // piece i of this wave: wave-uniform LDS offset inside a buffer (bit 30: dO tensor; < 0: none) ...
+  int pdst[K::NI];
+#pragma unroll
+  for (int i = 0; i < K::NI; ++i) {
+    const int g = wave + C::NW * i;
+    const int img = g < K::NPR ? 0 : g < K::NPR + K::NPC ? 1 : g < 2 * K::NPR + K::NPC ? 2 : 3;
+    const int start = img == 0 ? 0 : img == 1 ? K::NPR : img == 2 ? K::NPR + K::NPC : 2 * K::NPR + K::NPC;
+    const int ibase = img == 0 ? 0 : img == 1 ? K::RIMG : img == 2 ? K::RIMG + K::CIMG : 2 * K::RIMG + K::CIMG;
+    pdst[i] = g < K::NP ? __builtin_amdgcn_readfirstlane((ibase + (g - start) * 1024) | (img >= 2 ? (1 << 30) : 0)) : -1;
+  }
+  // ... and the lane's source byte offset inside a tile (pad chunks and the tail past the image point out of range)
+  auto piece_offset = [&](int i, int ln) {
+    const int g = wave + C::NW * i;
+    const int img = g < K::NPR ? 0 : g < K::NPR + K::NPC ? 1 : g < 2 * K::NPR + K::NPC ? 2 : 3;
+    const int start = img == 0 ? 0 : img == 1 ? K::NPR : img == 2 ? K::NPR + K::NPC : 2 * K::NPR + K::NPC;
+    const int c = (g - start) * 64 + ln;
+    int row, col;
+    if (img & 1) { row = c / (C::CS / 16); col = c % (C::CS / 16); }
+    else { row = c / (C::RS / 16); col = c % (C::RS / 16); }
+    return (row < QB && col < C::RB / 16) ? row * (img >= 2 ? ldo : ldq) + col * 16 : BUF_OOB;
+  };
+  LdsPtr pvtab = smem + K::VIMG + 2 * K::BUF;   // [NI][NT] ints
+  if constexpr (K::PVLDS) {
+#pragma unroll
+    for (int i = 0; i < K::NI; ++i)
+      *reinterpret_cast<__attribute__((address_space(3))) int*>(pvtab + (i * C::NT + threadIdx.x) * 4) = piece_offset(i, lane);
+  }
+  auto dma = [&](int buf, int t) {
+    int ln = lane;
+    if constexpr (!K::PVLDS) asm volatile("" : "+v"(ln));   // opaque: keeps the offset arithmetic inside the loop (hoisted, it costs a register per piece)
+    int pv[K::NI];
+#pragma unroll
+    for (int i = 0; i < K::NI; ++i) {
+      if constexpr (K::PVLDS) pv[i] = *reinterpret_cast<const __attribute__((address_space(3))) int*>(pvtab + (i * C::NT + threadIdx.x) * 4);
+      else pv[i] = piece_offset(i, ln);
+    }
+#pragma unroll
+    for (int i = 0; i < K::NI; ++i) {
+      if (pdst[i] < 0) continue;
+      LdsPtr dst = smem + K::VIMG + buf * K::BUF + (pdst[i] & 0xffffff);
+      if (pdst[i] & (1 << 30)) dma16(ro, dst, pv[i] + t * to_bytes);
+      else dma16(rq, dst, pv[i] + t * tq_bytes);
+    }
+  };
+  // row statistics of the tile's queries: wave 0 stages lse, wave 1 delta (lanes 0..QB-1).  A query beyond S reads zeros
+  // everywhere (Q, dO, lse, delta): P = 1 there but dO = 0 and delta = 0, so dV, dS and dK get nothing from it.
+  const BufRsrc rl = make_rsrc(lse_g, (long)a.S * 4), rdl = make_rsrc(delta_g, (long)a.S * 4);
+  float st_reg = 0.f;
+  auto stage_stats = [&](int q0) {   // the loaded value is not touched before commit_stats (a use would wait for it at once)
+    if (wave == 0) { if (lane < QB) st_reg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (lane + q0) * 4, 0, 0)); }
+    else if (wave == 1) { if (lane < QB) st_reg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdl, (lane + q0) * 4, 0, 0)); }
+  };
+  auto commit_stats = [&](int buf) {
+    if (wave == 0) { if (lane < QB) lds_write_f32(St(buf) + lane * 4, st_reg * LOG2E); }
+    else if (wave == 1) { if (lane < QB) lds_write_f32(St(buf) + (QB + lane) * 4, st_reg); }
+  };
+  dma(0, 0);
+  stage_stats(0);
+  commit_stats(0);
+  dma_wait_all();
+  __syncthreads();
+
+  auto tile = [&](auto buf_c, int t) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const lds_char* qr = Qr(BUF);
+    const lds_char* orow = Or(BUF);
+    const lds_char* stt = St(BUF);
+    const lds_char* qc = Qc(BUF);
+    const lds_char* oc = Oc(BUF);
+    // tile t+1 -> the other buffer (all waves are past the barrier that ended tile t-1, its last reader)
+    if (!(ABL & 1) && t + 1 < ntiles) {
+      dma(BUF ^ 1, t + 1);
+      stage_stats((t + 1) * QB);
+    }
+    // Register plan (head dim 128, bf16): 160 registers are pinned (K fragments, dK, dV); S and dP take 32 more; every operand
+    // stream therefore runs only PD k-steps ahead of its MFMAs and the two products run one after the other, the second
+    // one's first fragments requested under the first one's tail.
+    constexpr int PD = C::NKK < 2 ? C::NKK : 2;
+    // rows of the S / dP tiles are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
+    Frag<T> pf0, pf1;
+    {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      Frag<T> qfr[C::NKK];
+#pragma unroll
+      for (int kk = 0; kk < PD; ++kk) qfr[kk] = load_frag_row_p<T, C::RS>(qr, li, kk * 16);
+      PFN_PIN_LDS_MFMA();
+#pragma unroll
+      for (int kk = 0; kk < C::NKK; ++kk) {
+        if (kk + PD < C::NKK) qfr[kk + PD] = load_frag_row_p<T, C::RS>(qr, li, (kk + PD) * 16);
+        s = mma32(qfr[kk], kf[kk], s);
+        PFN_PIN_LDS_MFMA();
+      }
+      // P = exp2(S scale - lse), straight into operand precision: S is dead before the dP chain starts (register plan above)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (8 * rg + 4 * h) * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rg + e;
+          s[r] = (KVABL & 8) ? __builtin_fmaf(s[r], scale_log2, -l2[e]) : fast_exp2(__builtin_fmaf(s[r], scale_log2, -l2[e]));
+        }
+      }
+      pf0 = acc_to_frag<T>(s, 0);
+      pf1 = acc_to_frag<T>(s, 1);
+    }
+    Frag<T> df0, df1;
+    {
+      f32x16 dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+      Frag<T> ofr[C::NKK], vfr[K::VLDS ? C::NKK : 1];
+#pragma unroll
+      for (int kk = 0; kk < PD; ++kk) {
+        ofr[kk] = load_frag_row_p<T, C::RS>(orow, li, kk * 16);
+        if constexpr (K::VLDS && !(KVABL & 4)) vfr[kk] = load_frag_row_p<T, C::RS>(Vimg(), wave * 32 + li, kk * 16);
+      }
+      PFN_PIN_LDS_MFMA();
+#pragma unroll
+      for (int kk = 0; kk < C::NKK; ++kk) {
+        if (kk + PD < C::NKK) {
+          ofr[kk + PD] = load_frag_row_p<T, C::RS>(orow, li, (kk + PD) * 16);
+          if constexpr (K::VLDS && !(KVABL & 4)) vfr[kk + PD] = load_frag_row_p<T, C::RS>(Vimg(), wave * 32 + li, (kk + PD) * 16);
+        }
+        if constexpr (K::VLDS && (KVABL & 4)) dp = mma32(ofr[kk], ofr[kk], dp);
+        else if constexpr (K::VLDS) dp = mma32(ofr[kk], vfr[kk], dp);
+        else dp = mma32(ofr[kk], vf[kk], dp);
+        PFN_PIN_LDS_MFMA();
+      }
+      // dS = P (dP - delta), with the P the dV product consumes (operand precision)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 dl = __builtin_bit_cast(f32x4, lds_read16(stt + (QB + 8 * rg + 4 * h) * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rg + e;
+          dp[r] = frag_get(r < 8 ? pf0 : pf1, r & 7) * (dp[r] - dl[e]);
+        }
+      }
+      df0 = acc_to_frag<T>(dp, 0);
+      df1 = acc_to_frag<T>(dp, 1);
+    }
+    Frag<T> cf[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(oc, 0, db * 32);
+    PFN_PIN_LDS_MFMA();
+    // dV^T += dO^T P,  dK^T += Q^T dS: four groups of NDB MFMAs, the next group's transposed fragments requested under each
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) dv[db] = mma32(cf[db], pf0, dv[db]);
+    if (!(KVABL & 2)) {
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(oc, 16, db * 32);
+    }
+    PFN_PIN_LDS_MFMA();
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) dv[db] = mma32(cf[db], pf1, dv[db]);
+    if (!(KVABL & 2)) {
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(qc, 0, db * 32);
+    }
+    PFN_PIN_LDS_MFMA();
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df0, dk[db]);
+    if (!(KVABL & 2)) {
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(qc, 16, db * 32);
+    }
+    PFN_PIN_LDS_MFMA();
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df1, dk[db]);
+    // End of the tile.  gfx9 counts loads and stores in ONE counter and cannot tell them apart: a wait for a load is a wait
+    // for every store before it.  So: wait for the DMA of tile t+1 (issued a whole tile ago; the previous tile's dS^T stores
+    // are as old), barrier, and only THEN let this tile's dS^T go (block (key / 32, t), operand precision: exactly what the
+    // dK product consumed) -- it drains under the next tile.
+    if (!(ABL & 2)) commit_stats(BUF ^ 1);
+    dma_wait_all();
+    if (!(ABL & 4)) __syncthreads();
+    if (!(KVABL & 1)) store_frag_pair_blocked<T>(dsT + (long)t * DSBLK, df0, df1, li, h, kvalid);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(I0{}, t);
+    if (t + 1 < ntiles) tile(I1{}, t + 1);
+  }
+
+  {
+    T* outk = dbase + (long)kc * rs + a.E + hd * D;
+    T* outv = dbase + (long)kc * rs + 2 * a.E + hd * D;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = dk[db][r] * scale;
+      store_row_block<T>(outk + db * 32, v, h, kvalid);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = dv[db][r];
+      store_row_block<T>(outv + db * 32, v, h, kvalid);
+    }
+  }
+}
+
+// =============================================================================================
+// backward, query-block pass: dQ = scale * dS K over the train keys, from the dS^T the key-block pass stored
+// (one product unit, no softmax arithmetic), plus the self-key terms of the test rows (dQ_i, dK_i, dV_i, i >= sep).
+// A workgroup owns QBLK queries (lane <-> query) and streams key tiles: dS^T[keys][its queries] and K[keys][D]
+// both land in LDS as column images (rows = the contraction index) and are read transposed:
+//     dQ^T[d][i] += K^T[d][j] dS^T[j][i]
+// Reads 2 bytes per (query, key) pair: HBM-bound (449 MB per launch at the north star against 56 GFLOP).  The
+// workgroups walk the (dataset, head) pairs in the REVERSE of the key-block pass's order: what that pass wrote last is
+// still in the 256 MB Infinity Cache.
+// =============================================================================================
+template <typename T, int D> struct BwdDqCfg {
+  using C = AttnCfg<T, D>;
+  static constexpr int DSB = C::QBLK * (int)sizeof(T);        // bytes of one dS^T row segment (the workgroup's queries)
+  static constexpr int DSS = PadStride<DSB>::COL;
+  static constexpr int BUF = C::KVB * DSS + C::CIMG;          // dS^T tile + K tile (col images)
+  static constexpr int LDS = 2 * BUF;
+};
+
 template <typename T, int D>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
+  using Q = BwdDqCfg<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
-  // per buffer: K (row image), K (col image, transposed frags), V (row image)
-  constexpr int DQ_BUF = 2 * C::RIMG + C::CIMG;
-  auto Kr = [&](int buf) { return smem + buf * DQ_BUF; };
-  auto Kc = [&](int buf) { return smem + buf * DQ_BUF + C::RIMG; };
-  auto Vr = [&](int buf) { return smem + buf * DQ_BUF + C::RIMG + C::CIMG; };
+  auto Ds = [&](int buf) { return smem + buf * Q::BUF; };
+  auto Kc = [&](int buf) { return smem + buf * Q::BUF + C::KVB * Q::DSS; };
 
-  const AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
+  AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
+  wg.b = a.B - 1 - wg.b;            // most recently written dS^T first (see above)
+  wg.hd = a.H - 1 - wg.hd;
   const int b = wg.b, hd = wg.hd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
   const long rs = 3L * a.E;
@@ -377,140 +707,117 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   const T* Kp = base + a.E + hd * D;
   const T* Vp = base + 2 * a.E + hd * D;
   T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
-  const int qi = wg.blk * C::QBLK + wave * 32 + li;
+  const int q0 = wg.blk * C::QBLK;
+  const int qi = q0 + wave * 32 + li;
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
   const int sep = a.sep;
   const float scale = rsqrtf((float)D);
   const float scale_log2 = scale * LOG2E;
-  const T* dOp = reinterpret_cast<const T*>(a.dctx) + ((long)b * a.S + qc) * a.E + hd * D;
-
-  Frag<T> qf[C::NKK], dof[C::NKK];
-#pragma unroll
-  for (int kk = 0; kk < C::NKK; ++kk) {
-    qf[kk] = load_frag_global<T>(Qp + (long)qc * rs + kk * 16 + 8 * h);
-    dof[kk] = load_frag_global<T>(dOp + kk * 16 + 8 * h);
-  }
-  const long stat = ((long)b * a.H + hd) * a.S + qc;
-  const float lse2 = a.lse[stat] * LOG2E;
-  const float delta = a.delta[stat];
-
   f32x16 dq[C::NDB];
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
 
-  const int nfull = sep / C::KVB;
-  const bool has_edge = (sep % C::KVB) != 0;
-  const int ntiles = nfull + (has_edge ? 1 : 0);
-  TileStage<T, C::KVB, C::RB, C::NT> sk, sv;
-  if (ntiles > 0) {
-    sk.issue(Kp, rs, sep, D);
-    sv.issue(Vp, rs, sep, D);
-    sk.template commit_p<C::RS>(Kr(0));
-    sk.template commit_p<C::CS>(Kc(0));
-    sv.template commit_p<C::RS>(Vr(0));
-    if (ntiles > 1) {   // tile 1 stays in flight across the barrier (staging as in attn_fwd_kernel)
-      sk.issue(Kp + (long)C::KVB * rs, rs, sep - C::KVB, D);
-      sv.issue(Vp + (long)C::KVB * rs, rs, sep - C::KVB, D);
-    }
+  // dS^T of this (dataset, head) in 32 x 32 blocks (store_frag_pair_blocked); a key tile of this workgroup's queries is
+  // KVB / 32 x QBLK / 32 blocks, read in address order (every wave instruction 1 KiB contiguous) and scattered into the
+  // column image (rows = keys).  Keys >= sep were never written: their chunks are pointed out of the descriptor's range.
+  constexpr int DSBLK = 32 * 32;                 // elements per block
+  constexpr int BCH = DSBLK * (int)sizeof(T) / 16;   // 16-byte chunks per block
+  constexpr int NQBW = C::QBLK / 32, NDCH = (C::KVB / 32) * NQBW * BCH, DPER = NDCH / C::NT;
+  static_assert(NDCH % C::NT == 0, "dS^T tile chunks must divide over the threads");
+  const long ds_bh = ((long)b * a.H + hd) * a.ds_rows * a.ds_ld;
+  const BufRsrc rd = make_rsrc(reinterpret_cast<const T*>(a.ds) + ds_bh, (long)a.ds_rows * a.ds_ld * (long)sizeof(T));
+  const BufRsrc rk = make_rsrc(Kp, ((long)(sep - 1) * rs + D) * (long)sizeof(T));   // rows >= sep read as zero
+  int d_src[DPER], d_dst[DPER], d_row[DPER];
+#pragma unroll
+  for (int i = 0; i < DPER; ++i) {
+    const int id = threadIdx.x + i * C::NT;
+    const int blk = id / BCH, w = id % BCH;
+    const int kb = blk / NQBW, qb = blk % NQBW;
+    d_row[i] = kb * 32 + blocked_chunk_row<T>(w);
+    d_src[i] = ((kb * (a.ds_ld / 32) + q0 / 32 + qb) * BCH + w) * 16;
+    d_dst[i] = d_row[i] * Q::DSS + (qb * 32 + blocked_chunk_col<T>(w)) * (int)sizeof(T);
   }
-  __syncthreads();
-  // one key tile; BUF / EDGE compile-time as in the forward kernel
-  auto tile = [&](auto buf_c, auto edge_c, int t) {
-    constexpr int BUF = decltype(buf_c)::value;
-    constexpr bool EDGE = decltype(edge_c)::value;
-    const int k0 = t * C::KVB;
-    const lds_char* kr = Kr(BUF);
-    const lds_char* kc = Kc(BUF);
-    const lds_char* vr = Vr(BUF);
+  // Two staging register sets: tiles t+1 and t+2 are in flight while tile t is multiplied -- the kernel streams 2 bytes per
+  // (query, key) pair from HBM and one tile per CU in flight does not cover the memory latency.
+  u32x4 dregs[2][DPER];
+  TileStageBuf<T, C::KVB, C::RB, C::NT> sk[2];
+  sk[0].init((int)(rs * sizeof(T)));
+  sk[1].init((int)(rs * sizeof(T)));
+  const int ntiles = (sep + C::KVB - 1) / C::KVB;
+  const int tile_src_bytes = (C::KVB / 32) * (a.ds_ld / 32) * BCH * 16;
+  auto request = [&](auto set_c, int t) {
+    constexpr int SET = decltype(set_c)::value;
+    const int k1 = t * C::KVB;
 #pragma unroll
-    for (int kb = 0; kb < C::NKB; ++kb) {   // 32 keys at a time: only one S / dP pair is live
-      // operand fragments of the S / dP products run PD k-steps ahead of the MFMAs that consume them
-      constexpr int PD = C::NKK < 4 ? C::NKK : 4;
-      Frag<T> kfr[C::NKK], vfr[C::NKK];
+    for (int i = 0; i < DPER; ++i) dregs[SET][i] = buf_load16(rd, (k1 + d_row[i] < sep) ? d_src[i] + t * tile_src_bytes : BUF_OOB);
+    sk[SET].issue(rk, k1 * (int)(rs * sizeof(T)));
+  };
+  auto commit_all = [&](auto set_c, int buf) {
+    constexpr int SET = decltype(set_c)::value;
 #pragma unroll
-      for (int kk = 0; kk < PD; ++kk) {
-        kfr[kk] = load_frag_row_p<T, C::RS>(kr, kb * 32 + li, kk * 16);
-        vfr[kk] = load_frag_row_p<T, C::RS>(vr, kb * 32 + li, kk * 16);
-      }
-      PFN_PIN_LDS_MFMA();
-      f32x16 st, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int kk = 0; kk < C::NKK; ++kk) {
-        if (kk + PD < C::NKK) {
-          kfr[kk + PD] = load_frag_row_p<T, C::RS>(kr, kb * 32 + li, (kk + PD) * 16);
-          vfr[kk + PD] = load_frag_row_p<T, C::RS>(vr, kb * 32 + li, (kk + PD) * 16);
-        }
-        st = mma32(kfr[kk], qf[kk], st);
-        dp = mma32(vfr[kk], dof[kk], dp);
-        PFN_PIN_LDS_MFMA();
-      }
-      if (kb == 0) {   // staged tile t+1 -> the other buffer (stale and unread after the last tile), then request t+2
-        if (!(ABL & 2)) {
-          sk.template commit_p<C::RS>(Kr(BUF ^ 1));
-          sk.template commit_p<C::CS>(Kc(BUF ^ 1));
-          sv.template commit_p<C::RS>(Vr(BUF ^ 1));
-        }
-        if (!(ABL & 1) && t + 2 < ntiles) {
-          const long k2 = k0 + 2 * C::KVB;
-          sk.issue(Kp + k2 * rs, rs, sep - (int)k2, D);
-          sv.issue(Vp + k2 * rs, rs, sep - (int)k2, D);
-        }
-      }
-      // transposed K fragments of the dQ products: the first half is requested before the softmax arithmetic, the
-      // second before the first half's MFMAs
-      Frag<T> cf[2][C::NDB];
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) cf[0][db] = load_frag_tr_p<T, C::CS, 2>(kc, kb * 32, db * 32);
-      PFN_PIN_LDS_MFMA();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = fast_exp2(__builtin_fmaf(st[r], scale_log2, -lse2));
-        if (EDGE && (k0 + kb * 32 + acc_row(r, lane) >= sep)) p = 0.f;
-        st[r] = p * (dp[r] - delta);  // dS (unscaled)
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const Frag<T> dsf = acc_to_frag<T>(st, c);
-        if (c == 0) {
-#pragma unroll
-          for (int db = 0; db < C::NDB; ++db) cf[1][db] = load_frag_tr_p<T, C::CS, 2>(kc, kb * 32 + 16, db * 32);
-        }
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db) dq[db] = mma32(cf[c][db], dsf, dq[db]);
-        PFN_PIN_LDS_MFMA();
-      }
-    }
-    if (!(ABL & 4)) __syncthreads();
+    for (int i = 0; i < DPER; ++i) lds_write16(Ds(buf) + d_dst[i], dregs[SET][i]);
+    sk[SET].template commit_p<C::CS>(Kc(buf));
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  {
-    int t = 0;
-    for (; t + 2 <= nfull; t += 2) {
-      tile(I0{}, std::false_type{}, t);
-      tile(I1{}, std::false_type{}, t + 1);
+  if (ntiles > 0) {
+    request(I0{}, 0);
+    commit_all(I0{}, 0);
+    if (ntiles > 1) request(I1{}, 1);   // in flight across the barrier
+    if (ntiles > 2) request(I0{}, 2);
+  }
+  __syncthreads();
+  auto tile = [&](auto buf_c, int t) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const lds_char* dst = Ds(BUF);
+    const lds_char* kc = Kc(BUF);
+    constexpr int NKS = C::KVB / 16;     // contraction steps per tile
+    Frag<T> dsf[NKS];
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) dsf[c] = load_frag_tr_p<T, Q::DSS, 1>(dst, c * 16, wave * 32);
+    Frag<T> cf[2][C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) cf[0][db] = load_frag_tr_p<T, C::CS, 1>(kc, 0, db * 32);
+    PFN_PIN_LDS_MFMA();
+#pragma unroll
+    for (int c = 0; c < NKS; ++c) {
+      if (c + 1 < NKS) {
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) cf[(c + 1) & 1][db] = load_frag_tr_p<T, C::CS, 1>(kc, (c + 1) * 16, db * 32);
+      }
+      if (c == 0) {   // staged tile t+1 (register set of its parity) -> the other LDS buffer, then request t+3 into that set
+        if (!(ABL & 2)) commit_all(std::integral_constant<int, BUF ^ 1>{}, BUF ^ 1);
+        if (!(ABL & 1) && t + 3 < ntiles) request(std::integral_constant<int, BUF ^ 1>{}, t + 3);
+      }
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) dq[db] = mma32(cf[c & 1][db], dsf[c], dq[db]);
+      PFN_PIN_LDS_MFMA();
     }
-    if (t < nfull) {
-      tile(I0{}, std::false_type{}, t);
-      if (has_edge) tile(I1{}, std::true_type{}, t + 1);
-    } else if (has_edge) {
-      tile(I0{}, std::true_type{}, t);
-    }
+    if (!(ABL & 4)) __syncthreads();
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(I0{}, t);
+    if (t + 1 < ntiles) tile(I1{}, t + 1);
   }
 
   // self key of test rows
   const bool is_test = qc >= sep;
   float ds_self = 0.f, p_self = 0.f;
-  const bool wave_has_test = wg.blk * C::QBLK + wave * 32 + 31 >= sep;
-  if (wave_has_test) {   // only waves that hold a test row fetch the self K / V rows
+  const bool wave_has_test = q0 + wave * 32 + 31 >= sep;
+  Frag<T> qf[C::NKK], dof[C::NKK];
+  if (wave_has_test) {   // only waves that hold a test row fetch their Q / dO rows and the self K / V rows
+    const T* dOp = reinterpret_cast<const T*>(a.dctx) + ((long)b * a.S + qc) * a.E + hd * D;
+    const long stat = ((long)b * a.H + hd) * a.S + qc;
+    const float lse2 = a.lse[stat] * LOG2E;
+    const float delta = a.delta[stat];
     float tq = 0.f, dpv = 0.f;
 #pragma unroll
     for (int kk = 0; kk < C::NKK; ++kk) {
+      qf[kk] = load_frag_global<T>(Qp + (long)qc * rs + kk * 16 + 8 * h);
+      dof[kk] = load_frag_global<T>(dOp + kk * 16 + 8 * h);
       tq += dot8(qf[kk], load_frag_global<T>(Kp + (long)qc * rs + kk * 16 + 8 * h));
       dpv += dot8(dof[kk], load_frag_global<T>(Vp + (long)qc * rs + kk * 16 + 8 * h));
     }
@@ -537,194 +844,19 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
       store_row_block<T>(dQo + db * 32, v, h, qvalid);
     }
   }
-  if (qvalid) {
-    if (is_test) {
-      T* dKo = dbase + (long)qi * rs + a.E + hd * D;
-      T* dVo = dbase + (long)qi * rs + 2 * a.E + hd * D;
+  if (wave_has_test && qvalid && is_test) {
+    T* dKo = dbase + (long)qi * rs + a.E + hd * D;
+    T* dVo = dbase + (long)qi * rs + 2 * a.E + hd * D;
 #pragma unroll
-      for (int kk = 0; kk < C::NKK; ++kk) {
-        float xk[8], xv[8];
+    for (int kk = 0; kk < C::NKK; ++kk) {
+      float xk[8], xv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xk[e] = ds_self * scale * frag_get(qf[kk], e);
-          xv[e] = p_self * frag_get(dof[kk], e);
-        }
-        store_frag_global<T>(dKo + kk * 16 + 8 * h, xk);
-        store_frag_global<T>(dVo + kk * 16 + 8 * h, xv);
+      for (int e = 0; e < 8; ++e) {
+        xk[e] = ds_self * scale * frag_get(qf[kk], e);
+        xv[e] = p_self * frag_get(dof[kk], e);
       }
-    }
-  }
-}
-
-// =============================================================================================
-// backward, dK and dV for the train keys [0, sep): a workgroup owns QBLK keys (one per lane, 32 per
-// wave) and streams all S queries.  Two passes (MODE 0: dV = P^T dO, MODE 1: dK = dS^T Q) instead
-// of one fused kernel: a fused pass needs dK and dV accumulators plus the K and V fragments of
-// the wave's keys -- 240 registers before any temporary -- and would run one wave per SIMD with
-// nothing to cover its LDS waits and softmax; each split pass fits two (dK) or three (dV) waves per
-// SIMD at the price of recomputing S once.
-// Keys >= sep in the last key block run on clamped (finite or not: never stored, and a lane's key
-// column never mixes with another lane's) data instead of being masked.
-// =============================================================================================
-template <typename T, int D, int MODE>
-__global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dkv_kernel(AttnArgs a) {
-  using C = AttnCfg<T, D>;
-  constexpr int QB = C::KVB;                 // queries per tile (64 for bf16 up to D = 128, else 32)
-  constexpr int NQB = QB / 32;
-  // images per buffer -- dV: Q rows, dO cols;  dK: Q rows, Q cols, dO rows;  then lse2[QB], delta[QB]
-  constexpr int IMG_BYTES = C::RIMG + C::CIMG + (MODE == 1 ? C::RIMG : 0);
-  constexpr int BUF_BYTES = IMG_BYTES + 2 * QB * 4;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  LdsPtr smem = lds_cast(smem_raw);
-  auto Img = [&](int buf, int i) { return smem + buf * BUF_BYTES + (i == 0 ? 0 : i == 1 ? C::RIMG : C::RIMG + C::CIMG); };
-  auto St = [&](int buf) { return smem + buf * BUF_BYTES + IMG_BYTES; };  // [lse2 x QB][delta x QB]
-
-  const AttnBlock wg = attn_block((a.sep + C::QBLK - 1) / C::QBLK, a.H);
-  const int b = wg.b, hd = wg.hd;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
-  const long rs = 3L * a.E;
-  const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
-  const T* Qp = base + hd * D;
-  const T* Kp = base + a.E + hd * D;
-  const T* Vp = base + 2 * a.E + hd * D;
-  const T* dOp = reinterpret_cast<const T*>(a.dctx) + (long)b * a.S * a.E + hd * D;
-  T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
-  const int sep = a.sep;
-  const int key = wg.blk * C::QBLK + wave * 32 + li;
-  const bool kvalid = key < sep;
-  const int kc = min(key, a.S - 1);
-  const float scale = rsqrtf((float)D);
-  const float scale_log2 = scale * LOG2E;
-  const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
-  const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
-
-  Frag<T> kf[C::NKK], vf[MODE == 1 ? C::NKK : 1];
-#pragma unroll
-  for (int kk = 0; kk < C::NKK; ++kk) {
-    kf[kk] = load_frag_global<T>(Kp + (long)kc * rs + kk * 16 + 8 * h);
-    if constexpr (MODE == 1) vf[kk] = load_frag_global<T>(Vp + (long)kc * rs + kk * 16 + 8 * h);
-  }
-  f32x16 acc[C::NDB];
-#pragma unroll
-  for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
-
-  const int ntiles = (a.S + QB - 1) / QB;
-  TileStage<T, QB, C::RB, C::NT> sq, so;
-  float st_reg = 0.f;  // threads 0..2*QB-1 stage lse2 / delta
-  auto stage_stats = [&](int q0) {
-    if (threadIdx.x < 2 * QB) {
-      const int q = q0 + (threadIdx.x & (QB - 1));
-      if (threadIdx.x < QB) st_reg = (q < a.S) ? lse_g[q] * LOG2E : 1e30f;
-      else st_reg = (MODE == 1 && q < a.S) ? delta_g[q] : 0.f;
-    }
-  };
-  auto commit_all = [&](int buf) {
-    sq.template commit_p<C::RS>(Img(buf, 0));
-    if constexpr (MODE == 0) {
-      so.template commit_p<C::CS>(Img(buf, 1));
-    } else {
-      sq.template commit_p<C::CS>(Img(buf, 1));
-      so.template commit_p<C::RS>(Img(buf, 2));
-    }
-    if (threadIdx.x < 2 * QB) lds_write_f32(St(buf) + threadIdx.x * 4, st_reg);
-  };
-  sq.issue(Qp, rs, a.S, D);
-  so.issue(dOp, a.E, a.S, D);
-  stage_stats(0);
-  commit_all(0);
-  auto request = [&](int t) {   // tile t -> staging registers
-    const long q1 = (long)t * QB;
-    sq.issue(Qp + q1 * rs, rs, a.S - (int)q1, D);
-    so.issue(dOp + q1 * a.E, a.E, a.S - (int)q1, D);
-    stage_stats((int)q1);
-  };
-  if (ntiles > 1) request(1);   // stays in flight across the barrier (staging as in attn_fwd_kernel)
-  __syncthreads();
-
-  auto tile = [&](auto buf_c, int t) {
-    constexpr int BUF = decltype(buf_c)::value;
-    const lds_char* qr = Img(BUF, 0);
-    const lds_char* stt = St(BUF);
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-      // operand fragments run PD k-steps ahead of the MFMAs that consume them (see attn_bwd_dq_kernel)
-      constexpr int PD = C::NKK < 4 ? C::NKK : 4;
-      Frag<T> qfr[C::NKK], ofr[MODE == 1 ? C::NKK : 1];
-#pragma unroll
-      for (int kk = 0; kk < PD; ++kk) {
-        qfr[kk] = load_frag_row_p<T, C::RS>(qr, qb * 32 + li, kk * 16);
-        if constexpr (MODE == 1) ofr[kk] = load_frag_row_p<T, C::RS>(Img(BUF, 2), qb * 32 + li, kk * 16);
-      }
-      PFN_PIN_LDS_MFMA();
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int kk = 0; kk < C::NKK; ++kk) {
-        if (kk + PD < C::NKK) {
-          qfr[kk + PD] = load_frag_row_p<T, C::RS>(qr, qb * 32 + li, (kk + PD) * 16);
-          if constexpr (MODE == 1) ofr[kk + PD] = load_frag_row_p<T, C::RS>(Img(BUF, 2), qb * 32 + li, (kk + PD) * 16);
-        }
-        s = mma32(qfr[kk], kf[kk], s);
-        if constexpr (MODE == 1) dp = mma32(ofr[kk], vf[kk], dp);
-        PFN_PIN_LDS_MFMA();
-      }
-      if (qb == 0) {   // staged tile t+1 -> the other buffer (stale and unread after the last tile), then request t+2
-        if (!(ABL & 2)) commit_all(BUF ^ 1);
-        if (!(ABL & 1) && t + 2 < ntiles) request(t + 2);
-      }
-      // transposed dO / Q fragments of the second product: first half requested before the softmax arithmetic
-      const lds_char* col = Img(BUF, 1);   // dO (dV pass) or Q (dK pass), read transposed
-      Frag<T> cf[2][C::NDB];
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) cf[0][db] = load_frag_tr_p<T, C::CS, 2>(col, qb * 32, db * 32);
-      PFN_PIN_LDS_MFMA();
-      // rows of s/dp are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (qb * 32 + 8 * rg + 4 * h) * 4));
-        f32x4 dl = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == 1) dl = __builtin_bit_cast(f32x4, lds_read16(stt + (QB + qb * 32 + 8 * rg + 4 * h) * 4));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * rg + e;
-          const float p = fast_exp2(__builtin_fmaf(s[r], scale_log2, -l2[e]));
-          if constexpr (MODE == 0) s[r] = p;
-          else s[r] = p * (dp[r] - dl[e]);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const Frag<T> f = acc_to_frag<T>(s, c);
-        if (c == 0) {
-#pragma unroll
-          for (int db = 0; db < C::NDB; ++db) cf[1][db] = load_frag_tr_p<T, C::CS, 2>(col, qb * 32 + 16, db * 32);
-        }
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db) acc[db] = mma32(cf[c][db], f, acc[db]);
-        PFN_PIN_LDS_MFMA();
-      }
-    }
-    if (!(ABL & 4)) __syncthreads();
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  for (int t = 0; t < ntiles; t += 2) {
-    tile(I0{}, t);
-    if (t + 1 < ntiles) tile(I1{}, t + 1);
-  }
-
-  {
-    T* out = dbase + (long)kc * rs + (MODE == 0 ? 2 * a.E : a.E) + hd * D;
-    const float f = MODE == 0 ? 1.f : scale;
-#pragma unroll
-    for (int db = 0; db < C::NDB; ++db) {
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[db][r] * f;
-      store_row_block<T>(out + db * 32, v, h, kvalid);
+      store_frag_global<T>(dKo + kk * 16 + 8 * h, xk);
+      store_frag_global<T>(dVo + kk * 16 + 8 * h, xv);
     }
   }
 }
@@ -739,27 +871,23 @@ template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStrea
   hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
-template <typename T, int D, int MODE> static void launch_dkv_t(const AttnArgs& a, hipStream_t s) {
-  using C = AttnCfg<T, D>;
-  const size_t lds = 2 * (C::RIMG + C::CIMG + (MODE == 1 ? C::RIMG : 0) + 2 * C::KVB * 4);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, D, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, MODE>), dim3(((a.sep + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
-}
 template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
-  {
+  const int parts = a.parts ? a.parts : ~0;
+  if (parts & ATTN_BWD_DELTA) {
     const long pairs = (long)a.B * a.S * a.H;
     int grid = (int)std::min<long>((pairs + 15) / 16, 4096);
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, s, a, D);
   }
-  {
-    const size_t lds = 2 * (2 * C::RIMG + C::CIMG);
+  if ((parts & ATTN_BWD_KV) && a.sep > 0) {
+    const size_t lds = BwdKvCfg<T, D>::LDS;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<T, D>), dim3(((a.sep + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
+  }
+  if (parts & ATTN_BWD_DQ) {
+    const size_t lds = BwdDqCfg<T, D>::LDS;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
-  }
-  if (a.sep > 0) {
-    launch_dkv_t<T, D, 0>(a, s);
-    launch_dkv_t<T, D, 1>(a, s);
   }
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
@@ -796,9 +924,21 @@ int launch_attn_fwd(const AttnArgs& a, int precision, hipStream_t s) {
   if (rc != PFN_OK) return rc;
   PFN_ATTN_DISPATCH(launch_fwd_t)
 }
-int launch_attn_bwd(const AttnArgs& a, int precision, hipStream_t s) {
-  int rc = check_attn(a, precision);
+void attn_bwd_ds_dims(int S, int sep, int* rows, int* ld) {
+  *rows = (sep + 63) / 64 * 64;       // whole key tiles of the dQ pass
+  *ld = (S + 255) / 256 * 256;        // whole query blocks of the dQ pass (and 16-byte aligned rows)
+}
+int64_t attn_bwd_ds_bytes(int B, int S, int H, int precision) {
+  int rows, ld;
+  attn_bwd_ds_dims(S, S, &rows, &ld);
+  return (int64_t)B * H * rows * ld * (precision == PFN_PREC_BF16 ? 2 : 4);
+}
+int launch_attn_bwd(const AttnArgs& a_in, int precision, hipStream_t s) {
+  int rc = check_attn(a_in, precision);
   if (rc != PFN_OK) return rc;
+  if (!a_in.ds) return PFN_ERR_ARGUMENT;
+  AttnArgs a = a_in;
+  attn_bwd_ds_dims(a.S, a.sep, &a.ds_rows, &a.ds_ld);
   PFN_ATTN_DISPATCH(launch_bwd_t)
 }
 

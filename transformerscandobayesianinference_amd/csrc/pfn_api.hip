@@ -101,6 +101,7 @@ struct Ws {
   // backward scratch
   char *dlog_t, *dd_t, *dctx_t;
   float *dxt, *gA, *delta;   // gA: f32 gradient of the embedding output (the last dx of the backward)
+  char* ds;                  // dS^T of the attention backward (key-block pass -> query-block pass), one layer at a time
   char* gA_t;                // gradient w.r.t. a layer's output between layers, operand precision
   int64_t bytes;
 };
@@ -127,6 +128,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   w.gA = (float*)take(M * E * 4); w.gA_t = take(M * E * es);
   w.dctx_t = take(M * E * es);
   w.delta = (float*)take((int64_t)B * d.nhead * S * 4);
+  w.ds = take(attn_bwd_ds_bytes(B, S, d.nhead, d.precision));
   w.bytes = cur;
   return w;
 }
@@ -387,7 +389,7 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
     {
       AttnArgs at; memset(&at, 0, sizeof(at));
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
-      at.dctx = w.dctx_t; at.dqkv = a.dqkv_t; at.delta = w.delta;
+      at.dctx = w.dctx_t; at.dqkv = a.dqkv_t; at.delta = w.delta; at.ds = w.ds;
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     {  // dx = dqkv . Win + dy1
@@ -564,11 +566,15 @@ int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, i
   PFN_TRY(launch_attn_fwd(at, prec, (hipStream_t)stream));
   return PFN_OK;
 }
-int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta_ws,
-                         int B, int S, int E, int H, int sep, int prec, void* stream) {
+int64_t pfn_op_attention_bwd_ws_bytes(int B, int S, int H, int prec) {
+  if (B < 1 || S < 1 || H < 1) return -1;
+  return attn_bwd_ds_bytes(B, S, H, prec);
+}
+int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta_ws, void* ds_ws,
+                         int B, int S, int E, int H, int sep, int prec, int parts, void* stream) {
   AttnArgs at; memset(&at, 0, sizeof(at));
   at.qkv = qkv; at.ctx = const_cast<void*>(ctx); at.lse = const_cast<float*>(lse); at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
-  at.dctx = dctx; at.dqkv = dqkv; at.delta = delta_ws;
+  at.dctx = dctx; at.dqkv = dqkv; at.delta = delta_ws; at.ds = ds_ws; at.parts = parts;
   PFN_TRY(launch_attn_bwd(at, prec, (hipStream_t)stream));
   return PFN_OK;
 }

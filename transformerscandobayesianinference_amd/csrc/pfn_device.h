@@ -239,6 +239,121 @@ template <typename T> PFN_DEV void store_row_block(T* row_block, const float (&v
   }
 }
 
+// A 32 x 32 tile held as two operand fragments in accumulator order (mapping M2: lane = row j, f0 holds columns 8g + 4h + e of
+// groups g = 0, 1, f1 of groups 2, 3 -- what acc_to_frag produced) to a BLOCKED global layout in which every store
+// instruction of the wave covers one contiguous KiB (whole 128-byte lines; row-major stores of such a tile put 32 bytes on
+// each of 32 rows, and partial-line writes retire several times slower).  Block = 32 rows x 32 columns of T:
+//   bf16: chunk (p, j, h) at ((p * 32 + j) * 2 + h) * 16 bytes holds row j, columns 16 p + 8 h .. + 7
+//   f32 : chunk (p, s, j, h) at (((2 p + s) * 32 + j) * 2 + h) * 16 bytes holds row j, columns 16 p + 8 s + 4 h .. + 3
+// blocked_chunk_col / blocked_chunk_row invert the map for the reader (chunk index w in address order).
+template <typename T> PFN_DEV void store_frag_pair_blocked(T* block, const Frag<T>& f0, const Frag<T>& f1, int j, int h, bool valid) {
+  char* base = reinterpret_cast<char*>(block);
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const u32x4 d = __builtin_bit_cast(u32x4, p == 0 ? f0.v : f1.v);   // {group 2p: 2 dwords, group 2p+1: 2 dwords}
+      const auto r0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+      const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};                      // columns 16 p + 8 h .. + 7 of row j
+      // non-temporal: written once, read by a later kernel -- keep it from evicting the operand tiles this kernel re-reads from L2
+      if (valid) __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(base + ((p * 32 + j) * 2 + h) * 16));
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const Frag<T>& f = p == 0 ? f0 : f1;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+        if (valid) __builtin_nontemporal_store(f32x4{f.v[4 * sub], f.v[4 * sub + 1], f.v[4 * sub + 2], f.v[4 * sub + 3]},
+                                               reinterpret_cast<f32x4*>(base + (((2 * p + sub) * 32 + j) * 2 + h) * 16));
+    }
+  }
+}
+template <typename T> PFN_DEV int blocked_chunk_row(int w) { return (w >> 1) & 31; }
+template <typename T> PFN_DEV int blocked_chunk_col(int w) {
+  if constexpr (sizeof(T) == 2) return 16 * (w >> 6) + 8 * (w & 1);
+  else return 8 * (w >> 6) + 4 * (w & 1);          // w >> 6 = 2 p + s
+}
+
+// ---------------------------------------------------------------------------------------------
+// Buffer-descriptor loads: 32-bit per-lane byte offsets against a wave-uniform descriptor, and the hardware's range check
+// (an offset at or beyond num_records reads as zero) instead of exec-masked branches around every load.
+// ---------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+PFN_DEV BufRsrc make_rsrc(const void* base, long bytes) {
+  const int n = bytes > 0x7ffffff0L ? 0x7ffffff0 : (bytes < 0 ? 0 : (int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+PFN_DEV u32x4 buf_load16(BufRsrc r, int byte_offset) { return __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 0); }
+constexpr int BUF_OOB = 0x7ffffff0;
+
+// LDS-DMA of one 1-KiB piece (64 lanes x 16 bytes, lane-linear at the wave-uniform LDS address) through a buffer descriptor,
+// issued from inline assembly ON PURPOSE: hipcc tracks the builtin form as a pending LDS write and puts `s_waitcnt vmcnt(0)`
+// in front of the next LDS read it cannot prove disjoint -- every ds_read_b64_tr_b16 (the intrinsic carries no address
+// information), i.e. in the middle of the tile the DMA was meant to overlap.  The assembly form is invisible to that pass;
+// the kernel waits itself (`dma_wait_all`) where the data is needed.  Out-of-range lanes (offset >= the descriptor's
+// num_records) write zeros.  M0 carries the LDS address and is restored (the compiler owns it).
+struct DmaRsrc { u32x4 w; };
+PFN_DEV DmaRsrc make_dma_rsrc(const void* base, long bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  const int n = bytes > 0x7ffffff0L ? 0x7ffffff0 : (bytes < 0 ? 0 : (int)bytes);
+  DmaRsrc r;
+  r.w[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+  r.w[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xffffu);   // stride 0
+  r.w[2] = __builtin_amdgcn_readfirstlane((unsigned)n);
+  r.w[3] = 0x00020000u;
+  return r;
+}
+PFN_DEV void dma16(const DmaRsrc& r, LdsPtr lds_dst_uniform, int byte_offset) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_dst_uniform);
+  // readfirstlane again at the point of use: a descriptor that reaches here through a select or a loop-carried value is
+  // uniform in fact but not provably, and the "s" constraint would be handed a VGPR (a no-op copy when it already is scalar)
+  const u32x4 w = {(unsigned)__builtin_amdgcn_readfirstlane(r.w[0]), (unsigned)__builtin_amdgcn_readfirstlane(r.w[1]),
+                   (unsigned)__builtin_amdgcn_readfirstlane(r.w[2]), (unsigned)__builtin_amdgcn_readfirstlane(r.w[3])};
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(dst), "v"(byte_offset), "s"(w) : "memory");
+}
+// Two instructions on purpose.  The builtin is the one hipcc's wait-count pass sees: after it the pass knows nothing is pending
+// (without it, loads issued before a loop -- K fragments held in registers -- stay "possibly pending" in its model, and it
+// re-waits for them at every use inside the loop with vmcnt(7), (6), ... (0): against the real queue, which holds the DMA
+// it cannot see, that drains everything in the middle of the tile).  The pass may drop a builtin wait it considers redundant,
+// so the assembly form follows: free when the first one ran, the only one otherwise.
+PFN_DEV void dma_wait_all() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Register-staged global -> LDS tile copy through a buffer descriptor (see TileStage below for the pointer form).  The lane's
+// chunk offsets inside a tile are computed once (`init`); a tile is selected by a byte offset added to them; rows beyond
+// the descriptor's range read as zero.  ROWS x RB bytes, NT threads.
+template <typename T, int ROWS, int RB, int NT> struct TileStageBuf {
+  static constexpr int NCH = RB / 16;
+  static constexpr int TOTAL = ROWS * NCH;
+  static constexpr int PER = (TOTAL + NT - 1) / NT;
+  u32x4 regs[PER];
+  int voff[PER];
+  PFN_DEV void init(int ld_bytes) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = threadIdx.x + i * NT;
+      voff[i] = (TOTAL % NT == 0 || id < TOTAL) ? (id / NCH) * ld_bytes + (id % NCH) * 16 : BUF_OOB;
+    }
+  }
+  PFN_DEV void issue(BufRsrc r, int tile_byte_offset) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) regs[i] = buf_load16(r, voff[i] + tile_byte_offset);
+  }
+  template <int STRIDE> PFN_DEV void commit_p(LdsPtr tile) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int id = threadIdx.x + i * NT;
+      if (TOTAL % NT != 0 && id >= TOTAL) break;
+      lds_write16(tile + (id / NCH) * STRIDE + (id % NCH) * 16, regs[i]);
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Cooperative global -> LDS tile copy in 16-byte chunks (register staged so the issue and the
 // LDS write can be split around compute).  ROWS x RB bytes, NT threads.

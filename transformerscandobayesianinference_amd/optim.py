@@ -40,6 +40,31 @@ class FusedClipAdam(torch.optim.Optimizer):
                    'pfn_clip_adam_step')
         self.model.mark_params_updated()
 
+    # ---- checkpointing: the moments live in flat buffers outside torch's per-parameter `state`, so they are exposed here;
+    # `(model.state_dict(), optimizer.state_dict())` is the notebooks' checkpoint tuple (tabular.save_checkpoint) ----
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._m is not None:
+            sd['flat'] = {'step': self._step, 'exp_avg': self._m.detach().cpu().clone(), 'exp_avg_sq': self._v.detach().cpu().clone()}
+        else:
+            sd['flat'] = {'step': self._step}
+        sd['grad_multiplier'] = self.grad_multiplier
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        flat_state = state_dict.pop('flat', None)
+        self.grad_multiplier = state_dict.pop('grad_multiplier', self.grad_multiplier)
+        super().load_state_dict(state_dict)
+        if flat_state is not None:
+            self._step = int(flat_state['step'])
+            if 'exp_avg' in flat_state:
+                flat, _ = self._buffers()
+                if flat_state['exp_avg'].numel() != flat.numel():
+                    raise ValueError(f"optimizer state holds {flat_state['exp_avg'].numel()} moments, the model has {flat.numel()} flat parameters")
+                self._m.copy_(flat_state['exp_avg'])
+                self._v.copy_(flat_state['exp_avg_sq'])
+
     def zero_grad(self, set_to_none=False):
         _, grad = self._buffers()
         grad.zero_()

@@ -12,21 +12,55 @@ not reproduced.  No CPU fallback.
 import torch
 
 from transformerscandobayesianinference_amd import _hip
-from transformerscandobayesianinference_amd.priors.utils import get_batch_to_dataloader
+from transformerscandobayesianinference_amd.priors.utils import defer_draw_check, get_batch_to_dataloader
 from transformerscandobayesianinference_amd.utils import default_device
 
 KERNEL_RBF, KERNEL_MATERN52 = 0, 1
 
 _DEFAULT_HPS = {"noise": .1, "outputscale": .1, "lengthscale": .1}  # reference fast_gp.py:40
 _call_counter = [0]
+# gpytorch.utils.cholesky.psd_safe_cholesky (what ExactGP's prior draw and prediction go through, reference :53-56,
+# :101-104): on a failed factorisation the diagonal is raised by 1e-6, 1e-5, 1e-4 in turn, with a warning, and
+# NotPSDError is raised after the third failure (gpytorch 1.5.0 settings.cholesky_jitter = 1e-6 for float,
+# cholesky_max_tries = 3; restated from memory of the pinned version -- the library is not installed here).
+CHOLESKY_JITTERS = (1e-6, 1e-5, 1e-4)
+repair_log = []   # (number of failed datasets, jitter that fixed them) of every repaired draw: tests and monitoring read it
+
+
+class NotPSDError(RuntimeError):
+    """The covariance matrix of a dataset is not positive definite in f32 even with the largest diagonal jitter."""
+
+
+def _with_jitter(run, noise, info, what):
+    """`run(noise_vector)` refills the outputs of the failed datasets; called with the info flags of a finished attempt.
+    Re-runs with escalating diagonal jitter on the failed datasets until every factorisation succeeds; returns True if
+    anything had to be repaired."""
+    import warnings
+    bad = info != 0
+    if not bool(bad.any()):
+        return False
+    nbad = int(bad.sum())
+    for jitter in CHOLESKY_JITTERS:
+        warnings.warn(f'{what}: f32 Cholesky failed for {nbad} dataset(s); retrying those with {jitter:g} added to the diagonal '
+                      f'(gpytorch psd_safe_cholesky behaviour)', RuntimeWarning)
+        info2 = run(noise + jitter * bad.to(noise.dtype), bad)
+        still = (info2 != 0) & bad
+        if not bool(still.any()):
+            repair_log.append((nbad, jitter))
+            return True
+        bad = still
+    raise NotPSDError(f'{what}: covariance matrix of {int(bad.sum())} dataset(s) not positive definite after adding {CHOLESKY_JITTERS[-1]:g} to the diagonal')
 
 
 def gp_sample(batch_size, seq_len, num_features, device, lengthscale, outputscale, noise, kernel=KERNEL_RBF,
-              x=None, z=None, seed=None):
+              x=None, z=None, seed=None, check=True):
     """Batched draw through the C ABI.  lengthscale: float | [B] | [B,F]; outputscale, noise: float | [B].
     x ([B,T,F]) and z ([B,T] base normals) may be injected for parity tests; otherwise they come from
     the device generator, seeded from torch's global seed plus a per-call counter.
-    Returns (x[B,T,F], y[B,T], z[B,T])."""
+    check: the factorisation's failure flag is read (inside a prefetching loader: before the batch is handed out,
+    priors/utils.py; otherwise here, which synchronises) and failed datasets are redrawn from the same (x, z) with
+    gpytorch's jitter ladder; False leaves `info` to the caller.
+    Returns (x[B,T,F], y[B,T], z[B,T], info[B])."""
     dev = torch.device(device)
     if dev.type != 'cuda':
         raise _hip.HipExtensionError(f'the GP prior sampler runs on the GPU only (got device {device}); no CPU fallback')
@@ -57,11 +91,29 @@ def gp_sample(batch_size, seq_len, num_features, device, lengthscale, outputscal
     if seed is None:
         seed = torch.initial_seed()
     _call_counter[0] += 1
-    _hip.check(lib.pfn_gp_prior_sample(x.data_ptr(), z.data_ptr(), y.data_ptr(), K.data_ptr(), ls.data_ptr(), osc.data_ptr(),
-                                       nz.data_ptr(), B, Tp, F, kernel, int(gen_x), int(gen_z), seed & (2 ** 64 - 1),
-                                       _call_counter[0], info.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_prior_sample')
+    offset = _call_counter[0]
+
+    def run(noise_vec, y_out, info_out, gx, gz, K_ws):
+        _hip.check(lib.pfn_gp_prior_sample(x.data_ptr(), z.data_ptr(), y_out.data_ptr(), K_ws.data_ptr(), ls.data_ptr(), osc.data_ptr(),
+                                           noise_vec.data_ptr(), B, Tp, F, kernel, int(gx), int(gz), seed & (2 ** 64 - 1),
+                                           offset, info_out.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_prior_sample')
+
+    run(nz, y, info, gen_x, gen_z, K)
+    del K
+    if check:
+        def retry(noise_vec, bad):
+            # same (x, z) -- they are on the device now -- with a raised diagonal; only the failed datasets are replaced
+            y2, info2 = torch.empty_like(y), torch.zeros_like(info)
+            run(noise_vec.contiguous(), y2, info2, False, False, torch.empty(B, Tp, Tp, dtype=torch.float32, device=dev))
+            y[bad] = y2[bad]
+            return info2
+
+        verify = lambda: _with_jitter(retry, nz, info, 'GP prior draw')
+        if check == 'sync' or not defer_draw_check(verify):
+            verify()
     if Tp != T:
-        x, y, z = x[:, :T].contiguous(), y[:, :T].contiguous(), z[:, :T].contiguous()
+        # y stays a view of the padded draw so that a deferred repair (which writes y in place) reaches the consumer
+        x, y, z = x[:, :T], y[:, :T], z[:, :T]
     return x, y, z, info
 
 
@@ -88,10 +140,11 @@ DataLoader.num_outputs = 1
 
 
 @torch.no_grad()
-def gp_posterior(x, y, lengthscale, outputscale, noise, kernel=KERNEL_RBF):
+def gp_posterior(x, y, lengthscale, outputscale, noise, kernel=KERNEL_RBF, check=True):
     """Sequential exact-GP predictions through the C ABI (`pfn_gp_posterior`): for every dataset b and position t the
     posterior at x[b,t] given (x[b,:t], y[b,:t]).  x [B,T,F], y [B,T] on the GPU; hyper-parameters as in `gp_sample`.
-    Returns (mean[B,T], var[B,T] with observation noise, nll[B,T], info[B])."""
+    check: read the factorisation's failure flags (a host sync) and redo failed datasets with gpytorch's jitter ladder.
+    Returns (mean[B,T], var[B,T] with observation noise, nll[B,T], info[B] of the first attempt)."""
     dev = x.device
     if dev.type != 'cuda':
         raise _hip.HipExtensionError(f'the GP posterior runs on the GPU only (got device {dev}); no CPU fallback')
@@ -114,11 +167,23 @@ def gp_posterior(x, y, lengthscale, outputscale, noise, kernel=KERNEL_RBF):
     xp, yp = xp.contiguous(), yp.contiguous()
     K = torch.empty(B, Tp, Tp, dtype=torch.float32, device=dev)
     resid, w = torch.empty_like(yp), torch.empty_like(yp)
-    mean, var, nll = torch.empty_like(yp), torch.empty_like(yp), torch.empty_like(yp)
-    info = torch.zeros(B, dtype=torch.int32, device=dev)
-    _hip.check(lib.pfn_gp_posterior(xp.data_ptr(), yp.data_ptr(), K.data_ptr(), resid.data_ptr(), w.data_ptr(), ls.data_ptr(),
-                                    osc.data_ptr(), nz.data_ptr(), B, Tp, F, kernel, nll.data_ptr(), mean.data_ptr(),
-                                    var.data_ptr(), info.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_posterior')
+
+    def run(noise_vec):
+        mean, var, nll = torch.empty_like(yp), torch.empty_like(yp), torch.empty_like(yp)
+        info = torch.zeros(B, dtype=torch.int32, device=dev)
+        _hip.check(lib.pfn_gp_posterior(xp.data_ptr(), yp.data_ptr(), K.data_ptr(), resid.data_ptr(), w.data_ptr(), ls.data_ptr(),
+                                        osc.data_ptr(), noise_vec.data_ptr(), B, Tp, F, kernel, nll.data_ptr(), mean.data_ptr(),
+                                        var.data_ptr(), info.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_posterior')
+        return mean, var, nll, info
+
+    mean, var, nll, info = run(nz)
+    if check:
+        def retry(noise_vec, bad):
+            m2, v2, n2, info2 = run(noise_vec.contiguous())
+            mean[bad], var[bad], nll[bad] = m2[bad], v2[bad], n2[bad]
+            return info2
+
+        _with_jitter(retry, nz.reshape(B), info, 'exact-GP posterior')
     return mean[:, :T], var[:, :T], nll[:, :T], info
 
 

@@ -69,7 +69,11 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
             assert num_features == 1
             x = torch.linspace(0, 1., seq_len).unsqueeze(0).repeat(n, 1).unsqueeze(-1)
         ls, osc, nz = sample_hyperparameters(n, num_features, hyperparameters, device)
-        x, y, _, _ = fast_gp.gp_sample(n, seq_len, num_features, device, ls, osc, nz, fast_gp.KERNEL_MATERN52, x=x)
+        # anything below that copies y (normalisation, rejection) must see a verified draw: check at once there; a plain
+        # draw inside a prefetching loader is verified before its batch is handed out (priors/utils.py)
+        copies = bool(hyperparameters.get('y_minmax_norm') or hyperparameters.get('sigmoid') or fix_to_range is not None)
+        x, y, _, _ = fast_gp.gp_sample(n, seq_len, num_features, device, ls, osc, nz, fast_gp.KERNEL_MATERN52, x=x,
+                                       check='sync' if copies else True)
         if hyperparameters.get('y_minmax_norm'):
             lo, hi = y.min(1, keepdim=True)[0], y.max(1, keepdim=True)[0]
             y = (y - lo) / (hi - lo)

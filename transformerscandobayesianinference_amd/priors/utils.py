@@ -59,6 +59,34 @@ def get_batch_to_dataloader(get_batch_method_):
     return DL
 
 
+# ---- deferred draw checks ---------------------------------------------------------------------------------------------
+# A sampler whose failure flag lives on the device (the Cholesky `info` of priors.fast_gp) must not force a host sync
+# inside a draw that runs ahead on a side stream.  While a `deferred_draw_checks()` block is open such samplers append
+# a callable to the open list instead of checking at once; the prefetching iterator runs the callables after the
+# group's event has completed and BEFORE the first batch of the group is handed out.  A callable returns True when it
+# had to repair its draw (it then re-ran the sampler, in place, on the current stream).
+_open_check_lists = []
+
+
+class deferred_draw_checks:
+    def __enter__(self):
+        self.checks = []
+        _open_check_lists.append(self.checks)
+        return self.checks
+
+    def __exit__(self, *exc):
+        _open_check_lists.remove(self.checks)
+        return False
+
+
+def defer_draw_check(fn):
+    """Queue `fn` if a deferred block is open (returns True), else leave it to the caller (returns False)."""
+    if _open_check_lists:
+        _open_check_lists[-1].append(fn)
+        return True
+    return False
+
+
 def _tensors(obj):
     if torch.is_tensor(obj):
         yield obj
@@ -83,15 +111,23 @@ def prefetch_on_side_stream(draw_group, num_groups, num_steps, group):
     def enqueue(g):
         n = min(group, num_steps - g * group)
         side.wait_stream(origin)   # anything the draw reads (hyper-parameters ...) was produced on the caller's stream
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), deferred_draw_checks() as checks:
             batches = draw_group(n)
             done = torch.cuda.Event()
             done.record(side)
-        return batches, done
+        return batches, done, checks
 
     pending = enqueue(0) if num_groups > 0 else None
     for g in range(num_groups):
-        batches, done = pending
+        batches, done, checks = pending
+        if checks:
+            # the group was enqueued a whole group of training steps ago, so its event has normally completed long before
+            # the host gets here (the main stream still holds queued steps: the GPU does not idle while the host waits)
+            done.synchronize()
+            with torch.cuda.stream(side):
+                if any([check() for check in checks]):   # a failed factorisation was redrawn with jitter, in place
+                    done = torch.cuda.Event()
+                    done.record(side)
         pending = enqueue(g + 1) if g + 1 < num_groups else None
         for batch in batches:
             main = torch.cuda.current_stream()

@@ -24,7 +24,11 @@ class MicroBatchStreams:
         (over all groups) and returns the detached losses [T - sep, B]."""
         x, y = data
         B = x.shape[1]
-        n = self.n if (self.streams and B % self.n == 0 and B >= 2 * self.n) else 1
+        # only the all-HIP path is split: with a PyTorch-side embedding (custom encoders, SeqBN, positional encodings)
+        # SeqBN would normalise per group, a scrambled encoding would draw per group, and autograd's gradient
+        # accumulation into the shared flat buffer (non-atomic read-modify-write) would run on two streams at once
+        fused = getattr(model, '_fused_embedding', lambda: False)()
+        n = self.n if (self.streams and fused and B % self.n == 0 and B >= 2 * self.n) else 1
         if n == 1:
             output = model(data, single_eval_pos=single_eval_pos)
             losses = loss_fn(output, targets)

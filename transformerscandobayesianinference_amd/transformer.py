@@ -115,6 +115,8 @@ class _StackFunction(torch.autograd.Function):
 
 
 class TransformerModel(nn.Module):
+    requires_gpu = True   # train() checks this before building anything (the host-plumbing tests substitute a CPU stand-in)
+
     def __init__(self, encoder, n_out, ninp, nhead, nhid, nlayers, dropout=0.0, y_encoder=None, pos_encoder=None,
                  decoder=None, input_normalization=False, precision='bf16'):
         super().__init__()
@@ -133,7 +135,10 @@ class TransformerModel(nn.Module):
         self._flat = self._flat_grad = self._shadow = None
         self._shadow_version = None
         self._desc = None
+        self._views = []
         self.init_weights()
+        # a state dict loaded into a model that has already run keeps the flat views but changes their contents
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_updated())
 
     # ---- reference helpers kept for API parity (host-side, unused by the kernels) ----
     @staticmethod
@@ -242,11 +247,18 @@ class TransformerModel(nn.Module):
             p.grad = self._flat_grad[off:off + num].view(p.shape)
 
     def mark_params_updated(self):
-        """Called by optimizers that update the flat buffer through raw pointers."""
+        """Called by whoever writes the parameters behind autograd's back: optimizers that update the flat buffer
+        through raw pointers (FusedClipAdam), or code that assigns through `p.data` (which bumps no version counter)."""
         self._shadow_version = None
 
+    def _param_version(self):
+        """Every Parameter is a view of the flat buffer with its OWN version counter (`p.data = flat[...]` detaches
+        it from the buffer's), so in-place updates through the parameters -- `load_state_dict`, `torch.optim.*`,
+        `p.copy_()` -- are only visible there; updates of the flat buffer itself only on the buffer."""
+        return (self._flat._version, sum(p._version for p, _, _ in self._views))
+
     def _refresh_shadow(self, stream):
-        version = self._flat._version
+        version = self._param_version()
         if self._shadow_version != version:
             _hip.check(_hip.lib().pfn_prepare_params(ctypes.byref(self._desc), self._flat.data_ptr(), self._shadow.data_ptr(), stream),
                        'pfn_prepare_params')
