@@ -228,11 +228,13 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     dctx = r(batch, S, E)
     for name, rocprof, part, alg_units, exec_units in hipops.ATTENTION_BWD_PARTS:
         rocprof = rocprof.format(D=D)
+        if part == 2:
+            exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
         t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=part))
         add(name, rocprof, t, alg_units * unit, L, exec_units * unit)
-    t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16))
+    t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=7))
     out.append(dict(kernel='attn_bwd (whole launch set, for reference)', rocprof_name='attn_bwd_* + attn_delta_kernel', launches_per_step=0,
-                    seconds=t, flops=4 * unit, executed_flops=sum(p[4] for p in hipops.ATTENTION_BWD_PARTS) * unit))
+                    seconds=t, flops=4 * unit, executed_flops=(hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, 4.0) + 1.0) * unit))
     for k in out:
         k['tflops'] = k['flops'] / k['seconds'] / 1e12
         k['executed_tflops'] = k['executed_flops'] / k['seconds'] / 1e12

@@ -76,9 +76,11 @@ def attention_fwd(qkv, H, sep, prec):
 # it executes 5, the forward's S being recomputed once)
 ATTENTION_BWD_PARTS = [
     ('attn_bwd: delta = rowsum(dO * O)', 'attn_delta_kernel<__bf16>', 1, 0.0, 0.0),
-    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', 'attn_bwd_kv_kernel<__bf16, {D}>', 2, 3.0, 4.0),
+    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', 'attn_bwd_kv_kernel<__bf16, {D}, ', 2, 3.0, 4.0),
     ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', 'attn_bwd_dq_kernel<__bf16, {D}>', 4, 1.0, 1.0),
 ]
+# head dim 256 runs the key-block pass as two launches (dV: S, dV; dK: S, dP, dK) -- one more S product
+ATTENTION_BWD_KV_EXECUTED_UNITS = {256: 5.0}
 _bwd_scratch = {}
 
 

@@ -392,18 +392,23 @@ template <typename T, int D> struct BwdKvCfg {
   static constexpr int NI = (NP + C::NW - 1) / C::NW;         // pieces per wave
   static constexpr int IMG = 2 * (RIMG + CIMG);
   static constexpr int BUF = IMG + 2 * QB * 4;                // + lse2[QB], delta[QB]
-  // the lanes' DMA source offsets (one per piece of the wave) live in an LDS table when there is room (8-wave configurations):
+  // the lanes' DMA source offsets (one per piece of the wave) live in an LDS table when there is room (every shipped shape):
   // recomputing them per tile costs ~20 vector instructions per piece, keeping them in registers costs registers this kernel
   // does not have
-  static constexpr bool PVLDS = C::NW == 8;
+  static constexpr bool SPLIT = C::NW == 4 && D > 128;       // head dim 256: dV and dK in two passes (attn_bwd_kv_kernel MODE)
+  static constexpr bool PVLDS = VIMG + 2 * BUF + NI * C::NT * 4 <= 160 * 1024;
   static constexpr int PVTAB = PVLDS ? NI * C::NT * 4 : 0;
   static constexpr int LDS = VIMG + 2 * BUF + PVTAB;
 };
 
-template <typename T, int D>
+// MODE 0: dK and dV in one pass.  Head dim 256 cannot hold both accumulators beside the K and V fragments even in the whole
+// register file without copies and spills inside the loop, so it runs the pass twice: MODE 2 (S, dV) then MODE 1 (S, dP,
+// dK, dS^T) -- six product units for the backward instead of five.
+template <typename T, int D, int MODE>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
   using K = BwdKvCfg<T, D>;
+  constexpr bool DO_DK = MODE != 2, DO_DV = MODE != 1;
   constexpr int QB = K::QB;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
@@ -438,23 +443,26 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   constexpr int DSBLK = 32 * 32;   // elements per block
   T* dsT = reinterpret_cast<T*>(a.ds) + ((long)b * a.H + hd) * a.ds_rows * a.ds_ld + (long)(key0 / 32 + wave) * (a.ds_ld / 32) * DSBLK;
 
-  Frag<T> kf[C::NKK], vf[K::VLDS ? 1 : C::NKK];
+  Frag<T> kf[C::NKK], vf[(K::VLDS || !DO_DK) ? 1 : C::NKK];
 #pragma unroll
   for (int kk = 0; kk < C::NKK; ++kk) {
     kf[kk] = load_frag_global<T>(Kp + (long)kc * rs + kk * 16 + 8 * h);
-    if constexpr (!K::VLDS) vf[kk] = load_frag_global<T>(Vp + (long)kc * rs + kk * 16 + 8 * h);
+    if constexpr (!K::VLDS && DO_DK) vf[kk] = load_frag_global<T>(Vp + (long)kc * rs + kk * 16 + 8 * h);
   }
-  if constexpr (K::VLDS) {   // the workgroup's V rows -> LDS row image (rows >= S read as zero)
+  if constexpr (K::VLDS && DO_DK) {   // the workgroup's V rows -> LDS row image (rows >= S read as zero)
     TileStageBuf<T, C::QBLK, C::RB, C::NT> sv;
     sv.init((int)(rs * sizeof(T)));
     sv.issue(make_rsrc(Vp, ((long)(a.S - 1) * rs + D) * (long)sizeof(T)), key0 * (int)(rs * sizeof(T)));
     sv.template commit_p<C::RS>(Vimg());
   }
-  f32x16 dk[C::NDB], dv[C::NDB];
+  f32x16 dk[DO_DK ? C::NDB : 1], dv[DO_DV ? C::NDB : 1];
 #pragma unroll
   for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (DO_DK) dk[db][r] = 0.f;
+      if constexpr (DO_DV) dv[db][r] = 0.f;
+    }
 
   const int ntiles = (a.S + QB - 1) / QB;
   // Q / dO tiles: global -> LDS by LDS-DMA through buffer descriptors (rows >= S are out of the descriptor's range and
@@ -496,18 +504,26 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   auto dma = [&](int buf, int t) {
     int ln = lane;
     if constexpr (!K::PVLDS) asm volatile("" : "+v"(ln));   // opaque: keeps the offset arithmetic inside the loop (hoisted, it costs a register per piece)
-    int pv[K::NI];
+    if constexpr (K::PVLDS) {
+      int pv[K::NI];
 #pragma unroll
-    for (int i = 0; i < K::NI; ++i) {
-      if constexpr (K::PVLDS) pv[i] = *reinterpret_cast<const __attribute__((address_space(3))) int*>(pvtab + (i * C::NT + threadIdx.x) * 4);
-      else pv[i] = piece_offset(i, ln);
-    }
+      for (int i = 0; i < K::NI; ++i) pv[i] = *reinterpret_cast<const __attribute__((address_space(3))) int*>(pvtab + (i * C::NT + threadIdx.x) * 4);
 #pragma unroll
-    for (int i = 0; i < K::NI; ++i) {
-      if (pdst[i] < 0) continue;
-      LdsPtr dst = smem + K::VIMG + buf * K::BUF + (pdst[i] & 0xffffff);
-      if (pdst[i] & (1 << 30)) dma16(ro, dst, pv[i] + t * to_bytes);
-      else dma16(rq, dst, pv[i] + t * tq_bytes);
+      for (int i = 0; i < K::NI; ++i) {
+        if (pdst[i] < 0) continue;
+        LdsPtr dst = smem + K::VIMG + buf * K::BUF + (pdst[i] & 0xffffff);
+        if (pdst[i] & (1 << 30)) dma16(ro, dst, pv[i] + t * to_bytes);
+        else dma16(rq, dst, pv[i] + t * tq_bytes);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < K::NI; ++i) {   // one offset at a time: NI is 18 here and the offsets must not all be live at once
+        if (pdst[i] < 0) continue;
+        LdsPtr dst = smem + K::VIMG + buf * K::BUF + (pdst[i] & 0xffffff);
+        const int pv = piece_offset(i, ln);
+        if (pdst[i] & (1 << 30)) dma16(ro, dst, pv + t * to_bytes);
+        else dma16(rq, dst, pv + t * tq_bytes);
+      }
     }
   };
   // row statistics of the tile's queries: wave 0 stages lse, wave 1 delta (lanes 0..QB-1).  A query beyond S reads zeros
@@ -574,7 +590,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       pf1 = acc_to_frag<T>(s, 1);
     }
     Frag<T> df0, df1;
-    {
+    if constexpr (DO_DK) {
       f32x16 dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[r] = 0.f;
@@ -609,34 +625,40 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       df0 = acc_to_frag<T>(dp, 0);
       df1 = acc_to_frag<T>(dp, 1);
     }
+    // dV^T += dO^T P,  dK^T += Q^T dS: groups of NDB MFMAs, the next group's transposed fragments requested under each
     Frag<T> cf[C::NDB];
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(oc, 0, db * 32);
+    for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(DO_DV ? oc : qc, 0, db * 32);
     PFN_PIN_LDS_MFMA();
-    // dV^T += dO^T P,  dK^T += Q^T dS: four groups of NDB MFMAs, the next group's transposed fragments requested under each
+    if constexpr (DO_DV) {
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db) dv[db] = mma32(cf[db], pf0, dv[db]);
-    if (!(KVABL & 2)) {
+      for (int db = 0; db < C::NDB; ++db) dv[db] = mma32(cf[db], pf0, dv[db]);
+      if (!(KVABL & 2)) {
 #pragma unroll
-      for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(oc, 16, db * 32);
+        for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(oc, 16, db * 32);
+      }
+      PFN_PIN_LDS_MFMA();
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) dv[db] = mma32(cf[db], pf1, dv[db]);
+      if constexpr (DO_DK) {
+        if (!(KVABL & 2)) {
+#pragma unroll
+          for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(qc, 0, db * 32);
+        }
+      }
+      PFN_PIN_LDS_MFMA();
     }
-    PFN_PIN_LDS_MFMA();
+    if constexpr (DO_DK) {
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db) dv[db] = mma32(cf[db], pf1, dv[db]);
-    if (!(KVABL & 2)) {
+      for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df0, dk[db]);
+      if (!(KVABL & 2)) {
 #pragma unroll
-      for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(qc, 0, db * 32);
+        for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(qc, 16, db * 32);
+      }
+      PFN_PIN_LDS_MFMA();
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df1, dk[db]);
     }
-    PFN_PIN_LDS_MFMA();
-#pragma unroll
-    for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df0, dk[db]);
-    if (!(KVABL & 2)) {
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(qc, 16, db * 32);
-    }
-    PFN_PIN_LDS_MFMA();
-#pragma unroll
-    for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df1, dk[db]);
     // End of the tile.  gfx9 counts loads and stores in ONE counter and cannot tell them apart: a wait for a load is a wait
     // for every store before it.  So: wait for the DMA of tile t+1 (issued a whole tile ago; the previous tile's dS^T stores
     // are as old), barrier, and only THEN let this tile's dS^T go (block (key / 32, t), operand precision: exactly what the
@@ -644,7 +666,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     if (!(ABL & 2)) commit_stats(BUF ^ 1);
     dma_wait_all();
     if (!(ABL & 4)) __syncthreads();
-    if (!(KVABL & 1)) store_frag_pair_blocked<T>(dsT + (long)t * DSBLK, df0, df1, li, h, kvalid);
+    if constexpr (DO_DK) { if (!(KVABL & 1)) store_frag_pair_blocked<T>(dsT + (long)t * DSBLK, df0, df1, li, h, kvalid); }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -659,12 +681,16 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) {
       float v[16];
+      if constexpr (DO_DK) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = dk[db][r] * scale;
-      store_row_block<T>(outk + db * 32, v, h, kvalid);
+        for (int r = 0; r < 16; ++r) v[r] = dk[db][r] * scale;
+        store_row_block<T>(outk + db * 32, v, h, kvalid);
+      }
+      if constexpr (DO_DV) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = dv[db][r];
-      store_row_block<T>(outv + db * 32, v, h, kvalid);
+        for (int r = 0; r < 16; ++r) v[r] = dv[db][r];
+        store_row_block<T>(outv + db * 32, v, h, kvalid);
+      }
     }
   }
 }
@@ -881,8 +907,17 @@ template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStrea
   }
   if ((parts & ATTN_BWD_KV) && a.sep > 0) {
     const size_t lds = BwdKvCfg<T, D>::LDS;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_kv_kernel<T, D>), dim3(((a.sep + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
+    const dim3 grid(((a.sep + C::QBLK - 1) / C::QBLK) * a.H * a.B);
+    auto run = [&](auto kernel) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kernel, grid, dim3(C::NT), lds, s, a);
+    };
+    if constexpr (BwdKvCfg<T, D>::SPLIT) {
+      run(attn_bwd_kv_kernel<T, D, 2>);
+      run(attn_bwd_kv_kernel<T, D, 1>);
+    } else {
+      run(attn_bwd_kv_kernel<T, D, 0>);
+    }
   }
   if (parts & ATTN_BWD_DQ) {
     const size_t lds = BwdDqCfg<T, D>::LDS;

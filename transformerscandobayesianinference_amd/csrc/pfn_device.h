@@ -64,6 +64,18 @@ PFN_DEV f32x16 mma32(const Frag<float>& a, const Frag<float>& b, f32x16 c) {
   return c;
 }
 
+// The same step with the accumulator PINNED to the AGPR half of the register file (inline assembly: the only way to say so).
+// For kernels whose long-lived accumulators alone fill 256 registers (attention backward at head dim 256: dK and dV): left to
+// itself hipcc spreads every value over both halves and pays v_accvgpr copies plus scratch spills inside the loop; with the
+// accumulators fixed in AGPRs everything the vector ALU touches fits the VGPR half.  The leading s_nop covers an operand
+// the vector ALU wrote just before (hipcc pads nothing inside an asm statement); accumulate chains need no padding, and the
+// epilogue that reads the accumulators first waits out the MFMA -> reader hazard (mma32_acc_drain).
+PFN_DEV void mma32_acc(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a.v), "v"(b.v));
+}
+PFN_DEV void mma32_acc(f32x16& acc, const Frag<float>& a, const Frag<float>& b) { acc = mma32(a, b, acc); }
+PFN_DEV void mma32_acc_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
 // row index inside a 32x32 accumulator tile held by (lane, r)
 PFN_DEV int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

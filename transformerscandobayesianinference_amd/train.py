@@ -188,9 +188,9 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     return total_loss, total_positional_losses, model.to('cpu')
 
 
-def _parse_args(config_parser, parser):
+def _parse_args(config_parser, parser, argv=None):
     """Optional YAML overlay, then the normal parser (reference train.py:137-151)."""
-    args_config, remaining = config_parser.parse_known_args()
+    args_config, remaining = config_parser.parse_known_args(argv)
     if args_config.config:
         with open(args_config.config, 'r') as f:
             parser.set_defaults(**yaml.safe_load(f))
@@ -227,7 +227,7 @@ def main(argv=None):
     parser.add_argument('--batch_size', default=1000, type=int)
     parser.add_argument('--lr', '--learning_rate', default=.001, type=float)
     parser.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
-    args, _ = _parse_args(config_parser, parser)
+    args, _ = _parse_args(config_parser, parser, argv)
     cfg = dict(args.__dict__)
     cfg.pop('config', None)
     if cfg['nhid'] is None:
