@@ -710,8 +710,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
     for (int i = 0; i < 4; ++i) {
       // tail rows are re-zeroed in LDS below; debug_mask is all ones except when profiling with cache-resident operands
       const long r = min(r0 + prow[i], rows_total - 1) & g.debug_mask;
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + r * pr.lda), (lvoid_t*)(ta + i * 8192), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + r * pr.ldb), (lvoid_t*)(tb + i * 8192), 16, 0, 0);
+      // assembly form (pfn_device.h dma16): with the builtin hipcc waits vmcnt(0) in front of the first ds_read_b64_tr_b16 of
+      // the stage being MULTIPLIED -- the intrinsic carries no address, so the DMA just issued for the NEXT stage "may alias" --
+      // and the copy never overlapped the MFMAs (2.3 us per stage against 1.4 us for the same tile in the NT kernel)
+      dma16_global(pa[i] + r * pr.lda, ta + i * 8192);
+      dma16_global(pb[i] + r * pr.ldb, tb + i * 8192);
     }
   };
 
@@ -732,6 +735,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
 
   const int nt = (rows_total + TNB_KT - 1) / TNB_KT;
   stage(0, 0);
+  dma_wait_all();
   __syncthreads();
   // the main loop exists twice (with / without the bias-gradient MFMA) so neither carries a branch
   auto main_loop = [&](auto with_colsum) {
@@ -765,6 +769,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
         // bias gradient: Q wave wq sums the columns of P sub-tile wq (one more fragment read, one more MFMA)
         if constexpr (CS) cs = mma32(load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + wq * 32), ones, cs);
       }
+      dma_wait_all();   // the next stage has landed (it had this stage's 36 MFMAs per wave to do so)
       __syncthreads();
     }
   };

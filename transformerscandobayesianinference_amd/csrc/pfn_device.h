@@ -331,6 +331,13 @@ PFN_DEV void dma16(const DmaRsrc& r, LdsPtr lds_dst_uniform, int byte_offset) {
 // re-waits for them at every use inside the loop with vmcnt(7), (6), ... (0): against the real queue, which holds the DMA
 // it cannot see, that drains everything in the middle of the tile).  The pass may drop a builtin wait it considers redundant,
 // so the assembly form follows: free when the first one ran, the only one otherwise.
+// the same through a per-lane 64-bit global address (no range check: the caller clamps)
+PFN_DEV void dma16_global(const void* src, LdsPtr lds_dst_uniform) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_dst_uniform);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(dst), "v"(src) : "memory");
+}
 PFN_DEV void dma_wait_all() {
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
