@@ -223,7 +223,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     D = E // H
     t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16))
     unit = 2.0 * E * pairs(S, sep) * batch          # one S x keys x head-dim product over all heads
-    add('attn_fwd', f'attn_fwd_kernel<__bf16, {D}>', t, 2 * unit, L)
+    add('attn_fwd', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit, L)
     ctx, lse = hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16)
     dctx = r(batch, S, E)
     for name, rocprof, part, alg_units, exec_units in hipops.ATTENTION_BWD_PARTS:

@@ -75,10 +75,12 @@ def attention_fwd(qkv, H, sep, prec):
 # backward; one unit = one [S x keys x head-dim] product over all heads (the backward's algorithmic work is 4: dV, dP, dK, dQ;
 # it executes 5, the forward's S being recomputed once)
 ATTENTION_BWD_PARTS = [
-    ('attn_bwd: delta = rowsum(dO * O)', 'attn_delta_kernel<__bf16>', 1, 0.0, 0.0),
-    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', 'attn_bwd_kv_kernel<__bf16, {D}, ', 2, 3.0, 4.0),
-    ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', 'attn_bwd_dq_kernel<__bf16, {D}>', 4, 1.0, 1.0),
+    # (rocprofv3 prints these kernels by their mangled names: its demangler does not know the __bf16 template argument)
+    ('attn_bwd: delta = rowsum(dO * O)', '_ZN3pfn17attn_delta_kernelIDF16bEEvNS_8AttnArgsEi', 1, 0.0, 0.0),
+    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', '_ZN3pfn18attn_bwd_kv_kernelIDF16bLi{D}ELi', 2, 3.0, 4.0),
+    ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', '_ZN3pfn18attn_bwd_dq_kernelIDF16bLi{D}EEEvNS_8AttnArgsE', 4, 1.0, 1.0),
 ]
+ATTENTION_FWD_ROCPROF = '_ZN3pfn15attn_fwd_kernelIDF16bLi{D}EEEvNS_8AttnArgsE'
 # head dim 256 runs the key-block pass as two launches (dV: S, dV; dK: S, dP, dK) -- one more S product
 ATTENTION_BWD_KV_EXECUTED_UNITS = {256: 5.0}
 _bwd_scratch = {}

@@ -904,3 +904,49 @@ def test_validate_and_run_test_vs_oracle():
             assert abs(mse[j].item() - torch.stack(se).mean().item()) < (1e-4 if tight else 5e-3) * torch.stack(se).mean().item()
             if tight:
                 assert abs(mode_mse[j].item() - torch.stack(me).mean().item()) < 1e-4 * torch.stack(me).mean().item()
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_custom_decoder_module_vs_oracle(precision):
+    """`decoder=` generators (reference transformer.py:23, decoders.py): the HIP stack hands the encoder's test rows to the PyTorch
+    module and takes their gradient back; forward and every parameter gradient against the f64 oracle."""
+    from transformerscandobayesianinference_amd import decoders
+    cfg = dict(T=56, B=3, F=4, E=64, H=2, nhid=128, L=2, nbars=12)
+    torch.manual_seed(41)
+    borders = torch.sort(torch.randn(cfg['nbars'] + 1) * 1.5)[0]
+    model = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], 0.0,
+                             y_encoder=encoders.Linear(1, cfg['E']), decoder=decoders.FixedScaledDecoder, precision=precision)
+    assert isinstance(model.decoder, decoders.FixedScaledDecoder)
+    model.criterion = bar_distribution.FullSupportBarDistribution(borders)
+    with torch.no_grad():
+        for layer in model.transformer_encoder.layers:
+            for t in (layer.linear2.weight, layer.self_attn.out_proj.weight):
+                t.normal_(0, 0.03)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.rand(cfg['T'], cfg['B'], cfg['F'], generator=g), torch.randn(cfg['T'], cfg['B'], generator=g)
+    sep = 37
+    # oracle: encoder in f64, then the same decoder arithmetic (mapper(x) / T.sum())
+    leaves = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if not k.startswith('criterion.')}
+    hidden = pfn_oracle.forward({k: v for k, v in leaves.items() if not k.startswith('decoder.')}, x, y, sep, cfg['H'], return_hidden=True)[sep:]
+    h1 = torch.nn.functional.gelu(hidden @ leaves['decoder.mapper.0.weight'].t() + leaves['decoder.mapper.0.bias'])
+    lo = (h1 @ leaves['decoder.mapper.2.weight'].t() + leaves['decoder.mapper.2.bias']) / leaves['decoder.T'].sum()
+    loss_o = pfn_oracle.bar_nll(lo.reshape(-1, cfg['nbars']), y[sep:].reshape(-1).double(), borders.double()).mean()
+    loss_o.backward()
+    model.to(DEV).train()
+    logits = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
+    assert logits.shape == (cfg['T'] - sep, cfg['B'], cfg['nbars'])
+    loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
+    loss.backward()
+    tight = precision == 'f32'
+    assert relerr(logits, lo) < (1e-4 if tight else 1e-2)
+    assert abs(loss.item() - loss_o.item()) < (1e-4 if tight else 1e-3) * abs(loss_o.item())
+    got = {k: p.grad for k, p in model.named_parameters()}
+    tot_err = math.sqrt(sum(((got[k].double().cpu() - v.grad) ** 2).sum().item() for k, v in leaves.items()))
+    tot = math.sqrt(sum((v.grad ** 2).sum().item() for v in leaves.values()))
+    assert tot_err / tot < (2e-4 if tight else 5e-2), tot_err / tot
+    # the optimizer's flat buffer covers the decoder module's parameters too
+    opt = FusedClipAdam(model, lr=1e-3)
+    before = model.decoder.mapper[0].weight.detach().clone()
+    opt.step(zero_grad=True)
+    assert not torch.equal(before, model.decoder.mapper[0].weight.detach())

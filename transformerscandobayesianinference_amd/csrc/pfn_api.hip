@@ -37,8 +37,8 @@ inline int esize(int prec) { return prec == PFN_PREC_BF16 ? 2 : 4; }
 int check_desc(const pfn_model_desc* d) {
   if (!d) return fail(PFN_ERR_ARGUMENT, "null model descriptor");
   if (d->precision != PFN_PREC_BF16 && d->precision != PFN_PREC_F32) return fail(PFN_ERR_ARGUMENT, "bad precision %d", d->precision);
-  if (d->num_features < 1 || d->emsize < 8 || d->nhead < 1 || d->nhid < 8 || d->nlayers < 0 || d->n_out < 1)
-    return fail(PFN_ERR_ARGUMENT, "bad model dimensions");
+  if (d->num_features < 1 || d->emsize < 8 || d->nhead < 1 || d->nhid < 8 || d->nlayers < 0 || d->n_out < 0)
+    return fail(PFN_ERR_ARGUMENT, "bad model dimensions");   // n_out == 0: no decoder -- the stack returns the encoder's test rows
   if (d->emsize % d->nhead) return fail(PFN_ERR_ARGUMENT, "emsize %d not divisible by nhead %d", d->emsize, d->nhead);
   if (d->emsize % 8 || d->nhid % 8) return fail(PFN_ERR_UNSUPPORTED, "emsize and nhid must be multiples of 8 (16-byte operand rows)");
   const int dh = d->emsize / d->nhead;
@@ -74,15 +74,16 @@ Layout make_layout(const pfn_model_desc& d) {
     p.w1 = take(F * E); p.b1 = take(F); p.w2 = take(E * F); p.b2 = take(E);
     p.g1 = take(E); p.be1 = take(E); p.g2 = take(E); p.be2 = take(E);
   }
-  L.dec0_w = take(F * E); L.dec0_b = take(F); L.dec2_w = take(O * F); L.dec2_b = take(O);
+  if (O > 0) { L.dec0_w = take(F * E); L.dec0_b = take(F); L.dec2_w = take(O * F); L.dec2_b = take(O); }
+  else L.dec0_w = L.dec0_b = L.dec2_w = L.dec2_b = 0;
   L.total = cur;
   L.n_out_pad = (int)align_up(O, 8);
   int64_t ct = 0;
   auto take_t = [&](int64_t n) { int64_t o = ct; ct = align_up(ct + n, 64); return o; };
   L.layer_t.resize(d.nlayers);
   for (auto& p : L.layer_t) { p.w_in = take_t(3 * E * E); p.w_o = take_t(E * E); p.w1 = take_t(F * E); p.w2 = take_t(E * F); }
-  L.dec0_wt = take_t(F * E);
-  L.dec2_wt = take_t(F * (int64_t)L.n_out_pad);
+  if (O > 0) { L.dec0_wt = take_t(F * E); L.dec2_wt = take_t(F * (int64_t)L.n_out_pad); }
+  else L.dec0_wt = L.dec2_wt = 0;
   L.total_t = ct;
   return L;
 }
@@ -202,8 +203,10 @@ int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shado
     PFN_TRY(launch_transpose_cast(params + p.w1, tr + t.w1 * es, F, E, F, prec, s));               // [F,E] -> [E,F]
     PFN_TRY(launch_transpose_cast(params + p.w2, tr + t.w2 * es, E, F, E, prec, s));               // [E,F] -> [F,E]
   }
-  PFN_TRY(launch_transpose_cast(params + L.dec0_w, tr + L.dec0_wt * es, F, E, F, prec, s));
-  PFN_TRY(launch_transpose_cast(params + L.dec2_w, tr + L.dec2_wt * es, d->n_out, F, L.n_out_pad, prec, s));  // [O,F] -> [F,Opad]
+  if (d->n_out > 0) {
+    PFN_TRY(launch_transpose_cast(params + L.dec0_w, tr + L.dec0_wt * es, F, E, F, prec, s));
+    PFN_TRY(launch_transpose_cast(params + L.dec2_w, tr + L.dec2_wt * es, d->n_out, F, L.n_out_pad, prec, s));  // [O,F] -> [F,Opad]
+  }
   return PFN_OK;
 }
 
@@ -303,7 +306,10 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
     xin = a.x2; xin_t = a.x2_t;
   }
   // decoder on the test rows only (the reference decodes all rows, then slices: transformer.py:85,91)
-  if (Mt > 0) {
+  if (Mt > 0 && O == 0) {
+    // no decoder (a custom decoder module runs in PyTorch, reference transformer.py:23): hand out the test rows [Mt, E] in f32
+    PFN_TRY(launch_gather_test_rows(xin, logits, S, B, E, sep, PFN_PREC_F32, s));
+  } else if (Mt > 0) {
     PFN_TRY(launch_gather_test_rows(xin, w.xt_t, S, B, E, sep, prec, s));
     {
       GemmNT g = nt(w.xt_t, E, W(L.dec0_w), E, Mt, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
@@ -339,7 +345,11 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
   auto WT = [&](int64_t off) { return (const void*)(sh + (L.total + off) * es); };
 
   // ---- decoder ----
-  if (Mt > 0) {
+  const float* dxt = w.dxt;
+  if (Mt > 0 && O == 0) {
+    if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
+    dxt = dlogits;   // no decoder: the incoming gradient already is d(test rows) [Mt, E]
+  } else if (Mt > 0) {
     if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
     PFN_TRY(launch_cast_rows(dlogits, O, w.dlog_t, npad, Mt, O, prec, s));
     PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b), prec, s));
@@ -355,7 +365,7 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
   }
-  PFN_TRY(launch_scatter_test_rows(w.dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
+  PFN_TRY(launch_scatter_test_rows(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
 
   // ---- encoder layers, last to first; gA holds d(loss)/d(layer output) ----
   // Only the data-gradient chain runs here.  Each layer leaves the output-gradient operands of its four

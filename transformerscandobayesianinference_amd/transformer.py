@@ -81,7 +81,7 @@ class _StackFunction(torch.autograd.Function):
         ws_bytes = lib.pfn_workspace_bytes(ctypes.byref(desc), B, S)
         _hip.check(ws_bytes, 'pfn_workspace_bytes')
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        logits = torch.empty((S - sep, B, desc.n_out), dtype=torch.float32, device=dev)
+        logits = torch.empty((S - sep, B, desc.n_out or desc.emsize), dtype=torch.float32, device=dev)   # n_out 0: the encoder's test rows
         _hip.check(lib.pfn_stack_forward(ctypes.byref(desc), flat_params.data_ptr(), model._shadow.data_ptr(),
                                          x_ptr, x_st, x_sb, y_ptr, y_st, y_sb, _hip.ptr(src), B, S, sep,
                                          ws.data_ptr(), ws_bytes, logits.data_ptr(), stream), 'pfn_stack_forward')
@@ -121,15 +121,16 @@ class TransformerModel(nn.Module):
                  decoder=None, input_normalization=False, precision='bf16'):
         super().__init__()
         self.model_type = 'Transformer'
-        if decoder is not None:
-            raise NotImplementedError('custom decoder modules are not wired into the HIP stack yet; use the default decoder')
         self.transformer_encoder = _EncoderParams(ninp, nhid, nlayers)
         self.ninp, self.nhead, self.nhid, self.nlayers, self.n_out = ninp, nhead, nhid, nlayers, n_out
         self.dropout = dropout
         self.encoder = encoder
         self.y_encoder = y_encoder
         self.pos_encoder = pos_encoder
-        self.decoder = nn.Sequential(nn.Linear(ninp, nhid), nn.GELU(), nn.Linear(nhid, n_out))
+        # reference :23: a decoder generator replaces the default MLP.  The default runs inside the HIP stack; a custom module
+        # (decoders.ScaledDecoder ...) runs in PyTorch on the encoder's test rows, which the stack then returns instead of logits.
+        self._custom_decoder = decoder is not None
+        self.decoder = decoder(ninp, nhid, n_out) if decoder is not None else nn.Sequential(nn.Linear(ninp, nhid), nn.GELU(), nn.Linear(nhid, n_out))
         self.input_ln = SeqBN(ninp) if input_normalization else None
         self.precision = precision
         self._flat = self._flat_grad = self._shadow = None
@@ -180,19 +181,20 @@ class TransformerModel(nn.Module):
             ps += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias,
                    l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias,
                    l.norm1.weight, l.norm1.bias, l.norm2.weight, l.norm2.bias]
-        ps += [self.decoder[0].weight, self.decoder[0].bias, self.decoder[2].weight, self.decoder[2].bias]
+        if not self._custom_decoder:
+            ps += [self.decoder[0].weight, self.decoder[0].bias, self.decoder[2].weight, self.decoder[2].bias]
         return ps
 
     def _make_desc(self):
         nf = self.encoder.in_features if self._fused_embedding() else 1
         prec = {'bf16': _hip.PREC_BF16, 'f32': _hip.PREC_F32, 'fp32': _hip.PREC_F32}[self.precision]
-        return _hip.ModelDesc(nf, self.ninp, self.nhead, self.nhid, self.nlayers, self.n_out, prec, 1e-5)
+        return _hip.ModelDesc(nf, self.ninp, self.nhead, self.nhid, self.nlayers, 0 if self._custom_decoder else self.n_out, prec, 1e-5)
 
     def _is_flat(self):
         if self._flat is None:
             return False
-        first = next(p for p in self._stack_parameters() if p is not None)
-        last = self.decoder[2].bias
+        stack = [p for p in self._stack_parameters() if p is not None]
+        first, last = stack[0], stack[-1]
         lo, hi = self._flat.data_ptr(), self._flat.data_ptr() + self._flat.numel() * 4
         return all(p.is_cuda and p.device == self._flat.device and lo <= p.data_ptr() < hi for p in (first, last))
 
@@ -295,7 +297,8 @@ class TransformerModel(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             flat = flat.detach().requires_grad_(True)  # connects the node to autograd; grads go to the flat buffer directly
         if self._fused_embedding():
-            return _StackFunction.apply(flat, self, x_src, y_src.to(x_src.device), None, sep)
+            out = _StackFunction.apply(flat, self, x_src, y_src.to(x_src.device), None, sep)
+            return self.decoder(out) if self._custom_decoder else out
         # custom encoders / positional encodings / SeqBN: PyTorch computes the embedding, HIP runs the stack
         x_emb = self.encoder(x_src)
         y_emb = self.y_encoder(y_src.unsqueeze(-1))
@@ -304,4 +307,5 @@ class TransformerModel(nn.Module):
             emb = self.input_ln(emb)
         if self.pos_encoder is not None:
             emb = self.pos_encoder(emb)
-        return _StackFunction.apply(flat, self, None, None, emb, sep)
+        out = _StackFunction.apply(flat, self, None, None, emb, sep)
+        return self.decoder(out) if self._custom_decoder else out
