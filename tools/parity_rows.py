@@ -23,8 +23,12 @@ def main():
     for L in [int(a) for a in (sys.argv[1:] or ['0', '1', '6'])]:
         w['nlayers'] = L
         res = {}
+        first = bench.build_model(dev, 'f32', w)
+        sd = {k: v.detach().clone() for k, v in first.state_dict().items()}   # ONE state dict (weights and bar borders) for both precisions
         for prec in ('f32', 'bf16'):
-            model = bench.build_model(dev, prec, w).eval()
+            model = bench.build_model(dev, prec, w)
+            model.load_state_dict(sd)
+            model.eval()
             with torch.no_grad():
                 lg = model((x, y), single_eval_pos=sep)
                 nll = model.criterion(lg.reshape(-1, w['num_bars']), y[sep:].reshape(-1))
