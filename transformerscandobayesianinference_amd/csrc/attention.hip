@@ -161,7 +161,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   // initial state: the self key for test rows, empty for train rows.  The self K / V rows are only fetched by waves
   // that hold a test row at all (wave-uniform branch): 7 of 8 waves at the north star skip 24 loads per lane.
   const bool is_test = qc >= sep;
-  const bool wave_has_test = wg.blk * C::QBLK + wave * 32 + 31 >= sep;
+  const bool wave_has_test = !(ABL & 8) && wg.blk * C::QBLK + wave * 32 + 31 >= sep;   // ABL 8: profiling without the self-key work
   float m = -1e30f, lsum = 0.f;
   f32x16 o[C::NDB];
 #pragma unroll
@@ -442,6 +442,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   // (store_frag_pair_blocked); the wave owns block row key / 32
   constexpr int DSBLK = 32 * 32;   // elements per block
   T* dsT = reinterpret_cast<T*>(a.ds) + ((long)b * a.H + hd) * a.ds_rows * a.ds_ld + (long)(key0 / 32 + wave) * (a.ds_ld / 32) * DSBLK;
+  const bool ds_row_live = key0 + wave * 32 < a.ds_rows;   // wave-uniform: this wave's block row exists in the buffer
 
   Frag<T> kf[C::NKK], vf[(K::VLDS || !DO_DK) ? 1 : C::NKK];
 #pragma unroll
@@ -622,6 +623,10 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
           dp[r] = frag_get(r < 8 ? pf0 : pf1, r & 7) * (dp[r] - dl[e]);
         }
       }
+      if (!kvalid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+      }
       df0 = acc_to_frag<T>(dp, 0);
       df1 = acc_to_frag<T>(dp, 1);
     }
@@ -666,7 +671,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     if (!(ABL & 2)) commit_stats(BUF ^ 1);
     dma_wait_all();
     if (!(ABL & 4)) __syncthreads();
-    if constexpr (DO_DK) { if (!(KVABL & 1)) store_frag_pair_blocked<T>(dsT + (long)t * DSBLK, df0, df1, li, h, kvalid); }
+    // keys >= sep of a block row the dQ pass reads (rows < ds_rows) leave as zeros: that pass does not mask rows
+    if constexpr (DO_DK) { if (!(KVABL & 1) && ds_row_live) store_frag_pair_blocked<T>(dsT + (long)t * DSBLK, df0, df1, li, h, true); }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -710,7 +716,14 @@ template <typename T, int D> struct BwdDqCfg {
   static constexpr int DSB = C::QBLK * (int)sizeof(T);        // bytes of one dS^T row segment (the workgroup's queries)
   static constexpr int DSS = PadStride<DSB>::COL;
   static constexpr int BUF = C::KVB * DSS + C::CIMG;          // dS^T tile + K tile (col images)
-  static constexpr int LDS = 2 * BUF;
+  // both images go global -> LDS by LDS-DMA in 1-KiB pieces (they are whole numbers of pieces for every shipped shape);
+  // the lanes' source offsets sit in an LDS table (as in the key-block pass)
+  static constexpr int NPD = C::KVB * DSS / 1024, NPK = C::CIMG / 1024, NP = NPD + NPK;
+  static constexpr int NI = (NP + C::NW - 1) / C::NW;
+  static constexpr int PVTAB = NI * C::NT * 4;
+  static constexpr int TSELF = C::NW * 32 * (C::RB + 16);     // the self-key tail's image (re-uses the tile buffers after the loop)
+  static constexpr int LDS = 2 * BUF + PVTAB > TSELF ? 2 * BUF + PVTAB : TSELF;
+  static_assert((C::KVB * DSS) % 1024 == 0 && C::CIMG % 1024 == 0, "dQ-pass LDS images must be whole DMA pieces");
 };
 
 template <typename T, int D>
@@ -746,61 +759,65 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
 
-  // dS^T of this (dataset, head) in 32 x 32 blocks (store_frag_pair_blocked); a key tile of this workgroup's queries is
-  // KVB / 32 x QBLK / 32 blocks, read in address order (every wave instruction 1 KiB contiguous) and scattered into the
-  // column image (rows = keys).  Keys >= sep were never written: their chunks are pointed out of the descriptor's range.
-  constexpr int DSBLK = 32 * 32;                 // elements per block
+  // dS^T of this (dataset, head) in 32 x 32 blocks (store_frag_pair_blocked).  A key tile goes global -> LDS by LDS-DMA (issued
+  // from assembly, pfn_device.h dma16), no staging registers: the dS^T tile of this workgroup's queries into a column image
+  // (rows = keys; the lane's 16 bytes of a piece come from wherever the blocked layout keeps that (key, 8 queries) chunk), the K
+  // tile into a second column image.  Rows of keys >= sep: the key-block pass stored zeros for them (dS^T), the descriptor's
+  // range ends at sep (K).  Tile t+1 is issued at the top of tile t and waited for at its end.
+  constexpr int DSBLK = 32 * 32;                     // elements per block
   constexpr int BCH = DSBLK * (int)sizeof(T) / 16;   // 16-byte chunks per block
-  constexpr int NQBW = C::QBLK / 32, NDCH = (C::KVB / 32) * NQBW * BCH, DPER = NDCH / C::NT;
-  static_assert(NDCH % C::NT == 0, "dS^T tile chunks must divide over the threads");
   const long ds_bh = ((long)b * a.H + hd) * a.ds_rows * a.ds_ld;
-  const BufRsrc rd = make_rsrc(reinterpret_cast<const T*>(a.ds) + ds_bh, (long)a.ds_rows * a.ds_ld * (long)sizeof(T));
-  const BufRsrc rk = make_rsrc(Kp, ((long)(sep - 1) * rs + D) * (long)sizeof(T));   // rows >= sep read as zero
-  int d_src[DPER], d_dst[DPER], d_row[DPER];
+  const DmaRsrc rd = make_dma_rsrc(reinterpret_cast<const T*>(a.ds) + ds_bh, (long)a.ds_rows * a.ds_ld * (long)sizeof(T));
+  const DmaRsrc rk = make_dma_rsrc(Kp, ((long)(sep - 1) * rs + D) * (long)sizeof(T));   // rows >= sep read as zero
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  LdsPtr pvtab = smem + 2 * Q::BUF;   // [NI][NT] ints: the lane's source byte offset inside a tile, per piece of its wave
 #pragma unroll
-  for (int i = 0; i < DPER; ++i) {
-    const int id = threadIdx.x + i * C::NT;
-    const int blk = id / BCH, w = id % BCH;
-    const int kb = blk / NQBW, qb = blk % NQBW;
-    d_row[i] = kb * 32 + blocked_chunk_row<T>(w);
-    d_src[i] = ((kb * (a.ds_ld / 32) + q0 / 32 + qb) * BCH + w) * 16;
-    d_dst[i] = d_row[i] * Q::DSS + (qb * 32 + blocked_chunk_col<T>(w)) * (int)sizeof(T);
+  for (int i = 0; i < Q::NI; ++i) {
+    const int g = uwave + C::NW * i;
+    int off = BUF_OOB;
+    if (g < Q::NPD) {           // dS^T image: byte = 1024 g + 16 lane -> (key row, chunk of 16 bytes of its queries)
+      const int byte = g * 1024 + lane * 16;
+      const int row = byte / Q::DSS, cb = byte % Q::DSS;
+      if (cb < Q::DSB) {
+        const int q = cb / (int)sizeof(T);                       // first query of the chunk inside the workgroup's block
+        const int kb = row / 32, j = row % 32, qb = q / 32, qq = q % 32;
+        int w;                                                   // chunk index inside the 32 x 32 block (store_frag_pair_blocked)
+        if constexpr (sizeof(T) == 2) w = (((qq >> 4) * 32 + j) * 2 + ((qq >> 3) & 1));
+        else w = (((qq >> 3) * 32 + j) * 2 + ((qq >> 2) & 1));
+        off = ((kb * (a.ds_ld / 32) + q0 / 32 + qb) * BCH + w) * 16;
+      }
+    } else if (g < Q::NP) {     // K image: row = key, 16-byte chunks of the head's D columns
+      const int byte = (g - Q::NPD) * 1024 + lane * 16;
+      const int row = byte / C::CS, cb = byte % C::CS;
+      if (cb < C::RB) off = row * (int)(rs * sizeof(T)) + cb;
+    }
+    *reinterpret_cast<__attribute__((address_space(3))) int*>(pvtab + (i * C::NT + threadIdx.x) * 4) = off;
   }
-  // Two staging register sets: tiles t+1 and t+2 are in flight while tile t is multiplied -- the kernel streams 2 bytes per
-  // (query, key) pair from HBM and one tile per CU in flight does not cover the memory latency.
-  u32x4 dregs[2][DPER];
-  TileStageBuf<T, C::KVB, C::RB, C::NT> sk[2];
-  sk[0].init((int)(rs * sizeof(T)));
-  sk[1].init((int)(rs * sizeof(T)));
   const int ntiles = (sep + C::KVB - 1) / C::KVB;
-  const int tile_src_bytes = (C::KVB / 32) * (a.ds_ld / 32) * BCH * 16;
-  auto request = [&](auto set_c, int t) {
-    constexpr int SET = decltype(set_c)::value;
-    const int k1 = t * C::KVB;
+  const int tile_ds_bytes = (C::KVB / 32) * (a.ds_ld / 32) * BCH * 16, tile_k_bytes = C::KVB * (int)(rs * sizeof(T));
+  auto dma = [&](int buf, int t) {
+    int pv[Q::NI];
 #pragma unroll
-    for (int i = 0; i < DPER; ++i) dregs[SET][i] = buf_load16(rd, (k1 + d_row[i] < sep) ? d_src[i] + t * tile_src_bytes : BUF_OOB);
-    sk[SET].issue(rk, k1 * (int)(rs * sizeof(T)));
-  };
-  auto commit_all = [&](auto set_c, int buf) {
-    constexpr int SET = decltype(set_c)::value;
+    for (int i = 0; i < Q::NI; ++i) pv[i] = *reinterpret_cast<const __attribute__((address_space(3))) int*>(pvtab + (i * C::NT + threadIdx.x) * 4);
 #pragma unroll
-    for (int i = 0; i < DPER; ++i) lds_write16(Ds(buf) + d_dst[i], dregs[SET][i]);
-    sk[SET].template commit_p<C::CS>(Kc(buf));
+    for (int i = 0; i < Q::NI; ++i) {
+      const int g = uwave + C::NW * i;
+      if (g < Q::NPD) dma16(rd, smem + buf * Q::BUF + g * 1024, pv[i] + t * tile_ds_bytes);
+      else if (g < Q::NP) dma16(rk, smem + buf * Q::BUF + C::KVB * Q::DSS + (g - Q::NPD) * 1024, pv[i] + t * tile_k_bytes);
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  if (ntiles > 0) {
-    request(I0{}, 0);
-    commit_all(I0{}, 0);
-    if (ntiles > 1) request(I1{}, 1);   // in flight across the barrier
-    if (ntiles > 2) request(I0{}, 2);
-  }
+  __syncthreads();               // the offset table is complete
+  if (ntiles > 0) dma(0, 0);
+  dma_wait_all();
   __syncthreads();
   auto tile = [&](auto buf_c, int t) {
     constexpr int BUF = decltype(buf_c)::value;
     const lds_char* dst = Ds(BUF);
     const lds_char* kc = Kc(BUF);
     constexpr int NKS = C::KVB / 16;     // contraction steps per tile
+    if (!(ABL & 1) && t + 1 < ntiles) dma(BUF ^ 1, t + 1);   // the other buffer: every wave is past the barrier that ended tile t-1
     Frag<T> dsf[NKS];
 #pragma unroll
     for (int c = 0; c < NKS; ++c) dsf[c] = load_frag_tr_p<T, Q::DSS, 1>(dst, c * 16, wave * 32);
@@ -814,14 +831,11 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) cf[(c + 1) & 1][db] = load_frag_tr_p<T, C::CS, 1>(kc, (c + 1) * 16, db * 32);
       }
-      if (c == 0) {   // staged tile t+1 (register set of its parity) -> the other LDS buffer, then request t+3 into that set
-        if (!(ABL & 2)) commit_all(std::integral_constant<int, BUF ^ 1>{}, BUF ^ 1);
-        if (!(ABL & 1) && t + 3 < ntiles) request(std::integral_constant<int, BUF ^ 1>{}, t + 3);
-      }
 #pragma unroll
       for (int db = 0; db < C::NDB; ++db) dq[db] = mma32(cf[c & 1][db], dsf[c], dq[db]);
       PFN_PIN_LDS_MFMA();
     }
+    dma_wait_all();
     if (!(ABL & 4)) __syncthreads();
   };
   for (int t = 0; t < ntiles; t += 2) {
@@ -829,29 +843,81 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
     if (t + 1 < ntiles) tile(I1{}, t + 1);
   }
 
-  // self key of test rows
-  const bool is_test = qc >= sep;
-  float ds_self = 0.f, p_self = 0.f;
-  const bool wave_has_test = q0 + wave * 32 + 31 >= sep;
-  Frag<T> qf[C::NKK], dof[C::NKK];
-  if (wave_has_test) {   // only waves that hold a test row fetch their Q / dO rows and the self K / V rows
-    const T* dOp = reinterpret_cast<const T*>(a.dctx) + ((long)b * a.S + qc) * a.E + hd * D;
-    const long stat = ((long)b * a.H + hd) * a.S + qc;
-    const float lse2 = a.lse[stat] * LOG2E;
-    const float delta = a.delta[stat];
-    float tq = 0.f, dpv = 0.f;
+  // ---- self key of the test rows (i >= sep): p_i = exp(q_i.k_i scale - lse_i), ds_i = p_i (dO_i.v_i - delta_i),
+  //      dQ_i += ds_i k_i,  dK_i = scale ds_i q_i,  dV_i = p_i dO_i
+  // Only waves that hold a test row do this.  The rows are walked with the lanes ALONG a row (64 / CPR rows per step, CPR lanes of
+  // 16 bytes each on a row): every load and store instruction covers whole rows -- with one row per lane (the accumulator
+  // layout) each instruction touched 32 to 64 different cache lines and this tail cost 32 us of the pass's 144.  ds_i k_i reaches
+  // the accumulator layout through a wave-private LDS image (the tile buffers are free after the loop).
+  const bool wave_has_test = !(ABL & 8) && q0 + wave * 32 + 31 >= sep;
+  constexpr int TS = C::RB + 16;                       // row stride of the self-term image
+  LdsPtr tself = smem + wave * 32 * TS;
+  if (wave_has_test) {
+    constexpr int CPR = C::RB / 16, RPS = 64 / CPR, NST = 32 / RPS, EPC = 16 / (int)sizeof(T);
+    const int rsub = lane / CPR, c = lane % CPR;
+    const T* dOb = reinterpret_cast<const T*>(a.dctx) + (long)b * a.S * a.E + hd * D;
+    const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
+    const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
+    auto unpack = [](const u32x4& raw, float (&x)[EPC]) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
-    for (int kk = 0; kk < C::NKK; ++kk) {
-      qf[kk] = load_frag_global<T>(Qp + (long)qc * rs + kk * 16 + 8 * h);
-      dof[kk] = load_frag_global<T>(dOp + kk * 16 + 8 * h);
-      tq += dot8(qf[kk], load_frag_global<T>(Kp + (long)qc * rs + kk * 16 + 8 * h));
-      dpv += dot8(dof[kk], load_frag_global<T>(Vp + (long)qc * rs + kk * 16 + 8 * h));
+        for (int e = 0; e < EPC; ++e) x[e] = (float)v[e];
+      } else {
+        const f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) x[e] = v[e];
+      }
+    };
+    auto pack = [](const float (&x)[EPC]) {
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = (bf16)x[e];
+        return __builtin_bit_cast(u32x4, v);
+      } else {
+        return __builtin_bit_cast(u32x4, f32x4{x[0], x[1], x[2], x[3]});
+      }
+    };
+    // every load first, then every store: the compiler cannot prove that the dqkv rows written below do not alias the qkv /
+    // dctx rows read here, so a load placed after a store waits for it -- eight dependent round trips instead of one
+    u32x4 rq_[NST], rk_[NST], rv_[NST], ro_[NST];
+    float rl_[NST], rd_[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int qcl = min(q0 + wave * 32 + st * RPS + rsub, a.S - 1);
+      rq_[st] = *reinterpret_cast<const u32x4*>(Qp + (long)qcl * rs + c * EPC);
+      rk_[st] = *reinterpret_cast<const u32x4*>(Kp + (long)qcl * rs + c * EPC);
+      rv_[st] = *reinterpret_cast<const u32x4*>(Vp + (long)qcl * rs + c * EPC);
+      ro_[st] = *reinterpret_cast<const u32x4*>(dOb + (long)qcl * a.E + c * EPC);
+      rl_[st] = lse_g[qcl];
+      rd_[st] = delta_g[qcl];
     }
-    tq += __shfl_xor(tq, 32, 64);
-    dpv += __shfl_xor(dpv, 32, 64);
-    if (is_test) {
-      p_self = fast_exp2(tq * scale_log2 - lse2);
-      ds_self = p_self * (dpv - delta);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int row = st * RPS + rsub;
+      const int q = q0 + wave * 32 + row;
+      const bool test = q >= sep && q < a.S;
+      float qv[EPC], kv[EPC], vv[EPC], dv_[EPC];
+      unpack(rq_[st], qv);
+      unpack(rk_[st], kv);
+      unpack(rv_[st], vv);
+      unpack(ro_[st], dv_);
+      float tq = 0.f, dpv = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { tq += qv[e] * kv[e]; dpv += dv_[e] * vv[e]; }
+#pragma unroll
+      for (int off = 1; off < CPR; off <<= 1) { tq += __shfl_xor(tq, off, 64); dpv += __shfl_xor(dpv, off, 64); }
+      const float p_self = test ? fast_exp2(tq * scale_log2 - rl_[st] * LOG2E) : 0.f;
+      const float ds_self = p_self * (dpv - rd_[st]);
+      float xk[EPC], xv[EPC], xt[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { xk[e] = ds_self * scale * qv[e]; xv[e] = p_self * dv_[e]; xt[e] = ds_self * kv[e]; }
+      if (test) {
+        *reinterpret_cast<u32x4*>(dbase + (long)q * rs + a.E + hd * D + c * EPC) = pack(xk);
+        *reinterpret_cast<u32x4*>(dbase + (long)q * rs + 2 * a.E + hd * D + c * EPC) = pack(xv);
+      }
+      lds_write16(tself + row * TS + c * 16, pack(xt));
     }
   }
   {
@@ -862,27 +928,20 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int d0 = db * 32 + 8 * rg + 4 * h;
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f};
-        if (wave_has_test) kv = load4<T>(Kp + (long)qc * rs + d0);
+        f32x4 ts = {0.f, 0.f, 0.f, 0.f};
+        if (wave_has_test) {   // (the wave's own LDS writes above are ordered before these reads)
+          if constexpr (sizeof(T) == 2) {
+            const bf16x4 t4 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x4*>(tself + li * TS + d0 * 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * rg + e] = (dq[db][4 * rg + e] + ds_self * kv[e]) * scale;
+            for (int e = 0; e < 4; ++e) ts[e] = (float)t4[e];
+          } else {
+            ts = __builtin_bit_cast(f32x4, lds_read16(tself + li * TS + d0 * 4));
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * rg + e] = (dq[db][4 * rg + e] + ts[e]) * scale;
       }
       store_row_block<T>(dQo + db * 32, v, h, qvalid);
-    }
-  }
-  if (wave_has_test && qvalid && is_test) {
-    T* dKo = dbase + (long)qi * rs + a.E + hd * D;
-    T* dVo = dbase + (long)qi * rs + 2 * a.E + hd * D;
-#pragma unroll
-    for (int kk = 0; kk < C::NKK; ++kk) {
-      float xk[8], xv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        xk[e] = ds_self * scale * frag_get(qf[kk], e);
-        xv[e] = p_self * frag_get(dof[kk], e);
-      }
-      store_frag_global<T>(dKo + kk * 16 + 8 * h, xk);
-      store_frag_global<T>(dVo + kk * 16 + 8 * h, xv);
     }
   }
 }
