@@ -276,18 +276,52 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
   }
 
   // ---- epilogue straight from the accumulators: lane = output row, 4 consecutive columns per group ----
+  // Every load of the epilogue is issued BEFORE the stores that would otherwise precede it in program order.  The compiler
+  // cannot prove that the outputs do not alias bias / aux / resid, so it never moves a load above a store, and gfx9 counts loads
+  // and stores in one counter: written block by block (load, combine, store, next block) each of the tile's 8 blocks waited out
+  // a full memory round trip PLUS the drain of the previous block's stores -- 8 serial round trips per tile, a third of a
+  // K = 512 GEMM's time.  Now: the bias once, then the loads of NB blocks, then their stores (NB below).
   constexpr int flags = FLAGS;  // compile-time: one straight-line epilogue per flag combination in use
   const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
   bf16* out_t = reinterpret_cast<bf16*>(g.out_t);
   bf16* out2_t = reinterpret_cast<bf16*>(g.out2_t);
+  constexpr bool HAS_AUX = (flags & (EPI_GELU_BWD | EPI_RESID_T)) != 0;
+  constexpr bool HAS_RES = (flags & EPI_RESID) != 0;
+  // blocks (32 rows x 32 columns each; 8 per wave) per pass: 4 = half the tile, 2 when an f32 residual is read (twice the
+  // registers per block); the 4-wave shape (three workgroups per CU on 168 registers, latency hidden by occupancy) keeps 1
+  constexpr bool EARLY = NWM == 2;     // the 4-wave shape loads each 16-byte group where it is used, as before
+  constexpr int NB = !EARLY ? 1 : HAS_RES ? 2 : 4;
+  f32x4 bias_v[2][4];
+  if ((flags & EPI_BIAS) && EARLY) {   // once per tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long m_row = (long)m0 + wm * 128 + i * 32 + li;
-    const bool mvalid = m_row < g.M;
-    const long m = mvalid ? m_row : (long)g.M - 1;     // clamped for the loads; stores are guarded
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nb = n0 + wn * 64 + j * 32;            // first column of this 32-column block (wave-uniform)
+      for (int gq = 0; gq < 4; ++gq) bias_v[j][gq] = *reinterpret_cast<const f32x4*>(g.bias + min(n0 + wn * 64 + j * 32 + 8 * gq + 4 * h, g.N - 4));
+  }
+#pragma unroll
+  for (int pass = 0; pass < 8 / NB; ++pass) {
+    bf16x4 aux_v[HAS_AUX ? NB : 1][4];
+    f32x4 res_v[HAS_RES ? NB : 1][4];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int blk = pass * NB + bb, i = blk >> 1, j = blk & 1;
+      if (EARLY && (HAS_AUX || HAS_RES)) {
+        const long m = min((long)m0 + wm * 128 + i * 32 + li, (long)g.M - 1);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int n = min(n0 + wn * 64 + j * 32 + 8 * gq + 4 * h, g.N - 4);
+          if constexpr (HAS_AUX) aux_v[bb][gq] = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
+          if constexpr (HAS_RES) res_v[bb][gq] = *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
+        }
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int blk = pass * NB + bb, i = blk >> 1, j = blk & 1;
+      const long m_row = (long)m0 + wm * 128 + i * 32 + li;
+      const bool mvalid = m_row < g.M;
+      const long m = mvalid ? m_row : (long)g.M - 1;     // clamped for the loads; stores are guarded
+      const int nb = n0 + wn * 64 + j * 32;              // first column of this 32-column block (wave-uniform)
       float pre[16], post[16];
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
@@ -295,17 +329,20 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
-        if (flags & EPI_BIAS) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-        if (flags & EPI_GELU_BWD) {
-          const bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= (float)t[e];
+        if constexpr (!EARLY) {
+          if (flags & EPI_BIAS) bias_v[j][gq] = *reinterpret_cast<const f32x4*>(g.bias + n);
+          if constexpr (HAS_AUX) aux_v[bb][gq] = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
+          if constexpr (HAS_RES) res_v[bb][gq] = *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
         }
-        if (flags & EPI_RESID) v += *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
-        if (flags & EPI_RESID_T) {
-          const bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
+        if (flags & EPI_BIAS) v += bias_v[j][gq];
+        if (flags & EPI_GELU_BWD) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
+          for (int e = 0; e < 4; ++e) v[e] *= (float)aux_v[HAS_AUX ? bb : 0][gq][e];
+        }
+        if (flags & EPI_RESID) v += res_v[HAS_RES ? bb : 0][gq];
+        if (flags & EPI_RESID_T) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)aux_v[HAS_AUX ? bb : 0][gq][e];
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) pre[4 * gq + e] = v[e];   // second output: value before the activation ...
@@ -431,30 +468,55 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   }
 
   // ---- epilogue: v = acc + bias + residual (kept in the accumulator registers), row statistics, outputs ----
+  // The compiler never moves a global load above a global store and waits for each group of loads where it is used, so an
+  // epilogue written "load, combine, store" per 16-byte group is a chain of serialized memory round trips (measured: ~half
+  // of this kernel's time at K = 512).  So: the per-column vectors go to LDS once (their reads count on lgkmcnt, not
+  // vmcnt), the residual rows are fetched one 32-row block ahead of their use, and the store pass issues no global load.
   float* red = reinterpret_cast<float*>(smem_raw);          // [128 rows][NWN] partial sums; the stage buffers are dead
+  float* cvec = red + 128 * NWN;                            // [5][BN]: rgamma, rbeta, bias, gamma, beta
+  {
+    const int n = threadIdx.x;                              // blockDim.x == BN
+    float c0 = 0.f, c1 = 0.f;
+    if constexpr (RESID_LN) { c0 = g.rgamma[n]; c1 = g.rbeta[n]; }
+    const float c2 = g.bias[n], c3 = g.gamma[n], c4 = g.beta[n];
+    cvec[n] = c0; cvec[BN + n] = c1; cvec[2 * BN + n] = c2; cvec[3 * BN + n] = c3; cvec[4 * BN + n] = c4;
+  }
+  const float* rsrc = RESID_LN ? g.ry : g.resid;
+  float rm[4], rr[4];
+  long mrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mrow[i] = min((long)m0 + i * 32 + li, (long)g.M - 1);
+    rm[i] = 0.f; rr[i] = 1.f;
+    if constexpr (RESID_LN) { rm[i] = g.rmean[mrow[i]]; rr[i] = g.rrstd[mrow[i]]; }
+  }
+  f32x4 rv[2][8];
+  auto fetch_rows = [&](int i, f32x4 (&dst)[8]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) dst[j * 4 + gq] = *reinterpret_cast<const f32x4*>(rsrc + mrow[i] * BN + wave * 64 + j * 32 + 8 * gq + 4 * h);
+  };
+  fetch_rows(0, rv[0]);
+  __syncthreads();                                          // cvec visible
   float mean[4], rstd[4];
   const float invN = 1.f / (float)BN;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long m = min((long)m0 + i * 32 + li, (long)g.M - 1);
-    float rm = 0.f, rr = 0.f;
-    if constexpr (RESID_LN) { rm = g.rmean[m]; rr = g.rrstd[m]; }
+    if (i + 1 < 4) fetch_rows(i + 1, rv[(i + 1) & 1]);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
-        f32x4 r;
+        f32x4 r = rv[i & 1][j * 4 + gq];
         if constexpr (RESID_LN) {
-          const f32x4 yv = *reinterpret_cast<const f32x4*>(g.ry + m * BN + n);
-          const f32x4 ga = *reinterpret_cast<const f32x4*>(g.rgamma + n), be = *reinterpret_cast<const f32x4*>(g.rbeta + n);
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + n), be = *reinterpret_cast<const f32x4*>(cvec + BN + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = (yv[e] - rm) * rr * ga[e] + be[e];
-        } else {
-          r = *reinterpret_cast<const f32x4*>(g.resid + m * BN + n);
+          for (int e = 0; e < 4; ++e) r[e] = (r[e] - rm[i]) * rr[i] * ga[e] + be[e];
         }
-        const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(cvec + 2 * BN + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = acc[i][j][4 * gq + e] + bi[e] + r[e];
@@ -497,7 +559,7 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   for (int i = 0; i < 4; ++i) {
     const long m_row = (long)m0 + i * 32 + li;
     const bool mvalid = m_row < g.M;
-    const long m = mvalid ? m_row : (long)g.M - 1;
+    const long m = mrow[i];
     if (mvalid && wave == 0 && h == 0) { g.mean[m] = mean[i]; g.rstd[m] = rstd[i]; }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -506,7 +568,7 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = nb + 8 * gq + 4 * h;
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(g.gamma + n), be = *reinterpret_cast<const f32x4*>(g.beta + n);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + 3 * BN + n), be = *reinterpret_cast<const f32x4*>(cvec + 4 * BN + n);
         f32x4 v, xo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
