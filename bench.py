@@ -425,6 +425,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-kernel-breakdown', action='store_true')
     ap.add_argument('--fixed-sep', type=int, default=None, help='use one eval position instead of the sampler')
+    ap.add_argument('--tune', default='', help='experiments: comma-separated key=value pairs for pfn_set_tuning (include/pfn_hip.h); recorded in config')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
@@ -438,6 +439,10 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     w = CONFIGS[args.config]
+    tuning = {int(k): int(v) for k, v in (kv.split('=') for kv in args.tune.split(',') if kv)}
+    for k, v in tuning.items():
+        from transformerscandobayesianinference_amd import _hip
+        _hip.check(_hip.lib().pfn_set_tuning(k, v), 'pfn_set_tuning')
     batch = args.batch or w['batch']
     streams = args.streams or w['streams']
     S, nf, E, F, L, O = w['bptt'], w['num_features'], w['emsize'], w['nhid'], w['nlayers'], w['num_bars']
@@ -534,6 +539,8 @@ def main():
         'step_roofline': {'bound': 'mfma', 'achieved': step_flops / elapsed / 1e12 / world, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
                           'frac': step_flops / elapsed / world / MFMA_BF16_PEAK, 'note': 'whole step per GPU, algorithmic mask-aware FLOPs 3*fwd(S,sep)'},
     }
+    if tuning:
+        result['config']['tuning'] = tuning
     if world > 1:
         result['ranks_seen'] = int(ranks_seen.item())
         result['allreduce_ms'] = allreduce_ms

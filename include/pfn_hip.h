@@ -59,7 +59,7 @@ int pfn_abi_version(void);
 const char* pfn_last_error_string(void);
 /* Process-wide kernel-selection knobs for tests and profiling (results are identical up to rounding
  * order).  PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
- * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it. */
+ * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one. */
 enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_GEMM_TN_WRAP = 1 /* profiling only: > 0 makes the grouped TN kernel re-read its first `value` token rows (wrong results, cache-resident operands) */ };
 int pfn_set_tuning(int key, int value);

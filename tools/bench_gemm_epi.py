@@ -8,6 +8,7 @@ import bench, hipops
 from transformerscandobayesianinference_amd import _hip
 H = _hip
 ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=16); ap.add_argument('--modes', default='2,3')
+ap.add_argument('--k', type=int, default=0, help='override the contraction length (64: one stage = prologue + epilogue only)')
 ap.add_argument('--lib', default=None, help='alternative build of libpfn_hip.so (experiment variants under _build/exp)')
 a = ap.parse_args()
 if a.lib:
@@ -30,6 +31,7 @@ cases = [  # name, N, K, flags, count per step
 ]
 tot = {}
 for name, N, K, flags, cnt in cases:
+    K = a.k or K
     A, B = r(M, K), r(N, K)
     kw = {}
     if flags & H.EPI_BIAS: kw['bias'] = f(N)

@@ -952,7 +952,11 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
   const size_t lds = 2 * C::RIMG + 3 * C::CIMG;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
@@ -964,25 +968,31 @@ template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStrea
     int grid = (int)std::min<long>((pairs + 15) / 16, 4096);
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, s, a, D);
   }
+  const size_t lds_kv = BwdKvCfg<T, D>::LDS, lds_dq = BwdDqCfg<T, D>::LDS;
+  static bool attr_set = false;      // (hipFuncSetAttribute costs tens of microseconds of host time per call)
+  if (!attr_set) {
+    auto allow = [](auto kernel, size_t lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
+    allow(attn_bwd_kv_kernel<T, D, 0>, lds_kv);
+    allow(attn_bwd_kv_kernel<T, D, 1>, lds_kv);
+    allow(attn_bwd_kv_kernel<T, D, 2>, lds_kv);
+    allow(attn_bwd_dq_kernel<T, D>, lds_dq);
+    attr_set = true;
+  }
+  auto run_kv = [&](auto kernel, const AttnArgs& ac) {
+    hipLaunchKernelGGL(kernel, dim3(((ac.sep + C::QBLK - 1) / C::QBLK) * ac.H * ac.B), dim3(C::NT), lds_kv, s, ac);
+  };
+  // (Launching the pair for a few datasets at a time into one scratch, so that dS^T -- 436 MB per 16 datasets -- stays in the
+  // 256 MB memory-side cache, was measured: 432 vs 436 us with two chunks, slower with more: each launch ends in a partial round.)
   if ((parts & ATTN_BWD_KV) && a.sep > 0) {
-    const size_t lds = BwdKvCfg<T, D>::LDS;
-    const dim3 grid(((a.sep + C::QBLK - 1) / C::QBLK) * a.H * a.B);
-    auto run = [&](auto kernel) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kernel, grid, dim3(C::NT), lds, s, a);
-    };
     if constexpr (BwdKvCfg<T, D>::SPLIT) {
-      run(attn_bwd_kv_kernel<T, D, 2>);
-      run(attn_bwd_kv_kernel<T, D, 1>);
+      run_kv(attn_bwd_kv_kernel<T, D, 2>, a);
+      run_kv(attn_bwd_kv_kernel<T, D, 1>, a);
     } else {
-      run(attn_bwd_kv_kernel<T, D, 0>);
+      run_kv(attn_bwd_kv_kernel<T, D, 0>, a);
     }
   }
-  if (parts & ATTN_BWD_DQ) {
-    const size_t lds = BwdDqCfg<T, D>::LDS;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
-  }
+  if (parts & ATTN_BWD_DQ)
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds_dq, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 

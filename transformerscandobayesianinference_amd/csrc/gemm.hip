@@ -298,6 +298,15 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) bias_v[j][gq] = *reinterpret_cast<const f32x4*>(g.bias + min(n0 + wn * 64 + j * 32 + 8 * gq + 4 * h, g.N - 4));
   }
+  // Outputs leave through a wave-private LDS image of one 32-row x 64-column strip (both column blocks of a row block), so
+  // that every global store instruction writes whole 128-byte lines (8 rows x 128 B in operand precision, 4 rows x 256 B in
+  // f32) instead of 32-byte pieces of 32 different rows.  Padded rows (+16 B) keep both the lane-per-row writes and the
+  // row-contiguous reads free of bank conflicts.  No workgroup barrier: a wave only re-reads what it wrote itself.
+  constexpr int EP_T = 32 * 144, EP_F = 32 * 272, EP_WAVE = (2 * EP_T > EP_F ? 2 * EP_T : EP_F);
+  static_assert(C::NW * EP_WAVE <= 2 * C::STAGE, "epilogue staging must fit the (dead) stage buffers");
+  static_assert(!(flags & EPI_ACCUM), "accumulating outputs take the generic kernel");
+  LdsPtr ep = smem + wave * EP_WAVE;
+  const bool lines = n0 + wn * 64 + 64 <= g.N && g.wide_t;   // wave-uniform: the strip is inside N and rows are 16-byte aligned
 #pragma unroll
   for (int pass = 0; pass < 8 / NB; ++pass) {
     bf16x4 aux_v[HAS_AUX ? NB : 1][4];
@@ -353,12 +362,53 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
 #pragma unroll
         for (int e = 0; e < 4; ++e) post[4 * gq + e] = v[e];
         if (flags & EPI_OUT_F32) {
-          if (mvalid && nb + 8 * gq + 4 * h < g.N) {
-            float* o = g.out_f32 + m * g.ld_out_f32 + n;
-            if (flags & EPI_ACCUM) v += *reinterpret_cast<const f32x4*>(o);
-            *reinterpret_cast<f32x4*>(o) = v;
+          if (lines) lds_write16(ep + li * 272 + (j * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
+          else if (mvalid && nb + 8 * gq + 4 * h < g.N) *reinterpret_cast<f32x4*>(g.out_f32 + m * g.ld_out_f32 + n) = v;
+        }
+        if (lines && (flags & (EPI_OUT_T | EPI_OUT2_T))) {
+          typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+          if (flags & EPI_OUT_T) {
+            bf16x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e];
+            *reinterpret_cast<lds_bf16x4*>(ep + li * 144 + (j * 4 + gq) * 16 + h * 8) = t;
+          }
+          if (flags & EPI_OUT2_T) {
+            bf16x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = (bf16)pre[4 * gq + e];
+            *reinterpret_cast<lds_bf16x4*>(ep + EP_T + li * 144 + (j * 4 + gq) * 16 + h * 8) = t;
           }
         }
+      }
+      if (lines) {
+        if (j == 1) {   // the strip of row block i is complete: write it out row-contiguously
+          __builtin_amdgcn_wave_barrier();
+          const long mb = (long)m0 + wm * 128 + i * 32;
+          const int nw = n0 + wn * 64;
+          if (flags & EPI_OUT_F32) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              const int rr = it * 4 + (lane >> 4), c = lane & 15;
+              const u32x4 q = lds_read16(ep + rr * 272 + c * 16);
+              if (mb + rr < g.M) *reinterpret_cast<u32x4*>(g.out_f32 + (mb + rr) * g.ld_out_f32 + nw + c * 4) = q;
+            }
+          }
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            if (!(flags & (o ? EPI_OUT2_T : EPI_OUT_T))) continue;
+            bf16* dst = o ? out2_t : out_t;
+            const long ld = o ? g.ld_out2 : g.ld_out_t;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int rr = it * 8 + (lane >> 3), c = lane & 7;
+              const u32x4 q = lds_read16(ep + o * EP_T + rr * 144 + c * 16);
+              if (mb + rr < g.M) *reinterpret_cast<u32x4*>(dst + (mb + rr) * ld + nw + c * 8) = q;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        continue;
       }
       // operand-precision outputs: 16-byte stores after a half-wave exchange when the whole block is inside N
       // (wave-uniform test) and the row pitch keeps them aligned, else 8-byte stores per group

@@ -451,7 +451,11 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
     if (ti > 0 && tj > 0) hipLaunchKernelGGL(gp_syrk_kernel, dim3(tj, ti, B), dim3(256), 2 * 128 * SYRK_KC * 4, s, a, r0, r1, c0, c1, kp0, K);
   };
   const size_t tw_lds = 2 * 64 * TW_STRIDE + OBW * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_trsm_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tw_lds);
+  static bool tw_attr_set = false;   // (constant size; the call costs tens of microseconds of host time)
+  if (!tw_attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_trsm_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tw_lds);
+    tw_attr_set = true;
+  }
   for (int kout = 0; kout < S; kout += OBW) {
     const int kend = std::min(kout + OBW, S);
     for (int k0 = kout; k0 < kend; k0 += NB) {
