@@ -425,6 +425,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-kernel-breakdown', action='store_true')
     ap.add_argument('--fixed-sep', type=int, default=None, help='use one eval position instead of the sampler')
+    ap.add_argument('--prefetch-group', type=int, default=None, help='steps of datasets per sampler call (default: the loader class\'s; the bench uses its gcd with --steps)')
     ap.add_argument('--tune', default='', help='experiments: comma-separated key=value pairs for pfn_set_tuning (include/pfn_hip.h); recorded in config')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -491,7 +492,7 @@ def main():
     # loader is a whole number of groups long and extends one group past the window so that every one of those groups exists
     # and is full.
     loader_cls = prior_module(w).DataLoader
-    group = math.gcd(args.steps, int(getattr(loader_cls, 'prefetch_group', 1))) if getattr(loader_cls, 'prefetch', False) else 1
+    group = math.gcd(args.steps, int(args.prefetch_group or getattr(loader_cls, 'prefetch_group', 1))) if getattr(loader_cls, 'prefetch', False) else 1
     num_steps = (args.warmup + args.steps + group + group - 1) // group * group
     with quiet():   # DataLoader.__init__ prints its kwargs (reference behaviour)
         dl = loader_cls(num_steps=num_steps, batch_size=batch, seq_len=S, device=device, **prior_kwargs(w))

@@ -223,4 +223,5 @@ def evaluate(x, y, y_non_noisy, use_mse=False, hyperparameters={}, get_model_on_
         torch.cuda.synchronize(mean.device)
     return ls.to('cpu'), per_t.to('cpu'), time.time() - start_time
 DataLoader.prefetch = True        # draws run ahead of the training steps on a side stream (priors/utils.py)
-DataLoader.prefetch_group = 4     # ... four steps' worth of datasets per sampler call
+DataLoader.prefetch_group = 10    # ... ten steps' worth of datasets per sampler call (MI355X, bptt 2000: 64 us per dataset at 4 x 32, 54 us at 10 x 32;
+                                  # 16 MB of factorisation workspace per dataset: 5 GB of the 288)

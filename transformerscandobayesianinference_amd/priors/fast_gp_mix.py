@@ -98,7 +98,7 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
 class DataLoader(get_batch_to_dataloader(get_batch)):
     num_outputs = 1
     prefetch = True
-    prefetch_group = 4
+    prefetch_group = 10
 
     @torch.no_grad()
     def validate(self, model, step_size=1, start_pos=0):
