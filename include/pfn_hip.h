@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 2
+#define PFN_ABI_VERSION 3
 
 enum {
   PFN_OK = 0,
@@ -59,9 +59,12 @@ int pfn_abi_version(void);
 const char* pfn_last_error_string(void);
 /* Process-wide kernel-selection knobs for tests and profiling (results are identical up to rounding
  * order).  PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
- * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one. */
+ * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one.
+ * PFN_TUNE_FUSE_LNBWD: 1 (default) the stack backward runs LayerNorm backward inside the data-gradient GEMMs that feed it
+ * (pfn_op_gemm_lnbwd), 0 as separate kernels. */
 enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
-       PFN_TUNE_GEMM_TN_WRAP = 1 /* profiling only: > 0 makes the grouped TN kernel re-read its first `value` token rows (wrong results, cache-resident operands) */ };
+       PFN_TUNE_GEMM_TN_WRAP = 1, /* profiling only: > 0 makes the grouped TN kernel re-read its first `value` token rows (wrong results, cache-resident operands) */
+       PFN_TUNE_FUSE_LNBWD = 2 };
 int pfn_set_tuning(int key, int value);
 
 /* ---- parameter packing ------------------------------------------------------------------------
@@ -187,6 +190,15 @@ int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M
                    const float* resid, const float* ry, const float* rmean, const float* rrstd,
                    const float* rgamma, const float* rbeta, const float* gamma, const float* beta, float eps,
                    float* y, float* mean, float* rstd, void* x_t, void* stream);
+/* data-gradient GEMM + residual-branch gradient + the backward of the LayerNorm whose output gradient the sum is (bf16
+ * operands, N in {128, 256, 512}, K % 32 == 0):
+ *   v = A[M,K] . B[N,K]^T + aux[M,N];   xhat = (y - mean) rstd;
+ *   dx_t = bf16(rstd (gamma v - mean_n(gamma v) - xhat mean_n(gamma v xhat)));   dgamma += sum_m v xhat;   dbeta += sum_m v
+ * i.e. autograd of `norm(x + sublayer(x))` (torch nn/modules/transformer.py:952-957) w.r.t. the norm's input, taking the
+ * place of pfn_op_gemm_nt(EPI_RESID_T | EPI_OUT_T) followed by pfn_op_layernorm_bwd.  dgamma / dbeta accumulate atomically. */
+int pfn_op_gemm_lnbwd(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const void* aux,
+                      const float* y, const float* mean, const float* rstd, const float* gamma,
+                      void* dx_t, float* dgamma, float* dbeta, void* stream);
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep,
                          int prec, void* stream);
 /* Attention backward = three launches: delta = rowsum(dO * O); the key-block pass (dK, dV and dS^T into ds_ws); the

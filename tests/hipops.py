@@ -71,6 +71,19 @@ def attention_fwd(qkv, H, sep, prec):
     return ctx, lse
 
 
+def gemm_lnbwd(A, B, aux, y, mean, rstd, gamma, out=None):
+    """dx_t, dgamma, dbeta of  v = A . B^T + aux  pushed back through the LayerNorm (y, mean, rstd, gamma)  (pfn_op_gemm_lnbwd)."""
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = (torch.full((M + 2, N), float('nan'), dtype=torch.bfloat16, device=A.device), torch.zeros(N, device=A.device), torch.zeros(N, device=A.device))
+    dx_t, dgamma, dbeta = out
+    p = _hip.ptr
+    _hip.check(_hip.lib().pfn_op_gemm_lnbwd(p(A), A.stride(0), p(B), B.stride(0), M, N, K, p(aux), p(y), p(mean), p(rstd), p(gamma),
+                                            p(dx_t), p(dgamma), p(dbeta), sp()), 'pfn_op_gemm_lnbwd')
+    return dx_t, dgamma, dbeta
+
+
 # (name, rocprofv3 kernel name, `parts` bit, algorithmic product units, executed product units) of every launch of the attention
 # backward; one unit = one [S x keys x head-dim] product over all heads (the backward's algorithmic work is 4: dV, dP, dK, dQ;
 # it executes 5, the forward's S being recomputed once)

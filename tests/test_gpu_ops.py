@@ -193,6 +193,30 @@ def test_gemm_ln_fused(M, N, K):
     assert relerr(x2, torch.nn.functional.layer_norm(v2, (N,), gamma.double(), beta.double(), 1e-5)) < 4e-3
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (77, 512, 1536)])
+def test_gemm_lnbwd_fused(M, N, K):
+    """dgrad GEMM + residual-branch gradient + LayerNorm backward in one kernel, against f64 autograd of the LayerNorm."""
+    dt = torch.bfloat16
+    A, B = rnd(M, K, dtype=dt, seed=50), rnd(N, K, dtype=dt, seed=51, scale=0.1)
+    aux = rnd(M, N, dtype=dt, seed=52)
+    y = rnd(M, N, seed=53) * 2 + 0.3
+    gamma = rnd(N, seed=54) + 1
+    yd = y.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = torch.zeros(N, dtype=torch.float64, device=dev(), requires_grad=True)
+    v = A.double() @ B.double().t() + aux.double()
+    torch.nn.functional.layer_norm(yd, (N,), gd, bd, 1e-5).backward(v)
+    mean, var = y.double().mean(1), y.double().var(1, unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    dx_t, dgamma, dbeta = hipops.gemm_lnbwd(A, B, aux, y, mean.float(), rstd.float(), gamma)
+    assert torch.isnan(dx_t[M:].float()).all()            # nothing written past row M
+    assert relerr(dx_t[:M], yd.grad) < 4e-3, relerr(dx_t[:M], yd.grad)
+    assert relerr(dgamma, gd.grad) < 2e-3 and relerr(dbeta, bd.grad) < 1e-4, (relerr(dgamma, gd.grad), relerr(dbeta, bd.grad))
+    # accumulation: a second launch doubles the parameter gradients
+    hipops.gemm_lnbwd(A, B, aux, y, mean.float(), rstd.float(), gamma, out=(dx_t, dgamma, dbeta))
+    assert relerr(dgamma, 2 * gd.grad) < 2e-3 and relerr(dbeta, 2 * bd.grad) < 1e-4
+
+
 @pytest.mark.parametrize('M,splits', [(64, 1), (1000, 1), (1000, 0), (4100, 3), (37, 1)])
 def test_gemm_tn_group(M, splits):
     """Grouped 256x256 weight-gradient kernel: several problems in one launch, ragged token tail, fused bias gradient."""

@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import bench, hipops
 from transformerscandobayesianinference_amd import _hip
+if os.environ.get('PFN_LIB'):
+    _hip.LIB_PATH = os.path.abspath(os.environ['PFN_LIB'])
 H = _hip
 ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=16); ap.add_argument('--modes', default='2,3')
 ap.add_argument('--k', type=int, default=0, help='override the contraction length (64: one stage = prologue + epilogue only)')

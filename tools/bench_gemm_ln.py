@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import bench, hipops
 from transformerscandobayesianinference_amd import _hip
+if os.environ.get('PFN_LIB'):
+    _hip.LIB_PATH = os.path.abspath(os.environ['PFN_LIB'])
 H = _hip
 M, N = 32000, 512
 dev = torch.device('cuda'); bf = torch.bfloat16

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpfn_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 PREC_BF16 = 0
 PREC_F32 = 1
@@ -65,6 +65,7 @@ SIGNATURES = {
     'pfn_op_gemm_tn': (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
     'pfn_op_gemm_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'pfn_op_gemm_ln': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
+    'pfn_op_gemm_lnbwd': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pfn_op_attention_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_attention_bwd_ws_bytes': (_L, [_I, _I, _I, _I]),
     'pfn_op_attention_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

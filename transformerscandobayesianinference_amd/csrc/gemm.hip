@@ -449,6 +449,9 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
 // standalone kernel), then the pre-LN sum (f32), the normalised operand copy (bf16) and the statistics are written
 // once.  Saves, per LayerNorm, the f32 round trip of the pre-LN sum and the f32 LayerNorm output entirely.
 // ---------------------------------------------------------------------------------------------
+// (A note on these full-row kernels' main loop: 16-17 us per 512 of K against 10-12 us in the 256 x 256 kernel.  A is streamed from
+// HBM once and only one stage of it is in flight; touching the A lines of the stage after next to pull them into L2 ahead of the
+// LDS-DMA was measured and changed nothing -- 62.6 vs 63.3 us at K = 1024 -- so the stream is not latency-bound.)
 template <int NWN, bool RESID_LN, int BK>
 __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
@@ -633,6 +636,256 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
       }
       store_row_block<bf16>(x_t + m * BN + nb, xn, h, mvalid);   // 16-byte stores after a half-wave exchange
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_nt_lnbwd_kernel: a data-gradient GEMM whose output is the gradient w.r.t. a LayerNorm OUTPUT, with that LayerNorm's
+// backward fused into the epilogue (GemmLNB in pfn_kernels.h):
+//     v  = A . B^T + aux                                  (dx1 = dh . W1 + dy2   /   dx = dqkv . Win + dy1)
+//     dx = rstd (gamma v - mean_n(gamma v) - xhat mean_n(gamma v xhat)),   xhat = (y - mean) rstd
+//     dgamma += sum_rows v xhat,   dbeta += sum_rows v
+// Same tile as gemm_nt_ln_kernel (128 rows x all N = 64 NWN columns, so a workgroup owns whole rows).  v never reaches HBM:
+// the separate LayerNorm-backward kernel read it back (32.8 MB per launch at the north-star shape) together with y, and this
+// GEMM wrote it.  xhat is needed twice (row sums, then dx); between the two it waits in LDS in operand precision (the stage
+// buffers are dead), which only touches the xhat . mean_n(.) term of dx and the dgamma sum -- below the rounding of dx itself.
+// The bias gradient of the Linear in front of the LayerNorm (column sums of dx) is left to the weight-gradient GEMM that
+// consumes dx as its operand (gemm_tn_big_kernel's colsum).
+// ---------------------------------------------------------------------------------------------
+PFN_DEV float row16_sum(float v) {   // sum over the 16 lanes of a DPP row, left in every lane of the row
+  auto sh = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true)); };
+  v += sh(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += sh(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += sh(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += sh(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v;
+}
+
+template <int NWN, int BK> struct LnbCfg {
+  static constexpr int BN = NWN * 64;
+  static constexpr int STAGES = 2 * (128 + BN) * (BK * 2);
+  static constexpr int RED = 128 * NWN * 4;              // one [128 rows][NWN] f32 array of row partial sums
+  static constexpr int STRIP = 32 * 144;                 // a 32-row x 64-column strip in operand precision, rows padded by 16 B
+  static constexpr int STASH = 2 * RED + BN * 4;         // offset of the per-wave xhat / dx strips
+  static constexpr int EPI = STASH + NWN * 4 * STRIP;
+  static constexpr int LDS = STAGES > EPI ? STAGES : EPI;
+};
+
+template <int NWN, int BK>
+__global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
+  using C = LnbCfg<NWN, BK>;
+  constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
+  constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
+  constexpr int TILE_A = BM * RB, STAGE = TILE_A + BN * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  const int m0 = blockIdx.x * BM;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int h = lane >> 5, li = lane & 31;
+
+  const bf16* pa[PA];
+  const bf16* pb[PB];
+  constexpr int APIECES = BM / RPP;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave + NWN * i) * RPP + lane / CPR;
+    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + swz16<RB>(row, lane % CPR) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = (wave + NWN * i) * RPP + lane / CPR;
+    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)row * g.ldb + swz16<RB>(row, lane % CPR) * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    LdsPtr ta = smem + buf * STAGE + wave * 1024;
+    LdsPtr tb = smem + buf * STAGE + TILE_A + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      if (wave + NWN * i < APIECES) __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * NWN * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * NWN * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * STAGE;
+    const lds_char* tb = ta + TILE_A;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      Frag<bf16> fa[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, RB>(tb, wave * 64 + j * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, RB>(ta, i * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  float* red1 = reinterpret_cast<float*>(smem_raw);
+  float* red2 = red1 + 128 * NWN;
+  float* gam = red2 + 128 * NWN;
+  LdsPtr stash = smem + C::STASH + wave * 4 * C::STRIP;
+  const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
+  bf16* dx_t = reinterpret_cast<bf16*>(g.dx_t);
+  gam[threadIdx.x] = g.gamma[threadIdx.x];                  // blockDim.x == BN
+  int mrow[4];
+  bool mvalid[4];
+  float mu[4], rs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + i * 32 + li;
+    mvalid[i] = m < g.M;
+    mrow[i] = mvalid[i] ? m : g.M - 1;
+    mu[i] = g.mean[mrow[i]]; rs[i] = g.rstd[mrow[i]];
+  }
+  // y rows and the residual-branch gradient: one half row block (a 32-column block of the lane's row) ahead of its use -- a whole
+  // block ahead does not fit the registers.  v = product + that gradient replaces the accumulator; rows past M hold zeros.
+  f32x4 yv[2][4];
+  bf16x4 av[2][4];
+  auto fetch_half = [&](int hb, f32x4 (&dy)[4], bf16x4 (&da)[4]) {           // hb = 2 i + j
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const long off = (long)mrow[hb >> 1] * BN + wave * 64 + (hb & 1) * 32 + 8 * gq + 4 * h;
+      dy[gq] = *reinterpret_cast<const f32x4*>(g.y + off);
+      da[gq] = *reinterpret_cast<const bf16x4*>(aux + off);
+    }
+  };
+  fetch_half(0, yv[0], av[0]);
+  __syncthreads();                                          // gam visible
+  const float invN = 1.f / (float)BN;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int hb = 0; hb < 8; ++hb) {
+    const int i = hb >> 1, j = hb & 1;
+    asm volatile("" ::: "memory");                          // re-read gamma from LDS per block (kept in registers across blocks it costs 32 of them)
+    if (hb + 1 < 8) fetch_half(hb + 1, yv[(hb + 1) & 1], av[(hb + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);                      // (the scheduler would hoist the loads of every later block up here: spills)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n);
+      bf16x4 xh_t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = mvalid[i] ? acc[i][j][4 * gq + e] + (float)av[hb & 1][gq][e] : 0.f;
+        acc[i][j][4 * gq + e] = v;
+        const float xh = (yv[hb & 1][gq][e] - mu[i]) * rs[i];
+        const float gv = ga[e] * v;
+        s1 += gv;
+        s2 += gv * xh;
+        xh_t[e] = (bf16)xh;
+      }
+      *reinterpret_cast<lds_bf16x4*>(stash + i * C::STRIP + li * 144 + (j * 4 + gq) * 16 + h * 8) = xh_t;
+    }
+    if (j == 1) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) { red1[(i * 32 + li) * NWN + wave] = s1; red2[(i * 32 + li) * NWN + wave] = s2; }
+      s1 = 0.f; s2 = 0.f;
+    }
+  }
+  __syncthreads();
+  float m1[4], m2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWN; ++w) { t1 += red1[(i * 32 + li) * NWN + w]; t2 += red2[(i * 32 + li) * NWN + w]; }
+    m1[i] = t1 * invN; m2[i] = t2 * invN;
+  }
+  // dbeta / dgamma: column sums over this tile's rows -- the four row blocks inside the lane, the 16 lanes of a DPP row, then
+  // through LDS ([quantity][row half][column], the space of the row sums) so that the workgroup ends with ONE 64-lane atomic
+  // instruction per 64 columns (issued by the lanes that hold the sums -- 4 per instruction -- the same atomics took 270 us).
+  __syncthreads();                                          // every wave has read red1 / red2
+  float* csum = red1;
+  const int ccol = wave * 64 + 4 * h, chalf = (li >> 4) * BN;
+  {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * gq + e;
+          t[e] = row16_sum(acc[0][j][r] + acc[1][j][r] + acc[2][j][r] + acc[3][j][r]);
+        }
+        if ((li & 15) == 0) *reinterpret_cast<f32x4*>(csum + chalf + ccol + j * 32 + 8 * gq) = t;
+      }
+  }
+  float cg[2][16];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cg[j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    LdsPtr strip = stash + i * C::STRIP;
+    asm volatile("" ::: "memory");
+    bf16x4 xh_t[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xh_t[c] = *reinterpret_cast<const lds_bf16x4*>(strip + li * 144 + c * 16 + h * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (float)xh_t[j * 4 + gq][e], v = acc[i][j][4 * gq + e];
+          cg[j][4 * gq + e] += v * xh;
+          o[e] = (bf16)(rs[i] * (ga[e] * v - m1[i] - xh * m2[i]));
+        }
+        *reinterpret_cast<lds_bf16x4*>(strip + li * 144 + (j * 4 + gq) * 16 + h * 8) = o;   // (the lane's own xhat slot)
+      }
+    __builtin_amdgcn_wave_barrier();
+    const long mb = (long)m0 + i * 32;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                        // whole 128-byte lines: 8 rows x 128 B per store instruction
+      const int rr = it * 8 + (lane >> 3), c = lane & 7;
+      const u32x4 q = lds_read16(strip + rr * 144 + c * 16);
+      if (mb + rr < g.M) *reinterpret_cast<u32x4*>(dx_t + (mb + rr) * BN + wave * 64 + c * 8) = q;
+    }
+    // (else the dgamma additions are sunk to the end of the kernel and every block's 32 products stay in registers: spills)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(cg[j][r]));
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = row16_sum(cg[j][4 * gq + e]);
+      if ((li & 15) == 0) *reinterpret_cast<f32x4*>(csum + 2 * BN + chalf + ccol + j * 32 + 8 * gq) = t;
+    }
+  __syncthreads();
+  {
+    const int n = threadIdx.x;                              // blockDim.x == BN
+    unsafeAtomicAdd(g.dbeta + n, csum[n] + csum[BN + n]);
+    unsafeAtomicAdd(g.dgamma + n, csum[2 * BN + n] + csum[3 * BN + n]);
   }
 }
 
@@ -1034,6 +1287,32 @@ int launch_gemm_ln(const GemmLN& g, hipStream_t stream) {
     default: PFN_LN_CASE(8) break;
   }
 #undef PFN_LN_CASE
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+
+bool gemm_lnbwd_supported(const GemmLNB& g) {
+  return (g.N == 128 || g.N == 256 || g.N == 512) && g.K % 32 == 0 && g.K >= 32 && (g.lda * 2) % 16 == 0 && (g.ldb * 2) % 16 == 0 &&
+         aligned16(g.A) && aligned16(g.B) && aligned16(g.aux) && aligned16(g.y) && aligned16(g.gamma) && aligned16(g.dx_t) && g.dgamma && g.dbeta;
+}
+template <int NWN, int BK> static void launch_gemm_lnbwd_t(const GemmLNB& g, hipStream_t stream) {
+  const size_t lds = LnbCfg<NWN, BK>::LDS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_lnbwd_kernel<NWN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_lnbwd_kernel<NWN, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
+}
+int launch_gemm_lnbwd(const GemmLNB& g, hipStream_t stream) {
+  if (g.M <= 0) return PFN_OK;
+  if (!gemm_lnbwd_supported(g)) return PFN_ERR_UNSUPPORTED;
+#define PFN_LNB_CASE(NWN) if (g.K % 64 == 0) launch_gemm_lnbwd_t<NWN, 64>(g, stream); else launch_gemm_lnbwd_t<NWN, 32>(g, stream);
+  switch (g.N / 64) {
+    case 2: PFN_LNB_CASE(2) break;
+    case 4: PFN_LNB_CASE(4) break;
+    default: PFN_LNB_CASE(8) break;
+  }
+#undef PFN_LNB_CASE
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 

@@ -151,11 +151,13 @@ GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, 
 
 extern "C" {
 
+static bool g_fuse_lnbwd = true;
 int pfn_abi_version(void) { return PFN_ABI_VERSION; }
 int pfn_set_tuning(int key, int value) {
   switch (key) {
     case PFN_TUNE_GEMM_NT_KERNEL: set_gemm_nt_big_mode(value); return PFN_OK;
     case PFN_TUNE_GEMM_TN_WRAP: set_gemm_tn_debug_wrap(value); return PFN_OK;
+    case PFN_TUNE_FUSE_LNBWD: g_fuse_lnbwd = value != 0; return PFN_OK;
     default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);
   }
 }
@@ -372,25 +374,45 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
   // weight gradients (dy2, dh, dy1, dqkv) in its own buffers; all 4*nlayers weight (and fused bias)
   // gradients are then computed by ONE grouped launch of 256x256 tiles (gemm_tn_big_kernel) -- enough
   // tiles to fill the chip without splitting the token axis into hundreds of atomic partial sums.
+  // The two GEMMs whose output is the gradient w.r.t. a LayerNorm output (dx1 -> LN1, dx -> the previous layer's LN2) run that
+  // LayerNorm's backward in their epilogue (gemm_nt_lnbwd_kernel) when the shape allows: the sum never reaches HBM, and the
+  // bias gradient of the Linear in front of the LayerNorm moves to the weight-gradient GEMM that reads the same operand.
+  auto lnb = [&](const void* A, long lda, const void* Bw, long ldb, int K, const void* aux, const float* y, const float* mean, const float* rstd,
+                 const float* gamma, void* dx_t, float* dgamma, float* dbeta) {
+    GemmLNB g; memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = Bw; g.ldb = ldb; g.M = M; g.N = E; g.K = K; g.aux = aux;
+    g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta;
+    return g;
+  };
+  bool fuse_lnb = g_fuse_lnbwd && prec == PFN_PREC_BF16 && d->nlayers > 0;
+  if (fuse_lnb) {
+    const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
+    fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1)) &&
+               gemm_lnbwd_supported(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, a.y2, a.mean2, a.rstd2, params + p.g2, a.dy2_t, grads + p.g2, grads + p.be2));
+  }
   for (int l = d->nlayers - 1; l >= 0; --l) {
     const LayerP &p = L.layer[l], &t = L.layer_t[l];
     LayerWs& a = w.layer[l];
-    // LN2
     // LN2: the input gradient leaves only in operand precision (dy2_t); it is both the GEMM operand below and the
-    // residual-branch gradient that the dx1 GEMM adds back, so no f32 copy is written or re-read
-    PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
+    // residual-branch gradient that the dx1 GEMM adds back, so no f32 copy is written or re-read.  (Fused: the layer above
+    // already left dy2_t.)
+    if (!fuse_lnb || l == d->nlayers - 1)
+      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
       GemmNT g = nt(a.dy2_t, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = a.hpre; g.ld_aux = F; g.out_t = a.dh_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
-    {  // dx1 = dh . W1 + dy2
-      GemmNT g = nt(a.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID_T | EPI_OUT_T);
-      g.aux = a.dy2_t; g.ld_aux = E; g.out_t = w.gA_t; g.ld_out_t = E;
-      PFN_TRY(launch_gemm_nt(g, prec, s));
+    if (fuse_lnb) {  // dy1 = LN1 backward of (dh . W1 + dy2)
+      PFN_TRY(launch_gemm_lnbwd(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1), s));
+    } else {
+      {  // dx1 = dh . W1 + dy2
+        GemmNT g = nt(a.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID_T | EPI_OUT_T);
+        g.aux = a.dy2_t; g.ld_aux = E; g.out_t = w.gA_t; g.ld_out_t = E;
+        PFN_TRY(launch_gemm_nt(g, prec, s));
+      }
+      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, a.dy1_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
     }
-    // LN1
-    PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, a.dy1_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
     {  // d(ctx) = dy1 . Wo
       GemmNT g = nt(a.dy1_t, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
       g.out_t = w.dctx_t; g.ld_out_t = E;
@@ -402,7 +424,12 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       at.dctx = w.dctx_t; at.dqkv = a.dqkv_t; at.delta = w.delta; at.ds = w.ds;
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
-    {  // dx = dqkv . Win + dy1
+    if (fuse_lnb && l > 0) {  // dy2 of the layer below = its LN2 backward of (dqkv . Win + dy1)
+      const LayerP& pb = L.layer[l - 1];
+      LayerWs& ab = w.layer[l - 1];
+      PFN_TRY(launch_gemm_lnbwd(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, ab.y2, ab.mean2, ab.rstd2, params + pb.g2, ab.dy2_t,
+                                    grads + pb.g2, grads + pb.be2), s));
+    } else {  // dx = dqkv . Win + dy1
       // the gradient stays in operand precision between layers; the embedding's gradient (layer 0) leaves in f32
       GemmNT g = nt(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID_T | (l == 0 ? EPI_OUT_F32 : EPI_OUT_T));
       g.aux = a.dy1_t; g.ld_aux = E; g.out_f32 = w.gA; g.ld_out_f32 = E; g.out_t = w.gA_t; g.ld_out_t = E;
@@ -420,9 +447,10 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       const LayerP& p = L.layer[l];
       LayerWs& a = w.layer[l];
       const char* xin_t = (l == 0) ? w.x0_t : w.layer[l - 1].x2_t;
-      add(a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, nullptr);
+      // (b2 / b_o: column sums of dy2 / dy1 -- from the LayerNorm-backward kernel when that ran on its own)
+      add(a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, fuse_lnb && l < d->nlayers - 1 ? grads + p.b2 : nullptr);
       add(a.dh_t, F, a.x1_t, E, grads + p.w1, E, F, E, grads + p.b1);
-      add(a.dy1_t, E, a.ctx, E, grads + p.w_o, E, E, E, nullptr);
+      add(a.dy1_t, E, a.ctx, E, grads + p.w_o, E, E, E, fuse_lnb ? grads + p.b_o : nullptr);
       add(a.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, 3 * E, E, grads + p.b_in);
     }
     bool grouped = prec == PFN_PREC_BF16;
@@ -568,6 +596,16 @@ int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M
   g.ry = ry; g.rmean = rmean; g.rrstd = rrstd; g.rgamma = rgamma; g.rbeta = rbeta; g.gamma = gamma; g.beta = beta; g.eps = eps;
   g.y = y; g.mean = mean; g.rstd = rstd; g.x_t = x_t;
   PFN_TRY(launch_gemm_ln(g, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_gemm_lnbwd(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const void* aux,
+                      const float* y, const float* mean, const float* rstd, const float* gamma,
+                      void* dx_t, float* dgamma, float* dbeta, void* stream) {
+  GemmLNB g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.aux = aux;
+  g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta;
+  PFN_TRY(launch_gemm_lnbwd(g, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep, int prec, void* stream) {

@@ -84,6 +84,20 @@ struct GemmLN {
 bool gemm_ln_supported(const GemmLN& g);
 int launch_gemm_ln(const GemmLN& g, hipStream_t stream);
 
+// A data-gradient GEMM with the backward of the LayerNorm whose OUTPUT gradient it produces fused in (gemm_nt_lnbwd_kernel):
+//   v = A . B^T + aux;  dx_t = LayerNorm backward of v through (y, mean, rstd, gamma);  dgamma += sum_rows v xhat;  dbeta += sum_rows v
+struct GemmLNB {
+  const void* A; long lda;      // [M,K] bf16
+  const void* B; long ldb;      // [N,K] bf16
+  int M, N, K;
+  const void* aux;              // [M,N] bf16 (row pitch N): the residual-branch gradient added to the product
+  const float* y; const float* mean; const float* rstd; const float* gamma;   // the LayerNorm's input [M,N], row statistics [M], weight [N]
+  void* dx_t;                   // [M,N] bf16: gradient w.r.t. the LayerNorm input
+  float* dgamma; float* dbeta;  // [N] f32, accumulated with atomics
+};
+bool gemm_lnbwd_supported(const GemmLNB& g);
+int launch_gemm_lnbwd(const GemmLNB& g, hipStream_t stream);
+
 bool gemm_tn_group_supported(const TnProblem& p);
 int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream);
 
