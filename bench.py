@@ -196,6 +196,25 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
         add(f'gemm_nt_ln[{name} + residual + LayerNorm {M}x{E}x{k}]', 'gemm_nt_ln_kernel', t, 2.0 * M * E * k, count)
         return True
 
+    def gemm_lnbwd(name, k, count):
+        """a data-gradient GEMM with the backward of the LayerNorm it feeds in the epilogue (what the step runs when emsize allows)"""
+        A, B_, aux = r(M, k), r(E, k), r(M, E)
+        y, gamma = f32(M, E), f32(E)
+        mean, rstd = y.mean(1), 1 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
+        bufs = (torch.empty(M, E, dtype=bf, device=dev), torch.zeros(E, device=dev), torch.zeros(E, device=dev))
+        try:
+            t = time_kernel(lambda: hipops.gemm_lnbwd(A, B_, aux, y, mean, rstd, gamma, out=bufs))
+        except _hip.HipExtensionError:
+            return False
+        add(f'gemm_nt_lnbwd[{name} {M}x{E}x{k}]', 'gemm_nt_lnbwd_kernel', t, 2.0 * M * E * k, count)
+        return True
+
+    def layernorm_bwd(count):
+        gA, y, gamma = r(M, E), f32(M, E), f32(E)
+        mean, rstd = y.mean(1), 1 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
+        t = time_kernel(lambda: hipops.layernorm_bwd(gA, y, gamma, mean, rstd, Hh.PREC_BF16, want_f32=False))
+        add(f'layernorm_bwd[{M}x{E}, operand-precision gradient in and out]', 'layernorm_bwd_kernel', t, 0.0, count)
+
     def wgrad_group():
         # every weight gradient of the stack in ONE grouped launch (pfn_stack_backward defers them)
         probs = []
@@ -215,9 +234,16 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     if not gemm_ln('linear2', F, L):
         gemm('linear2 + residual', E, F, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
     gemm('d(hpre) = dy2.W2 * gelu\'', F, E, Hh.EPI_GELU_BWD | Hh.EPI_OUT_T, L)
-    gemm('dx1 = dh.W1 + dy2', E, F, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
+    if gemm_lnbwd('dy1 = LN1 backward of dh.W1 + dy2', F, L):
+        if L > 1:
+            gemm_lnbwd('dy2 = LN2 backward (layer below) of dqkv.Win + dy1', 3 * E, L - 1)
+        gemm('dx = dqkv.Win + dy1 (first layer, f32 out)', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_F32, 1)
+        layernorm_bwd(1)
+    else:
+        gemm('dx1 = dh.W1 + dy2', E, F, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
+        gemm('dx = dqkv.Win + dy1', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
+        layernorm_bwd(2 * L)
     gemm('d(ctx) = dy1.Wo', E, E, Hh.EPI_OUT_T, L)
-    gemm('dx = dqkv.Win + dy1', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
     wgrad_group()
     qkv = r(batch, S, 3 * E)
     D = E // H
