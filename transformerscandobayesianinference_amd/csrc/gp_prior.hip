@@ -248,18 +248,46 @@ __global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0, int r_en
 
 // ---------------------------------------------------------------------------------------------
 // syrk: C_ij -= P_i P_j^T on 128x128 tiles of rows >= r0, columns [c0, c1), lower triangle only, where
-// P = solved panel columns [kp0, kp0 + K), K a multiple of 64 up to 256.  Exact-f32 MFMA.
+// P = solved panel columns [kp0, kp0 + K), K a multiple of 64 up to 256.  f32-accurate (split-bf16 MFMA, below).
 // Two uses (two-level blocking, see launch_gp_sample): K = 64 restricted to the remaining columns of the
 // current 256-wide outer block, and K = 256 over the whole trailing matrix once per outer block -- the
 // trailing matrix is then read and written S/256 times instead of S/64 times.
 // ---------------------------------------------------------------------------------------------
-constexpr int SYRK_KC = 32;   // panel columns per LDS chunk: 2 x 16 KiB per workgroup, so 3-4 workgroups share a CU and
-                              // one's panel loads / C read-modify-write hide under another's MFMAs
+// Arithmetic: f32 accuracy on the bf16 matrix cores.  Every panel value is split into three bf16 terms when its chunk is written
+// to LDS, a = hi + mid + lo exactly to 2^-27 |a| (each residual is exact in f32), and a block product is the six bf16 MFMAs
+// hi.hi + (hi.mid + mid.hi) + (mid.mid + hi.lo + lo.hi); the dropped terms are below 2^-25 |a||b|, the products are exact in the f32
+// accumulator.  Six 32x32x16 bf16 MFMAs take 192 cycles per 16 panel columns where the eight 32x32x2 f32 MFMAs of the exact-f32 form
+// take 512.  (Three products -- 2^-17 per term -- would not do: the Gram matrices have condition numbers of 1e6..1e7 in f32 and a
+// noise floor of 1e-4 keeps them positive definite.)
+constexpr int SYRK_KC = 32;   // panel columns per LDS chunk: 2 operands x 3 planes x 8 KiB per workgroup, so 3 workgroups share a CU
+                              // and one's panel loads / C read-modify-write hide under another's MFMAs
+constexpr int SYRK_PLANE = 128 * SYRK_KC * 2;   // one bf16 plane of a 128-row operand chunk
+constexpr int SYRK_LDS = 2 * 3 * SYRK_PLANE;
+
+// hi / mid / lo planes of the 4 floats of one 16-byte chunk -> three 8-byte LDS writes (row r, float chunk c of the 32-column chunk)
+PFN_DEV void syrk_commit_split(LdsPtr tile, int r, int c, u32x4 raw) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const f32x4 v = __builtin_bit_cast(f32x4, raw);
+  bf16x4 hi, mid, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (bf16)v[e];
+    const float r1 = v[e] - (float)hi[e];
+    mid[e] = (bf16)r1;
+    lo[e] = (bf16)(r1 - (float)mid[e]);
+  }
+  const int off = lds_off16<SYRK_KC * 2>(r, c >> 1) + (c & 1) * 8;
+  *reinterpret_cast<lds_bf16x4*>(tile + off) = hi;
+  *reinterpret_cast<lds_bf16x4*>(tile + SYRK_PLANE + off) = mid;
+  *reinterpret_cast<lds_bf16x4*>(tile + 2 * SYRK_PLANE + off) = lo;
+}
+
 __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r1, int c0, int c1, int kp0, int K) {
-  constexpr int RB = SYRK_KC * 4;  // 128-byte chunk rows
+  constexpr int RB = SYRK_KC * 4;  // 128-byte chunk rows in global memory (f32)
+  constexpr int RBT = SYRK_KC * 2; // 64-byte rows of a bf16 plane in LDS
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr tA = lds_cast(smem_raw);
-  LdsPtr tB = tA + 128 * RB;
+  LdsPtr tB = tA + 3 * SYRK_PLANE;
   // Hardware places workgroup n on XCD n % 8.  All tiles of one dataset share its panel rows, so datasets are
   // dealt to XCDs (dataset b -> XCD b % 8) when the batch allows it: the panel then stays in that XCD's L2
   // instead of being re-fetched by every tile.
@@ -279,13 +307,21 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  TileStage<float, 128, RB, 256> sa, sb;
+  using Stage = TileStage<float, 128, RB, 256>;
+  Stage sa, sb;
+  auto commit = [&](const Stage& st, LdsPtr tile) {
+#pragma unroll
+    for (int i = 0; i < Stage::PER; ++i) {
+      const int id = threadIdx.x + i * 256;
+      syrk_commit_split(tile, id / Stage::NCH, id % Stage::NCH, st.regs[i]);
+    }
+  };
   sa.issue(Kb + (long)i0 * S + kp0, S, r1 - i0, SYRK_KC);
   sb.issue(Kb + (long)j0 * S + kp0, S, r1 - j0, SYRK_KC);
   for (int kc = 0; kc < K; kc += SYRK_KC) {
     if (kc > 0) __syncthreads();      // everyone is done reading the previous chunk
-    sa.template commit<false>(tA);
-    sb.template commit<false>(tB);
+    commit(sa, tA);
+    commit(sb, tB);
     __syncthreads();
     if (kc + SYRK_KC < K) {           // next chunk's loads fly under this chunk's MFMAs
       sa.issue(Kb + (long)i0 * S + kp0 + kc + SYRK_KC, S, r1 - i0, SYRK_KC);
@@ -293,15 +329,27 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r
     }
 #pragma unroll
     for (int ks = 0; ks < SYRK_KC; ks += 16) {
-      Frag<float> fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = load_frag_row<float, RB>(tA, wm * 64 + i * 32 + (lane & 31), ks);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<float, RB>(tB, wn * 64 + j * 32 + (lane & 31), ks);
+      Frag<bf16> fa[2][3], fb[2][3];   // [block][hi, mid, lo]
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);   // swapped: a lane owns one ROW of the tile
+        for (int pl = 0; pl < 3; ++pl) fa[i][pl] = load_frag_row<bf16, RBT>(tA + pl * SYRK_PLANE, wm * 64 + i * 32 + (lane & 31), ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fb[j][pl] = load_frag_row<bf16, RBT>(tB + pl * SYRK_PLANE, wn * 64 + j * 32 + (lane & 31), ks);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // swapped operands: a lane owns one ROW of the tile; smallest terms first
+          f32x16 c = acc[i][j];
+          c = mma32(fb[j][2], fa[i][0], c);
+          c = mma32(fb[j][0], fa[i][2], c);
+          c = mma32(fb[j][1], fa[i][1], c);
+          c = mma32(fb[j][1], fa[i][0], c);
+          c = mma32(fb[j][0], fa[i][1], c);
+          acc[i][j] = mma32(fb[j][0], fa[i][0], c);
+        }
     }
   }
   // read-modify-write of C in 16-byte pieces: lane = row, accumulator group g = 4 consecutive columns
@@ -448,7 +496,7 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
   //   rank-256 update of the trailing matrix.
   auto syrk = [&](int r0, int r1, int c0, int c1, int kp0, int K) {
     const int ti = (r1 - r0 + 127) / 128, tj = (c1 - c0 + 127) / 128;
-    if (ti > 0 && tj > 0) hipLaunchKernelGGL(gp_syrk_kernel, dim3(tj, ti, B), dim3(256), 2 * 128 * SYRK_KC * 4, s, a, r0, r1, c0, c1, kp0, K);
+    if (ti > 0 && tj > 0) hipLaunchKernelGGL(gp_syrk_kernel, dim3(tj, ti, B), dim3(256), SYRK_LDS, s, a, r0, r1, c0, c1, kp0, K);
   };
   const size_t tw_lds = 2 * 64 * TW_STRIDE + OBW * sizeof(float);
   static bool tw_attr_set = false;   // (constant size; the call costs tens of microseconds of host time)
