@@ -713,18 +713,44 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 // =============================================================================================
 template <typename T, int D> struct BwdDqCfg {
   using C = AttnCfg<T, D>;
-  static constexpr int DSB = C::QBLK * (int)sizeof(T);        // bytes of one dS^T row segment (the workgroup's queries)
-  static constexpr int DSS = PadStride<DSB>::COL;
-  static constexpr int BUF = C::KVB * DSS + C::CIMG;          // dS^T tile + K tile (col images)
-  // both images go global -> LDS by LDS-DMA in 1-KiB pieces (they are whole numbers of pieces for every shipped shape);
-  // the lanes' source offsets sit in an LDS table (as in the key-block pass)
-  static constexpr int NPD = C::KVB * DSS / 1024, NPK = C::CIMG / 1024, NP = NPD + NPK;
-  static constexpr int NI = (NP + C::NW - 1) / C::NW;
-  static constexpr int PVTAB = NI * C::NT * 4;
+  // dS^T reaches LDS exactly as the key-block pass stored it: 32 x 32 blocks of 1-KiB panels ([32 keys][32 bytes of queries],
+  // store_frag_pair_blocked).  A wave multiplies only ITS 32 queries, i.e. one block column, so each wave copies its own
+  // KVB/32 blocks of a key tile -- contiguous kilobytes, one whole-line LDS-DMA instruction per panel -- into a private ring and
+  // reads its fragments straight from the panels (the transposing LDS read wants 4 key rows x 32 bytes, which is a panel's shape).
+  // (The first version gathered a [keys][256 queries] image for the whole workgroup: every DMA instruction then touched ~28
+  // cache lines for 32 bytes each.)  The tiles come from HBM and the MFMAs of a tile (0.5 us) are far shorter than a fetch, so
+  // THREE tiles rotate (two in flight under the one being multiplied); the K tiles, shared by the workgroup and by the eight
+  // query blocks of a head through L2, keep two in a column image.
+  static constexpr int BLK = 32 * 32 * (int)sizeof(T);        // bytes of one block
+  static constexpr int DSW = (C::KVB / 32) * BLK;             // one wave's dS^T bytes per key tile
+  static constexpr int NPW = DSW / 1024;                      // ... = its DMA instructions per tile
+  static constexpr int NDS = 3, NK = 2;
+  static constexpr int NPK = C::CIMG / 1024, NIK = (NPK + C::NW - 1) / C::NW;
+  static constexpr int RING = C::NW * NDS * DSW + NK * C::CIMG;
   static constexpr int TSELF = C::NW * 32 * (C::RB + 16);     // the self-key tail's image (re-uses the tile buffers after the loop)
-  static constexpr int LDS = 2 * BUF + PVTAB > TSELF ? 2 * BUF + PVTAB : TSELF;
-  static_assert((C::KVB * DSS) % 1024 == 0 && C::CIMG % 1024 == 0, "dQ-pass LDS images must be whole DMA pieces");
+  static constexpr int LDS = RING > TSELF ? RING : TSELF;
+  static_assert(C::CIMG % 1024 == 0, "dQ-pass K image must be whole DMA pieces");
 };
+
+// dS^T fragment (contraction = keys k0 .. k0+15 of the tile, columns = the wave's 32 queries) from the wave's private copy of its blocks
+template <typename T> PFN_DEV Frag<T> load_frag_ds_blocked(const lds_char* blocks, int k0) {
+  const int l = lane_id(), h = l >> 5;
+  const lds_char* blk = blocks + (k0 >> 5) * (32 * 32 * (int)sizeof(T));
+  const int r0 = (k0 & 31) + 8 * h;
+  Frag<T> f;
+  if constexpr (sizeof(T) == 2) {
+    const int i = l & 15, g = (l >> 4) & 1;
+    const lds_char* p = blk + g * 1024 + (r0 + (i >> 2)) * 32 + 8 * (i & 3);
+    const bf16x4 lo = ds_read_tr16_b64(p), hi = ds_read_tr16_b64(p + 4 * 32);
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  } else {
+    const int n = l & 31;
+    const lds_char* p = blk + (n >> 3) * 1024 + (n & 7) * 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = lds_read_f32(p + (r0 + e) * 32);
+  }
+  return f;
+}
 
 template <typename T, int D>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnArgs a) {
@@ -732,8 +758,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   using Q = BwdDqCfg<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
-  auto Ds = [&](int buf) { return smem + buf * Q::BUF; };
-  auto Kc = [&](int buf) { return smem + buf * Q::BUF + C::KVB * Q::DSS; };
+  auto Kc = [&](int slot) { return smem + C::NW * Q::NDS * Q::DSW + slot * C::CIMG; };
 
   AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
   wg.b = a.B - 1 - wg.b;            // most recently written dS^T first (see above)
@@ -759,68 +784,63 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
 
-  // dS^T of this (dataset, head) in 32 x 32 blocks (store_frag_pair_blocked).  A key tile goes global -> LDS by LDS-DMA (issued
-  // from assembly, pfn_device.h dma16), no staging registers: the dS^T tile of this workgroup's queries into a column image
-  // (rows = keys; the lane's 16 bytes of a piece come from wherever the blocked layout keeps that (key, 8 queries) chunk), the K
-  // tile into a second column image.  Rows of keys >= sep: the key-block pass stored zeros for them (dS^T), the descriptor's
-  // range ends at sep (K).  Tile t+1 is issued at the top of tile t and waited for at its end.
-  constexpr int DSBLK = 32 * 32;                     // elements per block
-  constexpr int BCH = DSBLK * (int)sizeof(T) / 16;   // 16-byte chunks per block
+  // Key tiles go global -> LDS by LDS-DMA issued from assembly (pfn_device.h dma16), no staging registers: the wave's dS^T blocks
+  // verbatim into its ring (BwdDqCfg), the K tile into a column image shared by the workgroup.  Rows of keys >= sep: the key-block
+  // pass stored zeros for them (dS^T), the descriptor's range ends at sep (K).  At the top of tile t the K tile t+1 and then the
+  // dS^T tile t+2 are issued; the end of tile t waits for everything EXCEPT that last dS^T tile (vmcnt = its instruction count:
+  // loads return in order), so a dS^T fetch has two tile times to arrive.  (One tile ahead, the pass ran at 3.4 TB/s.)
   const long ds_bh = ((long)b * a.H + hd) * a.ds_rows * a.ds_ld;
   const DmaRsrc rd = make_dma_rsrc(reinterpret_cast<const T*>(a.ds) + ds_bh, (long)a.ds_rows * a.ds_ld * (long)sizeof(T));
   const DmaRsrc rk = make_dma_rsrc(Kp, ((long)(sep - 1) * rs + D) * (long)sizeof(T));   // rows >= sep read as zero
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
-  LdsPtr pvtab = smem + 2 * Q::BUF;   // [NI][NT] ints: the lane's source byte offset inside a tile, per piece of its wave
+  LdsPtr dsw = smem + uwave * Q::NDS * Q::DSW;                 // this wave's ring
+  const int blocks_per_row = a.ds_ld / 32;
+  const int pvd = (q0 / 32 + uwave) * Q::BLK + lane * 16;      // the wave's block column; + key block row * blocks_per_row * BLK
+  int pvk[Q::NIK];                                             // K image: row = key, 16-byte chunks of the head's D columns
 #pragma unroll
-  for (int i = 0; i < Q::NI; ++i) {
-    const int g = uwave + C::NW * i;
-    int off = BUF_OOB;
-    if (g < Q::NPD) {           // dS^T image: byte = 1024 g + 16 lane -> (key row, chunk of 16 bytes of its queries)
-      const int byte = g * 1024 + lane * 16;
-      const int row = byte / Q::DSS, cb = byte % Q::DSS;
-      if (cb < Q::DSB) {
-        const int q = cb / (int)sizeof(T);                       // first query of the chunk inside the workgroup's block
-        const int kb = row / 32, j = row % 32, qb = q / 32, qq = q % 32;
-        int w;                                                   // chunk index inside the 32 x 32 block (store_frag_pair_blocked)
-        if constexpr (sizeof(T) == 2) w = (((qq >> 4) * 32 + j) * 2 + ((qq >> 3) & 1));
-        else w = (((qq >> 3) * 32 + j) * 2 + ((qq >> 2) & 1));
-        off = ((kb * (a.ds_ld / 32) + q0 / 32 + qb) * BCH + w) * 16;
-      }
-    } else if (g < Q::NP) {     // K image: row = key, 16-byte chunks of the head's D columns
-      const int byte = (g - Q::NPD) * 1024 + lane * 16;
-      const int row = byte / C::CS, cb = byte % C::CS;
-      if (cb < C::RB) off = row * (int)(rs * sizeof(T)) + cb;
-    }
-    *reinterpret_cast<__attribute__((address_space(3))) int*>(pvtab + (i * C::NT + threadIdx.x) * 4) = off;
+  for (int i = 0; i < Q::NIK; ++i) {
+    const int byte = (uwave + C::NW * i) * 1024 + lane * 16;
+    const int row = byte / C::CS, cb = byte % C::CS;
+    pvk[i] = cb < C::RB ? row * (int)(rs * sizeof(T)) + cb : BUF_OOB;
   }
   const int ntiles = (sep + C::KVB - 1) / C::KVB;
-  const int tile_ds_bytes = (C::KVB / 32) * (a.ds_ld / 32) * BCH * 16, tile_k_bytes = C::KVB * (int)(rs * sizeof(T));
-  auto dma = [&](int buf, int t) {
-    int pv[Q::NI];
+  const int row_bytes = blocks_per_row * Q::BLK, tile_k_bytes = C::KVB * (int)(rs * sizeof(T));
+  auto dma_ds = [&](int slot, int t) {
 #pragma unroll
-    for (int i = 0; i < Q::NI; ++i) pv[i] = *reinterpret_cast<const __attribute__((address_space(3))) int*>(pvtab + (i * C::NT + threadIdx.x) * 4);
+    for (int i = 0; i < Q::NPW; ++i)      // piece i: block row i / (BLK / 1024) of the tile, KiB i % (BLK / 1024) of that block
+      dma16(rd, dsw + slot * Q::DSW + i * 1024, pvd + (t * (C::KVB / 32) + i / (Q::BLK / 1024)) * row_bytes + (i % (Q::BLK / 1024)) * 1024);
+  };
+  auto dma_k = [&](int slot, int t) {
 #pragma unroll
-    for (int i = 0; i < Q::NI; ++i) {
-      const int g = uwave + C::NW * i;
-      if (g < Q::NPD) dma16(rd, smem + buf * Q::BUF + g * 1024, pv[i] + t * tile_ds_bytes);
-      else if (g < Q::NP) dma16(rk, smem + buf * Q::BUF + C::KVB * Q::DSS + (g - Q::NPD) * 1024, pv[i] + t * tile_k_bytes);
+    for (int i = 0; i < Q::NIK; ++i)
+      if (uwave + C::NW * i < Q::NPK) dma16(rk, Kc(slot) + (uwave + C::NW * i) * 1024, pvk[i] + t * tile_k_bytes);
+  };
+  constexpr int my_ds_pieces = Q::NPW;
+  auto wait_all_but = [&](int n) {     // vmcnt(n): everything but the n most recent loads has landed (n is wave-uniform)
+    switch (n) {
+#define PFN_VMW(N) case N: __builtin_amdgcn_s_waitcnt(0x0F70 | N); asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+      PFN_VMW(1) PFN_VMW(2) PFN_VMW(3) PFN_VMW(4) PFN_VMW(5) PFN_VMW(6) PFN_VMW(7) PFN_VMW(8) PFN_VMW(9) PFN_VMW(10)
+#undef PFN_VMW
+      default: dma_wait_all();
     }
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  __syncthreads();               // the offset table is complete
-  if (ntiles > 0) dma(0, 0);
-  dma_wait_all();
+  static_assert(Q::NPW <= 10, "piece count per wave exceeds the vmcnt cases above");
+  if (ntiles > 0) { dma_k(0, 0); dma_ds(0, 0); }
+  if (ntiles > 1 && !(ABL & 1)) dma_ds(1, 1);
+  wait_all_but(ntiles > 1 && !(ABL & 1) ? my_ds_pieces : 0);
   __syncthreads();
-  auto tile = [&](auto buf_c, int t) {
-    constexpr int BUF = decltype(buf_c)::value;
-    const lds_char* dst = Ds(BUF);
-    const lds_char* kc = Kc(BUF);
+  int sd = 0, sk = 0;                  // ring slots of tile t
+  for (int t = 0; t < ntiles; ++t) {
+    const lds_char* dst = dsw + sd * Q::DSW;
+    const lds_char* kc = Kc(sk);
     constexpr int NKS = C::KVB / 16;     // contraction steps per tile
-    if (!(ABL & 1) && t + 1 < ntiles) dma(BUF ^ 1, t + 1);   // the other buffer: every wave is past the barrier that ended tile t-1
+    const int sd2 = sd == 0 ? 2 : sd - 1;                      // (t + 2) % 3
+    const bool more_ds = !(ABL & 1) && t + 2 < ntiles;
+    if (t + 1 < ntiles) dma_k(sk ^ 1, t + 1);                  // slots last read in tile t-1: every wave is past that tile's barrier
+    if (more_ds) dma_ds(sd2, t + 2);
     Frag<T> dsf[NKS];
 #pragma unroll
-    for (int c = 0; c < NKS; ++c) dsf[c] = load_frag_tr_p<T, Q::DSS, 1>(dst, c * 16, wave * 32);
+    for (int c = 0; c < NKS; ++c) dsf[c] = load_frag_ds_blocked<T>(dst, c * 16);
     Frag<T> cf[2][C::NDB];
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) cf[0][db] = load_frag_tr_p<T, C::CS, 1>(kc, 0, db * 32);
@@ -835,12 +855,10 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
       for (int db = 0; db < C::NDB; ++db) dq[db] = mma32(cf[c & 1][db], dsf[c], dq[db]);
       PFN_PIN_LDS_MFMA();
     }
-    dma_wait_all();
+    wait_all_but(more_ds ? my_ds_pieces : 0);
     if (!(ABL & 4)) __syncthreads();
-  };
-  for (int t = 0; t < ntiles; t += 2) {
-    tile(I0{}, t);
-    if (t + 1 < ntiles) tile(I1{}, t + 1);
+    sd = sd == 2 ? 0 : sd + 1;
+    sk ^= 1;
   }
 
   // ---- self key of the test rows (i >= sep): p_i = exp(q_i.k_i scale - lse_i), ds_i = p_i (dO_i.v_i - delta_i),
