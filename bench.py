@@ -45,7 +45,7 @@ PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
 # BASELINE.json configs (index = position in the list; 3 is configs[1] on 8 GPUs)
 CONFIGS = {
     2: dict(prior='fast_gp', bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, criterion='bar', num_bars=1000,
-            hyperparameters=dict(noise=1e-4, outputscale=1.0, lengthscale=0.6), batch=32, streams=2, eval_pos='weighted', parity_batch=2, parity_sep=1755,
+            hyperparameters=dict(noise=1e-4, outputscale=1.0, lengthscale=0.6), batch=64, streams=2, eval_pos='weighted', parity_batch=2, parity_sep=1755,
             metric='synthetic datasets/sec (GP prior, bptt=2000)',
             workload='priors.fast_gp, bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, 1000 bars (BASELINE.json configs[1])'),
     4: dict(prior='mlp', bptt=1000, num_features=60, emsize=512, nhead=4, nhid=1024, nlayers=6, criterion='bce', num_bars=1,

@@ -61,10 +61,12 @@ const char* pfn_last_error_string(void);
  * order).  PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
  * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one.
  * PFN_TUNE_FUSE_LNBWD: 1 (default) the stack backward runs LayerNorm backward inside the data-gradient GEMMs that feed it
- * (pfn_op_gemm_lnbwd), 0 as separate kernels. */
+ * (pfn_op_gemm_lnbwd), 0 as separate kernels.  PFN_TUNE_GEMM_PERSIST: > 0 runs the 256x256 NT GEMM as that many persistent
+ * workgroups walking tiles (gemm_nt_persist_kernel; measured, off by default). */
 enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_GEMM_TN_WRAP = 1, /* profiling only: > 0 makes the grouped TN kernel re-read its first `value` token rows (wrong results, cache-resident operands) */
-       PFN_TUNE_FUSE_LNBWD = 2 };
+       PFN_TUNE_FUSE_LNBWD = 2,
+       PFN_TUNE_GEMM_PERSIST = 3  /* workgroups of the persistent 256x256 NT GEMM (one per CU walking tiles); 0 = the one-tile-per-workgroup kernel */ };
 int pfn_set_tuning(int key, int value);
 
 /* ---- parameter packing ------------------------------------------------------------------------

@@ -117,6 +117,44 @@ def test_gemm_nt_big_plain(M, N, K, big_gemm):
     assert relerr(out[:M], out_small) < 1e-6
 
 
+@pytest.mark.parametrize('wgs', [256, 5])
+@pytest.mark.parametrize('M,N,K', [(1024, 512, 128), (1000, 768, 512), (2560, 256, 1536), (300, 1024, 256)])
+def test_gemm_nt_persistent(M, N, K, wgs):
+    """The persistent 256x256 kernel (one workgroup walking tiles, next tile's first stage requested during the last stage of the
+    current one, stores left in flight across the tile boundary): every epilogue the stack uses, full and ragged last row tiles,
+    many tiles per workgroup (wgs = 5) and one (256)."""
+    dt = torch.bfloat16
+    lib = _hip.lib()
+    A, B = rnd(M, K, dtype=dt, seed=3), rnd(N, K, dtype=dt, seed=4, scale=0.1)
+    bias, aux = rnd(N, seed=5), rnd(M, N, dtype=dt, seed=7)
+    base = A.double() @ B.double().t()
+    pre = base + bias.double()
+    _hip.check(lib.pfn_set_tuning(0, 2), 'tuning'); _hip.check(lib.pfn_set_tuning(3, wgs), 'tuning')
+    try:
+        out_t = torch.full((M + 2, N), float('nan'), dtype=dt, device=dev()); out2 = torch.full_like(out_t, float('nan'))
+        hipops.gemm_nt(A, B, _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_T | _hip.EPI_OUT2_T, BF, bias=bias, out_t=out_t[:M], out2_t=out2[:M])
+        assert relerr(out2[:M], gelu_grad(pre)) < 4e-3 and relerr(out_t[:M], torch.nn.functional.gelu(pre)) < 4e-3
+        assert torch.isnan(out_t[M:].float()).all() and torch.isnan(out2[M:].float()).all()
+        hipops.gemm_nt(A, B, _hip.EPI_BIAS | _hip.EPI_OUT_T, BF, bias=bias, out_t=out_t[:M])
+        assert relerr(out_t[:M], pre) < 4e-3
+        hipops.gemm_nt(A, B, _hip.EPI_OUT_T, BF, out_t=out_t[:M])
+        assert relerr(out_t[:M], base) < 4e-3
+        hipops.gemm_nt(A, B, _hip.EPI_GELU_BWD | _hip.EPI_OUT_T, BF, aux=aux, out_t=out_t[:M])
+        assert relerr(out_t[:M], base * aux.double()) < 4e-3
+        hipops.gemm_nt(A, B, _hip.EPI_RESID_T | _hip.EPI_OUT_T, BF, aux=aux, out_t=out_t[:M])
+        assert relerr(out_t[:M], base + aux.double()) < 4e-3
+        out = torch.full((M + 2, N), float('nan'), device=dev())
+        hipops.gemm_nt(A, B, _hip.EPI_RESID_T | _hip.EPI_OUT_F32, BF, aux=aux, out_f32=out[:M])
+        assert relerr(out[:M], base + aux.double()) < 1e-5 and torch.isnan(out[M:]).all()
+        # bit-identical to the one-tile-per-workgroup kernel (same stages, same MFMA order, same epilogue)
+        _hip.check(lib.pfn_set_tuning(3, 0), 'tuning')
+        ref = torch.empty(M, N, device=dev())
+        hipops.gemm_nt(A, B, _hip.EPI_RESID_T | _hip.EPI_OUT_F32, BF, aux=aux, out_f32=ref)
+        assert torch.equal(out[:M], ref)
+    finally:
+        lib.pfn_set_tuning(3, 0); lib.pfn_set_tuning(0, 0)
+
+
 def test_gemm_nt_big_asymmetric_identity(big_gemm):
     A = torch.eye(256, device=dev()).to(torch.bfloat16)
     B = (torch.arange(512 * 256, device=dev()).float().view(512, 256) % 251 / 16).to(torch.bfloat16)

@@ -11,6 +11,7 @@ if os.environ.get('PFN_LIB'):
 H = _hip
 ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=16); ap.add_argument('--modes', default='2,3')
 ap.add_argument('--k', type=int, default=0, help='override the contraction length (64: one stage = prologue + epilogue only)')
+ap.add_argument('--persist', type=int, default=0, help='PFN_TUNE_GEMM_PERSIST value: workgroups of the persistent kernel (0 = off)')
 ap.add_argument('--lib', default=None, help='alternative build of libpfn_hip.so (experiment variants under _build/exp)')
 a = ap.parse_args()
 if a.lib:
@@ -31,6 +32,7 @@ cases = [  # name, N, K, flags, count per step
     ('d(ctx)', E, E, H.EPI_OUT_T, L),
     ('dx', E, 3 * E, H.EPI_RESID | H.EPI_OUT_F32, L),
 ]
+H.check(H.lib().pfn_set_tuning(3, a.persist), 'tuning')
 tot = {}
 for name, N, K, flags, cnt in cases:
     K = a.k or K

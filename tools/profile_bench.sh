@@ -10,13 +10,13 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity > $OUT/bench_stats_run.log 2>&1
-# the same launch shapes (one micro-batch of 16 datasets) on ONE stream: kernel durations without co-runners
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --batch 16 --streams 1 --no-cpu-baseline --no-parity --no-kernel-breakdown > $OUT/bench_stats1_run.log 2>&1
+# the same launch shapes (one micro-batch of 32 datasets) on ONE stream: kernel durations without co-runners
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o bench -- python $ROOT/bench.py --steps 10 --warmup 3 --batch 32 --streams 1 --no-cpu-baseline --no-parity --no-kernel-breakdown > $OUT/bench_stats1_run.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
   name=$(echo $c | tr ' ' '_')
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$name -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-kernel-breakdown > $OUT/pmc_$name.log 2>&1
 done
 cd $ROOT
-python tools/pmc_summary.py $OUT 32 > $OUT/summary.txt 2>&1
+python tools/pmc_summary.py $OUT 64 > $OUT/summary.txt 2>&1
 grep '^{"metric"' $OUT/bench_stats_run.log > $OUT/bench.json
 cat $OUT/summary.txt | head -60

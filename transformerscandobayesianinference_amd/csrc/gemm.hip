@@ -168,113 +168,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// gemm_nt_big_kernel: the product-path NT GEMM for large token counts (bf16 only).
-//   256 x 256 output tile, 64-deep contraction stages (128-byte rows), 8 waves as 2 (M) x 4 (N),
-//   each wave a 128 x 64 sub-tile = 4 x 2 MFMA tiles of 32 x 32.
-//   * operands go HBM -> LDS by direct LDS-DMA (global_load_lds_dwordx4): the LDS image is
-//     lane-linear per wave instruction (8 rows x 128 B), so the bank-conflict swizzle of
-//     load_frag_row (16-byte chunk ^ ((row >> 1) & 7)) is applied to the per-lane SOURCE address;
-//   * two LDS stages (128 KiB): the DMA of stage t+1 is in flight under the MFMAs of stage t;
-//   * MFMAs are issued "swapped" (weights as the A operand) so a lane owns one output row and
-//     4 consecutive columns per accumulator group: the epilogue reads bias / residual / gelu'
-//     inputs and writes its outputs straight from registers in 8- and 16-byte pieces.
-// Requirements (checked by the launcher, otherwise gemm_nt_kernel runs): K % 64 == 0, N % 4 == 0,
-// 16-byte aligned rows on every stream.
-// ---------------------------------------------------------------------------------------------
-// Two shapes of the same kernel (template NWM = waves along M, BK = contraction depth per stage):
-//   NWM 2, BK 64 : 256 x 256 tile, 8 waves, 128 KiB LDS, one workgroup per CU  -- best per-tile rate, long K
-//   NWM 1, BK 32 : 128 x 256 tile, 4 waves,  48 KiB LDS, three workgroups per CU -- the encoder's K = 512..1536
-//                  GEMMs spend as long in their prologue + epilogue (first DMA, bias / GELU / residual, 64..256 MB of
-//                  output) as in the MFMA loop; with three independent workgroups per CU one's stores and first
-//                  loads run under another's MFMAs instead of the whole chip alternating between the two phases.
-constexpr int BIG_BN = 256;
-template <int NWM, int BK> struct BigCfg {
-  static constexpr int BM = NWM * 128, BN = BIG_BN, NW = NWM * 4, NT = NW * 64;
-  static constexpr int RB = BK * 2;                 // bytes per tile row
-  static constexpr int CPR = RB / 16;               // 16-byte chunks per row
-  static constexpr int RPP = 1024 / RB;             // rows per 1-KiB DMA piece
-  static constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;   // pieces per wave per operand
-  static constexpr int TILE_A = BM * RB, TILE_B = BN * RB, STAGE = TILE_A + TILE_B;
-  static constexpr int MIN_BLOCKS = NWM == 1 ? 3 : 1;
+// The epilogue of the big NT kernels, straight from the accumulators (a wave's 128 x 64 sub-tile of the tile at (m0, n0); ep_base:
+// BigEpi<NWM>::BYTES of LDS free for staging).
+template <int NWM> struct BigEpi {
+  static constexpr int EP_T = 32 * 144, EP_F = 32 * 272, EP_WAVE = (2 * EP_T > EP_F ? 2 * EP_T : EP_F), BYTES = NWM * 4 * EP_WAVE;
 };
-constexpr int BIG_BM = 256, BIG_BK = 64;            // the large shape (launcher heuristics, tests)
-
-typedef __attribute__((address_space(1))) const void gvoid_t;
-typedef __attribute__((address_space(3))) void lvoid_t;
-
-template <int FLAGS, int NWM, int BK>
-__global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS)) void gemm_nt_big_kernel(GemmNT g) {
-  using C = BigCfg<NWM, BK>;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  LdsPtr smem = lds_cast(smem_raw);
-
-  const int tiles_n = (g.N + C::BN - 1) / C::BN;
-  const int tiles_m = (g.M + C::BM - 1) / C::BM;
-  const int tid_lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = tid_lin / tiles_n, tn = tid_lin % tiles_n;
-  const int m0 = tm * C::BM, n0 = tn * C::BN;
-
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+template <int FLAGS, int NWM>
+PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n0, int wave, int lane, LdsPtr ep_base) {
   const int wm = wave >> 2, wn = wave & 3;
   const int h = lane >> 5, li = lane & 31;
-
-  // DMA sources: wave w moves the 1-KiB pieces w, w + NW, ... of each operand tile; the bank-conflict swizzle
-  // of load_frag_row goes on the source chunk (the LDS image of a piece is lane-linear)
-  const bf16* pa[C::PA];
-  const bf16* pb[C::PB];
-#pragma unroll
-  for (int i = 0; i < C::PA; ++i) {
-    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
-    const int chunk = swz16<C::RB>(row, lane % C::CPR);
-    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < C::PB; ++i) {
-    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
-    const int chunk = swz16<C::RB>(row, lane % C::CPR);
-    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
-  }
-  auto stage = [&](int buf, int k0) {
-    LdsPtr ta = smem + buf * C::STAGE + wave * 1024;
-    LdsPtr tb = smem + buf * C::STAGE + C::TILE_A + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < C::PA; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * C::NW * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < C::PB; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * C::NW * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = g.K / BK;
-  stage(0, 0);
-  __syncthreads();  // (carries the vmcnt(0) of the DMA)
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-    const lds_char* ta = smem + cur * C::STAGE;
-    const lds_char* tb = ta + C::TILE_A;
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += 16) {
-      Frag<bf16> fa[4], fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, C::RB>(tb, wn * 64 + j * 32 + li, ks);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, C::RB>(ta, wm * 128 + i * 32 + li, ks);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
-    }
-    __syncthreads();
-  }
-
   // ---- epilogue straight from the accumulators: lane = output row, 4 consecutive columns per group ----
   // Every load of the epilogue is issued BEFORE the stores that would otherwise precede it in program order.  The compiler
   // cannot prove that the outputs do not alias bias / aux / resid, so it never moves a load above a store, and gfx9 counts loads
@@ -303,9 +205,8 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
   // f32) instead of 32-byte pieces of 32 different rows.  Padded rows (+16 B) keep both the lane-per-row writes and the
   // row-contiguous reads free of bank conflicts.  No workgroup barrier: a wave only re-reads what it wrote itself.
   constexpr int EP_T = 32 * 144, EP_F = 32 * 272, EP_WAVE = (2 * EP_T > EP_F ? 2 * EP_T : EP_F);
-  static_assert(C::NW * EP_WAVE <= 2 * C::STAGE, "epilogue staging must fit the (dead) stage buffers");
   static_assert(!(flags & EPI_ACCUM), "accumulating outputs take the generic kernel");
-  LdsPtr ep = smem + wave * EP_WAVE;
+  LdsPtr ep = ep_base + wave * EP_WAVE;
   const bool lines = n0 + wn * 64 + 64 <= g.N && g.wide_t;   // wave-uniform: the strip is inside N and rows are 16-byte aligned
 #pragma unroll
   for (int pass = 0; pass < 8 / NB; ++pass) {
@@ -438,6 +339,230 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_nt_big_kernel: the product-path NT GEMM for large token counts (bf16 only).
+//   256 x 256 output tile, 64-deep contraction stages (128-byte rows), 8 waves as 2 (M) x 4 (N),
+//   each wave a 128 x 64 sub-tile = 4 x 2 MFMA tiles of 32 x 32.
+//   * operands go HBM -> LDS by direct LDS-DMA (global_load_lds_dwordx4): the LDS image is
+//     lane-linear per wave instruction (8 rows x 128 B), so the bank-conflict swizzle of
+//     load_frag_row (16-byte chunk ^ ((row >> 1) & 7)) is applied to the per-lane SOURCE address;
+//   * two LDS stages (128 KiB): the DMA of stage t+1 is in flight under the MFMAs of stage t;
+//   * MFMAs are issued "swapped" (weights as the A operand) so a lane owns one output row and
+//     4 consecutive columns per accumulator group: the epilogue reads bias / residual / gelu'
+//     inputs and writes its outputs straight from registers in 8- and 16-byte pieces.
+// Requirements (checked by the launcher, otherwise gemm_nt_kernel runs): K % 64 == 0, N % 4 == 0,
+// 16-byte aligned rows on every stream.
+// ---------------------------------------------------------------------------------------------
+// Two shapes of the same kernel (template NWM = waves along M, BK = contraction depth per stage):
+//   NWM 2, BK 64 : 256 x 256 tile, 8 waves, 128 KiB LDS, one workgroup per CU  -- best per-tile rate, long K
+//   NWM 1, BK 32 : 128 x 256 tile, 4 waves,  48 KiB LDS, three workgroups per CU -- the encoder's K = 512..1536
+//                  GEMMs spend as long in their prologue + epilogue (first DMA, bias / GELU / residual, 64..256 MB of
+//                  output) as in the MFMA loop; with three independent workgroups per CU one's stores and first
+//                  loads run under another's MFMAs instead of the whole chip alternating between the two phases.
+constexpr int BIG_BN = 256;
+template <int NWM, int BK> struct BigCfg {
+  static constexpr int BM = NWM * 128, BN = BIG_BN, NW = NWM * 4, NT = NW * 64;
+  static constexpr int RB = BK * 2;                 // bytes per tile row
+  static constexpr int CPR = RB / 16;               // 16-byte chunks per row
+  static constexpr int RPP = 1024 / RB;             // rows per 1-KiB DMA piece
+  static constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;   // pieces per wave per operand
+  static constexpr int TILE_A = BM * RB, TILE_B = BN * RB, STAGE = TILE_A + TILE_B;
+  static constexpr int MIN_BLOCKS = NWM == 1 ? 3 : 1;
+};
+constexpr int BIG_BM = 256, BIG_BK = 64;            // the large shape (launcher heuristics, tests)
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+template <int FLAGS, int NWM, int BK>
+__global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS)) void gemm_nt_big_kernel(GemmNT g) {
+  using C = BigCfg<NWM, BK>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+
+  const int tiles_n = (g.N + C::BN - 1) / C::BN;
+  const int tiles_m = (g.M + C::BM - 1) / C::BM;
+  const int tid_lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tid_lin / tiles_n, tn = tid_lin % tiles_n;
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int h = lane >> 5, li = lane & 31;
+
+  // DMA sources: wave w moves the 1-KiB pieces w, w + NW, ... of each operand tile; the bank-conflict swizzle
+  // of load_frag_row goes on the source chunk (the LDS image of a piece is lane-linear)
+  const bf16* pa[C::PA];
+  const bf16* pb[C::PB];
+#pragma unroll
+  for (int i = 0; i < C::PA; ++i) {
+    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
+    const int chunk = swz16<C::RB>(row, lane % C::CPR);
+    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < C::PB; ++i) {
+    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
+    const int chunk = swz16<C::RB>(row, lane % C::CPR);
+    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    LdsPtr ta = smem + buf * C::STAGE + wave * 1024;
+    LdsPtr tb = smem + buf * C::STAGE + C::TILE_A + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < C::PA; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * C::NW * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C::PB; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * C::NW * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  stage(0, 0);
+  __syncthreads();  // (carries the vmcnt(0) of the DMA)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * C::STAGE;
+    const lds_char* tb = ta + C::TILE_A;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      Frag<bf16> fa[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, C::RB>(tb, wn * 64 + j * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, C::RB>(ta, wm * 128 + i * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  static_assert(BigEpi<NWM>::BYTES <= 2 * C::STAGE, "epilogue staging must fit the (dead) stage buffers");
+  nt_big_epilogue<FLAGS, NWM>(g, acc, m0, n0, wave, lane, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_nt_persist_kernel: the 256 x 256 kernel as ONE workgroup per CU walking tiles (t = blockIdx.x, + gridDim.x, ...).
+// A tile of a K = 512 GEMM spends 7-8 of its ~20 us in latencies that sit in series: the first stage's DMA, the epilogue's loads, the
+// stores' acknowledgements before the workgroup may retire, the next workgroup's launch (tools/bench_gemm_epi.py --k 64).  Here
+//   * the first stage of the NEXT tile is requested during the last contraction stage of this one (into the buffer that stage
+//     does not read: the stage count is even);
+//   * the epilogue's stores are fire-and-forget: the next tile's first barrier waits with vmcnt(stores of this wave) -- loads and
+//     stores retire in order, so everything older than the stores, i.e. that first stage, has landed while the stores drain under
+//     the next tile's MFMAs.
+// All operand traffic is LDS-DMA issued from assembly (pfn_device.h dma16_global) and every barrier is a raw s_barrier with its own
+// s_waitcnt: the compiler's __syncthreads() carries vmcnt(0), which would wait for the stores.  The epilogue stages through the
+// second stage buffer (+ 8 KiB past it), the first one is receiving the next tile.
+// Requirements on top of the big kernel's: K / 64 even, every tile full in N.
+// ---------------------------------------------------------------------------------------------
+template <int FLAGS> struct PersistCfg {
+  using C = BigCfg<2, 64>;
+  static constexpr int EP_OFF = C::STAGE;                                  // epilogue strips start at the second stage buffer
+  static constexpr int LDS = EP_OFF + BigEpi<2>::BYTES > 2 * C::STAGE ? EP_OFF + BigEpi<2>::BYTES : 2 * C::STAGE;
+  // global store instructions of one wave's epilogue on the whole-line path (full tile)
+  static constexpr int NST = ((FLAGS & EPI_OUT_T) ? 16 : 0) + ((FLAGS & EPI_OUT2_T) ? 16 : 0) + ((FLAGS & EPI_OUT_F32) ? 32 : 0);
+  static_assert(NST > 0 && NST < 64, "vmcnt is a 6-bit counter");
+};
+
+template <int N> PFN_DEV void wait_vm_barrier() {   // everything but the N most recent vector-memory operations has landed; workgroup barrier
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(N) : "memory");
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(GemmNT g) {
+  using C = BigCfg<2, 64>;
+  using P = PersistCfg<FLAGS>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  const int tiles_n = g.N / C::BN;
+  const int tiles_m = (g.M + C::BM - 1) / C::BM;
+  const int ntiles = tiles_m * tiles_n;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31;
+  const int nk = g.K / 64;
+
+  // DMA sources of a tile: wave w moves the 1-KiB pieces w, w + 8, ... of each operand tile (swizzle on the source chunk, as in
+  // the big kernel); per lane: row inside the tile and swizzled chunk are tile-independent
+  int prow[C::PA], pchunk[C::PA];
+#pragma unroll
+  for (int i = 0; i < C::PA; ++i) {
+    prow[i] = (wave + C::NW * i) * C::RPP + lane / C::CPR;
+    pchunk[i] = swz16<C::RB>(prow[i], lane % C::CPR) * 8;
+  }
+  auto stage = [&](int buf, int m0, int n0, int k0) {
+    LdsPtr ta = smem + buf * C::STAGE + wave * 1024;
+    LdsPtr tb = ta + C::TILE_A;
+#pragma unroll
+    for (int i = 0; i < C::PA; ++i)
+      dma16_global(reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + prow[i], g.M - 1) * g.lda + pchunk[i] + k0, ta + i * C::NW * 1024);
+#pragma unroll
+    for (int i = 0; i < C::PB; ++i)
+      dma16_global(reinterpret_cast<const bf16*>(g.B) + (long)(n0 + prow[i]) * g.ldb + pchunk[i] + k0, tb + i * C::NW * 1024);
+  };
+  auto coords = [&](int t, int& m0, int& n0) {
+    const int lin = xcd_remap(t, ntiles);
+    m0 = (lin / tiles_n) * C::BM; n0 = (lin % tiles_n) * C::BN;
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  int m0, n0;
+  coords(t, m0, n0);
+  stage(0, m0, n0, 0);
+  bool stores_pending = false;        // the previous tile's epilogue went through the whole-line path with every row valid
+  for (; t < ntiles; t += gridDim.x) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int tn = t + gridDim.x;
+    int m0n = 0, n0n = 0;
+    if (tn < ntiles) coords(tn, m0n, n0n);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      // stage kt has landed (it is older than anything issued since), every wave is done with the other buffer
+      if (kt == 0 && stores_pending) wait_vm_barrier<P::NST>();
+      else wait_vm_barrier<0>();
+      if (kt + 1 < nk) stage(cur ^ 1, m0, n0, (kt + 1) * 64);
+      else if (tn < ntiles) stage(cur ^ 1, m0n, n0n, 0);
+      const lds_char* ta = smem + cur * C::STAGE;
+      const lds_char* tb = ta + C::TILE_A;
+#pragma unroll
+      for (int ks = 0; ks < 64; ks += 16) {
+        Frag<bf16> fa[4], fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, C::RB>(tb, wn * 64 + j * 32 + li, ks);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, C::RB>(ta, wm * 128 + i * 32 + li, ks);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
+      }
+    }
+    // every wave is done reading the last stage (buffer 1) before the epilogue's strips go there; the next tile's first stage
+    // (buffer 0) stays in flight
+    asm volatile("s_barrier" ::: "memory");
+    nt_big_epilogue<FLAGS, 2>(g, acc, m0, n0, wave, lane, smem + P::EP_OFF);
+    stores_pending = m0 + C::BM <= g.M && g.wide_t;
+    m0 = m0n; n0 = n0n;
   }
 }
 
@@ -1187,6 +1312,22 @@ static int gemm_nt_pick(const GemmNT& g) {
   return tiles256 >= 192 ? 1 : (tiles128 >= 192 ? 2 : 0);
 }
 
+static int g_nt_persist = 0;   // PFN_TUNE_GEMM_PERSIST: workgroups of the persistent kernel (0 = off)
+void set_gemm_nt_persist(int wgs) { g_nt_persist = wgs; }
+template <int FLAGS> static bool launch_persist_t(const GemmNT& g, hipStream_t stream) {
+  using C = BigCfg<2, 64>;
+  using P = PersistCfg<FLAGS>;
+  if (g_nt_persist <= 0 || (g.K / 64) % 2 || g.N % C::BN || !g.wide_t) return false;
+  if ((FLAGS & EPI_OUT_F32) && (g.ld_out_f32 % 4)) return false;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS);
+    attr_set = true;
+  }
+  const int tiles = ((g.M + C::BM - 1) / C::BM) * (g.N / C::BN);
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<FLAGS>), dim3(std::min(tiles, g_nt_persist)), dim3(512), P::LDS, stream, g);
+  return true;
+}
 template <int FLAGS, int NWM, int BK> static void launch_big_t(const GemmNT& g, hipStream_t stream) {
   using C = BigCfg<NWM, BK>;
   static bool attr_set = false;
@@ -1200,7 +1341,7 @@ template <int FLAGS, int NWM, int BK> static void launch_big_t(const GemmNT& g, 
 // the epilogue flag combinations the encoder stack uses; anything else takes the generic kernel
 static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
   switch (g.flags) {
-#define PFN_BIG_CASE(F) case (F): if (small_tile) launch_big_t<(F), 1, 32>(g, stream); else launch_big_t<(F), 2, 64>(g, stream); return true;
+#define PFN_BIG_CASE(F) case (F): if (small_tile) launch_big_t<(F), 1, 32>(g, stream); else if (!launch_persist_t<(F)>(g, stream)) launch_big_t<(F), 2, 64>(g, stream); return true;
     PFN_BIG_CASE(EPI_BIAS | EPI_OUT_T)                            // q/k/v projection
     PFN_BIG_CASE(EPI_BIAS | EPI_RESID | EPI_OUT_F32)              // out_proj, linear2 (+ residual)
     PFN_BIG_CASE(EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T)    // linear1 + GELU
