@@ -1156,8 +1156,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
 //     fragment in the workgroups of the first Q tile, split over the four Q waves.
 // Requirements: P % 256 == 0, Q % 256 == 0, 16-byte aligned rows.
 // ---------------------------------------------------------------------------------------------
-constexpr int TNB_KT = 64;                       // tokens per stage
-constexpr int TNB_TILE = TNB_KT * 512;           // 32 KiB per operand per stage
+// Stage depth / ring length (experiment builds: tools/build_variants.sh with -DPFN_TNB_KT= -DPFN_TNB_NS=).  Measured at the north
+// star (tools/bench_wgrad.py): 64 x 2 950 us, 32 x 3 952, 32 x 4 965, 32 x 5 965 -- up to four stages in flight instead of one change
+// nothing, i.e. the operand stream is bound by its rate (6.9 TB/s of LDS-DMA traffic, 2.6 TB/s of it from HBM), not by latency.
+#ifndef PFN_TNB_KT
+#define PFN_TNB_KT 64
+#define PFN_TNB_NS 2
+#endif
+constexpr int TNB_KT = PFN_TNB_KT;               // tokens per stage
+constexpr int TNB_NS = PFN_TNB_NS;               // stages in the LDS ring: TNB_NS - 1 of them in flight under the one being multiplied
+constexpr int TNB_TILE = TNB_KT * 512;           // bytes per operand per stage
+constexpr int TNB_PW = TNB_KT / 16;              // 1-KiB DMA pieces per wave per operand per stage (a piece = 2 token rows x 512 B)
+constexpr int TNB_LDS = TNB_NS * 2 * TNB_TILE;
+static_assert(TNB_LDS <= 160 * 1024 && TNB_KT % 16 == 0 && TNB_NS >= 2 && (TNB_NS - 2) * 2 * TNB_PW < 64, "weight-gradient ring does not fit");
 
 __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1180,12 +1191,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wp = wave >> 2, wq = wave & 3;
 
-  // DMA sources: a 1-KiB piece is 2 token rows x 512 B; wave w moves pieces w, w+8, w+16, w+24
-  const bf16* pa[4];
-  const bf16* pb[4];
-  int prow[4];
+  // DMA sources: a 1-KiB piece is 2 token rows x 512 B; wave w moves pieces w, w + 8, ... of each operand's stage
+  const bf16* pa[TNB_PW];
+  const bf16* pb[TNB_PW];
+  int prow[TNB_PW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TNB_PW; ++i) {
     const int row = (wave + 8 * i) * 2 + (lane >> 5);
     const int unit = ((lane & 31) >> 2) ^ (row & 3);
     const int col = unit * 32 + (lane & 3) * 8;
@@ -1193,16 +1204,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
     pa[i] = reinterpret_cast<const bf16*>(pr.A) + mbeg * pr.lda + p0 + col;
     pb[i] = reinterpret_cast<const bf16*>(pr.B) + mbeg * pr.ldb + q0 + col;
   }
-  auto stage = [&](int buf, int r0) {
-    LdsPtr ta = smem + buf * 2 * TNB_TILE + wave * 1024;
+  auto stage = [&](int slot, int r0) {
+    LdsPtr ta = smem + slot * 2 * TNB_TILE + wave * 1024;
     LdsPtr tb = ta + TNB_TILE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TNB_PW; ++i) {
       // tail rows are re-zeroed in LDS below; debug_mask is all ones except when profiling with cache-resident operands
       const long r = min(r0 + prow[i], rows_total - 1) & g.debug_mask;
       // assembly form (pfn_device.h dma16): with the builtin hipcc waits vmcnt(0) in front of the first ds_read_b64_tr_b16 of
-      // the stage being MULTIPLIED -- the intrinsic carries no address, so the DMA just issued for the NEXT stage "may alias" --
-      // and the copy never overlapped the MFMAs (2.3 us per stage against 1.4 us for the same tile in the NT kernel)
+      // the stage being MULTIPLIED -- the intrinsic carries no address, so the DMA just issued for a LATER stage "may alias" --
+      // and the copy never overlapped the MFMAs
       dma16_global(pa[i] + r * pr.lda, ta + i * 8192);
       dma16_global(pb[i] + r * pr.ldb, tb + i * 8192);
     }
@@ -1224,18 +1235,32 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
   for (int e = 0; e < 8; ++e) ones.v[e] = (bf16)1.0f;
 
   const int nt = (rows_total + TNB_KT - 1) / TNB_KT;
-  // (Not latency-bound: touching the lines of later stages to pull them into L2 ahead of their DMA made the launch SLOWER --
-  // 916 us without, 990 / 1030 / 1070 us touching 2 / 3 / 5 stages ahead; the extra requests compete with the operand stream.)
-  stage(0, 0);
-  dma_wait_all();
-  __syncthreads();
+  // Ring of TNB_NS stages: stage t is multiplied while stages t+1 .. t+TNB_NS-2 are in flight and stage t+TNB_NS-1 is requested
+  // into the slot stage t-1 has just released.  Loads retire in order, so "stage t has landed" is vmcnt(instructions of the
+  // younger stages) -- explicit s_waitcnt + raw s_barrier (wait_vm_barrier): __syncthreads() carries vmcnt(0).
+  // (Touching later stages' lines to pull them into L2 instead made the launch slower: 916 us without, 990 / 1030 / 1070 us
+  // touching 2 / 3 / 5 stages ahead.)
+#pragma unroll
+  for (int st = 0; st < TNB_NS - 1; ++st)
+    if (st < nt) stage(st, st * TNB_KT);
+  auto wait_stage = [&](int younger) {     // `younger` stages were requested after the one wanted now (wave-uniform)
+    switch (younger) {
+      case 0: wait_vm_barrier<0>(); break;
+      case 1: wait_vm_barrier<(TNB_NS > 2 ? 1 : 0) * 2 * TNB_PW>(); break;
+      case 2: wait_vm_barrier<(TNB_NS > 3 ? 2 : 0) * 2 * TNB_PW>(); break;
+      case 3: wait_vm_barrier<(TNB_NS > 4 ? 3 : 0) * 2 * TNB_PW>(); break;
+      default: wait_vm_barrier<(TNB_NS - 2) * 2 * TNB_PW>(); break;
+    }
+  };
+  static_assert(TNB_NS <= 6, "wait_stage cases");
   // the main loop exists twice (with / without the bias-gradient MFMA) so neither carries a branch
   auto main_loop = [&](auto with_colsum) {
     constexpr bool CS = decltype(with_colsum)::value;
+    int slot = 0, slot_next = TNB_NS - 1;
     for (int t = 0; t < nt; ++t) {
-      const int cur = t & 1;
-      if (t + 1 < nt) stage(cur ^ 1, (t + 1) * TNB_KT);
-      LdsPtr ta = smem + cur * 2 * TNB_TILE;
+      wait_stage(min(nt - t - 1, TNB_NS - 2));
+      if (t + TNB_NS - 1 < nt) stage(slot_next, (t + TNB_NS - 1) * TNB_KT);
+      LdsPtr ta = smem + slot * 2 * TNB_TILE;
       LdsPtr tb = ta + TNB_TILE;
       const int valid = rows_total - t * TNB_KT;
       if (valid < TNB_KT) {
@@ -1261,8 +1286,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
         // bias gradient: Q wave wq sums the columns of P sub-tile wq (one more fragment read, one more MFMA)
         if constexpr (CS) cs = mma32(load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + wq * 32), ones, cs);
       }
-      dma_wait_all();   // the next stage has landed (it had this stage's 36 MFMAs per wave to do so)
-      __syncthreads();
+      slot_next = slot;
+      slot = slot + 1 == TNB_NS ? 0 : slot + 1;
     }
   };
   if (do_colsum) main_loop(std::true_type{});
@@ -1493,10 +1518,10 @@ int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream) {
   g.debug_mask = g_tn_debug_wrap > 0 ? g_tn_debug_wrap - 1 : 0x7fffffff;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TNB_TILE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TNB_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(tiles * splits), dim3(512), 4 * TNB_TILE, stream, g);
+  hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(tiles * splits), dim3(512), TNB_LDS, stream, g);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 
