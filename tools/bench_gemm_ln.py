@@ -8,7 +8,7 @@ from transformerscandobayesianinference_amd import _hip
 if os.environ.get('PFN_LIB'):
     _hip.LIB_PATH = os.path.abspath(os.environ['PFN_LIB'])
 H = _hip
-M, N = 32000, 512
+M, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 16) * 2000, 512
 dev = torch.device('cuda'); bf = torch.bfloat16
 for K in (512, 1024):
     A, B = (torch.randn(M, K, device=dev) * .5).to(bf), (torch.randn(N, K, device=dev) * .1).to(bf)

@@ -577,6 +577,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(GemmNT g) {
 // (A note on these full-row kernels' main loop: 16-17 us per 512 of K against 10-12 us in the 256 x 256 kernel.  A is streamed from
 // HBM once and only one stage of it is in flight; touching the A lines of the stage after next to pull them into L2 ahead of the
 // LDS-DMA was measured and changed nothing -- 62.6 vs 63.3 us at K = 1024 -- so the stream is not latency-bound.)
+template <int NWN> struct LnEpi {   // LDS of gemm_nt_ln_kernel's epilogue: row partial sums, column vectors, the output strips
+  static constexpr int STRIPS = 128 * NWN * 4 + 5 * NWN * 64 * 4;
+  static constexpr int WAVE = 32 * 272 + 32 * 144;
+  static constexpr int BYTES = STRIPS + NWN * WAVE;
+};
 template <int NWN, bool RESID_LN, int BK>
 __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
@@ -732,7 +737,12 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
     for (int w = 0; w < NWN; ++w) t += red[(i * 32 + li) * NWN + w];
     rstd[i] = rsqrtf(t * invN + g.eps);
   }
+  // Outputs leave through wave-private LDS strips (one 32-row block at a time: f32 rows of 256 B + operand-precision rows of
+  // 128 B, padded by 16 B) so that every global store instruction writes whole lines -- 4 rows x 256 B of y, 8 rows x 128 B of
+  // x_t -- instead of 32 bytes of 32 different rows (as in nt_big_epilogue).
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
   bf16* x_t = reinterpret_cast<bf16*>(g.x_t);
+  LdsPtr sf = smem + LnEpi<NWN>::STRIPS + wave * LnEpi<NWN>::WAVE, st = sf + 32 * 272;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long m_row = (long)m0 + i * 32 + li;
@@ -742,25 +752,38 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int nb = wave * 64 + j * 32;
-      float xn[16];
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = nb + 8 * gq + 4 * h;
         const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + 3 * BN + n), be = *reinterpret_cast<const f32x4*>(cvec + 4 * BN + n);
         f32x4 v, xo;
+        bf16x4 xt;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[i][j][4 * gq + e];
           xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
-          xn[4 * gq + e] = xo[e];
+          xt[e] = (bf16)xo[e];
         }
-        if (mvalid) {
-          *reinterpret_cast<f32x4*>(g.y + m * BN + n) = v;
-          if (g.x_f32) *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;
-        }
+        lds_write16(sf + li * 272 + (j * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
+        *reinterpret_cast<lds_bf16x4*>(st + li * 144 + (j * 4 + gq) * 16 + h * 8) = xt;
+        if (g.x_f32 && mvalid) *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;   // (last layer only)
       }
-      store_row_block<bf16>(x_t + m * BN + nb, xn, h, mvalid);   // 16-byte stores after a half-wave exchange
     }
+    __builtin_amdgcn_wave_barrier();
+    const long mb = (long)m0 + i * 32;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rr = it * 4 + (lane >> 4), c = lane & 15;
+      const u32x4 q = lds_read16(sf + rr * 272 + c * 16);
+      if (mb + rr < g.M) *reinterpret_cast<u32x4*>(g.y + (mb + rr) * BN + wave * 64 + c * 4) = q;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = it * 8 + (lane >> 3), c = lane & 7;
+      const u32x4 q = lds_read16(st + rr * 144 + c * 16);
+      if (mb + rr < g.M) *reinterpret_cast<u32x4*>(x_t + (mb + rr) * BN + wave * 64 + c * 8) = q;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1433,7 +1456,7 @@ bool gemm_ln_supported(const GemmLN& g) {
          (g.resid ? aligned16(g.resid) : (aligned16(g.ry) && aligned16(g.rgamma) && aligned16(g.rbeta)));
 }
 template <int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g, hipStream_t stream) {
-  const size_t lds = 2 * (128 + NWN * 64) * (BK * 2);
+  const size_t lds = std::max<size_t>(2 * (128 + NWN * 64) * (BK * 2), LnEpi<NWN>::BYTES);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ln_kernel<NWN, RL, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
