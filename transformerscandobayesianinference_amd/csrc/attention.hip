@@ -544,6 +544,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   commit_stats(0);
   dma_wait_all();
   __syncthreads();
+  if (!(ABL & 1) && ntiles > 1) {     // tile 1 -> the second buffer; from here on a tile's successor-but-one is requested at its end
+    dma(1, 1);
+    stage_stats(QB);
+  }
+  constexpr int DS_STORES = DO_DK && !(KVABL & 1) ? (sizeof(T) == 2 ? 2 : 4) : 0;   // store instructions of one tile's dS^T per wave
+  bool stored = false;                // this wave's dS^T stores of the previous tile may still be in flight
 
   auto tile = [&](auto buf_c, int t) {
     constexpr int BUF = decltype(buf_c)::value;
@@ -552,11 +558,6 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     const lds_char* stt = St(BUF);
     const lds_char* qc = Qc(BUF);
     const lds_char* oc = Oc(BUF);
-    // tile t+1 -> the other buffer (all waves are past the barrier that ended tile t-1, its last reader)
-    if (!(ABL & 1) && t + 1 < ntiles) {
-      dma(BUF ^ 1, t + 1);
-      stage_stats((t + 1) * QB);
-    }
     // Register plan (head dim 128, bf16): 160 registers are pinned (K fragments, dK, dV); S and dP take 32 more; every operand
     // stream therefore runs only PD k-steps ahead of its MFMAs and the two products run one after the other, the second
     // one's first fragments requested under the first one's tail.
@@ -664,15 +665,24 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 #pragma unroll
       for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df1, dk[db]);
     }
-    // End of the tile.  gfx9 counts loads and stores in ONE counter and cannot tell them apart: a wait for a load is a wait
-    // for every store before it.  So: wait for the DMA of tile t+1 (issued a whole tile ago; the previous tile's dS^T stores
-    // are as old), barrier, and only THEN let this tile's dS^T go (block (key / 32, t), operand precision: exactly what the
-    // dK product consumed) -- it drains under the next tile.
+    // End of the tile.  gfx9 counts loads and stores in ONE counter and they retire in order: a wait for a load is a wait for
+    // every store issued before it.  So the order of issue at a tile's end is: the DMA of tile t+2 (into this tile's buffer, free
+    // behind the barrier), THEN this tile's dS^T stores (block (key / 32, t), operand precision: exactly what the dK product
+    // consumed) -- and the wait for tile t+1 one tile earlier is vmcnt(stores of the previous tile), which leaves those stores two
+    // tile times to be acknowledged instead of stalling every tile on them (with them in front of the DMA: 70 us of 372).
     if (!(ABL & 2)) commit_stats(BUF ^ 1);
-    dma_wait_all();
-    if (!(ABL & 4)) __syncthreads();
+    if (ABL & 4) dma_wait_all();
+    else if (stored) wait_vm_barrier<DS_STORES>();
+    else wait_vm_barrier<0>();
+    if (!(ABL & 1) && t + 2 < ntiles) {
+      dma(BUF, t + 2);
+      stage_stats((t + 2) * QB);
+    }
     // keys >= sep of a block row the dQ pass reads (rows < ds_rows) leave as zeros: that pass does not mask rows
-    if constexpr (DO_DK) { if (!(KVABL & 1) && ds_row_live) store_frag_pair_blocked<T>(dsT + (long)t * DSBLK, df0, df1, li, h, true); }
+    if constexpr (DS_STORES > 0) {
+      if (ds_row_live) store_frag_pair_blocked<T>(dsT + (long)t * DSBLK, df0, df1, li, h, true);
+      stored = ds_row_live;
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;

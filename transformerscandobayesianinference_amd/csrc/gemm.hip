@@ -476,11 +476,6 @@ template <int FLAGS> struct PersistCfg {
   static_assert(NST > 0 && NST < 64, "vmcnt is a 6-bit counter");
 };
 
-template <int N> PFN_DEV void wait_vm_barrier() {   // everything but the N most recent vector-memory operations has landed; workgroup barrier
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(N) : "memory");
-}
-
 template <int FLAGS>
 __global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(GemmNT g) {
   using C = BigCfg<2, 64>;

@@ -338,6 +338,13 @@ PFN_DEV void dma16_global(const void* src, LdsPtr lds_dst_uniform) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(dst), "v"(src) : "memory");
 }
+// Workgroup barrier behind an explicit wait: everything but the N most recent vector-memory operations of this wave has landed
+// (loads, LDS-DMA and stores retire in order on gfx9), and its LDS traffic is complete.  __syncthreads() instead carries a fence
+// that waits for vmcnt(0) -- i.e. for every store still in flight.
+template <int N> PFN_DEV void wait_vm_barrier() {
+  __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
+}
 PFN_DEV void dma_wait_all() {
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
