@@ -1433,6 +1433,7 @@ int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream) {
   int splits = (1024 + tp * tq - 1) / (tp * tq);
   const int max_splits = (g.M + 4 * TN_BMK - 1) / (4 * TN_BMK);
   if (splits > max_splits) splits = max_splits;
+  if (g.max_splits > 0 && splits > g.max_splits) splits = g.max_splits;
   if (splits < 1) splits = 1;
   if (!g.atomic) splits = 1;
   int chunk = (g.M + splits - 1) / splits;

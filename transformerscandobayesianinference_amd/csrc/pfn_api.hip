@@ -97,6 +97,8 @@ struct LayerWs {
 };
 struct Ws {
   float* x0; char* x0_t;
+  char* xaug_t;              // [M, EMB_AUG] operand precision: the embedding's augmented inputs (embed_fwd -> the backward's GEMM)
+  float* embacc;             // [E, EMB_AUG] f32: that GEMM's result before it is scattered into the encoder gradients
   std::vector<LayerWs> layer;
   char *xt_t, *dpre, *dt;
   // backward scratch
@@ -114,6 +116,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   int64_t cur = 0;
   auto take = [&](int64_t nbytes) { char* p = base ? base + cur : nullptr; cur = align_up(cur + nbytes, 256); return p; };
   w.x0 = (float*)take(M * E * 4); w.x0_t = take(M * E * es);
+  w.xaug_t = take(M * EMB_AUG * es); w.embacc = (float*)take(E * EMB_AUG * 4);
   w.layer.resize(d.nlayers);
   for (auto& l : w.layer) {
     l.qkv = take(M * 3 * E * es); l.ctx = take(M * E * es); l.lse = (float*)take((int64_t)B * d.nhead * S * 4);
@@ -239,6 +242,7 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
     e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;
     e.wx = params + L.enc_w; e.bx = params + L.enc_b; e.wy = params + L.yenc_w; e.by = params + L.yenc_b;
     e.out_f32 = w.x0; e.out_t = w.x0_t; e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep;
+    e.xaug_t = d->num_features + 2 <= EMB_AUG ? w.xaug_t : nullptr;
     PFN_TRY(launch_embed_fwd(e, prec, s));
   }
   const float* xin = w.x0;
@@ -385,6 +389,11 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
     g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta;
     return g;
   };
+  // The embedding's weight gradients d(src)^T . [x | masked y | train flag] are a (skinny) weight-gradient GEMM like the others:
+  // embed_fwd left the augmented inputs in operand precision, the first layer's dx leaves in operand precision, and the
+  // split-K TN kernel does the rest (the register kernel it replaces streamed d(src) at 0.7 TB/s).  Custom encoders
+  // (dsrc_sbe), the exact-f32 mode and wide encoders keep the f32 path.
+  const bool emb_gemm = !dsrc_sbe && prec == PFN_PREC_BF16 && d->nlayers > 0 && d->num_features + 2 <= EMB_AUG && E % 8 == 0;
   bool fuse_lnb = g_fuse_lnbwd && prec == PFN_PREC_BF16 && d->nlayers > 0;
   if (fuse_lnb) {
     const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
@@ -431,8 +440,9 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       PFN_TRY(launch_gemm_lnbwd(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, ab.y2, ab.mean2, ab.rstd2, params + pb.g2, ab.dy2_t,
                                     grads + pb.g2, grads + pb.be2), s));
     } else {  // dx = dqkv . Win + dy1
-      // the gradient stays in operand precision between layers; the embedding's gradient (layer 0) leaves in f32
-      GemmNT g = nt(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID_T | (l == 0 ? EPI_OUT_F32 : EPI_OUT_T));
+      // the gradient stays in operand precision between layers; the embedding's gradient (layer 0) too when its weight
+      // gradients are computed as a GEMM (emb_gemm below), else it leaves in f32
+      GemmNT g = nt(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, M, E, 3 * E, EPI_RESID_T | (l == 0 && !emb_gemm ? EPI_OUT_F32 : EPI_OUT_T));
       g.aux = a.dy1_t; g.ld_aux = E; g.out_f32 = w.gA; g.ld_out_f32 = E; g.out_t = w.gA_t; g.ld_out_t = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
@@ -473,6 +483,12 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
   // ---- embedding ----
   if (dsrc_sbe) {
     PFN_TRY(launch_bse_to_sbe(w.gA, dsrc_sbe, S, B, E, s));
+  } else if (emb_gemm) {
+    if (hipMemsetAsync(w.embacc, 0, sizeof(float) * E * EMB_AUG, s) != hipSuccess) return fail(PFN_ERR_LAUNCH, "memset");
+    GemmTN g = tn(w.gA_t, E, w.xaug_t, EMB_AUG, w.embacc, EMB_AUG, M, E, EMB_AUG, grads + L.enc_b);
+    g.max_splits = 128;      // a 512 x 32 result: measured 67 / 62 / 88 us with 64 / 128 / 256 splits (the partial sums are added atomically)
+    PFN_TRY(launch_gemm_tn(g, prec, s));
+    PFN_TRY(launch_embed_grad_scatter(w.embacc, grads + L.enc_w, grads + L.yenc_w, grads + L.yenc_b, E, d->num_features, s));
   } else {
     EmbedBwdArgs e;
     e.dsrc = w.gA; e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;

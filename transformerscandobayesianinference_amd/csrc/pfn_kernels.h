@@ -47,6 +47,7 @@ struct GemmTN {
   int atomic;               // 1: C += (split over M, f32 atomics); 0: C = (single split)
   int m_chunk;              // filled by the launcher
   float* colsum;            // optional [P]: += column sums of A (bias gradient), atomically
+  int max_splits;           // 0 = automatic; else an upper bound on the token-axis splits (small C: fewer atomic partial sums)
 };
 int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream);
 
@@ -133,8 +134,10 @@ struct EmbedArgs {
   const float* wx; const float* bx;  // [E,nf], [E]
   const float* wy; const float* by;  // [E,1],  [E]
   float* out_f32; void* out_t;
+  void* xaug_t;   // optional [B*S, EMB_AUG] T: the token's features, masked y, train flag, zero padding -- the B operand of the backward's GEMM
   int S, B, nf, E, sep;
 };
+constexpr int EMB_AUG = 32;   // columns of xaug_t (num_features + 2 <= EMB_AUG for the GEMM form of the backward)
 int launch_embed_fwd(const EmbedArgs& a, int precision, hipStream_t s);
 // backward: dsrc [B,S,E] f32 -> dwx, dbx, dwy, dby (accumulated, f32)
 struct EmbedBwdArgs {
@@ -143,6 +146,8 @@ struct EmbedBwdArgs {
   int S, B, nf, E, sep;
 };
 int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s);
+// the GEMM form: acc[E, EMB_AUG] = d(src)^T . xaug (launch_gemm_tn) -> dwx += acc[:, :nf], dwy += acc[:, nf], dby += acc[:, nf + 1]
+int launch_embed_grad_scatter(const float* acc, float* dwx, float* dwy, float* dby, int E, int nf, hipStream_t s);
 
 // src given in the reference layout [S,B,E] f32 (custom encoders): copy into [B,S,E] f32 + T
 int launch_sbe_to_bse(const float* src, float* out_f32, void* out_t, int S, int B, int E, int precision, hipStream_t s);

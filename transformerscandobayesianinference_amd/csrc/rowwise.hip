@@ -110,6 +110,13 @@ template <typename T> __global__ __launch_bounds__(256) void embed_fwd_kernel(Em
   }
   __syncthreads();
   T* out_t = reinterpret_cast<T*>(a.out_t);
+  if (a.xaug_t) {   // the same values in operand precision, EMB_AUG columns per token (zero padded)
+    T* xa = reinterpret_cast<T*>(a.xaug_t);
+    for (int i = threadIdx.x; i < EMB_TOK * EMB_AUG; i += 256) {
+      const int tk = i / EMB_AUG, f = i % EMB_AUG;
+      if (t0 + tk < ntok) xa[(t0 + tk) * EMB_AUG + f] = (T)(f < nfp ? xs[tk * nfp + f] : 0.f);
+    }
+  }
   for (int e = threadIdx.x; e < a.E; e += 256) {
     const float be = a.bx[e], wye = a.wy[e], bye = a.by[e];
     float acc[EMB_TOK];
@@ -248,12 +255,28 @@ __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(EmbedBwdArgs a) {
     unsafeAtomicAdd(a.dbx + e, db);
   }
 }
+__global__ __launch_bounds__(256) void embed_grad_scatter_kernel(const float* acc, float* dwx, float* dwy, float* dby, int E, int nf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= E * (nf + 2)) return;
+  const int e = i / (nf + 2), f = i % (nf + 2);
+  const float v = acc[e * EMB_AUG + f];
+  if (f < nf) unsafeAtomicAdd(dwx + (long)e * nf + f, v);
+  else if (f == nf) unsafeAtomicAdd(dwy + e, v);
+  else unsafeAtomicAdd(dby + e, v);
+}
+int launch_embed_grad_scatter(const float* acc, float* dwx, float* dwy, float* dby, int E, int nf, hipStream_t s) {
+  hipLaunchKernelGGL(embed_grad_scatter_kernel, dim3((E * (nf + 2) + 255) / 256), dim3(256), 0, s, acc, dwx, dwy, dby, E, nf);
+  return PFN_LAUNCH_OK();
+}
 int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s) {
   const long ntok = (long)a.B * a.S;
   const int nf8 = (a.nf + 2 + 7) / 8 * 8;
   if (nf8 <= EMBB_MAXF) {
     const int ey = (a.E + 63) / 64;
-    const dim3 grid((unsigned)std::max<long>(1, std::min<long>((ntok + EMBB_TOK - 1) / EMBB_TOK, std::max(1, 512 / ey))), ey);
+#ifndef PFN_EMBB_WGS
+#define PFN_EMBB_WGS 512
+#endif
+    const dim3 grid((unsigned)std::max<long>(1, std::min<long>((ntok + EMBB_TOK - 1) / EMBB_TOK, std::max(1, PFN_EMBB_WGS / ey))), ey);
     const size_t lds = std::max((size_t)EMBB_TOK * nf8, (size_t)4 * 64 * (nf8 + 1)) * sizeof(float);
     switch (nf8) {
       case 8: hipLaunchKernelGGL(embed_bwd_kernel<8>, grid, dim3(256), lds, s, a); break;
