@@ -77,7 +77,7 @@ Layout make_layout(const pfn_model_desc& d) {
   if (O > 0) { L.dec0_w = take(F * E); L.dec0_b = take(F); L.dec2_w = take(O * F); L.dec2_b = take(O); }
   else L.dec0_w = L.dec0_b = L.dec2_w = L.dec2_b = 0;
   L.total = cur;
-  L.n_out_pad = (int)align_up(O, 8);
+  L.n_out_pad = (int)align_up(O, O >= 64 ? 64 : 8);   // contraction length of the decoder's backward GEMM: whole 64-deep stages when it is long (zero padded on both operands)
   int64_t ct = 0;
   auto take_t = [&](int64_t n) { int64_t o = ct; ct = align_up(ct + n, 64); return o; };
   L.layer_t.resize(d.nlayers);
@@ -361,7 +361,8 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
     PFN_TRY(launch_cast_rows(dlogits, O, w.dlog_t, npad, Mt, O, prec, s));
     PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b), prec, s));
     {
-      GemmNT g = nt(w.dlog_t, npad, WT(L.dec2_wt), npad, Mt, F, O, EPI_GELU_BWD | EPI_OUT_T);
+      // (contraction over the zero-padded width when that is whole 64-deep stages: the LDS-DMA kernel then takes it)
+      GemmNT g = nt(w.dlog_t, npad, WT(L.dec2_wt), npad, Mt, F, npad % 64 == 0 ? npad : O, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = w.dpre; g.ld_aux = F; g.out_t = w.dd_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
