@@ -1311,9 +1311,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
   if (do_colsum) main_loop(std::true_type{});
   else main_loop(std::false_type{});
 
+  const int pv = pr.Pv > 0 ? pr.Pv : pr.P;    // rows of C that exist (A may end in zero-padding columns)
   if (do_colsum && (lane & 31) == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) unsafeAtomicAdd(pr.colsum + p0 + wp * 128 + wq * 32 + acc_row(r, lane), cs[r]);
+    for (int r = 0; r < 16; ++r) {
+      const int pp = p0 + wp * 128 + wq * 32 + acc_row(r, lane);
+      if (pp < pv) unsafeAtomicAdd(pr.colsum + pp, cs[r]);
+    }
   }
   // always atomic: token splits add into the same tile, and concurrent backward passes (micro-batches on several
   // HIP streams, streams.py) accumulate into the same gradient buffer
@@ -1327,6 +1331,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
         const int pp = p0 + wp * 128 + i * 32 + acc_row(r, lane);
         const int qq = q0 + wq * 64 + j * 32 + (lane & 31);
         float* c = pr.C + (long)pp * pr.ldc + qq;
+        if (pp >= pv) continue;
         if (atomic) unsafeAtomicAdd(c, acc[i][j][r]);
         else *c += acc[i][j][r];
       }
@@ -1524,7 +1529,7 @@ int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream) {
   int splits = g.splits;
   if (splits <= 0) {
     splits = 8;
-    for (int sp = 1; sp <= 8; ++sp) {
+    for (int sp = 1; sp <= 8; ++sp) {   // (a 256 x 256 partial tile is 65536 atomics: more than 8 splits cost more than they fill)
       const int blocks = tiles * sp, rounds = (blocks + 255) / 256;
       if (blocks >= 0.9 * rounds * 256) { splits = sp; break; }
     }

@@ -359,14 +359,28 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
   } else if (Mt > 0) {
     if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
     PFN_TRY(launch_cast_rows(dlogits, O, w.dlog_t, npad, Mt, O, prec, s));
-    PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b), prec, s));
+    // the decoder's two weight gradients: one grouped launch of 256 x 256 tiles when the shapes allow (bars padded to a multiple of
+    // 256 by the zero columns of dlog_t: Pv bounds the rows that exist), else a split-K launch each
+    TnProblem dp2; memset(&dp2, 0, sizeof(dp2));
+    dp2.A = w.dlog_t; dp2.lda = npad; dp2.B = w.dt; dp2.ldb = F; dp2.C = grads + L.dec2_w; dp2.ldc = F; dp2.P = npad; dp2.Q = F; dp2.Pv = O;
+    dp2.colsum = grads + L.dec2_b;
+    TnProblem dp0; memset(&dp0, 0, sizeof(dp0));
+    dp0.A = w.dd_t; dp0.lda = F; dp0.B = w.xt_t; dp0.ldb = E; dp0.C = grads + L.dec0_w; dp0.ldc = E; dp0.P = F; dp0.Q = E; dp0.colsum = grads + L.dec0_b;
+    const bool dec_grouped = prec == PFN_PREC_BF16 && gemm_tn_group_supported(dp2) && gemm_tn_group_supported(dp0);
+    if (!dec_grouped) PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b), prec, s));
     {
       // (contraction over the zero-padded width when that is whole 64-deep stages: the LDS-DMA kernel then takes it)
       GemmNT g = nt(w.dlog_t, npad, WT(L.dec2_wt), npad, Mt, F, npad % 64 == 0 ? npad : O, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = w.dpre; g.ld_aux = F; g.out_t = w.dd_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
-    PFN_TRY(launch_gemm_tn(tn(w.dd_t, F, w.xt_t, E, grads + L.dec0_w, E, Mt, F, E, grads + L.dec0_b), prec, s));
+    if (dec_grouped) {
+      GemmTNGroup g; memset(&g, 0, sizeof(g));
+      g.n = 2; g.M = Mt; g.p[0] = dp2; g.p[1] = dp0;
+      PFN_TRY(launch_gemm_tn_group(g, s));
+    } else {
+      PFN_TRY(launch_gemm_tn(tn(w.dd_t, F, w.xt_t, E, grads + L.dec0_w, E, Mt, F, E, grads + L.dec0_b), prec, s));
+    }
     {
       GemmNT g = nt(w.dd_t, F, WT(L.dec0_wt), F, Mt, E, F, EPI_OUT_F32);
       g.out_f32 = w.dxt; g.ld_out_f32 = E;
@@ -452,7 +466,7 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
   {
     std::vector<TnProblem> probs;
     auto add = [&](const void* A, long lda, const void* Bm, long ldb, float* C, long ldc, int P, int Q, float* colsum) {
-      TnProblem t; t.A = A; t.lda = lda; t.B = Bm; t.ldb = ldb; t.C = C; t.ldc = ldc; t.P = P; t.Q = Q; t.colsum = colsum;
+      TnProblem t; memset(&t, 0, sizeof(t)); t.A = A; t.lda = lda; t.B = Bm; t.ldb = ldb; t.C = C; t.ldc = ldc; t.P = P; t.Q = Q; t.colsum = colsum;
       probs.push_back(t);
     };
     for (int l = d->nlayers - 1; l >= 0; --l) {

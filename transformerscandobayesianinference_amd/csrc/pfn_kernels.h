@@ -59,6 +59,7 @@ struct TnProblem {
   const void* A; const void* B; float* C; float* colsum;  // colsum: optional [P] += column sums of A
   long lda, ldb, ldc;
   int P, Q;
+  int Pv;   // rows of C (and entries of colsum) that exist: 0 = all P; < P when A's last columns are zero padding (P still a multiple of 256)
 };
 struct GemmTNGroup {
   TnProblem p[TN_GROUP_MAX];
