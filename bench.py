@@ -237,7 +237,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     if gemm_lnbwd('dy1 = LN1 backward of dh.W1 + dy2', F, L):
         if L > 1:
             gemm_lnbwd('dy2 = LN2 backward (layer below) of dqkv.Win + dy1', 3 * E, L - 1)
-        gemm('dx = dqkv.Win + dy1 (first layer, f32 out)', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_F32, 1)
+        gemm('dx = dqkv.Win + dy1 (first layer: gradient of the embedding output)', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, 1)
         layernorm_bwd(1)
     else:
         gemm('dx1 = dh.W1 + dy2', E, F, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
