@@ -417,7 +417,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   auto Qc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::RIMG; };
   auto Or = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::RIMG + K::CIMG; };
   auto Oc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + 2 * K::RIMG + K::CIMG; };
-  auto St = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::IMG; };   // [lse2 x QB][delta x QB]
+  auto St = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::IMG; };   // [lse x QB][delta x QB]
 
   const AttnBlock wg = attn_block((a.sep + C::QBLK - 1) / C::QBLK, a.H);
   const int b = wg.b, hd = wg.hd;
@@ -527,26 +527,22 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       }
     }
   };
-  // row statistics of the tile's queries: wave 0 stages lse, wave 1 delta (lanes 0..QB-1).  A query beyond S reads zeros
-  // everywhere (Q, dO, lse, delta): P = 1 there but dO = 0 and delta = 0, so dV, dS and dK get nothing from it.
-  const BufRsrc rl = make_rsrc(lse_g, (long)a.S * 4), rdl = make_rsrc(delta_g, (long)a.S * 4);
-  float st_reg = 0.f;
-  auto stage_stats = [&](int q0) {   // the loaded value is not touched before commit_stats (a use would wait for it at once)
-    if (wave == 0) { if (lane < QB) st_reg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (lane + q0) * 4, 0, 0)); }
-    else if (wave == 1) { if (lane < QB) st_reg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdl, (lane + q0) * 4, 0, 0)); }
-  };
-  auto commit_stats = [&](int buf) {
-    if (wave == 0) { if (lane < QB) lds_write_f32(St(buf) + lane * 4, st_reg * LOG2E); }
-    else if (wave == 1) { if (lane < QB) lds_write_f32(St(buf) + (QB + lane) * 4, st_reg); }
+  // row statistics of the tile's queries: wave 0 brings lse, wave 1 delta (lanes 0..QB-1), by LDS-DMA like the tiles -- a load
+  // into a register would be waited for by the compiler with vmcnt(0) at its use (its count cannot see the branches around the
+  // dS^T stores), which made waves 0 and 1, and behind the barrier everyone, wait for those stores every tile.  A query beyond S
+  // reads zeros everywhere (Q, dO, lse, delta): P = 1 there but dO = 0 and delta = 0, so dV, dS and dK get nothing from it.
+  const DmaRsrc rl = make_dma_rsrc(lse_g, (long)a.S * 4), rdl = make_dma_rsrc(delta_g, (long)a.S * 4);
+  auto stage_stats = [&](int buf, int q0) {
+    if (wave == 0) { if (lane < QB) dma4(rl, St(buf), (lane + q0) * 4); }
+    else if (wave == 1) { if (lane < QB) dma4(rdl, St(buf) + QB * 4, (lane + q0) * 4); }
   };
   dma(0, 0);
-  stage_stats(0);
-  commit_stats(0);
+  stage_stats(0, 0);
   dma_wait_all();
   __syncthreads();
   if (!(ABL & 1) && ntiles > 1) {     // tile 1 -> the second buffer; from here on a tile's successor-but-one is requested at its end
     dma(1, 1);
-    stage_stats(QB);
+    stage_stats(1, QB);
   }
   constexpr int DS_STORES = DO_DK && !(KVABL & 1) ? (sizeof(T) == 2 ? 2 : 4) : 0;   // store instructions of one tile's dS^T per wave
   bool stored = false;                // this wave's dS^T stores of the previous tile may still be in flight
@@ -581,11 +577,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       // P = exp2(S scale - lse), straight into operand precision: S is dead before the dP chain starts (register plan above)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (8 * rg + 4 * h) * 4));
+        const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (8 * rg + 4 * h) * 4));   // lse (natural log): scaled to log2 units in the fma below
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rg + e;
-          s[r] = (KVABL & 8) ? __builtin_fmaf(s[r], scale_log2, -l2[e]) : fast_exp2(__builtin_fmaf(s[r], scale_log2, -l2[e]));
+          const float arg = __builtin_fmaf(l2[e], -LOG2E, s[r] * scale_log2);
+          s[r] = (KVABL & 8) ? arg : fast_exp2(arg);
         }
       }
       pf0 = acc_to_frag<T>(s, 0);
@@ -670,13 +667,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     // behind the barrier), THEN this tile's dS^T stores (block (key / 32, t), operand precision: exactly what the dK product
     // consumed) -- and the wait for tile t+1 one tile earlier is vmcnt(stores of the previous tile), which leaves those stores two
     // tile times to be acknowledged instead of stalling every tile on them (with them in front of the DMA: 70 us of 372).
-    if (!(ABL & 2)) commit_stats(BUF ^ 1);
     if (ABL & 4) dma_wait_all();
     else if (stored) wait_vm_barrier<DS_STORES>();
     else wait_vm_barrier<0>();
     if (!(ABL & 1) && t + 2 < ntiles) {
       dma(BUF, t + 2);
-      stage_stats((t + 2) * QB);
+      stage_stats(BUF, (t + 2) * QB);
     }
     // keys >= sep of a block row the dQ pass reads (rows < ds_rows) leave as zeros: that pass does not mask rows
     if constexpr (DS_STORES > 0) {
@@ -692,6 +688,14 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   }
 
   {
+    // row index and lane half are derived again from an opaque copy of the lane id: kept from before the loop they cost registers across
+    // it, i.e. a scratch slot (harmless, outside the loop, but the loop's budget is exactly the register file)
+    int lane2 = lane;
+    asm volatile("" : "+v"(lane2));
+    const int li2 = lane2 & 31, h2 = lane2 >> 5;
+    const int key2 = key0 + wave * 32 + li2;
+    const bool kvalid = key2 < sep;
+    const int kc = min(key2, a.S - 1);
     T* outk = dbase + (long)kc * rs + a.E + hd * D;
     T* outv = dbase + (long)kc * rs + 2 * a.E + hd * D;
 #pragma unroll
@@ -700,12 +704,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       if constexpr (DO_DK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = dk[db][r] * scale;
-        store_row_block<T>(outk + db * 32, v, h, kvalid);
+        store_row_block<T>(outk + db * 32, v, h2, kvalid);
       }
       if constexpr (DO_DV) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = dv[db][r];
-        store_row_block<T>(outv + db * 32, v, h, kvalid);
+        store_row_block<T>(outv + db * 32, v, h2, kvalid);
       }
     }
   }

@@ -326,6 +326,15 @@ PFN_DEV void dma16(const DmaRsrc& r, LdsPtr lds_dst_uniform, int byte_offset) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(dst), "v"(byte_offset), "s"(w) : "memory");
 }
+// one dword per lane: LDS address = lds_dst_uniform + 4 * lane
+PFN_DEV void dma4(const DmaRsrc& r, LdsPtr lds_dst_uniform, int byte_offset) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_dst_uniform);
+  const u32x4 w = {(unsigned)__builtin_amdgcn_readfirstlane(r.w[0]), (unsigned)__builtin_amdgcn_readfirstlane(r.w[1]),
+                   (unsigned)__builtin_amdgcn_readfirstlane(r.w[2]), (unsigned)__builtin_amdgcn_readfirstlane(r.w[3])};
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(dst), "v"(byte_offset), "s"(w) : "memory");
+}
 // Two instructions on purpose.  The builtin is the one hipcc's wait-count pass sees: after it the pass knows nothing is pending
 // (without it, loads issued before a loop -- K fragments held in registers -- stay "possibly pending" in its model, and it
 // re-waits for them at every use inside the loop with vmcnt(7), (6), ... (0): against the real queue, which holds the DMA
