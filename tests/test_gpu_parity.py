@@ -642,9 +642,15 @@ m1, m2 = build(), build()
 o1 = FusedClipAdam(m1, lr=1e-3, max_grad_norm=1.0); o1.grad_multiplier = 1.0 / world
 run(m1, slice(rank * h, (rank + 1) * h)); dp.all_reduce_gradients(m1.flat_parameters()[1]); o1.step(zero_grad=True)
 o2 = FusedClipAdam(m2, lr=1e-3, max_grad_norm=1.0)
-run(m2, slice(0, B)); o2.step(zero_grad=True)
-werr = ((m1.flat_parameters()[0] - m2.flat_parameters()[0]).abs().max()).item()
-assert werr < 2e-5, werr          # 2 % of one Adam step (lr 1e-3): elements whose gradient is ~eps move differently
+g2 = run(m2, slice(0, B))[1].clone(); o2.step(zero_grad=True)
+dw = (m1.flat_parameters()[0] - m2.flat_parameters()[0]).abs()
+# Adam's first step moves every element by lr * g / (|g| + eps): where the gradient is rounding noise around zero (the key bias:
+# softmax is invariant to it) the two summation orders may disagree about the whole step, so the tight bound is asserted where
+# the gradient is a gradient and the step size everywhere
+real = g2.abs() > 1e-6 * g2.abs().max()
+werr = dw[real].max().item()
+assert werr < 2e-5, werr          # 2 % of one Adam step (lr 1e-3)
+assert dw.max().item() <= 2.1e-3, dw.max().item()
 print('rank', rank, 'ok', err, werr)
 """
 
