@@ -6,7 +6,8 @@ travel to the GPU box):
 
 The reference imports gpytorch in priors/__init__.py:1 (absent here), so a stub `priors` package
 is registered first; only reference modules that import cleanly are used:
-transformer.TransformerModel, bar_distribution.*, encoders, positional_encodings, utils, train.
+transformer.TransformerModel, bar_distribution.*, encoders, positional_encodings, utils, train, priors.mlp,
+priors.gp (the reference's sklearn statement of the RBF GP: pins the oracle's Gram matrix and exact-GP evaluation).
 Weights: the reference zero-initialises out_proj / linear2 (transformer.py:49-53), which would make
 attention and the MLP invisible, so those tensors are re-drawn N(0, 0.05) before recording.
 """
@@ -192,6 +193,36 @@ def mlp_prior_case(ref):
     print('mlp prior', x.shape, y.shape, 'params', len(rec['params']), 'normals', len(rec['normals']), 'coins', rec['coins'], 'y mean', float(y.mean()))
 
 
+def gp_case(ref):
+    """Pins the GP part of the oracle to the reference's OWN sklearn statement of the same GP (priors/gp.py): the Gram
+    matrix of `get_gp(length_scale).kernel` (:14-17, RBF with fixed length scale, unit output scale) and the per-position
+    losses of `evaluate` (:41-62: a new regressor fitted on the first t points, `predict(return_std=True)` at point t,
+    Gaussian NLL with `full=True` / squared error) on fixed-seed inputs, in f64.  sklearn's regressor adds alpha = 1e-10 to
+    the diagonal of the training covariance and reports the LATENT predictive variance (no noise term at the test point).
+    For priors.fast_gp_mix (:28-34) the Matern-5/2 ARD Gram of sklearn's `Matern(nu=2.5, length_scale=<vector>)` -- the
+    same closed form gpytorch's MaternKernel(nu=2.5, ard_num_dims=F) evaluates -- is recorded as well."""
+    from priors import gp as ref_gp
+    from sklearn.gaussian_process.kernels import Matern
+    gen = torch.Generator().manual_seed(31)
+    rec = dict(alpha=1e-10, cases=[])
+    for (B, T, F, ls) in [(3, 24, 5, 0.6), (2, 40, 18, 0.6), (2, 16, 2, 0.25)]:
+        x = torch.rand(B, T, F, generator=gen, dtype=torch.float64)
+        z = torch.randn(B, T, generator=gen, dtype=torch.float64)
+        gram = torch.stack([torch.from_numpy(ref_gp.get_gp(ls).kernel(x[b].numpy())) for b in range(B)])       # priors/gp.py:14-17
+        y = (torch.linalg.cholesky(gram + 1e-6 * torch.eye(T, dtype=torch.float64)) @ z.unsqueeze(-1)).squeeze(-1)
+        xt, yt = x.transpose(0, 1).contiguous(), y.transpose(0, 1).contiguous()
+        nll, _ = ref_gp.evaluate(xt, yt, yt, use_mse=False, length_scale=ls)                                    # :41-62
+        mse, _ = ref_gp.evaluate(xt, yt, yt, use_mse=True, length_scale=ls)
+        rec['cases'].append(dict(B=B, T=T, F=F, length_scale=ls, x=x, y=y, gram=gram, evaluate_nll=nll.double(), evaluate_mse=mse.double()))
+    rec['matern'] = []
+    for (T, F) in [(20, 5), (12, 18)]:
+        x = torch.rand(T, F, generator=gen, dtype=torch.float64)
+        ls = torch.rand(F, generator=gen, dtype=torch.float64) * 2 + 0.1
+        rec['matern'].append(dict(x=x, lengthscale=ls, gram=torch.from_numpy(Matern(nu=2.5, length_scale=ls.numpy())(x.numpy()))))
+    torch.save(rec, os.path.join(OUT, 'gp_sklearn.pt'))
+    print('gp cases', [(c['B'], c['T'], c['F'], c['length_scale'], [round(float(v), 4) for v in c['evaluate_nll'][:4]]) for c in rec['cases']])
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -201,3 +232,4 @@ if __name__ == '__main__':
     bar_case(ref)
     utils_case(ref)
     mlp_prior_case(ref)
+    gp_case(ref)

@@ -13,7 +13,10 @@ Explicit-math restatement, in plain PyTorch on CPU tensors (f64 by default), of
     semantics restated: K = outputscale * exp(-0.5 |dx/l|^2) + noise I, y = chol(K) z)
   * priors.fast_gp_mix kernel                     reference priors/fast_gp_mix.py:28-47 (Matern-5/2 ARD)
   * priors.fast_gp.evaluate                       reference priors/fast_gp.py:88-120 (one exact GP per position;
-    gpytorch's ExactGP prediction equations restated -- parity unpinned like the GP prior)
+    gpytorch's ExactGP prediction equations restated)
+The GP parts are pinned to the reference's own sklearn statement of the same RBF GP (priors/gp.py:14-17, 41-62) and to
+sklearn's Matern-5/2 ARD Gram by tests/golden/gp_sklearn.pt; what stays unpinned is gpytorch-specific behaviour only
+(hyper-parameter tuple conventions, the jitter ladder of a failed factorisation) -- the library is not installed.
 Nothing here calls nn.TransformerEncoder: the layer math is written out, and is pinned against the
 real reference modules by tests/golden (oracle/make_golden.py).
 """
@@ -190,14 +193,18 @@ def get_batch_fast_gp(batch_size, seq_len, num_features, hyperparameters=None, g
     return x.transpose(0, 1), y.transpose(0, 1), y.transpose(0, 1)
 
 
-def gp_evaluate(x, y, use_mse=False, hyperparameters=None, step_size=1, start_pos=0, kernel='rbf', dtype=torch.float64):
+def gp_evaluate(x, y, use_mse=False, hyperparameters=None, step_size=1, start_pos=0, kernel='rbf', dtype=torch.float64,
+                min_noise=1e-9, noisy_predictive=True):
     """CPU statement of priors.fast_gp.evaluate (fast_gp.py:88-120), literally: for every t a NEW exact GP is
     conditioned on (x[:t], y[:t]) (train covariance = outputscale k + noise I, zero mean, fast_gp.py:13-32) and asked
     for the noisy predictive at x[t] (`likelihood(model(x[t]))`, :101-104); loss = -log N(y[t]; mean, var) (:115) or
     (mean - y[t])^2 (:112).  x [T,B,F], y [T,B].  Returns (losses [n_t,B], means [n_t,B], variances [n_t,B]).
     gpytorch itself is not installed here: this restates its ExactGP prediction equations,
     mean = k_t^T C_t^-1 y_t, var = k(x_t,x_t) + noise - k_t^T C_t^-1 k_t, with one Cholesky PER t -- on purpose a
-    different algorithm from the product's single factorisation."""
+    different algorithm from the product's single factorisation.
+    PINNED (tests/test_oracle.py::test_gp_oracle_matches_reference_sklearn_gp) against the reference's own sklearn
+    statement of the same model, priors/gp.py:41-62, whose regressor uses noise alpha = 1e-10 and reports the latent
+    variance: `min_noise=0, noisy_predictive=False` selects exactly that convention."""
     if isinstance(hyperparameters, (tuple, list)):
         hyperparameters = {"noise": hyperparameters[0], "outputscale": hyperparameters[1], "lengthscale": hyperparameters[2]}
     elif hyperparameters is None:
@@ -208,7 +215,7 @@ def gp_evaluate(x, y, use_mse=False, hyperparameters=None, step_size=1, start_po
     ls = as_t(hyperparameters["lengthscale"])
     ls = ls.reshape(B, 1, -1) if ls.dim() > 0 and ls.numel() > 1 else ls.reshape(1, 1, 1)
     os_ = as_t(hyperparameters["outputscale"]).reshape(-1, 1, 1)
-    nz = as_t(hyperparameters["noise"]).clamp_min(1e-9).reshape(-1, 1, 1)
+    nz = as_t(hyperparameters["noise"]).clamp_min(min_noise).reshape(-1, 1, 1)   # GaussianLikelihood(noise_constraint=GreaterThan(1e-9)), fast_gp.py:25
     C = gp_gram(xb, ls, os_, nz, kernel)                      # [B,T,T], noise on the diagonal
     losses, means, varis = [], [], []
     for t in range(max(start_pos, 1), T, step_size):
@@ -218,6 +225,8 @@ def gp_evaluate(x, y, use_mse=False, hyperparameters=None, step_size=1, start_po
         v = torch.linalg.solve_triangular(L, k, upper=False)
         mean = (k * alpha).sum((1, 2))
         var = C[:, t, t] - (v * v).sum((1, 2))                # C[t,t] = outputscale k(x_t,x_t) + noise
+        if not noisy_predictive:
+            var = var - nz.reshape(-1)
         means.append(mean)
         varis.append(var)
         if use_mse:

@@ -119,6 +119,29 @@ def test_gp_oracle_covariance():
     assert xs.shape == (10, 4, 3) and ys.shape == (10, 4) and ts.shape == (10, 4)
 
 
+def test_gp_oracle_matches_reference_sklearn_gp():
+    """The pin of the GP oracle: tests/golden/gp_sklearn.pt holds what the REFERENCE's sklearn GP (priors/gp.py) produced on
+    fixed-seed inputs (oracle/make_golden.py::gp_case) -- the RBF Gram of `get_gp(ls).kernel` (:14-17), the per-position
+    losses of `evaluate` (:41-62; alpha = 1e-10 as noise, latent predictive variance), and sklearn's Matern-5/2 ARD Gram."""
+    rec = torch.load(os.path.join(GOLD, 'gp_sklearn.pt'))
+    for c in rec['cases']:
+        one = torch.ones(1, 1, 1, dtype=torch.float64)
+        gram = pfn_oracle.gp_gram(c['x'], one * c['length_scale'], one, 0 * one, 'rbf')
+        assert (gram - c['gram']).abs().max().item() < 1e-9
+        xt, yt = c['x'].transpose(0, 1), c['y'].transpose(0, 1)
+        hps = dict(noise=rec['alpha'], outputscale=1.0, lengthscale=c['length_scale'])
+        nll, _, var = pfn_oracle.gp_evaluate(xt, yt, hyperparameters=hps, min_noise=0.0, noisy_predictive=False)
+        assert var.min().item() > 1e-6        # nn.GaussianNLLLoss clamps the variance at 1e-6 (priors/gp.py:54): not active in these cases
+        want = c['evaluate_nll'][1:]          # the reference returns [0.] + the batch mean per position
+        assert (nll.mean(1) - want).abs().max().item() < 1e-9        # measured 4e-14
+        mse, _, _ = pfn_oracle.gp_evaluate(xt, yt, use_mse=True, hyperparameters=hps, min_noise=0.0, noisy_predictive=False)
+        assert (mse.mean(1) - c['evaluate_mse'][1:]).abs().max().item() < 1e-9
+    for c in rec['matern']:
+        one = torch.ones(1, 1, 1, dtype=torch.float64)
+        gram = pfn_oracle.gp_gram(c['x'].unsqueeze(0), c['lengthscale'].reshape(1, 1, -1), one, 0 * one, 'matern')[0]
+        assert (gram - c['gram']).abs().max().item() < 1e-9
+
+
 def test_gp_evaluate_oracle_chain_rule_and_noise_limit():
     """The restated priors.fast_gp.evaluate (one exact GP per position): its per-position negative log densities are
     the chain-rule factors of the joint Gaussian, so with the prior term of position 0 they add up to

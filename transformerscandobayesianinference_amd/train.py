@@ -68,7 +68,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
           epochs=10, steps_per_epoch=100, batch_size=200, bptt=10, lr=None, warmup_epochs=10, input_normalization=False,
           y_encoder_generator=None, pos_encoder_generator=None, decoder=None, extra_prior_kwargs_dict={},
           scheduler=get_cosine_schedule_with_warmup, load_weights_from_this_state_dict=None, validation_period=10,
-          single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16', micro_streams=2):
+          single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16', micro_streams=2, epoch_callback=None):
     device = gpu_device if torch.cuda.is_available() else 'cpu:0'
     print(f'Using {device} device')
     if not str(device).startswith('cuda') and getattr(TransformerModel, 'requires_gpu', False):
@@ -184,6 +184,8 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
                 f' data time {time_to_get_batch:5.2f} step time {step_time:5.2f}'
                 f' forward time {forward_time:5.2f}' + (f'val score {val_score}' if val_score is not None else ''))
             print('-' * 89)
+        if epoch_callback is not None:      # (model, epoch, mean loss, learning rate of the epoch, seconds): loss curves / checkpoints
+            epoch_callback(model, epoch, total_loss, scheduler.get_last_lr()[0], time.time() - epoch_start_time)
         scheduler.step()
     return total_loss, total_positional_losses, model.to('cpu')
 
