@@ -19,8 +19,9 @@ The JSON line also carries
                  f64 CPU oracle on the SAME fixed-seed draw, weights and eval position: loss and posterior-predictive
                  means (rank 0, N = 1);
   val_bar_nll  : the loss of the benchmarked model on a fixed-seed validation draw (second half of BASELINE.json's metric);
-  cpu_baseline : the CPU oracle (a port of the reference math, torch f32 on the host cores) timed on a bounded sample of
-                 the same workload starting from the same weights and inputs (rank 0, N = 1 only).
+  cpu_baseline : the reference's CPU path timed on the host cores on a bounded sample of the same workload from the same
+                 weights and inputs (rank 0, N = 1 only): the torch nn.TransformerEncoder stack the reference instantiates
+                 (kind "torch-modules", the reported value) and the explicit-math port that is the parity checker.
 """
 import argparse
 import contextlib
@@ -156,8 +157,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     """Isolated timings of the step's kernels at the workload shape (through the single-op C ABI): one entry per kernel
     symbol, with the number of launches per step, so the dominant one can be picked by in-step time."""
     from transformerscandobayesianinference_amd import _hip
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import hipops
+    from transformerscandobayesianinference_amd import hipops
     dev = torch.device('cuda')
     S, E, F, H, L = w['bptt'], w['emsize'], w['nhid'], w['nhead'], w['nlayers']
     M = batch * S
@@ -363,46 +363,71 @@ def parity_check(model, w, device, precision):
 
 
 def cpu_baseline(w, inputs, steps=3, warm=1):
-    """The CPU oracle (port of the reference math, f32) on the host cores: [prior draw +] forward + loss + backward + clip +
-    Adam at the workload shape, bounded to a few steps, starting from the benchmarked weights and the parity inputs."""
-    from oracle import pfn_oracle
+    """The reference's CPU path on the host cores, two legs, each a few full training steps ([prior draw +] forward + loss +
+    backward + clip + Adam) at the workload shape from the benchmarked weights and the parity inputs:
+      torch-modules : the model as the reference BUILDS it -- torch's nn.TransformerEncoder(nn.TransformerEncoderLayer(...,
+                      activation='gelu')) with the dense host-built mask, embeddings and decoder on all rows
+                      (oracle/torch_modules.py; reference transformer.py:14-25, 55-91).  torch's modules take fused CPU kernels,
+                      so this is what a user of the reference gets on these cores: THE reported baseline.
+      port          : the explicit-math restatement that serves as the parity checker (oracle/pfn_oracle.py), for comparison."""
+    from oracle import pfn_oracle, torch_modules
     x0, y0, sd = inputs
     threads = usable_cores()
     torch.set_num_threads(threads)
-    torch.manual_seed(0)
     S, nf, B = w['bptt'], w['num_features'], x0.shape[1]
     if w['prior'] == 'fast_gp_mix':
         steps, warm = 1, 0
-    params = {k: v.detach().float().clone().requires_grad_(True) for k, v in sd.items() if not k.startswith('criterion.')}
-    opt = torch.optim.Adam(list(params.values()), lr=1e-4)
     sep = w['parity_sep']
-    times, draws = [], []
-    for it in range(warm + steps):
-        t0 = time.time()
+
+    def draw(it):
         if it == 0 or w['prior'] == 'mlp':
-            x, y = x0.float(), y0.float()            # the parity inputs (BNN prior: no host port of the sampler -- draw time not included)
-        elif w['prior'] == 'fast_gp':
+            return x0.float(), y0.float()            # the parity inputs (BNN prior: no host port of the sampler -- draw time not included)
+        if w['prior'] == 'fast_gp':
             x, y, _ = pfn_oracle.get_batch_fast_gp(B, S, nf, w['hyperparameters'], dtype=torch.float32)
+            return x, y
+        from transformerscandobayesianinference_amd.priors import fast_gp_mix
+        ls, osc, nz = fast_gp_mix.sample_hyperparameters(B, nf, w['hyperparameters'], 'cpu', generator=torch.Generator().manual_seed(it))
+        y = pfn_oracle.gp_sample(torch.rand(B, S, nf), torch.randn(B, S), ls, osc, nz, 'matern', torch.float32).float().transpose(0, 1)
+        return x0.float(), y
+
+    def leg(kind):
+        torch.manual_seed(0)
+        if kind == 'port':
+            params = {k: v.detach().float().clone().requires_grad_(True) for k, v in sd.items() if not k.startswith('criterion.')}
+            plist = list(params.values())
+            fwd = lambda x, y: pfn_oracle.forward(params, x, y, sep, w['nhead'], dtype=torch.float32)
         else:
-            from transformerscandobayesianinference_amd.priors import fast_gp_mix
-            ls, osc, nz = fast_gp_mix.sample_hyperparameters(B, nf, w['hyperparameters'], 'cpu', generator=torch.Generator().manual_seed(it))
-            y = pfn_oracle.gp_sample(torch.rand(B, S, nf), torch.randn(B, S), ls, osc, nz, 'matern', torch.float32).float().transpose(0, 1)
-            x = x0.float()
-        draws.append(time.time() - t0)
-        logits = pfn_oracle.forward(params, x, y, sep, w['nhead'], dtype=torch.float32)
-        loss = oracle_loss_and_means(w, sd, logits, y[sep:])[0].mean()
-        opt.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
-        opt.step()
-        if it >= warm:
-            times.append(time.time() - t0)
-    per_step = sum(times) / len(times)
+            module = torch_modules.from_state_dict(sd, w['nhead']).train()
+            plist = list(module.parameters())
+            fwd = lambda x, y: module((x, y), sep)
+        opt = torch.optim.Adam(plist, lr=1e-4)
+        times, loss0 = [], None
+        for it in range(warm + steps):
+            t0 = time.time()
+            x, y = draw(it)
+            logits = fwd(x, y)
+            loss = oracle_loss_and_means(w, sd, logits, y[sep:])[0].mean()
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(plist, 1.0)
+            opt.step()
+            if it == 0:
+                loss0 = loss.item()
+            if it >= warm:
+                times.append(time.time() - t0)
+        per_step = sum(times) / len(times)
+        return dict(kind=kind, value=B / per_step, unit='datasets/s', seconds_per_step=per_step, first_step_loss=loss0)
+
+    legs = [leg('torch-modules'), leg('port')]
     note = ' (BNN prior draw not included: the reference sampler is per-dataset Python, 57 datasets/s in BASELINE.md)' if w['prior'] == 'mlp' else ''
-    return dict(value=B / per_step, unit='datasets/s', cores=threads, kind='port',
-                sample=f'{steps} full training step(s) (prior draw + fwd + loss + bwd + clip + Adam), batch {B}, bptt {S}, eval position {sep}, torch f32 CPU '
-                       f'oracle from the benchmarked weights; step 0 reads the parity inputs' + note,
-                seconds_per_step=per_step)
+    best = max(legs, key=lambda l: l['value'])     # the faster leg is the honest baseline (torch-modules on every box seen so far)
+    return dict(value=best['value'], unit='datasets/s', cores=threads, kind=best['kind'],
+                sample=f'{steps} full training step(s) (prior draw + fwd + loss + bwd + clip + Adam), batch {B}, bptt {S}, eval position {sep}, torch f32 on the '
+                       f'host cores from the benchmarked weights; step 0 reads the parity inputs.  kind "torch-modules" = the nn.TransformerEncoder stack the '
+                       f'reference instantiates (transformer.py:17-18) with its dense mask and all-row decoder; the explicit-math port (the parity checker) is '
+                       f'timed beside it in `legs`' + note,
+                seconds_per_step=best['seconds_per_step'], legs=legs,
+                legs_agree=abs(legs[0]['first_step_loss'] - legs[1]['first_step_loss']) / abs(legs[1]['first_step_loss']))
 
 
 def validation_loss(model, w, device, n=8, seed=4321):

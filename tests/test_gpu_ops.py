@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from transformerscandobayesianinference_amd import _hip
-import hipops
+from transformerscandobayesianinference_amd import hipops
 
 pytestmark = pytest.mark.gpu
 BF, F32 = _hip.PREC_BF16, _hip.PREC_F32

@@ -183,3 +183,18 @@ def test_oracle_mlp_prior_matches_reference():
         assert torch.equal(y, rec['y'][:, i]), i
         assert torch.allclose(x, rec['x'][:, i, :], atol=1e-5, rtol=1e-5), i
         assert x[:, causes.shape[1]:].abs().max() == 0
+
+
+def test_torch_modules_model_matches_the_port():
+    """oracle/torch_modules.py (the nn.TransformerEncoder stack the reference instantiates: bench.py's cpu_baseline leg) against the
+    explicit-math port and the reference-generated logits, on a golden state dict."""
+    from oracle import torch_modules
+    rec = torch.load(os.path.join(GOLD, 'model_small_h32.pt'))
+    cfg, sd = rec['config'], rec['state_dict']
+    m = torch_modules.from_state_dict(sd, cfg['H']).train()
+    for sep, want in rec['per_sep'].items():
+        got = m((rec['x'], rec['y']), sep)
+        assert relerr(got.detach(), want['logits']) < 2e-5
+        port = pfn_oracle.forward({k: v for k, v in sd.items() if not k.startswith('criterion.')}, rec['x'], rec['y'], sep, cfg['H'])
+        assert relerr(got.detach(), port) < 2e-5
+    assert set(m.state_dict()) == {k for k in sd if not k.startswith('criterion.')}

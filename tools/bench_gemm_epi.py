@@ -3,8 +3,9 @@
 import argparse, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import bench, hipops
+sys.path.insert(0, ROOT)
+import bench
+from transformerscandobayesianinference_amd import hipops
 from transformerscandobayesianinference_amd import _hip
 if os.environ.get('PFN_LIB'):
     _hip.LIB_PATH = os.path.abspath(os.environ['PFN_LIB'])

@@ -9,9 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import bench  # noqa: E402
-import hipops  # noqa: E402
+from transformerscandobayesianinference_amd import hipops  # noqa: E402
 from transformerscandobayesianinference_amd import _hip  # noqa: E402
 
 

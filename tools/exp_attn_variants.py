@@ -8,10 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHILD = r'''
 import os, sys, torch
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT)
 from transformerscandobayesianinference_amd import _hip
 if LIB: _hip.LIB_PATH = LIB
-import hipops
+from transformerscandobayesianinference_amd import hipops
 B, S, E, H, sep = 16, 2000, 512, 4, 1603
 qkv = (torch.randn(B, S, 3 * E, device='cuda') * 0.5).to(torch.bfloat16)
 dctx = (torch.randn(B, S, E, device='cuda') * 0.5).to(torch.bfloat16)

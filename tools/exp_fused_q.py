@@ -7,8 +7,9 @@ every attention workgroup, at that kernel's efficiency instead of the GEMM's."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import bench, hipops
+sys.path.insert(0, ROOT)
+import bench
+from transformerscandobayesianinference_amd import hipops
 from transformerscandobayesianinference_amd import _hip
 M, E = 32000, 512
 bf = torch.bfloat16

@@ -2,8 +2,8 @@
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import hipops
+sys.path.insert(0, ROOT)
+from transformerscandobayesianinference_amd import hipops
 from transformerscandobayesianinference_amd import _hip
 B, S, E, H, sep = 16, 2000, 512, 4, 1604
 qkv = (torch.randn(B, S, 3 * E, device='cuda') * 0.5).to(torch.bfloat16)

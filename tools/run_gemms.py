@@ -3,8 +3,8 @@ passes; tools/pmc_gemm.sh)."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import hipops
+sys.path.insert(0, ROOT)
+from transformerscandobayesianinference_amd import hipops
 from transformerscandobayesianinference_amd import _hip
 H = _hip
 M, E, F, L = 32000, 512, 1024, 6

@@ -984,11 +984,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
   const size_t lds = 2 * C::RIMG + 3 * C::CIMG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsAllowance allowance;
+  allowance.ensure(attn_fwd_kernel<T, D>, lds);
   hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
@@ -1001,15 +998,11 @@ template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStrea
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, s, a, D);
   }
   const size_t lds_kv = BwdKvCfg<T, D>::LDS, lds_dq = BwdDqCfg<T, D>::LDS;
-  static bool attr_set = false;      // (hipFuncSetAttribute costs tens of microseconds of host time per call)
-  if (!attr_set) {
-    auto allow = [](auto kernel, size_t lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
-    allow(attn_bwd_kv_kernel<T, D, 0>, lds_kv);
-    allow(attn_bwd_kv_kernel<T, D, 1>, lds_kv);
-    allow(attn_bwd_kv_kernel<T, D, 2>, lds_kv);
-    allow(attn_bwd_dq_kernel<T, D>, lds_dq);
-    attr_set = true;
-  }
+  static LdsAllowance allow_kv[3], allow_dq;      // (per device; hipFuncSetAttribute costs tens of microseconds of host time per call)
+  allow_kv[0].ensure(attn_bwd_kv_kernel<T, D, 0>, lds_kv);
+  allow_kv[1].ensure(attn_bwd_kv_kernel<T, D, 1>, lds_kv);
+  allow_kv[2].ensure(attn_bwd_kv_kernel<T, D, 2>, lds_kv);
+  allow_dq.ensure(attn_bwd_dq_kernel<T, D>, lds_dq);
   auto run_kv = [&](auto kernel, const AttnArgs& ac) {
     hipLaunchKernelGGL(kernel, dim3(((ac.sep + C::QBLK - 1) / C::QBLK) * ac.H * ac.B), dim3(C::NT), lds_kv, s, ac);
   };

@@ -1369,22 +1369,16 @@ template <int FLAGS> static bool launch_persist_t(const GemmNT& g, hipStream_t s
   using P = PersistCfg<FLAGS>;
   if (g_nt_persist <= 0 || (g.K / 64) % 2 || g.N % C::BN || !g.wide_t) return false;
   if ((FLAGS & EPI_OUT_F32) && (g.ld_out_f32 % 4)) return false;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_persist_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS);
-    attr_set = true;
-  }
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_persist_kernel<FLAGS>, P::LDS);
   const int tiles = ((g.M + C::BM - 1) / C::BM) * (g.N / C::BN);
   hipLaunchKernelGGL((gemm_nt_persist_kernel<FLAGS>), dim3(std::min(tiles, g_nt_persist)), dim3(512), P::LDS, stream, g);
   return true;
 }
 template <int FLAGS, int NWM, int BK> static void launch_big_t(const GemmNT& g, hipStream_t stream) {
   using C = BigCfg<NWM, BK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<FLAGS, NWM, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::STAGE);
-    attr_set = true;
-  }
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_big_kernel<FLAGS, NWM, BK>, 2 * C::STAGE);
   const int tiles = ((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   hipLaunchKernelGGL((gemm_nt_big_kernel<FLAGS, NWM, BK>), dim3(tiles), dim3(C::NT), 2 * C::STAGE, stream, g);
 }
@@ -1460,11 +1454,8 @@ bool gemm_ln_supported(const GemmLN& g) {
 }
 template <int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g, hipStream_t stream) {
   const size_t lds = std::max<size_t>(2 * (128 + NWN * 64) * (BK * 2), LnEpi<NWN>::BYTES);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ln_kernel<NWN, RL, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_ln_kernel<NWN, RL, BK>, lds);
   hipLaunchKernelGGL((gemm_nt_ln_kernel<NWN, RL, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
 }
 int launch_gemm_ln(const GemmLN& g, hipStream_t stream) {
@@ -1490,11 +1481,8 @@ bool gemm_lnbwd_supported(const GemmLNB& g) {
 }
 template <int NWN, int BK> static void launch_gemm_lnbwd_t(const GemmLNB& g, hipStream_t stream) {
   const size_t lds = LnbCfg<NWN, BK>::LDS;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_lnbwd_kernel<NWN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_lnbwd_kernel<NWN, BK>, lds);
   hipLaunchKernelGGL((gemm_nt_lnbwd_kernel<NWN, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
 }
 int launch_gemm_lnbwd(const GemmLNB& g, hipStream_t stream) {
@@ -1542,11 +1530,8 @@ int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream) {
   g.splits = splits;
   g.m_chunk = chunk;
   g.debug_mask = g_tn_debug_wrap > 0 ? g_tn_debug_wrap - 1 : 0x7fffffff;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TNB_LDS);
-    attr_set = true;
-  }
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_tn_big_kernel, TNB_LDS);
   hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(tiles * splits), dim3(512), TNB_LDS, stream, g);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }

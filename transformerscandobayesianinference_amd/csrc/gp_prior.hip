@@ -499,11 +499,8 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
     if (ti > 0 && tj > 0) hipLaunchKernelGGL(gp_syrk_kernel, dim3(tj, ti, B), dim3(256), SYRK_LDS, s, a, r0, r1, c0, c1, kp0, K);
   };
   const size_t tw_lds = 2 * 64 * TW_STRIDE + OBW * sizeof(float);
-  static bool tw_attr_set = false;   // (constant size; the call costs tens of microseconds of host time)
-  if (!tw_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_trsm_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tw_lds);
-    tw_attr_set = true;
-  }
+  static LdsAllowance tw_allowance;   // (constant size; per device; the call costs tens of microseconds of host time)
+  tw_allowance.ensure(gp_trsm_wide_kernel, tw_lds);
   for (int kout = 0; kout < S; kout += OBW) {
     const int kend = std::min(kout + OBW, S);
     for (int k0 = kout; k0 < kend; k0 += NB) {

@@ -116,11 +116,8 @@ int launch_mlp_prior(const MlpPriorArgs& a, hipStream_t s) {
   if (a.B < 1 || a.T < 1 || a.HP < 4 || a.HP % 4 || a.Lmax < 1) return PFN_ERR_ARGUMENT;
   const size_t lds = ((size_t)a.HP * a.HP + 2 * (size_t)a.HP * MLP_TR) * sizeof(float);
   if (lds > 160 * 1024) return PFN_ERR_UNSUPPORTED;
-  static size_t lds_allowed = 0;
-  if (lds > lds_allowed) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_prior_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    lds_allowed = lds;
-  }
+  static LdsAllowance allowance;
+  allowance.ensure(mlp_prior_kernel, lds);
   hipLaunchKernelGGL(mlp_prior_kernel, dim3((a.T + MLP_TR - 1) / MLP_TR, a.B), dim3(256), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }

@@ -3,9 +3,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/pfn_hip.h"
 
 namespace pfn {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute and setting it costs tens of microseconds of host time, so
+// every launcher keeps one of these per kernel: the largest dynamic-LDS size granted so far on each device.  Lock-free; two host
+// threads racing on a first use at worst both set the attribute (idempotent) -- neither can launch before it is set.
+struct LdsAllowance {
+  std::atomic<size_t> granted[16];   // by device ordinal (a node has 8)
+  template <typename K> void ensure(K kernel, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& g = granted[dev & 15];
+    if (bytes <= g.load(std::memory_order_acquire)) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    size_t cur = g.load(std::memory_order_relaxed);
+    while (cur < bytes && !g.compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+  }
+};
 
 // ---- GEMM -----------------------------------------------------------------------------------
 enum : int {

@@ -556,8 +556,8 @@ int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const floa
   const int grid = grid_for(rows, LNB_WAVES * 8, 512);
   const size_t lds = LNB_WAVES * E * sizeof(float);
 #define LN_BWD_K(TT, NV, EV, DT) do { \
-    static size_t lds_allowed = 0; \
-    if (lds > lds_allowed) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_kernel<TT, NV, EV, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_allowed = lds; } \
+    static LdsAllowance allowance; \
+    allowance.ensure(layernorm_bwd_kernel<TT, NV, EV, DT>, lds); \
     hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, EV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E); } while (0)
 #define LN_BWD(TT, NV, EV) do { if (dy_is_t) LN_BWD_K(TT, NV, EV, true); else LN_BWD_K(TT, NV, EV, false); } while (0)
   // rows of >= 512 elements in 8-element lane chunks (16-byte operand-precision accesses), narrower rows in 4-element ones

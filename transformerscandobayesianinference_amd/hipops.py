@@ -1,4 +1,5 @@
-"""Thin test-side wrappers around the single-op C-ABI entry points (pfn_op_*)."""
+"""Tensor-level wrappers around the single-op C-ABI entry points (`pfn_op_*`, include/pfn_hip.h): one kernel launch per call on the
+current stream.  Used by the per-kernel parity tests (tests/test_gpu_ops.py), by bench.py's kernel table and by tools/."""
 import torch
 
 from transformerscandobayesianinference_amd import _hip

@@ -48,13 +48,14 @@ class FusedClipAdam(torch.optim.Optimizer):
             sd['flat'] = {'step': self._step, 'exp_avg': self._m.detach().cpu().clone(), 'exp_avg_sq': self._v.detach().cpu().clone()}
         else:
             sd['flat'] = {'step': self._step}
-        sd['grad_multiplier'] = self.grad_multiplier
+        # grad_multiplier (1 / world size) is run topology, not optimizer state: it is NOT persisted, so a checkpoint resumed
+        # on a different number of GPUs keeps the value train() / the DP wrapper set for THIS run
         return sd
 
     def load_state_dict(self, state_dict):
         state_dict = dict(state_dict)
         flat_state = state_dict.pop('flat', None)
-        self.grad_multiplier = state_dict.pop('grad_multiplier', self.grad_multiplier)
+        state_dict.pop('grad_multiplier', None)     # written by round-2 checkpoints; ignored (see state_dict)
         super().load_state_dict(state_dict)
         if flat_state is not None:
             self._step = int(flat_state['step'])

@@ -225,3 +225,5 @@ def evaluate(x, y, y_non_noisy, use_mse=False, hyperparameters={}, get_model_on_
 DataLoader.prefetch = True        # draws run ahead of the training steps on a side stream (priors/utils.py)
 DataLoader.prefetch_group = 10    # ... ten steps' worth of datasets per sampler call (MI355X, bptt 2000: 64 us per dataset at 4 x 32, 54 us at 10 x 32;
                                   # 16 MB of factorisation workspace per dataset: 5 GB of the 288)
+DataLoader.prefetch_memory_share = 0.125    # ... but never more than an eighth of the free device memory per group (two groups are alive at a time)
+DataLoader.prefetch_bytes_per_dataset = staticmethod(lambda kw: 4 * ((kw.get('seq_len', 0) + 3) // 4 * 4) ** 2)   # K_ws[Tp, Tp] f32

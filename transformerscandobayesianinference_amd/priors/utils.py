@@ -28,9 +28,13 @@ def get_batch_to_dataloader(get_batch_method_):
 
         @staticmethod
         def gbm(*args, fuse_x_y=True, **kwargs):
-            x, y, target_y = get_batch_method_(*args, **kwargs)
             if not fuse_x_y:
+                x, y, target_y = get_batch_method_(*args, **kwargs)
                 return (x, y), target_y
+            # the fused input COPIES y (torch.cat below), so a deferred repair of a failed factorisation -- which rewrites
+            # y in place after the draw returned -- would not reach it: check such draws at once
+            with undeferred_draw_checks():
+                x, y, target_y = get_batch_method_(*args, **kwargs)
             shifted_y = torch.cat([torch.zeros_like(y[:1]), y[:-1]], 0).unsqueeze(-1).float()
             return torch.cat([x, shifted_y], -1), target_y
 
@@ -41,6 +45,13 @@ def get_batch_to_dataloader(get_batch_method_):
             draw = lambda: self.gbm(**self.get_batch_kwargs, fuse_x_y=self.fuse_x_y)
             if getattr(self, 'prefetch', False) and torch.cuda.is_available():
                 group = max(1, int(getattr(self, 'prefetch_group', 1)))
+                budget = getattr(self, 'prefetch_bytes_per_dataset', None)
+                if budget is not None and 'batch_size' in self.get_batch_kwargs:
+                    # sampler workspace of one group (and the pending group holds as much again): keep it inside a fixed share
+                    # of the device memory -- the reference's per-step draw must not run out of memory here either
+                    per_step = budget(self.get_batch_kwargs) * self.get_batch_kwargs['batch_size']
+                    free = torch.cuda.mem_get_info()[0]
+                    group = max(1, min(group, int(free * self.prefetch_memory_share // max(per_step, 1))))
                 if group > 1 and not self.fuse_x_y and 'batch_size' in self.get_batch_kwargs:
                     return prefetch_on_side_stream(self._draw_group, (self.num_steps + group - 1) // group, self.num_steps, group)
                 return prefetch_on_side_stream(lambda n: [draw() for _ in range(n)], self.num_steps, self.num_steps, 1)
@@ -75,13 +86,24 @@ class deferred_draw_checks:
         return self.checks
 
     def __exit__(self, *exc):
-        _open_check_lists.remove(self.checks)
+        _open_check_lists[:] = [c for c in _open_check_lists if c is not self.checks]
+        return False
+
+
+class undeferred_draw_checks:
+    """Inside this block `defer_draw_check` declines (returns False): the sampler checks its draw before returning."""
+
+    def __enter__(self):
+        _open_check_lists.append(None)
+
+    def __exit__(self, *exc):
+        _open_check_lists.pop()
         return False
 
 
 def defer_draw_check(fn):
     """Queue `fn` if a deferred block is open (returns True), else leave it to the caller (returns False)."""
-    if _open_check_lists:
+    if _open_check_lists and _open_check_lists[-1] is not None:
         _open_check_lists[-1].append(fn)
         return True
     return False

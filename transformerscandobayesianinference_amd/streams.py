@@ -27,7 +27,9 @@ class MicroBatchStreams:
         # only the all-HIP path is split: with a PyTorch-side embedding (custom encoders, SeqBN, positional encodings)
         # SeqBN would normalise per group, a scrambled encoding would draw per group, and autograd's gradient
         # accumulation into the shared flat buffer (non-atomic read-modify-write) would run on two streams at once
-        fused = getattr(model, '_fused_embedding', lambda: False)()
+        # ... and so would a custom `decoder=` module: it runs in PyTorch on the stack's output, and AccumulateGrad's in-place
+        # `+=` on its parameters (views of the flat buffer) is not atomic across the two streams
+        fused = getattr(model, '_fused_embedding', lambda: False)() and not getattr(model, '_custom_decoder', False)
         n = self.n if (self.streams and fused and B % self.n == 0 and B >= 2 * self.n) else 1
         if n == 1:
             output = model(data, single_eval_pos=single_eval_pos)
