@@ -15,9 +15,9 @@ The JSON line also carries
                  with HIP events on the launch stream), algorithmic FLOPs (mask-aware) / duration vs
                  the dense bf16 MFMA peak, and the FLOPs it executes when that differs (recomputation);
   step_roofline: the same accounting for the whole step (train(S,sep) = 3 * fwd(S,sep) per dataset);
-  parity       : the benchmarked model (its weights after the timed steps) in the benchmarked precision against the
-                 f64 CPU oracle on the SAME fixed-seed draw, weights and eval position: loss and posterior-predictive
-                 means (rank 0, N = 1);
+  parity       : the benchmarked model (its weights after the timed steps) against the f64 CPU oracle on the SAME fixed-seed
+                 draw, weights and eval position: loss and posterior-predictive means of its inference outputs (eval mode:
+                 exact-f32 kernels by default) and, as `training_forward`, of the timed path's bf16 forward (rank 0, N = 1);
   val_bar_nll  : the loss of the benchmarked model on a fixed-seed validation draw (second half of BASELINE.json's metric);
   cpu_baseline : the reference's CPU path timed on the host cores on a bounded sample of the same workload from the same
                  weights and inputs (rank 0, N = 1 only): the torch nn.TransformerEncoder stack the reference instantiates
@@ -326,40 +326,59 @@ def hip_loss_and_means(w, model, logits, y_test):
 
 
 def parity_check(model, w, device, precision):
-    """HIP path (benchmarked precision, benchmarked weights) vs the f64 oracle on the same inputs."""
+    """HIP path (benchmarked weights) vs the f64 oracle on the same inputs, twice:
+      * the model's INFERENCE outputs -- model.eval() under no_grad, what validate / run_test / criterion.mean serve; these run in
+        `model.eval_precision` (exact-f32 kernels by default) and carry the north star's 1e-3 bound on NLL and posterior means;
+      * `training_forward`: the forward of the TIMED path (train mode, benchmarked precision), same inputs, reported beside it."""
     from oracle import pfn_oracle
     x, y = parity_inputs(w, device)
     sep = w['parity_sep']
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     was_training = model.training
-    model.eval()
-    with torch.no_grad():
-        xd, yd = x.float().to(device), y.float().to(device)
-        lg = model((xd, yd), single_eval_pos=sep)
-        loss_h, mean_h = hip_loss_and_means(w, model, lg, yd[sep:])
+    xd, yd = x.float().to(device), y.float().to(device)
+
+    def hip(train_mode):
+        model.train(train_mode)
+        with torch.no_grad():
+            lg = model((xd, yd), single_eval_pos=sep)
+            loss_h, mean_h = hip_loss_and_means(w, model, lg, yd[sep:])
+        return lg.double().cpu(), loss_h.double().cpu(), mean_h.double().cpu()
+
+    out_eval, out_train = hip(False), hip(True)
     model.train(was_training)
     t0 = time.time()
     with torch.no_grad():
         lo = pfn_oracle.forward({k: v for k, v in sd.items() if not k.startswith('criterion.')}, x, y, sep, w['nhead'], dtype=torch.float64)
         loss_o, mean_o = oracle_loss_and_means(w, sd, lo, y[sep:])
     oracle_s = time.time() - t0
-    lg, loss_h, mean_h = lg.double().cpu(), loss_h.double().cpu(), mean_h.double().cpu()
-    d = mean_h - mean_o
-    nll_h, nll_o = loss_h.mean().item(), loss_o.mean().item()
     y_test = y[sep:]
-    return dict(
+    nll_o = loss_o.mean().item()
+
+    def metrics(lg, loss_h, mean_h):
+        d = mean_h - mean_o
+        nll_h = loss_h.mean().item()
+        return dict(
+            nll_hip=nll_h, nll_oracle=nll_o, nll_rel=abs(nll_h - nll_o) / abs(nll_o),
+            nll_per_row_max_abs=(loss_h - loss_o).abs().max().item(),
+            logits_rel_l2=((lg - lo).norm() / lo.norm()).item(),
+            mean_rel_l2=(d.norm() / mean_o.norm()).item(),                                   # relative to the means' own norm
+            mean_max_over_range=(d.abs().max() / (mean_o.max() - mean_o.min())).item(),       # ... to the spread of the reference means
+            mean_rel_l2_vs_targets=(d.norm() / y_test.norm()).item(),                        # ... to the scale of the predicted quantity
+            mean_max_over_y_range=(d.abs().max() / (y.max() - y.min())).item(),
+            mean_abs_max=d.abs().max().item())
+
+    eval_prec = getattr(model, 'eval_precision', None) or precision
+    if getattr(model, '_eval_desc', None) is None:
+        eval_prec = precision                     # no separate inference precision configured / supported at this shape
+    res = dict(
         against='oracle/pfn_oracle.py forward + loss in f64 on the host (pinned to the reference modules by tests/golden)',
         inputs=f"fixed-seed draw of the configuration's prior (seed 1234), {w['parity_batch']} dataset(s), bptt {w['bptt']}, eval position {sep}; "
                f"weights = the benchmarked model's after the timed steps",
-        precision=precision,
-        nll_hip=nll_h, nll_oracle=nll_o, nll_rel=abs(nll_h - nll_o) / abs(nll_o),
-        logits_rel_l2=((lg - lo).norm() / lo.norm()).item(),
-        mean_rel_l2=(d.norm() / mean_o.norm()).item(),                                   # relative to the means' own norm
-        mean_max_over_range=(d.abs().max() / (mean_o.max() - mean_o.min())).item(),       # ... to the spread of the reference means
-        mean_rel_l2_vs_targets=(d.norm() / y_test.norm()).item(),                        # ... to the scale of the predicted quantity
-        mean_max_over_y_range=(d.abs().max() / (y.max() - y.min())).item(),
-        mean_abs_max=d.abs().max().item(), mean_ref_rms=mean_o.pow(2).mean().sqrt().item(), y_test_rms=y_test.pow(2).mean().sqrt().item(),
-        oracle_forward_s=oracle_s), (x, y, sd)
+        precision=eval_prec, outputs='model.eval() under no_grad (inference passes run in model.eval_precision)',
+        **metrics(*out_eval),
+        mean_ref_rms=mean_o.pow(2).mean().sqrt().item(), y_test_rms=y_test.pow(2).mean().sqrt().item(), oracle_forward_s=oracle_s,
+        training_forward=dict(precision=precision, note='forward of the timed path (train mode) on the same inputs and weights', **metrics(*out_train)))
+    return res, (x, y, sd)
 
 
 def cpu_baseline(w, inputs, steps=3, warm=1):

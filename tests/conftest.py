@@ -20,3 +20,9 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bounds
+    bounds.dump()

@@ -35,6 +35,8 @@ import bench  # noqa: E402
 HPS = dict(noise=1e-4, outputscale=1.0, lengthscale=0.6)
 SHAPES = {
     'config2': dict(bench.CONFIGS[2]),
+    # the recipe AS THE NOTEBOOK RUNS IT (SetupForGPFittingExperiments.ipynb cell 5): five features, otherwise configs[1]
+    'notebook5': dict(bench.CONFIGS[2], num_features=5),
     'config1': dict(prior='fast_gp', bptt=100, num_features=5, emsize=128, nhead=4, nhid=256, nlayers=2, criterion='bar', num_bars=100,
                     hyperparameters=HPS, parity_batch=8, parity_sep=81, eval_pos='weighted'),
 }
@@ -119,19 +121,26 @@ def paired_curves(model, w, device, positions, n, seed, sub=64):
                              pfn_mean_mse=pfn_se.mean().item(), exact_gp_mse=gp_se.mean().item()))
 
 
-def parity_of(sd, w, device, precisions=('bf16', 'f32'), seps=None):
-    """The trained state dict through the HIP path in each precision against the f64 oracle, same inputs."""
+def parity_of(sd, w, device, seps=None):
+    """The trained state dict through the product model (training precision bf16, inference precision f32) against the f64 oracle on
+    the same inputs: `outputs` = model.eval() under no_grad, `training_forward` = the bf16 forward of the training path."""
     out = {}
-    for prec in precisions:
-        model = bench.build_model(device, prec, w, criterion=_criterion_from(sd))
-        model.load_state_dict(sd)
-        model.to(device)
-        for sep in (seps or [w['parity_sep']]):
-            res, _ = bench.parity_check(model, dict(w, parity_sep=sep), device, prec)
-            res.pop('against', None); res.pop('inputs', None)
-            out[f'{prec}@sep{sep}'] = res
-        del model
+    model = bench.build_model(device, 'bf16', w, criterion=_criterion_from(sd))
+    model.load_state_dict(sd)
+    model.to(device)
+    for sep in (seps or [w['parity_sep']]):
+        res, _ = bench.parity_check(model, dict(w, parity_sep=sep), device, 'bf16')
+        res.pop('against', None); res.pop('inputs', None)
+        out[f'sep{sep}'] = res
     return out
+
+
+def log_parity(parity, log):
+    for k, v in parity.items():
+        t = v['training_forward']
+        log(f"  {k}: outputs ({v['precision']}) nll_rel {v['nll_rel']:.2e} mean_rel_l2 {v['mean_rel_l2']:.2e} logits_rel_l2 {v['logits_rel_l2']:.2e} | "
+            f"training forward ({t['precision']}) nll_rel {t['nll_rel']:.2e} mean_rel_l2 {t['mean_rel_l2']:.2e} mean_max_over_range {t['mean_max_over_range']:.2e} "
+            f"logits_rel_l2 {t['logits_rel_l2']:.2e}  (means rms {v['mean_ref_rms']:.3f}, targets rms {v['y_test_rms']:.3f})")
 
 
 def _criterion_from(sd):
@@ -139,10 +148,10 @@ def _criterion_from(sd):
     return bar_distribution.FullSupportBarDistribution(sd['criterion.borders'].clone())
 
 
-def stage_config2(args, device, log):
+def stage_config2(args, device, log, shape='config2'):
     from transformerscandobayesianinference_amd import evaluation
-    w = SHAPES['config2']
-    log(f"config2: {args.epochs} epochs x {args.steps_per_epoch} steps x {args.batch} datasets, lr {args.lr}, precision {args.precision}")
+    w = SHAPES[shape]
+    log(f"{shape}: {args.epochs} epochs x {args.steps_per_epoch} steps x {args.batch} datasets, lr {args.lr}, precision {args.precision}")
     model, curve, seconds = run_training(w, device, args.precision, args.epochs, args.steps_per_epoch, args.batch, args.lr, args.seed, log,
                                          aggregate=args.aggregate)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -171,13 +180,12 @@ def stage_config2(args, device, log):
                gp_baseline_nll=gnll.tolist(), gp_baseline_nll_conf=gconf.tolist(), gp_baseline_mse=gmse.tolist())
     log('parity of the trained weights vs the f64 oracle')
     parity = parity_of(sd, w, device, seps=[1755, 1000])
-    for k, v in parity.items():
-        log(f"  {k}: nll_rel {v['nll_rel']:.2e}  mean_rel_l2 {v['mean_rel_l2']:.2e}  mean_max_over_range {v['mean_max_over_range']:.2e}  "
-            f"logits_rel_l2 {v['logits_rel_l2']:.2e}  (means rms {v['mean_ref_rms']:.3f}, targets rms {v['y_test_rms']:.3f})")
+    log_parity(parity, log)
     val = bench.validation_loss(model, w, device)
-    result = dict(what='BASELINE.json configs[1] trained with the HIP stack (tools/train_pfn.py --stage config2)',
+    result = dict(what=('BASELINE.json configs[1]' if shape == 'config2' else 'the GP-fitting notebook recipe (5 features) at the configs[1] model and bptt') +
+                       f' trained with the HIP stack (tools/train_pfn.py --stage {shape})',
                   recipe=dict(prior='priors.fast_gp', hyperparameters=HPS, bptt=w['bptt'], num_features=w['num_features'], emsize=w['emsize'], nhead=w['nhead'],
-                              nhid=w['nhid'], nlayers=w['nlayers'], bars=w['num_bars'], borders='get_bucket_limits(1000, ys of get_batch(100000, 20, 18))',
+                              nhid=w['nhid'], nlayers=w['nlayers'], bars=w['num_bars'], borders=f"get_bucket_limits(1000, ys of get_batch(100000, 20, {w['num_features']}))",
                               epochs=args.epochs, steps_per_epoch=args.steps_per_epoch, batch_size=args.batch, aggregate_k_gradients=args.aggregate, lr=args.lr,
                               warmup_epochs=args.epochs // 4, schedule='get_cosine_schedule_with_warmup, stepped per epoch (lr 0 in epoch 1, reference quirk Q5)',
                               eval_pos='get_weighted_single_eval_pos_sampler(2000)', precision=args.precision, seed=args.seed,
@@ -219,8 +227,7 @@ def stage_config1(args, device, log):
     trained = paired_curves(model, w, device, positions, 256, seed=777)
     log(f"  trained: PFN bar NLL {trained['summary']['pfn_bar_nll']:.4f}  exact GP {trained['summary']['exact_gp_nll']:.4f}  prior {trained['summary']['prior_nll']:.4f}")
     parity = parity_of(sd, w, device, seps=[81, 50])
-    for k, v in parity.items():
-        log(f"  {k}: nll_rel {v['nll_rel']:.2e}  mean_rel_l2 {v['mean_rel_l2']:.2e}  logits_rel_l2 {v['logits_rel_l2']:.2e}  (means rms {v['mean_ref_rms']:.3f})")
+    log_parity(parity, log)
     if args.ckpt1:
         torch.save((sd, None), args.ckpt1)
     return dict(what='configs[0] shape trained with the HIP stack; the checkpoint is tests/golden/trained_config1.pt',
@@ -230,7 +237,7 @@ def stage_config1(args, device, log):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--stage', nargs='+', default=['config2'], choices=['config2', 'curves', 'config1'])
+    ap.add_argument('--stage', nargs='+', default=['config2'], choices=['config2', 'notebook5', 'curves', 'config1'])
     ap.add_argument('--epochs', type=int, default=80)
     ap.add_argument('--steps-per-epoch', type=int, default=100)
     ap.add_argument('--batch', type=int, default=64)
@@ -256,7 +263,8 @@ def main():
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     result = json.load(open(args.out)) if os.path.exists(args.out) else {}
     for stage in args.stage:
-        result[stage] = {'config2': stage_config2, 'curves': stage_curves, 'config1': stage_config1}[stage](args, device, log)
+        result[stage] = {'config2': stage_config2, 'notebook5': lambda *a: stage_config2(*a, shape='notebook5'), 'curves': stage_curves,
+                         'config1': stage_config1}[stage](args, device, log)
         json.dump(result, open(args.out, 'w'), indent=1)
     log(f'wrote {args.out}')
 

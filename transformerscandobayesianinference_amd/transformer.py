@@ -61,8 +61,7 @@ class _StackFunction(torch.autograd.Function):
         lib = _hip.lib()
         dev = flat_params.device
         stream = _hip.stream_ptr(dev)
-        desc = model._desc
-        model._refresh_shadow(stream)
+        desc, shadow = model._operands(stream, model._inference_pass())
         if src is not None:
             src = src.contiguous().float()
             S, B = src.shape[0], src.shape[1]
@@ -82,7 +81,7 @@ class _StackFunction(torch.autograd.Function):
         _hip.check(ws_bytes, 'pfn_workspace_bytes')
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         logits = torch.empty((S - sep, B, desc.n_out or desc.emsize), dtype=torch.float32, device=dev)   # n_out 0: the encoder's test rows
-        _hip.check(lib.pfn_stack_forward(ctypes.byref(desc), flat_params.data_ptr(), model._shadow.data_ptr(),
+        _hip.check(lib.pfn_stack_forward(ctypes.byref(desc), flat_params.data_ptr(), shadow.data_ptr(),
                                          x_ptr, x_st, x_sb, y_ptr, y_st, y_sb, _hip.ptr(src), B, S, sep,
                                          ws.data_ptr(), ws_bytes, logits.data_ptr(), stream), 'pfn_stack_forward')
         ctx.model, ctx.ws, ctx.dims = model, ws, (B, S, sep)
@@ -118,7 +117,7 @@ class TransformerModel(nn.Module):
     requires_gpu = True   # train() checks this before building anything (the host-plumbing tests substitute a CPU stand-in)
 
     def __init__(self, encoder, n_out, ninp, nhead, nhid, nlayers, dropout=0.0, y_encoder=None, pos_encoder=None,
-                 decoder=None, input_normalization=False, precision='bf16'):
+                 decoder=None, input_normalization=False, precision='bf16', eval_precision='f32'):
         super().__init__()
         self.model_type = 'Transformer'
         self.transformer_encoder = _EncoderParams(ninp, nhid, nlayers)
@@ -132,10 +131,17 @@ class TransformerModel(nn.Module):
         self._custom_decoder = decoder is not None
         self.decoder = decoder(ninp, nhid, n_out) if decoder is not None else nn.Sequential(nn.Linear(ninp, nhid), nn.GELU(), nn.Linear(nhid, n_out))
         self.input_ln = SeqBN(ninp) if input_normalization else None
+        # `precision`: operand type of the TRAINING path (bf16 MFMA, the benchmarked mode; 'f32' = exact-f32 parity mode).
+        # `eval_precision`: operand type of INFERENCE passes -- model.eval() under torch.no_grad(), i.e. everything that produces
+        # posterior-predictive outputs (validate / run_test / criterion.mean).  Default 'f32': the same kernels on the f32 matrix
+        # instructions, so the outputs match the reference's CPU path to 1e-6 where bf16 operands leave 2-5e-3 on a TRAINED model
+        # (profiles/r03_trained_*.json); a forward-only pass is not the throughput path.  None / 'bf16' = as in training.
         self.precision = precision
+        self.eval_precision = eval_precision
         self._flat = self._flat_grad = self._shadow = None
         self._shadow_version = None
         self._desc = None
+        self._eval_desc = self._eval_shadow = self._eval_shadow_version = None
         self._views = []
         self.init_weights()
         # a state dict loaded into a model that has already run keeps the flat views but changes their contents
@@ -185,9 +191,9 @@ class TransformerModel(nn.Module):
             ps += [self.decoder[0].weight, self.decoder[0].bias, self.decoder[2].weight, self.decoder[2].bias]
         return ps
 
-    def _make_desc(self):
+    def _make_desc(self, precision=None):
         nf = self.encoder.in_features if self._fused_embedding() else 1
-        prec = {'bf16': _hip.PREC_BF16, 'f32': _hip.PREC_F32, 'fp32': _hip.PREC_F32}[self.precision]
+        prec = {'bf16': _hip.PREC_BF16, 'f32': _hip.PREC_F32, 'fp32': _hip.PREC_F32}[precision or self.precision]
         return _hip.ModelDesc(nf, self.ninp, self.nhead, self.nhid, self.nlayers, 0 if self._custom_decoder else self.n_out, prec, 1e-5)
 
     def _is_flat(self):
@@ -234,6 +240,11 @@ class TransformerModel(nn.Module):
         self._stack_numel = total
         self._shadow = torch.empty(lib.pfn_shadow_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=device)
         self._shadow_version = None
+        self._eval_desc = self._eval_shadow = self._eval_shadow_version = None
+        if self.eval_precision not in (None, self.precision) and self._make_desc(self.eval_precision).precision != desc.precision:
+            self._eval_desc = self._make_desc(self.eval_precision)        # its operand copies are allocated at the first inference pass
+            if lib.pfn_shadow_bytes(ctypes.byref(self._eval_desc)) < 0:   # shape outside that precision's kernels (exact-f32 has no head dim 256):
+                self._eval_desc = None                                    # inference then runs in the training precision
 
     def _attach_grads(self):
         """Point every .grad at its slice of the flat gradient buffer (after zero_grad(set_to_none=True)
@@ -252,6 +263,7 @@ class TransformerModel(nn.Module):
         """Called by whoever writes the parameters behind autograd's back: optimizers that update the flat buffer
         through raw pointers (FusedClipAdam), or code that assigns through `p.data` (which bumps no version counter)."""
         self._shadow_version = None
+        self._eval_shadow_version = None
 
     def _param_version(self):
         """Every Parameter is a view of the flat buffer with its OWN version counter (`p.data = flat[...]` detaches
@@ -265,6 +277,24 @@ class TransformerModel(nn.Module):
             _hip.check(_hip.lib().pfn_prepare_params(ctypes.byref(self._desc), self._flat.data_ptr(), self._shadow.data_ptr(), stream),
                        'pfn_prepare_params')
             self._shadow_version = version
+
+    def _inference_pass(self):
+        """True when this forward produces outputs only (eval mode, no autograd) and a separate inference precision is configured."""
+        return self._eval_desc is not None and not self.training and not torch.is_grad_enabled()
+
+    def _operands(self, stream, inference):
+        """(model descriptor, operand copies of the weights) of a pass, refreshed if the parameters changed."""
+        if not inference:
+            self._refresh_shadow(stream)
+            return self._desc, self._shadow
+        lib = _hip.lib()
+        if self._eval_shadow is None:
+            self._eval_shadow = torch.empty(lib.pfn_shadow_bytes(ctypes.byref(self._eval_desc)), dtype=torch.uint8, device=self._flat.device)
+        version = self._param_version()
+        if self._eval_shadow_version != version:
+            _hip.check(lib.pfn_prepare_params(ctypes.byref(self._eval_desc), self._flat.data_ptr(), self._eval_shadow.data_ptr(), stream), 'pfn_prepare_params')
+            self._eval_shadow_version = version
+        return self._eval_desc, self._eval_shadow
 
     def flat_parameters(self):
         """(flat f32 parameter buffer, flat f32 gradient buffer); packs the model on first use."""
