@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 3
+#define PFN_ABI_VERSION 4
 
 enum {
   PFN_OK = 0,
@@ -108,6 +108,21 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
                        int B, int S, int sep,
                        void* workspace, int64_t workspace_bytes,
                        const float* dlogits, float* grads, float* dsrc_sbe, void* stream);
+/* The same backward for data-parallel runs (no counterpart in the reference, which is single-process: train.py:29): the weight
+ * gradients of the TOP `first_group_layers` encoder layers are launched as their own group as soon as the data-gradient chain has
+ * passed those layers, and `on_first_group(user)` is called on the host right after that launch has been enqueued on `stream` --
+ * every gradient of the parameters from layer (nlayers - first_group_layers) to the end of the flat buffer (those layers and the
+ * decoder) is then complete in stream order, so the caller can record an event there and start the all-reduce of that part of the
+ * buffer while the lower layers' backward still runs.  first_group_layers <= 0 or >= nlayers, or a NULL callback: exactly
+ * pfn_stack_backward. */
+typedef void (*pfn_host_callback)(void* user);
+int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const void* shadow,
+                             const float* x, int64_t x_st, int64_t x_sb,
+                             const float* y, int64_t y_st, int64_t y_sb,
+                             int B, int S, int sep,
+                             void* workspace, int64_t workspace_bytes,
+                             const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
+                             int first_group_layers, pfn_host_callback on_first_group, void* user);
 
 /* ---- bar distribution: replaces BarDistribution / FullSupportBarDistribution.forward and .mean
  * (bar_distribution.py:19-38, 83-117).  logits [R, nbars] f32 (row stride ld), y [R], borders

@@ -632,8 +632,14 @@ def run(model, cols):
     return loss.detach(), model.flat_parameters()[1]
 model = build()
 h = B // world
+# the production path: two collectives, the top layer's half of the buffer enqueued behind its (early) weight-gradient launch
+reducer = dp.OverlappedGradientReducer(model)
+assert reducer.first_group_layers == 1 and reducer.split == model.layer_offset(1)
+reducer.arm(1)
 loss, grad = run(model, slice(rank * h, (rank + 1) * h))        # this rank's shard of the global batch
-dp.all_reduce_gradients(grad)
+assert len(reducer.events) == 1                                  # pfn_stack_backward_split called back behind the first group
+reducer.finish()
+assert reducer.overlapped_last_step
 grad = grad / world
 ref_loss, ref_grad = run(build(), slice(0, B))                   # the global batch in one process
 err = ((grad - ref_grad).norm() / ref_grad.norm()).item()
@@ -641,7 +647,7 @@ assert err < 1e-5, err
 # one fused clip + Adam step with the 1/world factor folded in leaves every rank with the single-process weights
 m1, m2 = build(), build()
 o1 = FusedClipAdam(m1, lr=1e-3, max_grad_norm=1.0); o1.grad_multiplier = 1.0 / world
-run(m1, slice(rank * h, (rank + 1) * h)); dp.all_reduce_gradients(m1.flat_parameters()[1]); o1.step(zero_grad=True)
+run(m1, slice(rank * h, (rank + 1) * h)); dp.all_reduce_gradients(m1.flat_parameters()[1]); o1.step(zero_grad=True)   # (the one-collective helper)
 o2 = FusedClipAdam(m2, lr=1e-3, max_grad_norm=1.0)
 g2 = run(m2, slice(0, B))[1].clone(); o2.step(zero_grad=True)
 dw = (m1.flat_parameters()[0] - m2.flat_parameters()[0]).abs()
@@ -658,8 +664,9 @@ print('rank', rank, 'ok', err, werr)
 
 def test_data_parallel_gradient_equals_global_batch(tmp_path):
     """SURVEY.md 8(e) end to end on the GPU: two ranks, each running the HIP forward / backward on its half of a batch,
-    all-reduce the flat gradient buffer; the average equals the single-process gradient of the whole batch and one fused
-    optimizer step leaves identical weights.  RCCL refuses two ranks on one device, so the one-GPU box runs the ranks over
+    all-reduce the flat gradient buffer -- as the two collectives of dp.OverlappedGradientReducer, the upper layer's half behind the
+    early weight-gradient launch of pfn_stack_backward_split; the average equals the single-process gradient of the whole batch and
+    one fused optimizer step leaves identical weights.  RCCL refuses two ranks on one device, so the one-GPU box runs the ranks over
     gloo on cuda:0 (dp.py test hooks); the collective call, the buffers and the optimizer path are the production ones."""
     import subprocess, sys
     script = tmp_path / 'dp_gpu_check.py'

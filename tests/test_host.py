@@ -226,6 +226,17 @@ full = torch.arange(16, dtype=torch.float32).view(8, 2)
 w2 = w.detach().clone().requires_grad_(True)
 ((full @ w2[:2]) ** 2).mean().backward()
 assert torch.allclose(flat, w2.grad, rtol=1e-6), (flat, w2.grad)
+# the two-collective reducer of the training loop (tail = upper layers + decoder first, then the head) on a host buffer
+buf = torch.arange(10, dtype=torch.float32) * (rank + 1)
+red = dp.OverlappedGradientReducer(flat_grad=buf, split=6, first_group_layers=1)
+red.arm(1)
+assert red.armed()
+red.finish()
+assert torch.equal(buf, torch.arange(10, dtype=torch.float32) * 3) and not red.overlapped_last_step and not red.armed()
+assert red.layout() == dict(total_bytes=40, overlapped_bytes=16, exposed_bytes=24, first_group_layers=1)
+whole = dp.OverlappedGradientReducer(flat_grad=torch.ones(4) * (rank + 1))      # no split: one collective
+whole.finish()
+assert torch.equal(whole.grad, torch.ones(4) * 3)
 print('rank', rank, 'ok')
 '''
 

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpfn_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PREC_BF16 = 0
 PREC_F32 = 1
@@ -35,6 +35,8 @@ class ModelDesc(ctypes.Structure):
         return (self.num_features, self.emsize, self.nhead, self.nhid, self.nlayers, self.n_out, self.precision, self.ln_eps)
 
 
+HOST_CALLBACK = ctypes.CFUNCTYPE(None, ctypes.c_void_p)     # pfn_host_callback
+
 _lib = None
 
 _c = ctypes
@@ -54,6 +56,7 @@ SIGNATURES = {
     'pfn_workspace_bytes': (_L, [_D, _I, _I]),
     'pfn_stack_forward': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P, _L, _P, _P]),
     'pfn_stack_backward': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P]),
+    'pfn_stack_backward_split': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P]),
     'pfn_bar_nll_forward': (_I, [_P, _L, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
     'pfn_bar_nll_backward': (_I, [_P, _L, _P, _P, _P, _L, _I, _P, _P]),
     'pfn_bar_mean': (_I, [_P, _L, _P, _L, _I, _I, _P, _P]),

@@ -336,6 +336,15 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
                        const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
                        int B, int S, int sep, void* workspace, int64_t workspace_bytes,
                        const float* dlogits, float* grads, float* dsrc_sbe, void* stream) {
+  return pfn_stack_backward_split(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, B, S, sep, workspace, workspace_bytes, dlogits, grads, dsrc_sbe,
+                                  stream, 0, nullptr, nullptr);
+}
+
+int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const void* shadow,
+                             const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                             int B, int S, int sep, void* workspace, int64_t workspace_bytes,
+                             const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
+                             int first_group_layers, pfn_host_callback on_first_group, void* user) {
   PFN_TRY(check_desc(d));
   if (!params || !shadow || !workspace || !grads) return fail(PFN_ERR_ARGUMENT, "null pointer");
   if (!dsrc_sbe && (!x || !y)) return fail(PFN_ERR_ARGUMENT, "need x and y (or dsrc_sbe)");
@@ -415,6 +424,42 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
     fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1)) &&
                gemm_lnbwd_supported(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, a.y2, a.mean2, a.rstd2, params + p.g2, a.dy2_t, grads + p.g2, grads + p.be2));
   }
+  // ---- weight gradients of the layers [l_lo, l_hi] as one grouped launch (called once after the chain, or -- data-parallel runs,
+  // pfn_stack_backward_split -- once for the top layers in the middle of the chain and once for the rest) ----
+  auto launch_weight_gradients = [&](int l_hi, int l_lo) -> int {
+    std::vector<TnProblem> probs;
+    auto add = [&](const void* A, long lda, const void* Bm, long ldb, float* C, long ldc, int P, int Q, float* colsum) {
+      TnProblem t; memset(&t, 0, sizeof(t)); t.A = A; t.lda = lda; t.B = Bm; t.ldb = ldb; t.C = C; t.ldc = ldc; t.P = P; t.Q = Q; t.colsum = colsum;
+      probs.push_back(t);
+    };
+    for (int l = l_hi; l >= l_lo; --l) {
+      const LayerP& p = L.layer[l];
+      LayerWs& a = w.layer[l];
+      const char* xin_t = (l == 0) ? w.x0_t : w.layer[l - 1].x2_t;
+      // (b2 / b_o: column sums of dy2 / dy1 -- from the LayerNorm-backward kernel when that ran on its own)
+      add(a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, fuse_lnb && l < d->nlayers - 1 ? grads + p.b2 : nullptr);
+      add(a.dh_t, F, a.x1_t, E, grads + p.w1, E, F, E, grads + p.b1);
+      add(a.dy1_t, E, a.ctx, E, grads + p.w_o, E, E, E, fuse_lnb ? grads + p.b_o : nullptr);
+      add(a.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, 3 * E, E, grads + p.b_in);
+    }
+    bool grouped = prec == PFN_PREC_BF16;
+    for (const TnProblem& t : probs) grouped = grouped && gemm_tn_group_supported(t);
+    if (grouped) {
+      for (size_t i0 = 0; i0 < probs.size(); i0 += TN_GROUP_MAX) {
+        GemmTNGroup g;
+        memset(&g, 0, sizeof(g));
+        g.n = (int)std::min<size_t>(TN_GROUP_MAX, probs.size() - i0);
+        g.M = M;
+        for (int i = 0; i < g.n; ++i) g.p[i] = probs[i0 + i];
+        PFN_TRY(launch_gemm_tn_group(g, s));
+      }
+    } else {  // exact-f32 parity mode and shapes outside the 256-tile kernel: one split-K launch per gradient
+      for (const TnProblem& t : probs)
+        PFN_TRY(launch_gemm_tn(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, M, t.P, t.Q, t.colsum), prec, s));
+    }
+    return PFN_OK;
+  };
+  const int split_at = (on_first_group && first_group_layers > 0 && first_group_layers < d->nlayers) ? d->nlayers - first_group_layers : -1;
   for (int l = d->nlayers - 1; l >= 0; --l) {
     const LayerP &p = L.layer[l], &t = L.layer_t[l];
     LayerWs& a = w.layer[l];
@@ -461,40 +506,14 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
       g.aux = a.dy1_t; g.ld_aux = E; g.out_f32 = w.gA; g.ld_out_f32 = E; g.out_t = w.gA_t; g.ld_out_t = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
-  }
-  // ---- weight gradients of every layer ----
-  {
-    std::vector<TnProblem> probs;
-    auto add = [&](const void* A, long lda, const void* Bm, long ldb, float* C, long ldc, int P, int Q, float* colsum) {
-      TnProblem t; memset(&t, 0, sizeof(t)); t.A = A; t.lda = lda; t.B = Bm; t.ldb = ldb; t.C = C; t.ldc = ldc; t.P = P; t.Q = Q; t.colsum = colsum;
-      probs.push_back(t);
-    };
-    for (int l = d->nlayers - 1; l >= 0; --l) {
-      const LayerP& p = L.layer[l];
-      LayerWs& a = w.layer[l];
-      const char* xin_t = (l == 0) ? w.x0_t : w.layer[l - 1].x2_t;
-      // (b2 / b_o: column sums of dy2 / dy1 -- from the LayerNorm-backward kernel when that ran on its own)
-      add(a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, fuse_lnb && l < d->nlayers - 1 ? grads + p.b2 : nullptr);
-      add(a.dh_t, F, a.x1_t, E, grads + p.w1, E, F, E, grads + p.b1);
-      add(a.dy1_t, E, a.ctx, E, grads + p.w_o, E, E, E, fuse_lnb ? grads + p.b_o : nullptr);
-      add(a.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, 3 * E, E, grads + p.b_in);
-    }
-    bool grouped = prec == PFN_PREC_BF16;
-    for (const TnProblem& t : probs) grouped = grouped && gemm_tn_group_supported(t);
-    if (grouped) {
-      for (size_t i0 = 0; i0 < probs.size(); i0 += TN_GROUP_MAX) {
-        GemmTNGroup g;
-        memset(&g, 0, sizeof(g));
-        g.n = (int)std::min<size_t>(TN_GROUP_MAX, probs.size() - i0);
-        g.M = M;
-        for (int i = 0; i < g.n; ++i) g.p[i] = probs[i0 + i];
-        PFN_TRY(launch_gemm_tn_group(g, s));
-      }
-    } else {  // exact-f32 parity mode and shapes outside the 256-tile kernel: one split-K launch per gradient
-      for (const TnProblem& t : probs)
-        PFN_TRY(launch_gemm_tn(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, M, t.P, t.Q, t.colsum), prec, s));
+    if (l == split_at) {
+      // the chain has left the top layers: their four operand sets are complete, and so is every LayerNorm / bias gradient of theirs
+      PFN_TRY(launch_weight_gradients(d->nlayers - 1, split_at));
+      on_first_group(user);
     }
   }
+  // ---- weight gradients of every layer not launched yet ----
+  if (d->nlayers > 0) PFN_TRY(launch_weight_gradients(split_at >= 0 ? split_at - 1 : d->nlayers - 1, 0));
   // ---- embedding ----
   if (dsrc_sbe) {
     PFN_TRY(launch_bse_to_sbe(w.gA, dsrc_sbe, S, B, E, s));

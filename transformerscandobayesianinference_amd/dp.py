@@ -78,3 +78,84 @@ def all_reduce_gradients(flat_grad):
     if is_distributed():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
+
+
+class OverlappedGradientReducer:
+    """The gradient all-reduce of one optimizer step as TWO collectives, the first overlapped with the backward.
+
+    The flat gradient buffer is in state-dict order: [embedding | layer 0 ... layer L-1 | decoder].  The backward walks the layers
+    top-down, and `pfn_stack_backward_split` launches the weight gradients of the top `first_group_layers` layers as soon as the
+    data-gradient chain has left them (instead of with everything else at the very end), calling back on the host right behind that
+    launch.  The callback records an event on the launching stream; `finish()` then issues
+        tail = grad[offset of layer L - first_group_layers :]   on a side stream that waits for those events only, and
+        head = grad[: that offset]                              on the caller's stream (after the whole backward),
+    so the tail's all-reduce (half of the bytes at first_group_layers = L/2) runs over xGMI while the lower layers' data gradients and
+    weight gradients are still being computed; only the head is exposed.  All collectives are issued from the caller's thread, in the
+    same order on every rank.  The split is used only when every parameter's gradient comes out of the HIP stack (fused embedding,
+    built-in decoder): a PyTorch-side encoder finishes its gradients after the stack and a custom decoder's parameters sit behind the
+    stack's in the buffer, so those models reduce the whole buffer in one collective.
+
+    Usage per optimizer step:   reducer.arm(n)  ->  n forward/backward passes (micro-batch streams)  ->  reducer.finish()."""
+
+    def __init__(self, model=None, flat_grad=None, split=None, first_group_layers=None):
+        self.model = model
+        self.events, self._armed, self.expected = [], False, 0
+        self.overlapped_last_step = False
+        if model is not None:
+            _, flat_grad = model.flat_parameters()
+            L = model.nlayers
+            ok = L >= 2 and model._fused_embedding() and not model._custom_decoder
+            first_group_layers = (L // 2 if first_group_layers is None else first_group_layers) if ok else 0
+            split = model.layer_offset(L - first_group_layers) if first_group_layers > 0 else None
+            model._first_group_hook = self if first_group_layers > 0 else None
+        self.grad = flat_grad
+        self.split = split if split and 0 < split < flat_grad.numel() else None
+        self.first_group_layers = first_group_layers or 0
+        self.comm = torch.cuda.Stream(flat_grad.device) if flat_grad.is_cuda else None
+
+    # ---- called by _StackFunction.backward ----
+    def armed(self):
+        return self._armed and self.split is not None
+
+    def first_group_launched(self):
+        """Host callback of pfn_stack_backward_split, on the thread and stream that run the backward."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.grad.device))
+        self.events.append(ev)
+
+    # ---- called by the training loop ----
+    def arm(self, passes=1):
+        """The next `passes` backward passes complete this optimizer step's gradients (not armed: accumulation micro-steps)."""
+        self.events, self._armed, self.expected = [], True, passes
+
+    def finish(self):
+        """All-reduce (sum) the whole buffer; returns after the collectives are ordered before further work of the current stream."""
+        self._armed = False
+        if not is_distributed():
+            self.events = []
+            return self.grad
+        works = []
+        overlapped = self.split is not None and self.comm is not None and len(self.events) == self.expected and self.expected > 0
+        if overlapped:
+            with torch.cuda.stream(self.comm):
+                for ev in self.events:
+                    self.comm.wait_event(ev)
+                works.append(dist.all_reduce(self.grad[self.split:], op=dist.ReduceOp.SUM, async_op=True))
+            works.append(dist.all_reduce(self.grad[:self.split], op=dist.ReduceOp.SUM, async_op=True))
+        elif self.split is not None:      # same two collectives on every rank even when nothing could overlap (CPU tensors, hook not fired)
+            works.append(dist.all_reduce(self.grad[self.split:], op=dist.ReduceOp.SUM, async_op=True))
+            works.append(dist.all_reduce(self.grad[:self.split], op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            works.append(dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, async_op=True))
+        for wk in works:
+            wk.wait()
+        if overlapped:
+            self.grad.record_stream(self.comm)
+        self.events = []
+        self.overlapped_last_step = overlapped
+        return self.grad
+
+    def layout(self):
+        n = self.grad.numel()
+        return dict(total_bytes=4 * n, overlapped_bytes=4 * (n - self.split) if self.split else 0, exposed_bytes=4 * (self.split or n),
+                    first_group_layers=self.first_group_layers)

@@ -18,19 +18,22 @@ class MicroBatchStreams:
         self.n = max(1, int(n))
         self.streams = [torch.cuda.Stream() for _ in range(self.n)] if self.n > 1 and torch.cuda.is_available() else []
 
-    def forward_backward(self, model, data, targets, single_eval_pos, loss_fn):
-        """data = (x[T,B,F], y[T,B]); targets [T,B] (already sliced to the test rows by the caller's loss_fn if needed).
-        loss_fn(output, targets_group) -> per-(position, dataset) losses [T - sep, b].  Runs backward of the mean loss
-        (over all groups) and returns the detached losses [T - sep, B]."""
-        x, y = data
-        B = x.shape[1]
+    def groups(self, model, batch):
+        """Number of concurrent column groups (= backward passes) a batch of `batch` datasets runs as."""
         # only the all-HIP path is split: with a PyTorch-side embedding (custom encoders, SeqBN, positional encodings)
         # SeqBN would normalise per group, a scrambled encoding would draw per group, and autograd's gradient
         # accumulation into the shared flat buffer (non-atomic read-modify-write) would run on two streams at once
         # ... and so would a custom `decoder=` module: it runs in PyTorch on the stack's output, and AccumulateGrad's in-place
         # `+=` on its parameters (views of the flat buffer) is not atomic across the two streams
         fused = getattr(model, '_fused_embedding', lambda: False)() and not getattr(model, '_custom_decoder', False)
-        n = self.n if (self.streams and fused and B % self.n == 0 and B >= 2 * self.n) else 1
+        return self.n if (self.streams and fused and batch % self.n == 0 and batch >= 2 * self.n) else 1
+
+    def forward_backward(self, model, data, targets, single_eval_pos, loss_fn):
+        """data = (x[T,B,F], y[T,B]); targets [T,B] (already sliced to the test rows by the caller's loss_fn if needed).
+        loss_fn(output, targets_group) -> per-(position, dataset) losses [T - sep, b].  Runs backward of the mean loss
+        (over all groups) and returns the detached losses [T - sep, B]."""
+        x, y = data
+        n = self.groups(model, x.shape[1])
         if n == 1:
             output = model(data, single_eval_pos=single_eval_pos)
             losses = loss_fn(output, targets)
@@ -39,7 +42,7 @@ class MicroBatchStreams:
         main = torch.cuda.current_stream()
         model.flat_parameters()
         model._refresh_shadow(_hip.stream_ptr(x.device))      # operand copies of the weights: once, before the fork
-        h = B // n
+        h = x.shape[1] // n
         outs = []
         for i, s in enumerate(self.streams[:n]):
             s.wait_stream(main)

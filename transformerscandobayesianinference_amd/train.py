@@ -116,6 +116,8 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     optimizer.grad_multiplier = 1.0 / world
     scheduler = scheduler(optimizer, warmup_epochs, epochs)
     micro = MicroBatchStreams(micro_streams if str(device).startswith('cuda') else 1)   # concurrent half-batches (streams.py)
+    # data-parallel runs: the flat gradient buffer is all-reduced as two collectives, the upper layers' half under the backward
+    reducer = dp.OverlappedGradientReducer(model) if world > 1 and hasattr(model, 'flat_parameters') else None
 
     def train_epoch():
         model.train()
@@ -130,13 +132,18 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
             before_forward = time.time()
             single_eval_pos = single_eval_pos_gen() if callable(single_eval_pos_gen) else single_eval_pos_gen
             data = tuple(e.to(device) for e in data) if isinstance(data, tuple) else data.to(device)
+            last_micro_step = batch % aggregate_k_gradients == aggregate_k_gradients - 1
             if isinstance(data, tuple) and single_eval_pos is not None:
                 targets = targets.to(device)
+                if reducer is not None and last_micro_step:
+                    reducer.arm(micro.groups(model, data[0].shape[1]))
                 losses = micro.forward_backward(model, data, targets, single_eval_pos,
                                                 lambda out, tg: compute_losses(criterion, out, tg[single_eval_pos:], n_out))
                 loss = losses.mean()
                 forward_time = time.time() - before_forward
             else:
+                if reducer is not None and last_micro_step:
+                    reducer.arm(1)
                 output = model(data, single_eval_pos=single_eval_pos)
                 forward_time = time.time() - before_forward
                 if single_eval_pos is not None:
@@ -144,8 +151,10 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
                 losses = compute_losses(criterion, output, targets.to(device), n_out)
                 loss = losses.mean()
                 loss.backward()
-            if batch % aggregate_k_gradients == aggregate_k_gradients - 1:
-                if world > 1:
+            if last_micro_step:
+                if reducer is not None:
+                    reducer.finish()
+                elif world > 1:
                     dp.all_reduce_gradients(model.flat_parameters()[1])
                 optimizer.step(zero_grad=True)
             step_time = time.time() - before_forward

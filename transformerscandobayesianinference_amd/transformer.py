@@ -106,9 +106,19 @@ class _StackFunction(torch.autograd.Function):
             args = (0, 0, 0, 0, 0, 0)
         else:
             args = (x.data_ptr(), x.stride(0), x.stride(1), y.data_ptr(), y.stride(0), y.stride(1))
-        _hip.check(lib.pfn_stack_backward(ctypes.byref(desc), model._flat.data_ptr(), model._shadow.data_ptr(), *args,
-                                          B, S, sep, ws.data_ptr(), ws.numel(), dlogits.data_ptr(),
-                                          model._flat_grad.data_ptr(), _hip.ptr(dsrc), stream), 'pfn_stack_backward')
+        hook = model._first_group_hook
+        if hook is not None and hook.armed():
+            # data-parallel runs (dp.OverlappedGradientReducer): the top layers' weight gradients are launched early and the hook
+            # records an event right behind them, so their all-reduce can run under the rest of this backward
+            cb = _hip.HOST_CALLBACK(lambda user: hook.first_group_launched())
+            _hip.check(lib.pfn_stack_backward_split(ctypes.byref(desc), model._flat.data_ptr(), model._shadow.data_ptr(), *args,
+                                                    B, S, sep, ws.data_ptr(), ws.numel(), dlogits.data_ptr(),
+                                                    model._flat_grad.data_ptr(), _hip.ptr(dsrc), stream, hook.first_group_layers, cb, None),
+                       'pfn_stack_backward_split')
+        else:
+            _hip.check(lib.pfn_stack_backward(ctypes.byref(desc), model._flat.data_ptr(), model._shadow.data_ptr(), *args,
+                                              B, S, sep, ws.data_ptr(), ws.numel(), dlogits.data_ptr(),
+                                              model._flat_grad.data_ptr(), _hip.ptr(dsrc), stream), 'pfn_stack_backward')
         ctx.ws = None
         return None, None, None, None, (dsrc if ctx.src_needs_grad else None), None
 
@@ -142,6 +152,7 @@ class TransformerModel(nn.Module):
         self._shadow_version = None
         self._desc = None
         self._eval_desc = self._eval_shadow = self._eval_shadow_version = None
+        self._first_group_hook = None      # set by dp.OverlappedGradientReducer
         self._views = []
         self.init_weights()
         # a state dict loaded into a model that has already run keeps the flat views but changes their contents
@@ -295,6 +306,13 @@ class TransformerModel(nn.Module):
             _hip.check(lib.pfn_prepare_params(ctypes.byref(self._eval_desc), self._flat.data_ptr(), self._eval_shadow.data_ptr(), stream), 'pfn_prepare_params')
             self._eval_shadow_version = version
         return self._eval_desc, self._eval_shadow
+
+    def layer_offset(self, layer):
+        """Offset (in elements) of encoder layer `layer`'s first parameter in the flat buffers: everything from there to the end of the
+        buffer belongs to that layer, the layers above it and the decoder (state-dict order)."""
+        self.flat_parameters()
+        first = self.transformer_encoder.layers[layer].self_attn.in_proj_weight
+        return next(off for p, off, _ in self._views if p is first)
 
     def flat_parameters(self):
         """(flat f32 parameter buffer, flat f32 gradient buffer); packs the model on first use."""
