@@ -167,9 +167,12 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     Hh = _hip
     out = []
 
-    def add(kernel, rocprof, seconds, flops, count, executed=None):
+    def add(kernel, rocprof, seconds, flops, count, executed=None, nbytes=None):
+        # nbytes: ALGORITHMIC HBM bytes of one launch (every operand read once, every output written once); its floor at the 6.3 TB/s
+        # a stream achieves on this part (MI355X_MICROARCH.md) next to the MFMA floor says which of the two bounds the launch
         out.append(dict(kernel=kernel, rocprof_name=rocprof, launches_per_step=count, seconds=seconds, flops=flops,
-                        executed_flops=executed if executed is not None else flops))
+                        executed_flops=executed if executed is not None else flops, bytes=nbytes,
+                        hbm_floor_us=None if nbytes is None else nbytes / 6.3e12 * 1e6, mfma_floor_us=flops / MFMA_BF16_PEAK * 1e6))
 
     def gemm(name, n, k, flags, count):
         """One encoder GEMM with its REAL epilogue (bias / GELU / residual / output streams), M = batch * bptt rows."""
@@ -182,7 +185,8 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
         if flags & Hh.EPI_OUT_T: kw['out_t'] = torch.empty(M, n, dtype=bf, device=dev)
         if flags & Hh.EPI_OUT2_T: kw['out2_t'] = torch.empty(M, n, dtype=bf, device=dev)
         t = time_kernel(lambda: hipops.gemm_nt(A, B_, flags, Hh.PREC_BF16, **kw))
-        add(f'gemm_nt[{name} {M}x{n}x{k}]', f'gemm_nt_big_kernel<{flags}, ', t, 2.0 * M * n * k, count)
+        nbytes = sum(v.numel() * v.element_size() for v in [A, B_] + list(kw.values()))
+        add(f'gemm_nt[{name} {M}x{n}x{k}]', f'gemm_nt_big_kernel<{flags}, ', t, 2.0 * M * n * k, count, nbytes=nbytes)
 
     def gemm_ln(name, k, count):
         """out_proj / linear2 with bias + residual + LayerNorm in the epilogue (the kernel the step runs when emsize allows)."""
@@ -193,7 +197,8 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
             t = time_kernel(lambda: hipops.gemm_ln(A, B_, bias, gamma, beta, 1e-5, resid=resid, out=bufs))
         except _hip.HipExtensionError:   # shape outside the fused kernel (emsize 1024): the step runs GEMM + LayerNorm kernels there
             return False
-        add(f'gemm_nt_ln[{name} + residual + LayerNorm {M}x{E}x{k}]', 'gemm_nt_ln_kernel', t, 2.0 * M * E * k, count)
+        nbytes = sum(v.numel() * v.element_size() for v in (A, B_, resid) + bufs)     # operands, f32 residual in, f32 sum + bf16 LN output + statistics out
+        add(f'gemm_nt_ln[{name} + residual + LayerNorm {M}x{E}x{k}]', 'gemm_nt_ln_kernel', t, 2.0 * M * E * k, count, nbytes=nbytes)
         return True
 
     def gemm_lnbwd(name, k, count):
@@ -206,7 +211,8 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
             t = time_kernel(lambda: hipops.gemm_lnbwd(A, B_, aux, y, mean, rstd, gamma, out=bufs))
         except _hip.HipExtensionError:
             return False
-        add(f'gemm_nt_lnbwd[{name} {M}x{E}x{k}]', 'gemm_nt_lnbwd_kernel', t, 2.0 * M * E * k, count)
+        nbytes = sum(v.numel() * v.element_size() for v in (A, B_, aux, y, mean, rstd, bufs[0]))
+        add(f'gemm_nt_lnbwd[{name} {M}x{E}x{k}]', 'gemm_nt_lnbwd_kernel', t, 2.0 * M * E * k, count, nbytes=nbytes)
         return True
 
     def layernorm_bwd(count):

@@ -66,7 +66,8 @@ const char* pfn_last_error_string(void);
 enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_GEMM_TN_WRAP = 1, /* profiling only: > 0 makes the grouped TN kernel re-read its first `value` token rows (wrong results, cache-resident operands) */
        PFN_TUNE_FUSE_LNBWD = 2,
-       PFN_TUNE_GEMM_PERSIST = 3  /* workgroups of the persistent 256x256 NT GEMM (one per CU walking tiles); 0 = the one-tile-per-workgroup kernel */ };
+       PFN_TUNE_GEMM_PERSIST = 3, /* workgroups of the persistent 256x256 NT GEMM (one per CU walking tiles); 0 = the one-tile-per-workgroup kernel */
+       PFN_TUNE_ATTN_PINGPONG = 4 /* bit 0: attention forward, bit 1: backward key-block pass -- the two waves of a SIMD run half a tile apart (default: see attention.hip) */ };
 int pfn_set_tuning(int key, int value);
 
 /* ---- parameter packing ------------------------------------------------------------------------

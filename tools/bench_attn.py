@@ -9,6 +9,9 @@ from transformerscandobayesianinference_amd import _hip
 if os.environ.get('PFN_LIB'):
     _hip.LIB_PATH = os.path.abspath(os.environ['PFN_LIB'])
 import bench
+for kv in os.environ.get('PFN_TUNE', '').split(','):      # e.g. PFN_TUNE=4=0 (pfn_set_tuning keys, include/pfn_hip.h)
+    if kv:
+        _hip.check(_hip.lib().pfn_set_tuning(*[int(v) for v in kv.split('=')]), 'pfn_set_tuning')
 
 B, S, E, H, sep = [int(v) for v in (sys.argv[1:6] if len(sys.argv) >= 6 else (16, 2000, 512, 4, 1604))]
 bf = torch.bfloat16

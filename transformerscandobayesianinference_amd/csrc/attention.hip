@@ -136,13 +136,22 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   using C = AttnCfg<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
-  // two K buffers (row images) followed by three V buffers (col images): P.V runs one tile behind Q.K (below)
+  // two K buffers (row images) followed by four V buffers (col images): P.V runs one tile behind Q.K (below), and with the
+  // ping-pong schedule half of the waves run another half tile behind the others
   auto Kt = [&](int buf) { return smem + buf * C::RIMG; };
   auto Vt = [&](int buf) { return smem + 2 * C::RIMG + buf * C::CIMG; };
+  constexpr int NVB = 4;
 
   const AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
   const int b = wg.b, hd = wg.hd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
+  // PING-PONG (8-wave configurations): a SIMD holds waves w and w + 4.  With one barrier at the end of every tile all eight waves
+  // run in lock-step -- both waves of a SIMD issue their 16 Q.K MFMAs together (vector ALU idle) and then their exponentials together
+  // (the matrix pipe has only the P.V MFMAs to chew on).  The per-wave instruction sequence stays what it is; waves 4..7 merely take
+  // their one barrier per tile BETWEEN the Q.K half and the softmax / P.V half instead of after it, so they run half a tile behind
+  // waves 0..3 and one wave's MFMA-only half overlaps the other's vector-heavy half.  LDS cost: a fourth V buffer (tile t-1 is
+  // still being read by the lagging waves while tile t+2 is being written).
+  const int lag = (C::NW == 8 && (a.pingpong & 1)) ? (wave >> 2) : 0;
   const long rs = 3L * a.E;
   const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
   const T* Qp = base + hd * D;
@@ -247,7 +256,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
     // them sits behind the queued Q.K MFMAs -- and at once re-used for the request of tile t+2.  On the last tile the
     // registers are stale and go to buffers nobody reads again (a branch here would split the block and strand the
     // exponentials behind the P.V MFMAs).
-    const int vb_next = vb_cur == 2 ? 0 : vb_cur + 1;   // the slot tile t-2 has released
+    const int vb_next = vb_cur == NVB - 1 ? 0 : vb_cur + 1;   // the slot tile t-3 has released
     if (!(ABL & 2)) {
       sk.template commit_p<C::RS>(Kt((t + 1) & 1));
       sv.template commit_p<C::CS>(Vt(vb_next));
@@ -287,6 +296,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
           for (int e = 0; e < 8; ++e) pf[c].set(e, frag_get(pf[c], e) * alpha);
       }
     }
+    if (lag && !(ABL & 4)) __syncthreads();     // the lagging waves' barrier of this tile (ping-pong, above)
     if (t > 0) {
       // one basic block: exponentials of tile t + P.V MFMAs of tile t-1
       float rsum = 0.f;
@@ -316,7 +326,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
     for (int c = 0; c < NPF; ++c) pf[c] = acc_to_frag<T>(st[c >> 1], c & 1);
     vb_prev = vb_cur;
     vb_cur = vb_next;
-    if (!(ABL & 4)) __syncthreads();
+    if (!lag && !(ABL & 4)) __syncthreads();
   }
   if (ntiles > 0) pv_prev(vb_prev);
 
@@ -983,7 +993,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 // =============================================================================================
 template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
-  const size_t lds = 2 * C::RIMG + 3 * C::CIMG;
+  const size_t lds = 2 * C::RIMG + 4 * C::CIMG;
   static LdsAllowance allowance;
   allowance.ensure(attn_fwd_kernel<T, D>, lds);
   hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
@@ -1048,9 +1058,13 @@ static int check_attn(const AttnArgs& a, int precision) {
     }                                                                                      \
   }
 
-int launch_attn_fwd(const AttnArgs& a, int precision, hipStream_t s) {
-  int rc = check_attn(a, precision);
+static int g_attn_pingpong = 1;      // measured default: see DESIGN.md section 3 (round 3)
+void set_attn_pingpong(int mask) { g_attn_pingpong = mask; }
+int launch_attn_fwd(const AttnArgs& a_in, int precision, hipStream_t s) {
+  int rc = check_attn(a_in, precision);
   if (rc != PFN_OK) return rc;
+  AttnArgs a = a_in;
+  a.pingpong = g_attn_pingpong;
   PFN_ATTN_DISPATCH(launch_fwd_t)
 }
 void attn_bwd_ds_dims(int S, int sep, int* rows, int* ld) {

@@ -162,6 +162,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_GEMM_TN_WRAP: set_gemm_tn_debug_wrap(value); return PFN_OK;
     case PFN_TUNE_FUSE_LNBWD: g_fuse_lnbwd = value != 0; return PFN_OK;
     case PFN_TUNE_GEMM_PERSIST: set_gemm_nt_persist(value); return PFN_OK;
+    case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
     default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);
   }
 }

@@ -133,7 +133,9 @@ struct AttnArgs {
   void* ds;   // dS^T scratch [B, H, ds_rows, ds_ld] T: written by the key-block pass, read by the query-block pass (attn_bwd_ds_bytes)
   int ds_rows, ds_ld;  // filled by the launcher
   int parts;  // backward launches to run, bit mask over ATTN_BWD_*; 0 = all (profiling entry point pfn_op_attention_bwd_parts)
+  int pingpong;  // filled by the launcher (PFN_TUNE_ATTN_PINGPONG): bit 0 forward, bit 1 key-block pass
 };
+void set_attn_pingpong(int mask);
 enum : int { ATTN_BWD_DELTA = 1, ATTN_BWD_KV = 2, ATTN_BWD_DQ = 4 };
 int64_t attn_bwd_ds_bytes(int B, int S, int H, int precision);   // size of AttnArgs::ds for any sep <= S
 int launch_attn_fwd(const AttnArgs& a, int precision, hipStream_t stream);
