@@ -221,7 +221,7 @@ int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, i
                          int prec, void* stream);
 /* Attention backward = three launches: delta = rowsum(dO * O); the key-block pass (dK, dV and dS^T into ds_ws); the
  * query-block pass (dQ from ds_ws, plus the self-key terms of the test rows).  ds_ws: pfn_op_attention_bwd_ws_bytes(B, S, H,
- * prec) bytes of scratch.  parts: 0 = all, else a bit mask (1 delta, 2 key-block pass, 4 query-block pass) that lets bench.py
+ * prec) bytes of scratch; delta_ws: 2 * B * H * S floats (the first launch leaves [delta | lse in log2 units] there).  parts: 0 = all, else a bit mask (1 delta, 2 key-block pass, 4 query-block pass) that lets bench.py
  * time every launch on its own; a partial run leaves the outputs of the skipped launches untouched. */
 int64_t pfn_op_attention_bwd_ws_bytes(int B, int S, int H, int prec);
 int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx,

@@ -67,6 +67,13 @@ template <typename T> PFN_DEV void store_frag_global(T* p, const float (&x)[8]) 
   }
 }
 template <typename T> PFN_DEV float frag_get(const Frag<T>& f, int e) { return (float)f.v[e]; }
+// the same value read out of the PACKED registers: element e of a bf16 fragment is the low (e even) or high half of dword e / 2
+template <typename T> PFN_DEV float frag_get_bits(const Frag<T>& f, int e) {
+  if constexpr (sizeof(T) == 2) {
+    const unsigned w = __builtin_bit_cast(u32x4, f.v)[e >> 1];
+    return __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+  } else return f.v[e];
+}
 template <typename T> PFN_DEV float dot8(const Frag<T>& a, const Frag<T>& b) {
   float s = 0.f;
 #pragma unroll
@@ -121,6 +128,20 @@ constexpr int ABL = PFN_ATTN_ABLATE;
 // products read once instead of four times (2), V row fragments not read (4), exponentials replaced by a multiply (8)
 #ifndef PFN_KV_ABLATE
 #define PFN_KV_ABLATE 0
+#endif
+// fragment prefetch depth (k-steps of 16) of the two row-operand chains of the key-block pass: how far the LDS reads of the Q / dO (and V)
+// row fragments run ahead of their MFMAs.  Round 2 ran both at 2 ("no register left for more" -- true of the dP chain only)
+// s_setprio experiments (guide T5 / MI355X_MICROARCH.md "two waves per SIMD"): bit 0 forward Q.K cluster at priority 1, bit 1 forward
+// waves 4..7 at static priority 1, bit 2 key-block pass S / dP chains, bit 3 key-block pass dV / dK cluster
+#ifndef PFN_ATTN_PRIO
+#define PFN_ATTN_PRIO 0
+#endif
+constexpr int PRIO = PFN_ATTN_PRIO;
+#ifndef PFN_KV_PD_S
+#define PFN_KV_PD_S 2
+#endif
+#ifndef PFN_KV_PD_DP
+#define PFN_KV_PD_DP 2
 #endif
 constexpr int KVABL = PFN_KV_ABLATE;
 typedef __attribute__((address_space(3))) void lvoid_t;
@@ -230,6 +251,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
         o[db] = mma32(load_frag_tr_p<T, C::CS, 2>(vt, c * 16, db * 32), pf[c], o[db]);
   };
   int vb_prev = 0, vb_cur = 0;           // V buffer of tile t-1 / tile t
+  if constexpr (PRIO & 2) { if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1); }
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * C::KVB;
     // all K fragments of the tile are requested before anything else: the LDS round trip (>100 cycles under load)
@@ -246,10 +268,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
     for (int kb = 0; kb < C::NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+    if constexpr (PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < C::NKK; ++kk)
 #pragma unroll
       for (int kb = 0; kb < C::NKB; ++kb) st[kb] = mma32(kfr[kk][kb], qf[kk], st[kb]);
+    if constexpr (PRIO & 1) __builtin_amdgcn_s_setprio(0);
     PFN_PIN_LDS_MFMA();
     // Global -> LDS staging, one tile ahead with the loads in flight across the barrier: the staged registers hold
     // tile t+1 (requested one iteration ago); they are written to the buffers tile t-1 has released -- the wait for
@@ -368,6 +392,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, int D) {
     if (sub == 0) {
       const long bb = tok / a.S, i = tok % a.S;
       a.delta[(bb * a.H + hd) * a.S + i] = s;
+      // second half of the scratch: the row's log-sum-exp in log2 units, so the key-block pass forms P = exp2(S c - lse2) with ONE fma per
+      // element (it read the natural-log value and paid a multiply per element for the conversion: 16 of ~190 vector slots per tile)
+      a.delta[(long)a.B * a.H * a.S + (bb * a.H + hd) * a.S + i] = a.lse[(bb * a.H + hd) * a.S + i] * LOG2E;
     }
   }
 }
@@ -446,8 +473,9 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   const int kc = min(key, a.S - 1);
   const float scale = rsqrtf((float)D);
   const float scale_log2 = scale * LOG2E;
-  const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
+  const float* lse_g = a.delta + (long)a.B * a.H * a.S + ((long)b * a.H + hd) * a.S;    // lse in log2 units (attn_delta_kernel)
   const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
+  const bool wave_all_valid = __builtin_amdgcn_readfirstlane(key0 + wave * 32 + 31) < sep;   // only the last key block has keys >= sep
   // dS^T of this (dataset, head): 32 x 32 blocks, block (key / 32, query / 32) at ((key / 32) * (ds_ld / 32) + query / 32) blocks
   // (store_frag_pair_blocked); the wave owns block row key / 32
   constexpr int DSBLK = 32 * 32;   // elements per block
@@ -567,7 +595,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     // Register plan (head dim 128, bf16): 160 registers are pinned (K fragments, dK, dV); S and dP take 32 more; every operand
     // stream therefore runs only PD k-steps ahead of its MFMAs and the two products run one after the other, the second
     // one's first fragments requested under the first one's tail.
-    constexpr int PD = C::NKK < 2 ? C::NKK : 2;
+    constexpr int PD = C::NKK < PFN_KV_PD_S ? C::NKK : PFN_KV_PD_S;       // S = Q K^T chain
+    constexpr int PD2 = C::NKK < PFN_KV_PD_DP ? C::NKK : PFN_KV_PD_DP;    // dP = dO V^T chain
     // rows of the S / dP tiles are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
     Frag<T> pf0, pf1;
     {
@@ -578,25 +607,30 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 #pragma unroll
       for (int kk = 0; kk < PD; ++kk) qfr[kk] = load_frag_row_p<T, C::RS>(qr, li, kk * 16);
       PFN_PIN_LDS_MFMA();
+      if constexpr (PRIO & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < C::NKK; ++kk) {
         if (kk + PD < C::NKK) qfr[kk + PD] = load_frag_row_p<T, C::RS>(qr, li, (kk + PD) * 16);
         s = mma32(qfr[kk], kf[kk], s);
         PFN_PIN_LDS_MFMA();
       }
+      if constexpr (PRIO & 4) __builtin_amdgcn_s_setprio(0);
       // P = exp2(S scale - lse), straight into operand precision: S is dead before the dP chain starts (register plan above)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (8 * rg + 4 * h) * 4));   // lse (natural log): scaled to log2 units in the fma below
+        const f32x4 l2 = __builtin_bit_cast(f32x4, lds_read16(stt + (8 * rg + 4 * h) * 4));   // lse in log2 units
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rg + e;
-          const float arg = __builtin_fmaf(l2[e], -LOG2E, s[r] * scale_log2);
+          const float arg = __builtin_fmaf(s[r], scale_log2, -l2[e]);
           s[r] = (KVABL & 8) ? arg : fast_exp2(arg);
         }
       }
       pf0 = acc_to_frag<T>(s, 0);
       pf1 = acc_to_frag<T>(s, 1);
+      // opaque to the optimizer: the dS stage below unpacks P from these packed registers (a shift or a mask per element); left to
+      // see through the packing, hipcc re-rounds every element from the f32 value with a second, single-element conversion + shift
+      if constexpr (sizeof(T) == 2) asm volatile("" : "+v"(pf0.v), "+v"(pf1.v));
     }
     Frag<T> df0, df1;
     if constexpr (DO_DK) {
@@ -605,16 +639,16 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       for (int r = 0; r < 16; ++r) dp[r] = 0.f;
       Frag<T> ofr[C::NKK], vfr[K::VLDS ? C::NKK : 1];
 #pragma unroll
-      for (int kk = 0; kk < PD; ++kk) {
+      for (int kk = 0; kk < PD2; ++kk) {
         ofr[kk] = load_frag_row_p<T, C::RS>(orow, li, kk * 16);
         if constexpr (K::VLDS && !(KVABL & 4)) vfr[kk] = load_frag_row_p<T, C::RS>(Vimg(), wave * 32 + li, kk * 16);
       }
       PFN_PIN_LDS_MFMA();
 #pragma unroll
       for (int kk = 0; kk < C::NKK; ++kk) {
-        if (kk + PD < C::NKK) {
-          ofr[kk + PD] = load_frag_row_p<T, C::RS>(orow, li, (kk + PD) * 16);
-          if constexpr (K::VLDS && !(KVABL & 4)) vfr[kk + PD] = load_frag_row_p<T, C::RS>(Vimg(), wave * 32 + li, (kk + PD) * 16);
+        if (kk + PD2 < C::NKK) {
+          ofr[kk + PD2] = load_frag_row_p<T, C::RS>(orow, li, (kk + PD2) * 16);
+          if constexpr (K::VLDS && !(KVABL & 4)) vfr[kk + PD2] = load_frag_row_p<T, C::RS>(Vimg(), wave * 32 + li, (kk + PD2) * 16);
         }
         if constexpr (K::VLDS && (KVABL & 4)) dp = mma32(ofr[kk], ofr[kk], dp);
         else if constexpr (K::VLDS) dp = mma32(ofr[kk], vfr[kk], dp);
@@ -628,13 +662,11 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rg + e;
-          dp[r] = frag_get(r < 8 ? pf0 : pf1, r & 7) * (dp[r] - dl[e]);
+          dp[r] = frag_get_bits(r < 8 ? pf0 : pf1, r & 7) * (dp[r] - dl[e]);
         }
       }
-      if (!kvalid) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
-      }
+      // (keys >= sep of the last key block: their dS is garbage from clamped rows; it only reaches accumulator columns that are never
+      // stored, and is zeroed where it leaves the kernel -- the dS^T store below -- instead of element by element here)
       df0 = acc_to_frag<T>(dp, 0);
       df1 = acc_to_frag<T>(dp, 1);
     }
@@ -661,6 +693,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       }
       PFN_PIN_LDS_MFMA();
     }
+    if constexpr (PRIO & 8) __builtin_amdgcn_s_setprio(1);
     if constexpr (DO_DK) {
 #pragma unroll
       for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df0, dk[db]);
@@ -672,6 +705,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 #pragma unroll
       for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df1, dk[db]);
     }
+    if constexpr (PRIO & 8) __builtin_amdgcn_s_setprio(0);
     // End of the tile.  gfx9 counts loads and stores in ONE counter and they retire in order: a wait for a load is a wait for
     // every store issued before it.  So the order of issue at a tile's end is: the DMA of tile t+2 (into this tile's buffer, free
     // behind the barrier), THEN this tile's dS^T stores (block (key / 32, t), operand precision: exactly what the dK product
@@ -686,6 +720,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     }
     // keys >= sep of a block row the dQ pass reads (rows < ds_rows) leave as zeros: that pass does not mask rows
     if constexpr (DS_STORES > 0) {
+      if (!wave_all_valid) {      // last key block only (wave-uniform)
+        if (!kvalid) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { df0.set(e, 0.f); df1.set(e, 0.f); }
+        }
+      }
       if (ds_row_live) store_frag_pair_blocked<T>(dsT + (long)t * DSBLK, df0, df1, li, h, true);
       stored = ds_row_live;
     }

@@ -131,7 +131,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   w.dlog_t = take(M * npad * es); w.dd_t = take(M * F * es); w.dxt = (float*)take(M * E * 4);
   w.gA = (float*)take(M * E * 4); w.gA_t = take(M * E * es);
   w.dctx_t = take(M * E * es);
-  w.delta = (float*)take((int64_t)B * d.nhead * S * 4);
+  w.delta = (float*)take(2 * (int64_t)B * d.nhead * S * 4);      // [delta | lse in log2 units], both [B,H,S] (attn_delta_kernel)
   w.ds = take(attn_bwd_ds_bytes(B, S, d.nhead, d.precision));
   w.bytes = cur;
   return w;

@@ -110,7 +110,7 @@ def attention_bwd(qkv, ctx, lse, dctx, H, sep, prec, parts=0):
     if key not in _bwd_scratch:
         _bwd_scratch.clear()
         ws = _hip.check(_hip.lib().pfn_op_attention_bwd_ws_bytes(B, S, H, prec), 'attn bwd ws')
-        _bwd_scratch[key] = (torch.zeros_like(qkv), torch.zeros(B, H, S, dtype=torch.float32, device=qkv.device),
+        _bwd_scratch[key] = (torch.zeros_like(qkv), torch.zeros(2, B, H, S, dtype=torch.float32, device=qkv.device),     # [delta | lse in log2 units]
                              torch.empty(ws, dtype=torch.uint8, device=qkv.device))
     dqkv, delta, ds = _bwd_scratch[key]
     if not parts:
