@@ -41,7 +41,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK = 2.5e15     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+KERNEL_STATS = os.path.join(ROOT, 'profiles', 'r03_bench_kernel_stats.csv')      # rocprofv3 --kernel-trace --stats of the default command
+TRAINED = os.path.join(ROOT, 'profiles', 'r03_trained_config2.json')
 
 # BASELINE.json configs (index = position in the list; 3 is configs[1] on 8 GPUs)
 CONFIGS = {
@@ -466,9 +468,19 @@ def validation_loss(model, w, device, n=8, seed=4321):
         xd, yd = x.float().to(device), y.float().to(device)
         loss = hip_loss_and_means(w, model, model((xd, yd), single_eval_pos=sep), yd[sep:])[0].mean().item()
     model.train(was_training)
-    return dict(value=loss, datasets=x.shape[1], eval_position=sep, seed=seed,
-                note='bar NLL (BCE for the BNN configuration) of the benchmarked model -- random initialisation plus the few optimizer steps of this '
-                     'run -- on a fixed-seed draw; it is a regression value for the step, not a trained model\'s score')
+    out = dict(value=loss, datasets=x.shape[1], eval_position=sep, seed=seed, checkpoint='none: random initialisation + the optimizer steps of this run',
+               note='bar NLL (BCE for the BNN configuration) of the benchmarked model -- random initialisation plus the few optimizer steps of this '
+                    'run -- on a fixed-seed draw; it is a regression value for the step, not a trained model\'s score (see `trained`)')
+    if w is CONFIGS[2] and os.path.exists(TRAINED):
+        # what this stack reaches when it TRAINS (tools/train_pfn.py, one MI355X, 512 k datasets each): the notebook's own recipe
+        # (5 features) and BASELINE.json's 18-feature variant of it, PFN bar NLL next to the exact GP posterior on the same draws
+        tr = json.load(open(TRAINED))
+        pick = lambda k: {kk: tr[k]['paired_eval_trained']['summary'][kk] for kk in ('pfn_bar_nll', 'exact_gp_nll', 'prior_nll')}
+        out['trained'] = dict(source='profiles/' + os.path.basename(TRAINED),
+                              notebook_recipe_5_features=dict(pick('notebook_recipe_5_features'), val_bar_nll_at_1755=tr['notebook_recipe_5_features']['val_bar_nll']['value'],
+                                                              training_seconds=tr['notebook_recipe_5_features']['training_seconds']),
+                              config2_18_features=dict(pick('config2_18_features_lr3e-4_batch64'), note='still at the prior after 512 k datasets (two recipes)'))
+    return out
 
 
 def self_launch(args):
@@ -655,7 +667,17 @@ def main():
             if hit:
                 traffic = hit[0].get('read_bytes', 0) + hit[0].get('write_bytes', 0)
                 traffic_src = f"profiles/{os.path.basename(PMC_TRAFFIC)} ({pmc.get('note', '')})"
+        in_step_us, in_step_src = None, None
+        if os.path.exists(KERNEL_STATS) and args.config == 2 and batch == w['batch'] and streams == w['streams']:
+            import csv
+            for row in csv.DictReader(open(KERNEL_STATS)):      # the committed rocprofv3 trace of THIS command: the same symbol inside the step
+                if row.get('Name', '').startswith(dom['rocprof_name']):
+                    in_step_us = float(row['AverageNs']) / 1e3
+                    in_step_src = f'profiles/{os.path.basename(KERNEL_STATS)} (rocprofv3 --kernel-trace --stats of this command: two micro-batch streams + the sampler share the chip)'
+                    break
         result['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'rocprof_kernel': dom['rocprof_name'], 'achieved': dom['tflops'],
+                              'in_step_avg_launch_us': in_step_us, 'in_step_source': in_step_src,
+                              'in_step_frac': None if in_step_us is None else dom['flops'] / (in_step_us * 1e-6) / MFMA_BF16_PEAK,
                               'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': dom['tflops'] * 1e12 / MFMA_BF16_PEAK,
                               'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_flops_per_launch': dom['flops'],
                               'executed_flops_per_launch': dom['executed_flops'], 'executed_frac': dom['executed_tflops'] * 1e12 / MFMA_BF16_PEAK,

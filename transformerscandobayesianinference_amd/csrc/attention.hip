@@ -117,6 +117,29 @@ PFN_DEV AttnBlock attn_block(int nblk, int H) {
   return o;
 }
 
+// The same for the key-block pass, whose LAST block of every (dataset, head) pair is ragged (sep mod 256 keys; its dead waves skip
+// the tile work) and therefore cheap: every XCD gets its share of the full blocks first (block index fastest inside a pair, so a
+// pair's blocks still run together on one L2) and its share of the ragged blocks last -- longest first.  At the north-star
+// micro-batch (32 datasets x 4 heads, sep 1604: 6 full blocks + 68 keys) the full blocks are exactly 3 rounds of 256 workgroups
+// and the fourth round holds only the cheap ones, instead of four rounds of mixed work.
+PFN_DEV AttnBlock attn_block_ragged_last(int nblk, int nfull, int H) {
+  if (nfull == nblk) return attn_block(nblk, H);
+  const int nwg = gridDim.x, bid = blockIdx.x, npairs = nwg / nblk;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+  const int n_x = q + (xcd < r ? 1 : 0);                                  // workgroups of this XCD (hardware round-robin)
+  const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q; // workgroups of the XCDs before this one
+  const int r_lo = (int)((long)first * npairs / nwg), r_hi = (int)((long)(first + n_x) * npairs / nwg);   // its ragged blocks: pairs [r_lo, r_hi)
+  const int f_x = n_x - (r_hi - r_lo);
+  const int f_off = first - r_lo;                                         // full blocks handed to the XCDs before this one
+  AttnBlock o;
+  int pair;
+  if (j < f_x) { const int id = f_off + j; pair = id / nfull; o.blk = id % nfull; }
+  else { pair = r_lo + (j - f_x); o.blk = nfull; }
+  o.hd = pair % H;
+  o.b = pair / H;
+  return o;
+}
+
 // Profiling builds only (tools/exp_attn_variants.py): -DPFN_ATTN_ABLATE=<bits> drops, in every main loop, the
 // global tile requests (1), the LDS tile writes (2), the barrier (4).  Results are then garbage; the timing
 // differences price the three parts (MI355X, north-star shape: requests 9-14 %, writes 6-7 %, barrier 4 %).
@@ -456,7 +479,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   auto Oc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + 2 * K::RIMG + K::CIMG; };
   auto St = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::IMG; };   // [lse x QB][delta x QB]
 
-  const AttnBlock wg = attn_block((a.sep + C::QBLK - 1) / C::QBLK, a.H);
+  const AttnBlock wg = attn_block_ragged_last((a.sep + C::QBLK - 1) / C::QBLK, a.sep / C::QBLK, a.H);
   const int b = wg.b, hd = wg.hd;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
   const long rs = 3L * a.E;
@@ -476,6 +499,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   const float* lse_g = a.delta + (long)a.B * a.H * a.S + ((long)b * a.H + hd) * a.S;    // lse in log2 units (attn_delta_kernel)
   const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
   const bool wave_all_valid = __builtin_amdgcn_readfirstlane(key0 + wave * 32 + 31) < sep;   // only the last key block has keys >= sep
+  const bool wave_live = __builtin_amdgcn_readfirstlane(key0 + wave * 32) < sep;             // ... and waves with no key below sep at all
   // dS^T of this (dataset, head): 32 x 32 blocks, block (key / 32, query / 32) at ((key / 32) * (ds_ld / 32) + query / 32) blocks
   // (store_frag_pair_blocked); the wave owns block row key / 32
   constexpr int DSBLK = 32 * 32;   // elements per block
@@ -599,6 +623,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     constexpr int PD2 = C::NKK < PFN_KV_PD_DP ? C::NKK : PFN_KV_PD_DP;    // dP = dO V^T chain
     // rows of the S / dP tiles are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
     Frag<T> pf0, pf1;
+    Frag<T> df0, df1;
+    // A wave whose 32 keys all lie at or beyond sep (the tail of the last key block) has nothing to compute: it keeps moving its
+    // DMA pieces and keeps the barriers, and leaves the matrix pipe, the vector ALU and the LDS ports of its SIMD to its partner.
+    // The workgroup of a ragged last block therefore finishes early and frees its CU for the next one (sep mod 256 is uniform:
+    // on average half of that block's waves are dead).
+    if (wave_live) {
     {
       f32x16 s;
 #pragma unroll
@@ -632,7 +662,6 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       // see through the packing, hipcc re-rounds every element from the f32 value with a second, single-element conversion + shift
       if constexpr (sizeof(T) == 2) asm volatile("" : "+v"(pf0.v), "+v"(pf1.v));
     }
-    Frag<T> df0, df1;
     if constexpr (DO_DK) {
       f32x16 dp;
 #pragma unroll
@@ -706,6 +735,10 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df1, dk[db]);
     }
     if constexpr (PRIO & 8) __builtin_amdgcn_s_setprio(0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { df0.set(e, 0.f); df1.set(e, 0.f); }    // its dS^T rows (if the dQ pass reads them at all) are zeros
+    }
     // End of the tile.  gfx9 counts loads and stores in ONE counter and they retire in order: a wait for a load is a wait for
     // every store issued before it.  So the order of issue at a tile's end is: the DMA of tile t+2 (into this tile's buffer, free
     // behind the barrier), THEN this tile's dS^T stores (block (key / 32, t), operand precision: exactly what the dK product
