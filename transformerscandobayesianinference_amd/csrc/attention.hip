@@ -160,6 +160,9 @@ constexpr int ABL = PFN_ATTN_ABLATE;
 #define PFN_ATTN_PRIO 0
 #endif
 constexpr int PRIO = PFN_ATTN_PRIO;
+#ifndef PFN_KV_SPLIT_D256
+#define PFN_KV_SPLIT_D256 0
+#endif
 #ifndef PFN_KV_PD_S
 #define PFN_KV_PD_S 2
 #endif
@@ -455,7 +458,11 @@ template <typename T, int D> struct BwdKvCfg {
   // the lanes' DMA source offsets (one per piece of the wave) live in an LDS table when there is room (every shipped shape):
   // recomputing them per tile costs ~20 vector instructions per piece, keeping them in registers costs registers this kernel
   // does not have
-  static constexpr bool SPLIT = C::NW == 4 && D > 128;       // head dim 256: dV and dK in two passes (attn_bwd_kv_kernel MODE)
+  // head dim 256 ran dV and dK as two passes in round 2 (attn_bwd_kv_kernel MODE 2, then MODE 1: six product units): the single pass
+  // spilled 116 bytes per lane.  Round 3: with the transposed fragments of the dV / dK products held one group of four at a time and
+  // P unpacked from its packed registers the single pass fits the register file (508 VGPRs, no scratch) -- 64 MFMAs per tile instead
+  // of 80, one sweep over the Q / dO tiles instead of two.  -DPFN_KV_SPLIT_D256=1 restores the two passes (A/B builds).
+  static constexpr bool SPLIT = PFN_KV_SPLIT_D256 && C::NW == 4 && D > 128;
   static constexpr bool PVLDS = VIMG + 2 * BUF + NI * C::NT * 4 <= 160 * 1024;
   static constexpr int PVTAB = PVLDS ? NI * C::NT * 4 : 0;
   static constexpr int LDS = VIMG + 2 * BUF + PVTAB;
@@ -699,40 +706,33 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       df0 = acc_to_frag<T>(dp, 0);
       df1 = acc_to_frag<T>(dp, 1);
     }
-    // dV^T += dO^T P,  dK^T += Q^T dS: groups of NDB MFMAs, the next group's transposed fragments requested under each
-    Frag<T> cf[C::NDB];
+    // dV^T += dO^T P,  dK^T += Q^T dS as a list of steps (product, column group): product 0 / 1 = dV with the two halves of P, 2 / 3 = dK
+    // with the two halves of dS; a group is CG of the NDB 32-column blocks of the head dimension.  One set of CG transposed fragments
+    // is live: the next step's are requested right behind the MFMAs that consume the current ones (head dim 256 takes its 8 blocks
+    // as two groups of 4 -- 16 registers instead of 32, which is what the single-pass variant lacked).
+    constexpr int CG = C::NDB > 4 ? 4 : C::NDB, NG = C::NDB / CG;
+    constexpr int P0 = DO_DV ? 0 : 2, P1 = DO_DK ? 4 : 2;       // products [P0, P1)
+    Frag<T> cf[CG];
+    auto request = [&](int step) __attribute__((always_inline)) {
+      const int prod = P0 + step / NG, grp = step % NG;
+      const lds_char* img = prod < 2 ? oc : qc;
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(DO_DV ? oc : qc, 0, db * 32);
+      for (int c = 0; c < CG; ++c) cf[c] = load_frag_tr_p<T, C::CS, 2>(img, (prod & 1) * 16, (grp * CG + c) * 32);
+    };
+    request(0);
     PFN_PIN_LDS_MFMA();
-    if constexpr (DO_DV) {
 #pragma unroll
-      for (int db = 0; db < C::NDB; ++db) dv[db] = mma32(cf[db], pf0, dv[db]);
-      if (!(KVABL & 2)) {
+    for (int step = 0; step < (P1 - P0) * NG; ++step) {
+      const int prod = P0 + step / NG, grp = step % NG;
+      if constexpr (PRIO & 8) { if (prod == 2 && grp == 0) __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(oc, 16, db * 32);
+      for (int c = 0; c < CG; ++c) {
+        const int db = grp * CG + c;
+        if (prod < 2) { if constexpr (DO_DV) dv[db] = mma32(cf[c], prod == 0 ? pf0 : pf1, dv[db]); }
+        else { if constexpr (DO_DK) dk[db] = mma32(cf[c], prod == 2 ? df0 : df1, dk[db]); }
       }
+      if (step + 1 < (P1 - P0) * NG && !(KVABL & 2)) request(step + 1);
       PFN_PIN_LDS_MFMA();
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) dv[db] = mma32(cf[db], pf1, dv[db]);
-      if constexpr (DO_DK) {
-        if (!(KVABL & 2)) {
-#pragma unroll
-          for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(qc, 0, db * 32);
-        }
-      }
-      PFN_PIN_LDS_MFMA();
-    }
-    if constexpr (PRIO & 8) __builtin_amdgcn_s_setprio(1);
-    if constexpr (DO_DK) {
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df0, dk[db]);
-      if (!(KVABL & 2)) {
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db) cf[db] = load_frag_tr_p<T, C::CS, 2>(qc, 16, db * 32);
-      }
-      PFN_PIN_LDS_MFMA();
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) dk[db] = mma32(cf[db], df1, dk[db]);
     }
     if constexpr (PRIO & 8) __builtin_amdgcn_s_setprio(0);
     } else {

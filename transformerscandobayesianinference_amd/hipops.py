@@ -95,8 +95,8 @@ ATTENTION_BWD_PARTS = [
     ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', '_ZN3pfn18attn_bwd_dq_kernelIDF16bLi{D}EEEvNS_8AttnArgsE', 4, 1.0, 1.0),
 ]
 ATTENTION_FWD_ROCPROF = '_ZN3pfn15attn_fwd_kernelIDF16bLi{D}EEEvNS_8AttnArgsE'
-# head dim 256 runs the key-block pass as two launches (dV: S, dV; dK: S, dP, dK) -- one more S product
-ATTENTION_BWD_KV_EXECUTED_UNITS = {256: 5.0}
+# (round 2: head dim 256 ran the key-block pass as two launches with one more S product -- {256: 5.0}; round 3: one pass everywhere)
+ATTENTION_BWD_KV_EXECUTED_UNITS = {}
 _bwd_scratch = {}
 
 
