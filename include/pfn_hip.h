@@ -151,7 +151,7 @@ int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
  * y_b ~ N(0, outputscale_b * k(x_b, x_b; lengthscale_b) + noise_b * I) by Gram -> Cholesky -> L z.
  * x [B,S,nf] f32: filled with U[0,1) from the counter-based generator when gen_x != 0, else input.
  * z [B,S] f32 base normals: generated when gen_z != 0 (and written back), else input.
- * lengthscale [B,nf], outputscale [B], noise [B].  kernel: 0 = RBF, 1 = Matern nu=2.5.
+ * lengthscale [B,nf], outputscale [B], noise [B].  kernel: 0 = RBF, 1 / 2 / 3 = Matern nu = 2.5 / 1.5 / 0.5 (gpytorch MaternKernel's three closed forms).
  * K_ws: [B,S,S] f32 workspace.  info [B]: 0 or (index+1) of the first non-positive pivot. */
 int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws,
                         const float* lengthscale, const float* outputscale, const float* noise,

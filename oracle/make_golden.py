@@ -218,7 +218,8 @@ def gp_case(ref):
     for (T, F) in [(20, 5), (12, 18)]:
         x = torch.rand(T, F, generator=gen, dtype=torch.float64)
         ls = torch.rand(F, generator=gen, dtype=torch.float64) * 2 + 0.1
-        rec['matern'].append(dict(x=x, lengthscale=ls, gram=torch.from_numpy(Matern(nu=2.5, length_scale=ls.numpy())(x.numpy()))))
+        rec['matern'].append(dict(x=x, lengthscale=ls, gram=torch.from_numpy(Matern(nu=2.5, length_scale=ls.numpy())(x.numpy())),
+                                  gram_nu={nu: torch.from_numpy(Matern(nu=nu, length_scale=ls.numpy())(x.numpy())) for nu in (0.5, 1.5, 2.5)}))
     torch.save(rec, os.path.join(OUT, 'gp_sklearn.pt'))
     print('gp cases', [(c['B'], c['T'], c['F'], c['length_scale'], [round(float(v), 4) for v in c['evaluate_nll'][:4]]) for c in rec['cases']])
 

@@ -158,9 +158,16 @@ def gp_gram(x, lengthscale, outputscale, noise, kernel='rbf'):
     d2 = (xs.unsqueeze(2) - xs.unsqueeze(1)).pow(2).sum(-1).clamp_min(0)
     if kernel == 'rbf':
         k = torch.exp(-0.5 * d2)
-    else:
+    elif kernel in ('matern', 'matern52'):
         r = torch.sqrt(5.0 * d2)
         k = (1 + r + r * r / 3) * torch.exp(-r)
+    elif kernel == 'matern32':
+        r = torch.sqrt(3.0 * d2)
+        k = (1 + r) * torch.exp(-r)
+    elif kernel == 'matern12':
+        k = torch.exp(-torch.sqrt(d2))
+    else:
+        raise ValueError(kernel)
     eye = torch.eye(x.shape[1], dtype=x.dtype, device=x.device)
     return outputscale * k + noise * eye
 

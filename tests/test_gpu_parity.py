@@ -261,12 +261,14 @@ def test_gp_prior_sampler_vs_oracle():
     from transformerscandobayesianinference_amd.priors import fast_gp
     g = torch.Generator().manual_seed(3)
     for (B, T, F, hp, kernel) in [(3, 100, 5, (1e-4, 1.0, 0.6), 'rbf'), (2, 332, 18, (0.1, 0.1, 0.1), 'rbf'),
-                                  (2, 2000, 18, (1e-4, 1.0, 0.6), 'rbf'), (2, 260, 4, (1e-2, 0.7, 0.5), 'matern')]:
+                                  (2, 2000, 18, (1e-4, 1.0, 0.6), 'rbf'), (2, 260, 4, (1e-2, 0.7, 0.5), 'matern'),
+                                  (2, 196, 6, (1e-2, 1.3, 0.4), 'matern32'), (2, 132, 3, (1e-2, 0.9, 0.7), 'matern12')]:   # hyperparameters['nu'] of fast_gp_mix.py:40
         x = torch.rand(B, T, F, generator=g)
         z = torch.randn(B, T, generator=g)
         noise, os_, ls = hp
         want = pfn_oracle.gp_sample(x, z, ls, os_, noise, kernel)
-        _, got, _, info = fast_gp.gp_sample(B, T, F, DEV, ls, os_, noise, fast_gp.KERNEL_RBF if kernel == 'rbf' else fast_gp.KERNEL_MATERN52, x=x, z=z)
+        kid = {'rbf': fast_gp.KERNEL_RBF, 'matern': fast_gp.KERNEL_MATERN52, 'matern32': fast_gp.KERNEL_MATERN32, 'matern12': fast_gp.KERNEL_MATERN12}[kernel]
+        _, got, _, info = fast_gp.gp_sample(B, T, F, DEV, ls, os_, noise, kid, x=x, z=z)
         assert int(info.abs().sum()) == 0
         err = relerr(got, want)
         assert err < 2e-3, (B, T, F, hp, err)   # f32 Cholesky of a cond ~1e6 matrix (6e-4 at nf=5)

@@ -140,6 +140,9 @@ def test_gp_oracle_matches_reference_sklearn_gp():
         one = torch.ones(1, 1, 1, dtype=torch.float64)
         gram = pfn_oracle.gp_gram(c['x'].unsqueeze(0), c['lengthscale'].reshape(1, 1, -1), one, 0 * one, 'matern')[0]
         assert (gram - c['gram']).abs().max().item() < 1e-9
+        for nu, name in ((0.5, 'matern12'), (1.5, 'matern32'), (2.5, 'matern52')):      # hyperparameters['nu'] of priors/fast_gp_mix.py:40
+            gram = pfn_oracle.gp_gram(c['x'].unsqueeze(0), c['lengthscale'].reshape(1, 1, -1), one, 0 * one, name)[0]
+            assert (gram - c['gram_nu'][nu]).abs().max().item() < 1e-9
 
 
 def test_gp_evaluate_oracle_chain_rule_and_noise_limit():

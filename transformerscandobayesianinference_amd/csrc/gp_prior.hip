@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void gp_gram_kernel(GpArgs a) {
       if (gj >= S) continue;
       float k;
       if (a.kernel == 0) k = __expf(-0.5f * d2[i][j]);
-      else { const float r = sqrtf(5.f * d2[i][j]); k = (1.f + r + r * r * (1.f / 3.f)) * __expf(-r); }
+      else if (a.kernel == 1) { const float r = sqrtf(5.f * d2[i][j]); k = (1.f + r + r * r * (1.f / 3.f)) * __expf(-r); }   // Matern nu = 5/2
+      else if (a.kernel == 2) { const float r = sqrtf(3.f * d2[i][j]); k = (1.f + r) * __expf(-r); }                        // nu = 3/2
+      else k = __expf(-sqrtf(d2[i][j]));                                                                                     // nu = 1/2
       Kb[(long)gi * S + gj] = os * k + (gi == gj ? nz : 0.f);
     }
   }

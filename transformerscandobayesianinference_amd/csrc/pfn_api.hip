@@ -574,7 +574,7 @@ int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws, const float* 
                         const float* noise, int B, int S, int nf, int kernel, int gen_x, int gen_z, uint64_t seed, uint64_t offset,
                         int32_t* info, void* stream) {
   if (!x || !z || !y || !K_ws || !lengthscale || !outputscale || !noise || !info || B < 1 || S < 1 || nf < 1) return fail(PFN_ERR_ARGUMENT, "bad gp_prior_sample arguments");
-  if (kernel != 0 && kernel != 1) return fail(PFN_ERR_UNSUPPORTED, "kernel %d (0 = RBF, 1 = Matern-5/2)", kernel);
+  if (kernel < 0 || kernel > 3) return fail(PFN_ERR_UNSUPPORTED, "kernel %d (0 = RBF, 1 / 2 / 3 = Matern nu 5/2, 3/2, 1/2)", kernel);
   GpArgs a;
   a.x = x; a.z = z; a.y = y; a.K = K_ws; a.lengthscale = lengthscale; a.outputscale = outputscale; a.noise = noise;
   a.B = B; a.S = S; a.nf = nf; a.kernel = kernel; a.seed = seed; a.offset = offset; a.gen_x = gen_x; a.gen_z = gen_z; a.info = info;
@@ -588,7 +588,7 @@ int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_w
                      float* var, int32_t* info, void* stream) {
   if (!x || !y || !K_ws || !resid_ws || !w_ws || !lengthscale || !outputscale || !noise || !info || B < 1 || S < 1 || nf < 1)
     return fail(PFN_ERR_ARGUMENT, "bad gp_posterior arguments");
-  if (kernel != 0 && kernel != 1) return fail(PFN_ERR_UNSUPPORTED, "kernel %d (0 = RBF, 1 = Matern-5/2)", kernel);
+  if (kernel < 0 || kernel > 3) return fail(PFN_ERR_UNSUPPORTED, "kernel %d (0 = RBF, 1 / 2 / 3 = Matern nu 5/2, 3/2, 1/2)", kernel);
   GpArgs a;
   a.x = const_cast<float*>(x); a.z = nullptr; a.y = resid_ws; a.K = K_ws; a.lengthscale = lengthscale; a.outputscale = outputscale;
   a.noise = noise; a.B = B; a.S = S; a.nf = nf; a.kernel = kernel; a.seed = 0; a.offset = 0; a.gen_x = 0; a.gen_z = 0; a.info = info;

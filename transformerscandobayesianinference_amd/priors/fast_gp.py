@@ -15,7 +15,8 @@ from transformerscandobayesianinference_amd import _hip
 from transformerscandobayesianinference_amd.priors.utils import defer_draw_check, get_batch_to_dataloader
 from transformerscandobayesianinference_amd.utils import default_device
 
-KERNEL_RBF, KERNEL_MATERN52 = 0, 1
+KERNEL_RBF, KERNEL_MATERN52, KERNEL_MATERN32, KERNEL_MATERN12 = 0, 1, 2, 3
+MATERN_KERNEL_OF_NU = {2.5: KERNEL_MATERN52, 1.5: KERNEL_MATERN32, 0.5: KERNEL_MATERN12}    # gpytorch MaternKernel(nu=...) accepts exactly these
 
 _DEFAULT_HPS = {"noise": .1, "outputscale": .1, "lengthscale": .1}  # reference fast_gp.py:40
 _call_counter = [0]

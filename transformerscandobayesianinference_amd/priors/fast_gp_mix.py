@@ -13,7 +13,7 @@ with torch on the device and the whole batch goes through ONE call of the HIP sa
 the reference's Python loop over groups of `batch_size_per_gp_sample` datasets (:87) only exists to bound
 gpytorch's memory and has no effect on the distribution, so the argument is accepted and ignored except for the
 divisibility check.  `y_minmax_norm`, `sigmoid` (:100-103) and the `fix_to_range` rejection step (:104-122) are
-kept.  Always exact Cholesky; only nu = 2.5 (the reference default) is implemented.
+kept.  Always exact Cholesky; nu in {0.5, 1.5, 2.5} (gpytorch MaternKernel's closed forms; the reference default is 2.5, :40).
 
 Model fitting / MCMC comparison code of the reference file (get_fitted_model, get_mcmc_model, evaluate_, :156-287)
 needs gpytorch / botorch / pyro and is out of scope.
@@ -54,8 +54,10 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
     """Same signature and return layout as the reference: (x[T,B,F], y[T,B], target_y[T,B])."""
     assert num_outputs == 1
     hyperparameters = hyperparameters or {}
-    if hyperparameters.get('nu', 2.5) != 2.5:
-        raise _hip.HipExtensionError('priors.fast_gp_mix: only the Matern nu=2.5 kernel (the reference default) is implemented')
+    nu = float(hyperparameters.get('nu', 2.5))
+    if nu not in fast_gp.MATERN_KERNEL_OF_NU:
+        raise ValueError(f'priors.fast_gp_mix: Matern nu must be 0.5, 1.5 or 2.5 (gpytorch MaternKernel, reference :40), got {nu}')
+    matern = fast_gp.MATERN_KERNEL_OF_NU[nu]
     if batch_size_per_gp_sample is not None:   # grouping has no effect here (one batched sampler call); keep the reference's check (:77)
         assert batch_size % batch_size_per_gp_sample == 0
     factor = 2 if fix_to_range is not None else 1
@@ -72,7 +74,7 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
         # anything below that copies y (normalisation, rejection) must see a verified draw: check at once there; a plain
         # draw inside a prefetching loader is verified before its batch is handed out (priors/utils.py)
         copies = bool(hyperparameters.get('y_minmax_norm') or hyperparameters.get('sigmoid') or fix_to_range is not None)
-        x, y, _, _ = fast_gp.gp_sample(n, seq_len, num_features, device, ls, osc, nz, fast_gp.KERNEL_MATERN52, x=x,
+        x, y, _, _ = fast_gp.gp_sample(n, seq_len, num_features, device, ls, osc, nz, matern, x=x,
                                        check='sync' if copies else True)
         if hyperparameters.get('y_minmax_norm'):
             lo, hi = y.min(1, keepdim=True)[0], y.max(1, keepdim=True)[0]
