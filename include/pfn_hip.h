@@ -178,9 +178,11 @@ int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_w
  * <= 152); biases [num_models][Lmax][HP]; dims [num_models][3] = (num_causes, hidden, num_layers); noise_std [num_models].
  * causes [B][T][HP]: filled with N(0,1) in the first num_causes columns when gen_causes != 0 (the x of the dataset),
  * else taken as input.  noise: NULL (generated, Philox) or [B][Lmax-1][T][HP] standard normals.
+ * hidden: NULL, or [B][Lmax-1][T][HP] receiving the outputs (noise included) of layers 1 .. L-1 -- the node pool from which the
+ * causal variant (priors/mlp.py:158-166, `outputs[2:]`) picks its features and target.
  * activation: 0 identity, 1 relu, 2 tanh, 3 sigmoid. */
 int pfn_mlp_prior_forward(const float* weights, const float* biases, const int32_t* model_of, const int32_t* dims,
-                          const float* noise_std, float* causes, const float* noise, float* y,
+                          const float* noise_std, float* causes, const float* noise, float* y, float* hidden,
                           int B, int T, int HP, int Lmax, int activation, int gen_causes,
                           uint64_t seed, uint64_t offset, void* stream);
 

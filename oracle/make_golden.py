@@ -193,6 +193,55 @@ def mlp_prior_case(ref):
     print('mlp prior', x.shape, y.shape, 'params', len(rec['params']), 'normals', len(rec['normals']), 'coins', rec['coins'], 'y mean', float(y.mean()))
 
 
+def mlp_prior_causal_case(ref):
+    """The OTHER branches of the reference's priors.mlp forward, recorded the same way: the causal-graph variant with pre-sampled
+    causes (:94-104, :139-140, :158-166), categorical features -- one ordinal, one not (:168-179) -- and per-unit pre-sampled
+    noise scales (`pre_sample_weights`, :119-121).  Intercepted: parameter initialisations, every torch.normal (construction: the
+    noise-scale vectors; forward: causes, then each layer's noise), every torch.randperm (node selection, then categorical
+    columns), the order_by_y coins."""
+    import numpy as np
+    from priors import mlp as ref_mlp
+    T, B, NF, PER, NFU, HID = 40, 4, 6, 2, 4, 7
+    cats = ([np.array([0.2, 0.7, 0.4]), np.array([0.6, 0.1])], [True, False])
+    cause_law = (np.array([0.5, -1.0, 0.2, 1.5, 0.0]), np.array([1.0, 0.3, 2.0, 0.7, 1.2]))
+    hps = (lambda: 3, lambda: HID, torch.nn.Tanh, lambda: 0.8, lambda: 0.05, lambda: 0.0, True, lambda: NFU,
+           lambda: cause_law, True, True, True, False, True, False, lambda n: cats, 0.0)
+    torch.manual_seed(33); random.seed(33); np.random.seed(33)
+    rec = dict(config=dict(T=T, B=B, NF=NF, PER=PER, NFU=NFU, hidden=max(HID, 2 * NFU + 1), activation='tanh', cats=[c.tolist() for c in cats[0]], ordinal=cats[1]),
+               params=[], normals=[], perms=[], coins=[])
+    orig_init, orig_normal, orig_randint, orig_randperm = torch.nn.init.normal_, torch.normal, random.randint, torch.randperm
+
+    def init_normal(p, mean=0., std=1.):
+        out = orig_init(p, mean=mean, std=std)
+        rec['params'].append(p.detach().clone())
+        return out
+
+    def normal(*a, **k):
+        out = orig_normal(*a, **k)
+        rec['normals'].append(out.detach().clone())
+        return out
+
+    def randint(a, b):
+        v = orig_randint(a, b)
+        rec['coins'].append(v)
+        return v
+
+    def randperm(*a, **k):
+        out = orig_randperm(*a, **k)
+        rec['perms'].append(out.detach().clone())
+        return out
+
+    torch.nn.init.normal_, torch.normal, random.randint, torch.randperm = init_normal, normal, randint, randperm
+    try:
+        x, y, _ = ref_mlp.get_batch(B, T, NF, device='cpu', hyperparameters=hps, batch_size_per_gp_sample=PER)
+    finally:
+        torch.nn.init.normal_, torch.normal, random.randint, torch.randperm = orig_init, orig_normal, orig_randint, orig_randperm
+    rec['x'], rec['y'] = x.clone(), y.clone()
+    torch.save(rec, os.path.join(OUT, 'mlp_prior_causal.pt'))
+    print('mlp prior (causal + categorical + pre-sampled noise scales)', x.shape, 'params', len(rec['params']), 'normals', len(rec['normals']),
+          [tuple(n.shape) for n in rec['normals'][:7]], 'perms', [len(p) for p in rec['perms']], 'coins', rec['coins'])
+
+
 def gp_case(ref):
     """Pins the GP part of the oracle to the reference's OWN sklearn statement of the same GP (priors/gp.py): the Gram
     matrix of `get_gp(length_scale).kernel` (:14-17, RBF with fixed length scale, unit output scale) and the per-position
@@ -233,4 +282,5 @@ if __name__ == '__main__':
     bar_case(ref)
     utils_case(ref)
     mlp_prior_case(ref)
+    mlp_prior_causal_case(ref)
     gp_case(ref)

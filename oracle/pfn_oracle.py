@@ -260,6 +260,42 @@ def mlp_prior_forward(weights, biases, causes, noises, activation='tanh'):
     return h.squeeze(-1)
 
 
+def mlp_prior_layers(weights, biases, causes, noises, activation='tanh'):
+    """As `mlp_prior_forward`, but returns the outputs of layers 1 .. L-1 (noise included) -- `outputs[2:]` of the reference's
+    forward (priors/mlp.py:150-157), the node pool of the causal variant."""
+    act = _activation(activation)
+    h = causes @ weights[0].t() + biases[0]
+    outs = []
+    for l in range(1, len(weights)):
+        h = act(h) @ weights[l].t() + biases[l] + noises[l - 1]
+        outs.append(h)
+    return outs
+
+
+def mlp_prior_causal_select(outs, perm, nfu, y_is_effect=False):
+    """Reference priors/mlp.py:158-166 for one dataset: concatenate the layer outputs, take the target at perm[0] (or the last node when
+    `y_is_effect`) and the features at perm[1 : 1 + nfu]; perm is a permutation of all nodes but the last."""
+    flat = torch.cat(outs, -1)
+    y = flat[:, -1] if y_is_effect else flat[:, perm[0]]
+    return flat[:, perm[1:1 + nfu]], y
+
+
+def mlp_prior_categorical(x, features, ordinal, perm):
+    """Reference priors/mlp.py:168-179 for one dataset x [T, nfu]: column perm[i] becomes the count of feature i's thresholds
+    (values - 0.5) below its standardised value; class ids of non-ordinal features are scrambled by * (127 k + 1) % k."""
+    x = x.clone()
+    for i, (feat, is_ordinal) in enumerate(zip(features, ordinal)):
+        idx = int(perm[i])
+        v = x[:, idx]
+        temp = (v - v.mean(0)) / (v.std(0) + .000001)
+        thr = torch.as_tensor(feat, dtype=x.dtype) - 0.5
+        cls = (temp[None, :] > thr[:, None]).sum(0).to(x.dtype)
+        if not is_ordinal:
+            cls = cls * (127 * len(feat) + 1) % len(feat)
+        x[:, idx] = cls
+    return x
+
+
 def mlp_prior_postprocess(x, y, num_features, binary=True, order_sign=None, nfu_scale=None):
     """x [T, nfu], y [T] of one dataset -> (x [T, num_features], y [T]) as the reference's MLP.forward does after the
     network (:185-201): normalize_data over the sequence axis (unbiased std, + 1e-6; priors/utils.py:73-78), median

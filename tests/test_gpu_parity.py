@@ -416,6 +416,62 @@ def test_mlp_prior_kernel_vs_reference_golden():
             assert torch.allclose(a_[a_[:, 0].argsort()], b_[b_[:, 0].argsort()], atol=2e-5, rtol=2e-5), (i, cls)
 
 
+def test_mlp_prior_causal_branches_vs_reference_golden():
+    """The causal-graph / categorical / pre-sampled-noise-scale branches (reference priors/mlp.py:94-104, 119-121, 139-140, 158-179) on the
+    tensors the reference drew (tests/golden/mlp_prior_causal.pt): the kernel's per-layer node outputs, the node selection, the
+    categorical discretisation and the tail of the forward must reproduce the reference's get_batch output."""
+    from transformerscandobayesianinference_amd.priors import mlp
+    rec = torch.load(os.path.join(GOLD, 'mlp_prior_causal.pt'))
+    cfg = rec['config']
+    T, B, NF, PER, NFU, HID = cfg['T'], cfg['B'], cfg['NF'], cfg['PER'], cfg['NFU'], cfg['hidden']
+    M = B // PER
+    weights = [[rec['params'][6 * m + 2 * l] for l in range(3)] for m in range(M)]
+    biases = [[rec['params'][6 * m + 2 * l + 1] for l in range(3)] for m in range(M)]
+    W, b, dims, HP = mlp.pack_networks(weights, biases, DEV)
+    causes = torch.zeros(B, T, HP)
+    noise = torch.zeros(B, 2, T, HP)
+    for i in range(B):
+        c, n1, n2 = [t[:, 0, :].float() for t in rec['normals'][2 * M + 3 * i: 2 * M + 3 * i + 3]]
+        causes[i, :, :c.shape[1]] = c
+        noise[i, 0, :, :n1.shape[1]] = n1
+        noise[i, 1, :, :n2.shape[1]] = n2
+    model_of = (torch.arange(B, dtype=torch.int32) // PER).to(DEV)
+    ones = torch.ones(M, device=DEV)   # the recorded noise tensors already carry their per-unit scales
+    _, _, hidden = mlp.forward_networks(W, b, dims, ones, model_of, T, 2, causes=causes.to(DEV), noise=noise.to(DEV), want_hidden=True)
+    x_raw = torch.zeros(B, T, 4, device=DEV)
+    y_raw = torch.zeros(B, T, device=DEV)
+    for i in range(B):
+        xs, ys = mlp.causal_select(hidden[i:i + 1], 3, HID, NFU, False, perm=rec['perms'][2 * i][None].to(DEV))
+        x_raw[i:i + 1] = mlp.categorical_columns(xs.clone(), cfg['cats'], cfg['ordinal'], perm=rec['perms'][2 * i + 1][None].to(DEV))
+        y_raw[i:i + 1] = ys
+        m = i // PER
+        outs = pfn_oracle.mlp_prior_layers([w_.double() for w_ in weights[m]], [b_.double() for b_ in biases[m]], causes[i, :, :5].double(),
+                                           [noise[i, 0, :, :HID].double(), noise[i, 1, :, :1].double()], 'tanh')
+        want_x, want_y = pfn_oracle.mlp_prior_causal_select(outs, rec['perms'][2 * i], NFU)
+        assert relerr(ys[0], want_y) < 1e-5 and relerr(xs[0], want_x) < 1e-5
+    sign = torch.tensor([1.0 if c else -1.0 for c in rec['coins']], device=DEV)
+    nfu = torch.full((B,), NFU, device=DEV)
+    x, y = mlp.postprocess(x_raw, y_raw, nfu, NF, True, sign)
+    assert torch.equal(y.cpu().t(), rec['y'])
+    xr = rec['x'].transpose(0, 1)
+    for i in range(B):
+        for cls in (0.0, 1.0):
+            a_ = x[i][y[i] == cls].cpu()
+            b_ = xr[i][rec['y'][:, i] == cls]
+            key = lambda t_: t_[:, 0] * 1000 + t_[:, 1]           # columns can be categorical (ties): sort on two columns
+            assert torch.allclose(a_[key(a_).argsort()], b_[key(b_).argsort()], atol=2e-4, rtol=2e-4), (i, cls)
+    # and the public entry point runs every branch end to end
+    import numpy as np
+    hps = (lambda: 3, lambda: 7, torch.nn.Tanh, lambda: 0.8, lambda: 0.05, lambda: 0.1, True, lambda: 4,
+           lambda: (np.random.normal(0, 1, 5), np.abs(np.random.normal(0, 1, 5))), True, True, True, False, True, True,
+           lambda n: ([np.random.rand(3), np.random.rand(2)], [True, False]), 0.0)
+    xg, yg, _ = mlp.get_batch(8, 64, 6, device=DEV, hyperparameters=hps, batch_size_per_gp_sample=4)
+    assert xg.shape == (64, 8, 6) and yg.shape == (64, 8) and set(yg.unique().tolist()) <= {0.0, 1.0}
+    assert torch.isfinite(xg).all() and (xg[:, :, 4:] == 0).all() and (xg[:, :, :4].abs().sum(0) > 0).all()
+    xe, ye, _ = mlp.get_batch(8, 64, 6, device=DEV, hyperparameters=hps[:12] + (True,) + hps[13:], batch_size_per_gp_sample=4)   # y_is_effect
+    assert torch.isfinite(xe).all() and set(ye.unique().tolist()) <= {0.0, 1.0}
+
+
 def test_mlp_prior_get_batch():
     from transformerscandobayesianinference_amd.priors import mlp
     from transformerscandobayesianinference_amd.priors.utils import gamma_sampler_f, scaled_beta_sampler_f

@@ -201,3 +201,25 @@ def test_torch_modules_model_matches_the_port():
         port = pfn_oracle.forward({k: v for k, v in sd.items() if not k.startswith('criterion.')}, rec['x'], rec['y'], sep, cfg['H'])
         assert relerr(got.detach(), port) < 2e-5
     assert set(m.state_dict()) == {k for k in sd if not k.startswith('criterion.')}
+
+
+def test_oracle_mlp_prior_causal_matches_reference():
+    """The remaining branches of the reference's priors.mlp forward -- causal graph with pre-sampled causes, categorical features,
+    per-unit pre-sampled noise scales -- re-built by the oracle from the tensors the reference drew (tests/golden/mlp_prior_causal.pt,
+    oracle/make_golden.py::mlp_prior_causal_case)."""
+    rec = torch.load(os.path.join(GOLD, 'mlp_prior_causal.pt'))
+    cfg = rec['config']
+    T, B, NF, PER, NFU = cfg['T'], cfg['B'], cfg['NF'], cfg['PER'], cfg['NFU']
+    M = B // PER
+    for i in range(B):
+        m = i // PER
+        W = [rec['params'][6 * m + 2 * l] for l in range(3)]
+        b = [rec['params'][6 * m + 2 * l + 1] for l in range(3)]
+        causes, n1, n2 = [t[:, 0, :].float() for t in rec['normals'][2 * M + 3 * i: 2 * M + 3 * i + 3]]     # (2 M construction draws: the noise scales; the causes are drawn in f64 and cast, :140)
+        outs = pfn_oracle.mlp_prior_layers(W, b, causes, [n1, n2], cfg['activation'])
+        x_sel, y_raw = pfn_oracle.mlp_prior_causal_select(outs, rec['perms'][2 * i], NFU)
+        x_cat = pfn_oracle.mlp_prior_categorical(x_sel, cfg['cats'], cfg['ordinal'], rec['perms'][2 * i + 1])
+        sign = 1.0 if rec['coins'][i] else -1.0
+        x, y = pfn_oracle.mlp_prior_postprocess(x_cat, y_raw, NF, binary=True, order_sign=sign)
+        assert torch.equal(y, rec['y'][:, i]), i
+        assert torch.allclose(x, rec['x'][:, i, :], atol=1e-5, rtol=1e-5), i

@@ -63,7 +63,7 @@ SIGNATURES = {
     'pfn_clip_adam_step': (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     'pfn_gp_prior_sample': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P, _P]),
     'pfn_gp_posterior': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
-    'pfn_mlp_prior_forward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P]),
+    'pfn_mlp_prior_forward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P]),
     'pfn_op_gemm_nt': (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _P]),
     'pfn_op_gemm_tn': (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
     'pfn_op_gemm_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -105,6 +105,13 @@ __global__ __launch_bounds__(256) void mlp_prior_kernel(MlpPriorArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(aout + (j4 + u) * MLP_TR + r4) = f32x4{acc[u][0], acc[u][1], acc[u][2], acc[u][3]};
+      if (a.hidden && l > 0) {      // causal variant (priors/mlp.py:158-166): every node after the first layer is a candidate feature / target
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int t = t0 + r4 + v;
+          if (t < a.T) *reinterpret_cast<f32x4*>(a.hidden + (((long)b * (a.Lmax - 1) + (l - 1)) * a.T + t) * HP + j4) = f32x4{acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
+        }
+      }
     }
     float* tmp = ain; ain = aout; aout = tmp;
   }

@@ -598,12 +598,12 @@ int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_w
 }
 
 int pfn_mlp_prior_forward(const float* weights, const float* biases, const int32_t* model_of, const int32_t* dims, const float* noise_std,
-                          float* causes, const float* noise, float* y, int B, int T, int HP, int Lmax, int activation, int gen_causes,
+                          float* causes, const float* noise, float* y, float* hidden, int B, int T, int HP, int Lmax, int activation, int gen_causes,
                           uint64_t seed, uint64_t offset, void* stream) {
   if (!weights || !biases || !model_of || !dims || !noise_std || !causes || !y) return fail(PFN_ERR_ARGUMENT, "bad mlp_prior_forward arguments");
   if (activation < 0 || activation > 3) return fail(PFN_ERR_UNSUPPORTED, "activation %d (0 identity, 1 relu, 2 tanh, 3 sigmoid)", activation);
   MlpPriorArgs a;
-  a.weights = weights; a.biases = biases; a.model_of = model_of; a.dims = dims; a.noise_std = noise_std; a.causes = causes; a.noise = noise; a.y = y;
+  a.weights = weights; a.biases = biases; a.model_of = model_of; a.dims = dims; a.noise_std = noise_std; a.causes = causes; a.noise = noise; a.y = y; a.hidden = hidden;
   a.B = B; a.T = T; a.HP = HP; a.Lmax = Lmax; a.activation = activation; a.gen_causes = gen_causes; a.seed = seed; a.offset = offset;
   PFN_TRY(launch_mlp_prior(a, (hipStream_t)stream));
   return PFN_OK;

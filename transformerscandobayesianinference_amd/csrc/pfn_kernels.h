@@ -250,6 +250,7 @@ struct MlpPriorArgs {
   float* causes;          // [B][T][HP]: N(0,1) in the first num_causes columns, written when gen_causes != 0, else input
   const float* noise;     // optional [B][Lmax-1][T][HP] injected standard normals (else generated)
   float* y;               // [B][T] last layer, column 0
+  float* hidden;          // optional [B][Lmax-1][T][HP]: the outputs (noise included) of layers 1 .. L-1, the node pool of the causal variant
   int B, T, HP, Lmax, activation, gen_causes;
   unsigned long long seed, offset;
 };

@@ -1,6 +1,6 @@
 """BNN ("MLP") prior: every synthetic dataset is the output of a small random network on Gaussian inputs.
 
-Replaces reference priors/mlp.py `get_batch` (:62-203) for the NON-CAUSAL configuration the tabular experiments use
+Replaces reference priors/mlp.py `get_batch` (:62-203); the hot configuration is the NON-CAUSAL one the tabular experiments use
 (`is_causal=False`, no categorical features, `pre_sample_weights=False`):
 per group of `batch_size_per_gp_sample` datasets one network is drawn -- dropout share, noise std, init std, number
 of used features, depth, width from the caller's samplers, in the reference's order (:87-104); every parameter
@@ -13,8 +13,10 @@ becomes: two torch launches that draw ALL parameters of the batch into padded te
 forwards (`pfn_mlp_prior_forward`, csrc/mlp_prior.hip; causes and layer noise from the device generator), and a few
 batched torch ops for the order statistics (median, argsort).  No CPU fallback.
 
-Not implemented (raise): the causal graph variant (`is_causal`, :146-166), categorical features (:168-179),
-`pre_sample_weights`, `sampling='uniform'` is supported, `canonical_args` is ignored like in the reference (:72-81).
+Round 3 added the remaining branches of the reference's forward on top of the same kernel: the causal-graph variant (`is_causal`,
+`pre_sample_causes`, `y_is_effect`, :94-104, :139-140, :158-166 -- the kernel hands out every layer's nodes, features and target are
+gathered from them per dataset), categorical features (:168-179) and per-unit pre-sampled noise scales (`pre_sample_weights`,
+:119-121).  `canonical_args` and `nan_prob` are ignored like in the reference (:72-81, :181-183 are commented out there).
 """
 import random
 
@@ -56,8 +58,9 @@ def pack_networks(weights, biases, device):
     return W, b, dims.to(device), HP
 
 
-def forward_networks(W, b, dims, noise_std, model_of, seq_len, activation, causes=None, noise=None, seed=None):
-    """The batched forward through the C ABI.  Returns (causes [B,T,HP], y_raw [B,T])."""
+def forward_networks(W, b, dims, noise_std, model_of, seq_len, activation, causes=None, noise=None, seed=None, want_hidden=False):
+    """The batched forward through the C ABI.  Returns (causes [B,T,HP], y_raw [B,T]) and, with `want_hidden`, the outputs of
+    layers 1 .. L-1 [B, Lmax-1, T, HP] (noise included) -- the node pool of the causal variant."""
     dev = W.device
     if dev.type != 'cuda':
         raise _hip.HipExtensionError(f'the BNN prior sampler runs on the GPU only (got device {dev}); no CPU fallback')
@@ -66,13 +69,48 @@ def forward_networks(W, b, dims, noise_std, model_of, seq_len, activation, cause
     gen = causes is None
     causes = torch.empty(B, seq_len, HP, dtype=torch.float32, device=dev) if gen else causes.to(dev).float().contiguous()
     y = torch.empty(B, seq_len, dtype=torch.float32, device=dev)
+    hidden = torch.zeros(B, max(Lmax - 1, 1), seq_len, HP, dtype=torch.float32, device=dev) if want_hidden else None
     if seed is None:
         seed = torch.initial_seed()
     _call_counter[0] += 1
     _hip.check(_hip.lib().pfn_mlp_prior_forward(W.data_ptr(), b.data_ptr(), model_of.data_ptr(), dims.data_ptr(), noise_std.data_ptr(),
-                                                causes.data_ptr(), _hip.ptr(noise), y.data_ptr(), B, seq_len, HP, Lmax, activation, int(gen),
-                                                seed & (2 ** 64 - 1), _call_counter[0], _hip.stream_ptr(dev)), 'pfn_mlp_prior_forward')
-    return causes, y
+                                                causes.data_ptr(), _hip.ptr(noise), y.data_ptr(), _hip.ptr(hidden), B, seq_len, HP, Lmax, activation,
+                                                int(gen), seed & (2 ** 64 - 1), _call_counter[0], _hip.stream_ptr(dev)), 'pfn_mlp_prior_forward')
+    return (causes, y, hidden) if want_hidden else (causes, y)
+
+
+def causal_select(hidden, nl, hid, nfu, y_is_effect, perm=None):
+    """The causal variant's node selection for ONE dataset group that shares a network (reference :158-166): the outputs of layers
+    1 .. L-1 (`outputs[2:]`: every node behind the first layer, noise included) are concatenated; a random permutation of all
+    nodes but the last picks the target (position 0, or the network output itself when `y_is_effect`) and the `nfu` features
+    (positions 1 .. nfu).  hidden [g, Lmax-1, T, HP]; perm [g, n-1] optional (tests inject the reference's draws).
+    Returns (x [g, T, nfu], y [g, T])."""
+    flat = torch.cat([hidden[:, l, :, :hid] for l in range(nl - 2)] + [hidden[:, nl - 2, :, :1]], -1)       # [g, T, (L-2) hid + 1]
+    g, T, n = flat.shape
+    if perm is None:
+        perm = torch.rand(g, n - 1, device=flat.device).argsort(1)          # one uniform permutation per dataset (reference: randperm per forward)
+    pick = lambda cols: torch.gather(flat, 2, cols[:, None, :].expand(g, T, cols.shape[1]))
+    y = flat[:, :, -1] if y_is_effect else pick(perm[:, 0:1])[:, :, 0]
+    return pick(perm[:, 1:1 + nfu]), y
+
+
+def categorical_columns(x, features, ordinal, perm=None):
+    """Discretise randomly chosen columns of x [g, T, nfu] in place (reference :168-179): column perm[i] of a dataset becomes the
+    number of the i-th categorical feature's thresholds (class boundaries - 0.5) its standardised value exceeds; non-ordinal
+    features have their class ids scrambled by `* (127 k + 1) % k`."""
+    g, T, nfu = x.shape
+    if perm is None:
+        perm = torch.rand(g, nfu, device=x.device).argsort(1)
+    for i, (feat, is_ordinal) in enumerate(zip(features, ordinal)):
+        col = perm[:, i][:, None, None].expand(g, T, 1)                      # the dataset's i-th randomly chosen column
+        v = torch.gather(x, 2, col)[:, :, 0]                                 # [g, T]
+        temp = (v - v.mean(1, keepdim=True)) / (v.std(1, keepdim=True) + .000001)
+        thr = torch.as_tensor(feat, dtype=torch.float32, device=x.device) - 0.5
+        cls = (temp[None] > thr[:, None, None]).sum(0).to(x.dtype)
+        if not is_ordinal:
+            cls = cls * (127 * len(feat) + 1) % len(feat)
+        x.scatter_(2, col, cls[:, :, None])
+    return x
 
 
 def postprocess(causes, y_raw, nfu, num_features, is_binary, order_sign, nfu_scale=None):
@@ -110,8 +148,6 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
     (num_layers_sampler, hidden_dim_sampler, activation_module, init_std_sampler, noise_std_sampler, dropout_prob_sampler,
      is_binary_classification, num_features_used_sampler, causes_sampler, is_causal, pre_sample_causes, pre_sample_weights,
      y_is_effect, order_y, normalize_by_used_features, categorical_features_sampler, nan_prob) = hyperparameters
-    if is_causal or pre_sample_weights:
-        raise NotImplementedError('priors.mlp: the causal-graph / pre-sampled-weight variants are outside the MI355X hot path')
     if sampling not in ('normal', 'uniform'):
         raise ValueError(f'Sampling is set to invalid setting: {sampling}.')
     dev = torch.device(device)
@@ -121,28 +157,34 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
     assert sample_batch_size % batch_size_per_gp_sample == 0, 'Please choose a batch_size divisible by batch_size_per_gp_sample.'
     num_models = sample_batch_size // batch_size_per_gp_sample
 
-    # per-network scalars, drawn in the reference's order (:87-104)
+    # per-network scalars, drawn in the reference's order (:87-104): dropout, noise std, init std, used features, categorical
+    # features, [causes of the causal variant], depth, width
     cfg = []
     for _ in range(num_models):
         dropout_prob, noise_std, init_std = dropout_prob_sampler(), noise_std_sampler(), init_std_sampler()
         nfu = int(num_features_used_sampler())
-        if categorical_features_sampler is not None:
-            cats, _ = categorical_features_sampler(nfu)
-            if len(cats) > 0:
-                raise NotImplementedError('priors.mlp: categorical features are outside the MI355X hot path')
+        cats, ordinal = categorical_features_sampler(nfu) if categorical_features_sampler is not None else ([], [])   # None: SURVEY.md Q12
+        cause_means = cause_std = None
+        if is_causal:
+            cause_means, cause_std = causes_sampler()                       # (:94-97) the network's inputs are these causes, not the features
         num_layers, hidden = int(num_layers_sampler()), int(hidden_dim_sampler())
+        if is_causal:
+            hidden = max(hidden, 2 * nfu + 1)                               # (:103-104) enough nodes to pick nfu features + 1 target from
         assert num_layers > 2
-        cfg.append((float(dropout_prob), float(noise_std), float(init_std), nfu, num_layers, hidden))
-    Lmax = max(c[4] for c in cfg)
-    HP = (max(max(c[3], c[5]) for c in cfg) + 3) // 4 * 4
+        cfg.append(dict(dropout=float(dropout_prob), noise_std=float(noise_std), init_std=float(init_std), nfu=nfu, cats=list(cats),
+                        ordinal=list(ordinal), means=cause_means, std=cause_std, nl=num_layers, hid=hidden,
+                        nin=len(cause_means) if is_causal else nfu))
+    Lmax = max(c['nl'] for c in cfg)
+    HP = (max(max(c['nin'], c['hid']) for c in cfg) + 3) // 4 * 4
 
     # all parameters of the batch in two launches: N(0,1) * std * Bernoulli mask, inside each network's own shape
     lay = torch.arange(Lmax, device=dev)[None, :, None, None]
     kin = torch.arange(HP, device=dev)[None, None, :, None]
     jout = torch.arange(HP, device=dev)[None, None, None, :]
-    t = lambda i, dt=torch.float32: torch.tensor([c[i] for c in cfg], dtype=dt, device=dev)
-    p_drop, nstd, istd, nfu, nl, hid = t(0), t(1), t(2), t(3, torch.int64), t(4, torch.int64), t(5, torch.int64)
-    in_dim = torch.where(lay == 0, nfu[:, None, None, None], hid[:, None, None, None])
+    t = lambda k, dt=torch.float32: torch.tensor([c[k] for c in cfg], dtype=dt, device=dev)
+    p_drop, nstd, istd = t('dropout'), t('noise_std'), t('init_std')
+    nfu, nin, nl, hid = t('nfu', torch.int64), t('nin', torch.int64), t('nl', torch.int64), t('hid', torch.int64)
+    in_dim = torch.where(lay == 0, nin[:, None, None, None], hid[:, None, None, None])
     out_dim = torch.where(lay == nl[:, None, None, None] - 1, torch.ones_like(hid)[:, None, None, None], hid[:, None, None, None])
     live = (lay < nl[:, None, None, None]) & (kin < in_dim) & (jout < out_dim)
     std = (istd / (1. - p_drop))[:, None, None, None]
@@ -152,20 +194,59 @@ def get_batch(batch_size, seq_len, num_features, device=default_device, hyperpar
     keep_b = (1. - p_drop)[:, None, None]
     live_b = live[:, :, 0, :] | ((lay[:, :, 0, :] < nl[:, None, None]) & (jout[:, :, 0, :] < out_dim[:, :, 0, :]))
     b = torch.randn(num_models, Lmax, HP, device=dev) * std[:, :, 0, :] * torch.bernoulli(keep_b.expand(num_models, Lmax, HP)) * live_b
-    dims = torch.stack([nfu, hid, nl], 1).to(torch.int32)
+    dims = torch.stack([nin, hid, nl], 1).to(torch.int32)
     model_of = torch.arange(sample_batch_size, device=dev, dtype=torch.int32) // batch_size_per_gp_sample
+    mo = model_of.long()
 
+    # network inputs: generated in the kernel (N(0,1) in the first `nin` columns) unless they are uniform or pre-sampled causes
     causes = None
+    in_cols = kin[0, 0, :, 0][None, None, :] < nin[mo][:, None, None]
     if sampling == 'uniform':
-        causes = torch.rand(sample_batch_size, seq_len, HP, device=dev) * (kin[0, 0, :, 0][None, None, :] < nfu[model_of.long()][:, None, None])
-    causes, y_raw = forward_networks(W, b, dims, nstd, model_of, seq_len, act, causes=causes)
+        causes = torch.rand(sample_batch_size, seq_len, HP, device=dev) * in_cols
+    elif is_causal and pre_sample_causes:                                   # (:139-140) N(means, |std|) per cause, the same law for every row
+        mean_t = torch.zeros(num_models, HP, device=dev)
+        std_t = torch.zeros(num_models, HP, device=dev)
+        for m, c in enumerate(cfg):
+            mean_t[m, :c['nin']] = torch.as_tensor(c['means'], dtype=torch.float32, device=dev)
+            std_t[m, :c['nin']] = torch.as_tensor(c['std'], dtype=torch.float32, device=dev).abs()
+        causes = (mean_t[mo][:, None, :] + std_t[mo][:, None, :] * torch.randn(sample_batch_size, seq_len, HP, device=dev)) * in_cols
+    # layer noise: a scalar std per network (generated in the kernel), or -- pre_sample_weights (:119-121) -- one |N(0, noise_std)| std per
+    # unit, fixed per network: drawn here and injected already scaled
+    noise = None
+    nstd_k = nstd
+    if pre_sample_weights:
+        unit_std = (torch.randn(num_models, max(Lmax - 1, 1), HP, device=dev) * nstd[:, None, None]).abs()
+        noise = torch.randn(sample_batch_size, max(Lmax - 1, 1), seq_len, HP, device=dev) * unit_std[mo][:, :, None, :]
+        nstd_k = torch.ones_like(nstd)
+    need_hidden = bool(is_causal)
+    out = forward_networks(W, b, dims, nstd_k, model_of, seq_len, act, causes=causes, noise=noise, want_hidden=need_hidden)
+    causes, y_raw = out[0], out[1]
+
+    if is_causal:
+        # features and target are nodes of the network (:158-163), chosen per dataset; groups share their network's shape
+        HX = (max(c['nfu'] for c in cfg) + 3) // 4 * 4
+        x_raw = torch.zeros(sample_batch_size, seq_len, max(HX, 4), device=dev)
+        y_raw = y_raw.clone()
+        for m, c in enumerate(cfg):
+            rows = slice(m * batch_size_per_gp_sample, (m + 1) * batch_size_per_gp_sample)
+            xs, ys = causal_select(out[2][rows], c['nl'], c['hid'], c['nfu'], y_is_effect)
+            x_raw[rows, :, :c['nfu']] = xs
+            y_raw[rows] = ys
+    else:
+        x_raw = causes
+    if any(len(c['cats']) > 0 for c in cfg):                               # (:168-179)
+        x_raw = x_raw.clone() if x_raw is causes else x_raw
+        for m, c in enumerate(cfg):
+            if len(c['cats']) > 0:
+                rows = slice(m * batch_size_per_gp_sample, (m + 1) * batch_size_per_gp_sample)
+                x_raw[rows, :, :c['nfu']] = categorical_columns(x_raw[rows, :, :c['nfu']].clone(), c['cats'], c['ordinal'])
 
     order_sign = None
     if is_binary_classification and order_y:
         order_sign = torch.tensor([1.0 if random.randint(0, 1) else -1.0 for _ in range(sample_batch_size)], device=dev)
-    nfu_b = nfu[model_of.long()]
+    nfu_b = nfu[mo]
     scale = (nfu_b.float() / num_features) if normalize_by_used_features else None
-    x, y = postprocess(causes, y_raw, nfu_b, num_features, is_binary_classification, order_sign, scale)
+    x, y = postprocess(x_raw, y_raw, nfu_b, num_features, is_binary_classification, order_sign, scale)
     x, y = x.transpose(0, 1), y.transpose(0, 1)
     return x, y, y
 
