@@ -53,6 +53,10 @@ typedef struct pfn_model_desc {
   int32_t n_out;        /* decoder output width (criterion.num_bars for bar losses, train.py:39) */
   int32_t precision;    /* PFN_PREC_* */
   float ln_eps;         /* 1e-5 (torch LayerNorm default) */
+  float dropout;        /* TransformerEncoderLayer's dropout probability (transformer.py:17; train.py:22 default 0.2).  0: no dropout
+                         * buffers are carved.  > 0: pfn_stack_forward_dropout / pfn_stack_backward_split(use_dropout = 1) apply it at the
+                         * layer's four sites (attention probabilities, after out_proj, after the FFN activation, after linear2);
+                         * pfn_stack_forward is the inference pass (model.eval()) and applies none. */
 } pfn_model_desc;
 
 int pfn_abi_version(void);
@@ -100,6 +104,16 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
                       int B, int S, int sep,
                       void* workspace, int64_t workspace_bytes,
                       float* logits, void* stream);
+/* The training forward with dropout (desc.dropout > 0).  Masks are counter-based functions of (dropout_seed, layer, site, element)
+ * -- csrc/pfn_device.h `dropout_keep`; the backward regenerates them from the same seed, nothing is stored.  torch's own Philox
+ * stream cannot be reproduced, so parity is against the oracle evaluating the SAME masks (oracle/pfn_oracle.py dropout_masks). */
+int pfn_stack_forward_dropout(const pfn_model_desc* d, const float* params, const void* shadow,
+                              const float* x, int64_t x_st, int64_t x_sb,
+                              const float* y, int64_t y_st, int64_t y_sb,
+                              const float* src_sbe,
+                              int B, int S, int sep,
+                              void* workspace, int64_t workspace_bytes,
+                              float* logits, void* stream, uint64_t dropout_seed);
 /* replaces loss.backward() through the model (train.py:93).  dlogits: [(T-sep)*B, n_out] f32.
  * grads: flat f32 buffer in pfn_param_layout order; gradients are ACCUMULATED into it
  * (train.py:92-97 sums micro-batch gradients). */
@@ -123,7 +137,8 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
                              int B, int S, int sep,
                              void* workspace, int64_t workspace_bytes,
                              const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
-                             int first_group_layers, pfn_host_callback on_first_group, void* user);
+                             int first_group_layers, pfn_host_callback on_first_group, void* user,
+                             int use_dropout, uint64_t dropout_seed);   /* use_dropout: the forward was pfn_stack_forward_dropout(dropout_seed) */
 
 /* ---- bar distribution: replaces BarDistribution / FullSupportBarDistribution.forward and .mean
  * (bar_distribution.py:19-38, 83-117).  logits [R, nbars] f32 (row stride ld), y [R], borders

@@ -47,8 +47,38 @@ def d_q_mask(T, sep, dtype, device):
     return torch.zeros(T, T, dtype=dtype, device=device).masked_fill(~allowed, float('-inf'))
 
 
-def forward(sd, x, y, sep, nhead, dtype=torch.float64, return_hidden=False):
-    """logits[T-sep, B, n_out] from a reference-format state dict `sd` (keys as in SURVEY.md 8(b))."""
+# ---- dropout masks: the integers of csrc/pfn_kernels.h (mix32 / dropout_site_seed / dropout_pair_seed / dropout_keep), in numpy ----
+_M32 = 0xFFFFFFFF
+
+
+def _mix32(h):
+    import numpy as np
+    h = np.asarray(h, dtype=np.uint64) & _M32
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x7feb352d)) & _M32
+    h ^= h >> np.uint64(15); h = (h * np.uint64(0x846ca68b)) & _M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def dropout_site_seed(seed, layer, site):
+    return int(_mix32(int(_mix32((seed & _M32) ^ ((0x9E3779B1 * (layer * 4 + site + 1)) & _M32))) ^ (seed >> 32)))
+
+
+def dropout_keep_mask(site_seed, rows, cols, p):
+    """keep[i, j] (bool tensor [len(rows), len(cols)]) for integer index vectors rows / cols; p as the kernels see it (float32)."""
+    import numpy as np
+    thr = min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF)
+    i = (np.asarray(rows, dtype=np.uint64) * np.uint64(0x9E3779B1)) & _M32
+    j = (np.asarray(cols, dtype=np.uint64) * np.uint64(0x85EBCA77)) & _M32
+    h = _mix32(np.uint64(site_seed) ^ i[:, None] ^ j[None, :])
+    return torch.from_numpy(h >= np.uint64(thr))
+
+
+def forward(sd, x, y, sep, nhead, dtype=torch.float64, return_hidden=False, dropout=None):
+    """logits[T-sep, B, n_out] from a reference-format state dict `sd` (keys as in SURVEY.md 8(b)).
+    dropout = (p, seed): TransformerEncoderLayer's four dropout sites (attention probabilities; after out_proj; after the FFN
+    activation; after linear2 -- torch nn/modules/transformer.py, functional.py multi_head_attention_forward) with the masks the HIP
+    stack generates from `seed` (element-wise sites: row = b * T + t, column = feature; attention: (query, key) per (dataset, head))."""
     p = {k: v.detach().to(dtype) if not v.requires_grad else v.to(dtype) for k, v in sd.items()}
     x, y = x.to(dtype), y.to(dtype)
     T, B, _ = x.shape
@@ -66,10 +96,28 @@ def forward(sd, x, y, sep, nhead, dtype=torch.float64, return_hidden=False):
         qkv = _linear(h, p[pre + 'self_attn.in_proj_weight'], p[pre + 'self_attn.in_proj_bias'])   # [T,B,3E]
         q, k, v = [t.reshape(T, B, nhead, D).permute(1, 2, 0, 3) for t in qkv.split(E, -1)]        # [B,H,T,D]
         scores = q @ k.transpose(-1, -2) / math.sqrt(D) + mask
-        ctx = (torch.softmax(scores, -1) @ v).permute(2, 0, 1, 3).reshape(T, B, E)
+        probs = torch.softmax(scores, -1)
+        if dropout is not None:
+            pd, seed = dropout
+            import numpy as np
+            keep_scale = 1.0 / (1.0 - float(np.float32(pd)))
+            s0 = dropout_site_seed(seed, l, 0)
+            pm = torch.stack([torch.stack([dropout_keep_mask(int(_mix32(s0 ^ ((0xC2B2AE35 * (bb * nhead + hh + 1)) & _M32))), range(T), range(T), pd)
+                                           for hh in range(nhead)]) for bb in range(B)])                       # [B,H,T,T]
+            probs = probs * pm.to(dtype) * keep_scale
+            rows = [bb * T + t for t in range(T) for bb in range(B)]                                        # token row of element [t, b]
+            elem = lambda site, width: dropout_keep_mask(dropout_site_seed(seed, l, site), rows, range(width), pd).reshape(T, B, width).to(dtype) * keep_scale
+        ctx = (probs @ v).permute(2, 0, 1, 3).reshape(T, B, E)
         att = _linear(ctx, p[pre + 'self_attn.out_proj.weight'], p[pre + 'self_attn.out_proj.bias'])
+        if dropout is not None:
+            att = att * elem(1, E)
         h = _layer_norm(h + att, p[pre + 'norm1.weight'], p[pre + 'norm1.bias'])
-        ff = _linear(_gelu(_linear(h, p[pre + 'linear1.weight'], p[pre + 'linear1.bias'])), p[pre + 'linear2.weight'], p[pre + 'linear2.bias'])
+        act = _gelu(_linear(h, p[pre + 'linear1.weight'], p[pre + 'linear1.bias']))
+        if dropout is not None:
+            act = act * elem(2, act.shape[-1])
+        ff = _linear(act, p[pre + 'linear2.weight'], p[pre + 'linear2.bias'])
+        if dropout is not None:
+            ff = ff * elem(3, E)
         h = _layer_norm(h + ff, p[pre + 'norm2.weight'], p[pre + 'norm2.bias'])
     if return_hidden:
         return h
@@ -122,11 +170,11 @@ def bar_mean(logits, borders, full_support=True):
 
 
 # ---- one training step ------------------------------------------------------------------------------
-def loss_and_grads(sd, x, y, target_y, sep, nhead, borders, full_support=True, dtype=torch.float64):
+def loss_and_grads(sd, x, y, target_y, sep, nhead, borders, full_support=True, dtype=torch.float64, dropout=None):
     """mean bar-NLL over the test rows and d loss / d parameter for every state-dict tensor
     (train.py:70-93 with criterion = FullSupportBarDistribution)."""
     leaves = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items() if not k.startswith('criterion.')}
-    logits = forward(leaves, x, y, sep, nhead, dtype)
+    logits = forward(leaves, x, y, sep, nhead, dtype, dropout=dropout)
     T = x.shape[0]
     s = sep if sep >= 0 else sep + T
     losses = bar_nll(logits.reshape(-1, logits.shape[-1]), target_y[s:].reshape(-1), borders, full_support).view(logits.shape[:2])

@@ -656,6 +656,8 @@ def test_train_option_matrix():
         dict(criterion=bars(), single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(32), pos_encoder_generator=pe.LearnedPositionalEncoding),
         dict(criterion=bars(), single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(32), input_normalization=True),
         dict(criterion=bars(), single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(32), micro_streams=1),
+        dict(criterion=bars(), single_eval_pos_gen=u.get_weighted_single_eval_pos_sampler(32), dropout=0.2),          # the reference's default (train.py:22)
+        dict(criterion=bars(), single_eval_pos_gen=20, dropout=0.5, pos_encoder_generator=pe.PositionalEncoding),      # (the tabular notebook's value; PyTorch-side embedding)
     ]
     for extra in cases:
         kw = dict(base); kw.update(extra)
@@ -1077,3 +1079,60 @@ def test_trained_checkpoint_parity():
             within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3 if tight else 6e-2)
             within(f'{mode}: means rel l2 (own norm)', relerr(mean, mean_o), 1e-3 if tight else 0.12)
             within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 0.12)
+
+
+@pytest.mark.parametrize('emsize', [64, 256, 512])       # head dims 32, 128 (the benchmarked kernels) and 256
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_dropout_vs_oracle_with_the_same_masks(precision, emsize):
+    """Training with dropout > 0 (reference train.py:22 default 0.2; torch TransformerEncoderLayer drops the attention probabilities,
+    the out_proj output, the FFN activation and the linear2 output): the HIP stack's masks are counter-based functions of a per-pass
+    seed (csrc/pfn_kernels.h dropout_keep), the oracle evaluates the SAME masks in f64, and logits, loss and every parameter
+    gradient must agree -- forward masks in the flash kernel's register layout, backward masks regenerated in the key-block pass's
+    (transposed) layout and in the query-block pass's self-key terms."""
+    if precision == 'f32' and emsize == 512:
+        pytest.skip('head dim 256 exists in the product precision only')
+    cfg = dict(T=200, B=2, F=4, E=emsize, H=2, nhid=128, L=2, nbars=20)
+    pdrop, sep = 0.3, 150
+    torch.manual_seed(51)
+    borders = torch.sort(torch.randn(cfg['nbars'] + 1) * 1.5)[0]
+    model = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], pdrop,
+                             y_encoder=encoders.Linear(1, cfg['E']), precision=precision, eval_precision=precision)
+    model.criterion = bar_distribution.FullSupportBarDistribution(borders)
+    with torch.no_grad():
+        for layer in model.transformer_encoder.layers:
+            for t in (layer.linear2.weight, layer.self_attn.out_proj.weight):
+                t.normal_(0, 0.05)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(cfg['T'], cfg['B'], cfg['F'], generator=g)
+    y = torch.randn(cfg['T'], cfg['B'], generator=g)
+    model.zero_grad()
+    logits = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
+    seed = model._last_dropout_seed
+    loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
+    loss.backward()
+    loss_o, logits_o, grads_o = pfn_oracle.loss_and_grads(sd, x, y, y, sep, cfg['H'], borders, dropout=(pdrop, seed))
+    _, logits_plain, _ = pfn_oracle.loss_and_grads(sd, x, y, y, sep, cfg['H'], borders)
+    assert relerr(logits_o, logits_plain) > 0.05                       # the masks do something
+    tight = precision == 'f32'
+    within(f'{precision} logits rel l2', relerr(logits, logits_o), 1e-4 if tight else 2e-2)
+    assert abs(loss.item() - loss_o.item()) < (1e-4 if tight else 5e-3) * abs(loss_o.item()), (loss.item(), loss_o.item())
+    got = {k: p.grad for k, p in model.named_parameters()}
+    tot_err = math.sqrt(sum(((got[k].double().cpu() - v) ** 2).sum().item() for k, v in grads_o.items()))
+    tot = math.sqrt(sum((v ** 2).sum().item() for v in grads_o.values()))
+    within(f'{precision} global gradient rel l2', tot_err / tot, 2e-4 if tight else 2e-2)
+    if tight:
+        for k, v in grads_o.items():
+            if v.norm() > 1e-7:
+                assert relerr(got[k], v) < 2e-3, (k, relerr(got[k], v))
+    # a second pass draws new masks; eval mode applies none
+    logits2 = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
+    assert model._last_dropout_seed != seed and relerr(logits2, logits) > 0.05
+    model.eval()
+    with torch.no_grad():
+        lg_eval = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
+    within(f'{precision} eval-mode logits rel l2 (no dropout)', relerr(lg_eval, logits_plain), 1e-4 if tight else 2e-2)
+    # the keep rate of a mask is 1 - p
+    keep = pfn_oracle.dropout_keep_mask(pfn_oracle.dropout_site_seed(seed, 0, 1), range(400), range(64), pdrop)
+    assert abs(keep.float().mean().item() - (1 - pdrop)) < 0.01

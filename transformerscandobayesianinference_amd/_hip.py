@@ -29,10 +29,10 @@ class HipExtensionError(RuntimeError):
 class ModelDesc(ctypes.Structure):
     _fields_ = [('num_features', ctypes.c_int32), ('emsize', ctypes.c_int32), ('nhead', ctypes.c_int32),
                 ('nhid', ctypes.c_int32), ('nlayers', ctypes.c_int32), ('n_out', ctypes.c_int32),
-                ('precision', ctypes.c_int32), ('ln_eps', ctypes.c_float)]
+                ('precision', ctypes.c_int32), ('ln_eps', ctypes.c_float), ('dropout', ctypes.c_float)]
 
     def key(self):
-        return (self.num_features, self.emsize, self.nhead, self.nhid, self.nlayers, self.n_out, self.precision, self.ln_eps)
+        return (self.num_features, self.emsize, self.nhead, self.nhid, self.nlayers, self.n_out, self.precision, self.ln_eps, self.dropout)
 
 
 HOST_CALLBACK = ctypes.CFUNCTYPE(None, ctypes.c_void_p)     # pfn_host_callback
@@ -56,7 +56,8 @@ SIGNATURES = {
     'pfn_workspace_bytes': (_L, [_D, _I, _I]),
     'pfn_stack_forward': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P, _L, _P, _P]),
     'pfn_stack_backward': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P]),
-    'pfn_stack_backward_split': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P]),
+    'pfn_stack_forward_dropout': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P, _L, _P, _P, _U64]),
+    'pfn_stack_backward_split': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P, _I, _U64]),
     'pfn_bar_nll_forward': (_I, [_P, _L, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
     'pfn_bar_nll_backward': (_I, [_P, _L, _P, _P, _P, _L, _I, _P, _P]),
     'pfn_bar_mean': (_I, [_P, _L, _P, _L, _I, _I, _P, _P]),

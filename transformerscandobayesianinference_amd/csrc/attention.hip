@@ -178,7 +178,7 @@ constexpr float RESCALE_THR = 6.f;  // log2 units: lazily raised running max of 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <typename T, int D>
+template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -209,6 +209,11 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   const int qc = min(qi, a.S - 1);
   const int sep = a.sep;
   const float scale_log2 = rsqrtf((float)D) * LOG2E;
+  // DROP: dropout on the probabilities (pfn_device.h dropout_keep with i = query, j = key).  The normaliser (row sum, lse) is that of
+  // the UNMASKED softmax -- torch drops entries of the normalised P -- so only the values fed to the P.V product are masked, and the
+  // 1 / (1 - p) is folded into the final 1 / l.
+  const unsigned dseed = DROP ? dropout_pair_seed(a.drop_seed, b * a.H + hd) : 0u;
+  const unsigned dthr = DROP ? dropout_threshold(a.p_drop) : 0u;
 
   Frag<T> qf[C::NKK];
 #pragma unroll
@@ -237,7 +242,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
       for (int rg = 0; rg < 4; ++rg) {
         f32x4 v = load4<T>(Vp + (long)qc * rs + db * 32 + 8 * rg + 4 * h);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[db][4 * rg + e] = is_test ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e) o[db][4 * rg + e] = (is_test && (!DROP || dropout_keep(dseed, (unsigned)qc, (unsigned)qc, dthr))) ? v[e] : 0.f;
       }
   }
 
@@ -372,6 +377,13 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
         }
       lsum += rsum;
     }
+    if constexpr (DROP) {     // (after the row sums: they belong to the unmasked softmax)
+#pragma unroll
+      for (int kb = 0; kb < C::NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!dropout_keep(dseed, (unsigned)qc, (unsigned)(k0 + kb * 32 + acc_row(r, lane)), dthr)) st[kb][r] = 0.f;
+    }
 #pragma unroll
     for (int c = 0; c < NPF; ++c) pf[c] = acc_to_frag<T>(st[c >> 1], c & 1);
     vb_prev = vb_cur;
@@ -381,7 +393,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   if (ntiles > 0) pv_prev(vb_prev);
 
   lsum += __shfl_xor(lsum, 32, 64);
-  const float inv = 1.f / lsum;
+  const float inv = DROP ? 1.f / (lsum * (1.f - a.p_drop)) : 1.f / lsum;
   {
     T* out = reinterpret_cast<T*>(a.ctx) + ((long)b * a.S + qc) * a.E + hd * D;
 #pragma unroll
@@ -471,7 +483,7 @@ template <typename T, int D> struct BwdKvCfg {
 // MODE 0: dK and dV in one pass.  Head dim 256 cannot hold both accumulators beside the K and V fragments even in the whole
 // register file without copies and spills inside the loop, so it runs the pass twice: MODE 2 (S, dV) then MODE 1 (S, dP,
 // dK, dS^T) -- six product units for the backward instead of five.
-template <typename T, int D, int MODE>
+template <typename T, int D, int MODE, bool DROP = false>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
   using K = BwdKvCfg<T, D>;
@@ -505,6 +517,11 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   const float scale_log2 = scale * LOG2E;
   const float* lse_g = a.delta + (long)a.B * a.H * a.S + ((long)b * a.H + hd) * a.S;    // lse in log2 units (attn_delta_kernel)
   const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
+  // DROP (dropout on the probabilities): dV takes P' = P keep / (1 - p), dP = dP' keep / (1 - p) with dP' = dO V^T, and dS = P (dP - delta)
+  // with the UNMASKED P (delta = rowsum(dO O) already is sum_k P'_k dP'_k).  The 1 / (1 - p) of dV is applied when dV is stored.
+  const unsigned dseed = DROP ? dropout_pair_seed(a.drop_seed, b * a.H + hd) : 0u;
+  const unsigned dthr = DROP ? dropout_threshold(a.p_drop) : 0u;
+  const float dscale = DROP ? 1.f / (1.f - a.p_drop) : 1.f;
   const bool wave_all_valid = __builtin_amdgcn_readfirstlane(key0 + wave * 32 + 31) < sep;   // only the last key block has keys >= sep
   const bool wave_live = __builtin_amdgcn_readfirstlane(key0 + wave * 32) < sep;             // ... and waves with no key below sep at all
   // dS^T of this (dataset, head): 32 x 32 blocks, block (key / 32, query / 32) at ((key / 32) * (ds_ld / 32) + query / 32) blocks
@@ -631,6 +648,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     // rows of the S / dP tiles are queries: acc_row(r) = 8*(r>>2) + 4h + (r&3)
     Frag<T> pf0, pf1;
     Frag<T> df0, df1;
+    unsigned mbits = 0xffffu;      // DROP: bit r = keep flag of (query row r of the tile, this lane's key)
     // A wave whose 32 keys all lie at or beyond sep (the tail of the last key block) has nothing to compute: it keeps moving its
     // DMA pieces and keeps the barriers, and leaves the matrix pipe, the vector ALU and the LDS ports of its SIMD to its partner.
     // The workgroup of a ragged last block therefore finishes early and frees its CU for the next one (sep mod 256 is uniform:
@@ -662,6 +680,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
           const float arg = __builtin_fmaf(s[r], scale_log2, -l2[e]);
           s[r] = (KVABL & 8) ? arg : fast_exp2(arg);
         }
+      }
+      if constexpr (DROP) {
+        mbits = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          mbits |= (dropout_keep(dseed, (unsigned)(t * QB + acc_row(r, lane)), (unsigned)key, dthr) ? 1u : 0u) << r;
       }
       pf0 = acc_to_frag<T>(s, 0);
       pf1 = acc_to_frag<T>(s, 1);
@@ -698,13 +722,21 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * rg + e;
-          dp[r] = frag_get_bits(r < 8 ? pf0 : pf1, r & 7) * (dp[r] - dl[e]);
+          const float dpr = DROP ? (((mbits >> r) & 1u) ? dp[r] * dscale : 0.f) : dp[r];
+          dp[r] = frag_get_bits(r < 8 ? pf0 : pf1, r & 7) * (dpr - dl[e]);
         }
       }
       // (keys >= sep of the last key block: their dS is garbage from clamped rows; it only reaches accumulator columns that are never
       // stored, and is zeroed where it leaves the kernel -- the dS^T store below -- instead of element by element here)
       df0 = acc_to_frag<T>(dp, 0);
       df1 = acc_to_frag<T>(dp, 1);
+    }
+    if constexpr (DROP) {     // the dV product sees the masked probabilities (the dS stage above wanted the unmasked ones)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (!((mbits >> e) & 1u)) pf0.set(e, 0.f);
+        if (!((mbits >> (8 + e)) & 1u)) pf1.set(e, 0.f);
+      }
     }
     // dV^T += dO^T P,  dK^T += Q^T dS as a list of steps (product, column group): product 0 / 1 = dV with the two halves of P, 2 / 3 = dK
     // with the two halves of dS; a group is CG of the NDB 32-column blocks of the head dimension.  One set of CG transposed fragments
@@ -791,7 +823,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       }
       if constexpr (DO_DV) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = dv[db][r];
+        for (int r = 0; r < 16; ++r) v[r] = dv[db][r] * dscale;
         store_row_block<T>(outv + db * 32, v, h2, kvalid);
       }
     }
@@ -849,7 +881,7 @@ template <typename T> PFN_DEV Frag<T> load_frag_ds_blocked(const lds_char* block
   return f;
 }
 
-template <typename T, int D>
+template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
   using Q = BwdDqCfg<T, D>;
@@ -1024,10 +1056,13 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 #pragma unroll
       for (int off = 1; off < CPR; off <<= 1) { tq += __shfl_xor(tq, off, 64); dpv += __shfl_xor(dpv, off, 64); }
       const float p_self = test ? fast_exp2(tq * scale_log2 - rl_[st] * LOG2E) : 0.f;
-      const float ds_self = p_self * (dpv - rd_[st]);
+      float mfac = 1.f;      // DROP: keep(i, i) / (1 - p) of the self key's probability
+      if constexpr (DROP)
+        mfac = dropout_keep(dropout_pair_seed(a.drop_seed, b * a.H + hd), (unsigned)q, (unsigned)q, dropout_threshold(a.p_drop)) ? 1.f / (1.f - a.p_drop) : 0.f;
+      const float ds_self = p_self * (mfac * dpv - rd_[st]);
       float xk[EPC], xv[EPC], xt[EPC];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { xk[e] = ds_self * scale * qv[e]; xv[e] = p_self * dv_[e]; xt[e] = ds_self * kv[e]; }
+      for (int e = 0; e < EPC; ++e) { xk[e] = ds_self * scale * qv[e]; xv[e] = p_self * mfac * dv_[e]; xt[e] = ds_self * kv[e]; }
       if (test) {
         *reinterpret_cast<u32x4*>(dbase + (long)q * rs + a.E + hd * D + c * EPC) = pack(xk);
         *reinterpret_cast<u32x4*>(dbase + (long)q * rs + 2 * a.E + hd * D + c * EPC) = pack(xv);
@@ -1064,15 +1099,18 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 // =============================================================================================
 // launchers
 // =============================================================================================
-template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
+template <typename T, int D, bool DROP> static int launch_fwd_k(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
   const size_t lds = 2 * C::RIMG + 4 * C::CIMG;
   static LdsAllowance allowance;
-  allowance.ensure(attn_fwd_kernel<T, D>, lds);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
+  allowance.ensure(attn_fwd_kernel<T, D, DROP>, lds);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
-template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
+template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
+  return a.p_drop > 0.f ? launch_fwd_k<T, D, true>(a, s) : launch_fwd_k<T, D, false>(a, s);     // dropout: the variants with the mask arithmetic
+}
+template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
   const int parts = a.parts ? a.parts : ~0;
   if (parts & ATTN_BWD_DELTA) {
@@ -1082,26 +1120,28 @@ template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStrea
   }
   const size_t lds_kv = BwdKvCfg<T, D>::LDS, lds_dq = BwdDqCfg<T, D>::LDS;
   static LdsAllowance allow_kv[3], allow_dq;      // (per device; hipFuncSetAttribute costs tens of microseconds of host time per call)
-  allow_kv[0].ensure(attn_bwd_kv_kernel<T, D, 0>, lds_kv);
-  allow_kv[1].ensure(attn_bwd_kv_kernel<T, D, 1>, lds_kv);
-  allow_kv[2].ensure(attn_bwd_kv_kernel<T, D, 2>, lds_kv);
-  allow_dq.ensure(attn_bwd_dq_kernel<T, D>, lds_dq);
-  auto run_kv = [&](auto kernel, const AttnArgs& ac) {
+  auto run_kv = [&](auto kernel, LdsAllowance& allow, const AttnArgs& ac) {
+    allow.ensure(kernel, lds_kv);
     hipLaunchKernelGGL(kernel, dim3(((ac.sep + C::QBLK - 1) / C::QBLK) * ac.H * ac.B), dim3(C::NT), lds_kv, s, ac);
   };
   // (Launching the pair for a few datasets at a time into one scratch, so that dS^T -- 436 MB per 16 datasets -- stays in the
   // 256 MB memory-side cache, was measured: 432 vs 436 us with two chunks, slower with more: each launch ends in a partial round.)
   if ((parts & ATTN_BWD_KV) && a.sep > 0) {
-    if constexpr (BwdKvCfg<T, D>::SPLIT) {
-      run_kv(attn_bwd_kv_kernel<T, D, 2>, a);
-      run_kv(attn_bwd_kv_kernel<T, D, 1>, a);
+    if constexpr (BwdKvCfg<T, D>::SPLIT && !DROP) {      // (A/B builds only: -DPFN_KV_SPLIT_D256=1)
+      run_kv(attn_bwd_kv_kernel<T, D, 2, false>, allow_kv[2], a);
+      run_kv(attn_bwd_kv_kernel<T, D, 1, false>, allow_kv[1], a);
     } else {
-      run_kv(attn_bwd_kv_kernel<T, D, 0>, a);
+      run_kv(attn_bwd_kv_kernel<T, D, 0, DROP>, allow_kv[0], a);
     }
   }
-  if (parts & ATTN_BWD_DQ)
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds_dq, s, a);
+  if (parts & ATTN_BWD_DQ) {
+    allow_dq.ensure(attn_bwd_dq_kernel<T, D, DROP>, lds_dq);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds_dq, s, a);
+  }
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
+  return a.p_drop > 0.f ? launch_bwd_k<T, D, true>(a, s) : launch_bwd_k<T, D, false>(a, s);
 }
 
 static int check_attn(const AttnArgs& a, int precision) {

@@ -45,6 +45,7 @@ int check_desc(const pfn_model_desc* d) {
   const bool ok = dh == 32 || dh == 64 || dh == 128 || (dh == 256 && d->precision == PFN_PREC_BF16);
   if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128, 256 in bf16)", dh);
   if (d->emsize > 2048) return fail(PFN_ERR_UNSUPPORTED, "emsize > 2048 unsupported by the LayerNorm kernels");
+  if (!(d->dropout >= 0.f && d->dropout < 1.f)) return fail(PFN_ERR_ARGUMENT, "dropout %g outside [0, 1)", (double)d->dropout);
   return PFN_OK;
 }
 
@@ -94,6 +95,7 @@ struct LayerWs {
   char *qkv, *ctx, *x1_t, *hpre, *h, *x2_t; float *lse, *y1, *mean1, *rstd1, *x1, *y2, *mean2, *rstd2, *x2;
   // backward: output-gradient operands of this layer's four weight gradients, kept until the grouped launch
   char *dy2_t, *dh_t, *dy1_t, *dqkv_t;
+  char *dy2m_t, *dy1m_t;   // dropout > 0 only: the LayerNorm-input gradients times the dropout2 / dropout1 masks (the GEMM operands; the residual path keeps the unmasked ones)
 };
 struct Ws {
   float* x0; char* x0_t;
@@ -126,6 +128,8 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
     l.y2 = (float*)take(M * E * 4); l.mean2 = (float*)take(M * 4); l.rstd2 = (float*)take(M * 4);
     l.x2 = (float*)take(M * E * 4); l.x2_t = take(M * E * es);
     l.dy2_t = take(M * E * es); l.dh_t = take(M * F * es); l.dy1_t = take(M * E * es); l.dqkv_t = take(M * 3 * E * es);
+    l.dy2m_t = l.dy1m_t = nullptr;
+    if (d.dropout > 0.f) { l.dy2m_t = take(M * E * es); l.dy1m_t = take(M * E * es); }
   }
   w.xt_t = take(M * E * es); w.dpre = take(M * F * es); w.dt = take(M * F * es);
   w.dlog_t = take(M * npad * es); w.dd_t = take(M * F * es); w.dxt = (float*)take(M * E * 4);
@@ -217,11 +221,29 @@ int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shado
   return PFN_OK;
 }
 
+static int stack_forward_impl(const pfn_model_desc* d, const float* params, const void* shadow,
+                              const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                              const float* src_sbe, int B, int S, int sep, void* workspace, int64_t workspace_bytes,
+                              float* logits, void* stream, bool use_dropout, uint64_t dropout_seed);
 int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* shadow,
                       const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
                       const float* src_sbe, int B, int S, int sep, void* workspace, int64_t workspace_bytes,
                       float* logits, void* stream) {
+  return stack_forward_impl(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, src_sbe, B, S, sep, workspace, workspace_bytes, logits, stream, false, 0);
+}
+int pfn_stack_forward_dropout(const pfn_model_desc* d, const float* params, const void* shadow,
+                              const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                              const float* src_sbe, int B, int S, int sep, void* workspace, int64_t workspace_bytes,
+                              float* logits, void* stream, uint64_t dropout_seed) {
+  return stack_forward_impl(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, src_sbe, B, S, sep, workspace, workspace_bytes, logits, stream, true, dropout_seed);
+}
+static int stack_forward_impl(const pfn_model_desc* d, const float* params, const void* shadow,
+                              const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                              const float* src_sbe, int B, int S, int sep, void* workspace, int64_t workspace_bytes,
+                              float* logits, void* stream, bool use_dropout, uint64_t dropout_seed) {
   PFN_TRY(check_desc(d));
+  const float pdrop = use_dropout ? d->dropout : 0.f;     // > 0: TransformerEncoderLayer's four dropout sites are live (training)
+  auto dseed = [&](int layer, int site) { return dropout_site_seed(dropout_seed, layer, site); };
   if (!params || !shadow || !workspace) return fail(PFN_ERR_ARGUMENT, "null pointer");
   if (!src_sbe && (!x || !y)) return fail(PFN_ERR_ARGUMENT, "need x and y (or src_sbe)");
   if (B < 1 || S < 1 || sep < 0 || sep > S) return fail(PFN_ERR_ARGUMENT, "bad B=%d S=%d sep=%d", B, S, sep);
@@ -254,7 +276,8 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
   GemmLN probe; memset(&probe, 0, sizeof(probe));
   probe.A = w.x0_t; probe.lda = E; probe.B = sh; probe.ldb = E; probe.M = M; probe.N = E; probe.K = E;
   probe.bias = params; probe.gamma = params; probe.beta = params; probe.resid = w.x0; probe.y = w.x0; probe.x_t = w.x0_t;
-  const bool fuse_ln = prec == PFN_PREC_BF16 && gemm_ln_supported(probe) && F % 32 == 0;
+  // (dropout sits between the bias and the residual add: it takes the unfused GEMM / LayerNorm kernels with an element-wise pass between)
+  const bool fuse_ln = prec == PFN_PREC_BF16 && gemm_ln_supported(probe) && F % 32 == 0 && pdrop == 0.f;
   struct Resid { const float* plain; const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; };
   Resid res = {w.x0, nullptr, nullptr, nullptr, nullptr, nullptr};   // where the layer input lives in f32
   auto set_resid = [](GemmLN& g, const Resid& r) {
@@ -271,6 +294,7 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
     {
       AttnArgs at; memset(&at, 0, sizeof(at));
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
+      at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
       PFN_TRY(launch_attn_fwd(at, prec, s));
     }
     if (fuse_ln) {  // x1 = LN1(x + out_proj(ctx))
@@ -282,10 +306,11 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
       PFN_TRY(launch_gemm_ln(g, s));
       res = Resid{nullptr, a.y1, a.mean1, a.rstd1, params + p.g1, params + p.be1};
     } else {
-      {  // out_proj + residual
-        GemmNT g = nt(a.ctx, E, W(p.w_o), E, M, E, E, EPI_BIAS | EPI_RESID | EPI_OUT_F32);
+      {  // out_proj + residual  (dropout1: the product leaves alone and the element-wise pass adds the residual)
+        GemmNT g = nt(a.ctx, E, W(p.w_o), E, M, E, E, EPI_BIAS | (pdrop > 0.f ? 0 : EPI_RESID) | EPI_OUT_F32);
         g.bias = params + p.b_o; g.resid = xin; g.ld_resid = E; g.out_f32 = a.y1; g.ld_out_f32 = E;
         PFN_TRY(launch_gemm_nt(g, prec, s));
+        if (pdrop > 0.f) PFN_TRY(launch_dropout_add(a.y1, xin, M, E, dseed(l, 1), pdrop, s));
       }
       PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, a.x1, a.x1_t, a.mean1, a.rstd1, M, E, d->ln_eps, prec, s));
     }
@@ -293,6 +318,8 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
       GemmNT g = nt(a.x1_t, E, W(p.w1), E, M, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
       g.bias = params + p.b1; g.out_t = a.h; g.ld_out_t = F; g.out2_t = a.hpre; g.ld_out2 = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
+      // FFN dropout: h and the stored GELU derivative take the same mask, so linear2, its weight gradient and d(hpre) need nothing more
+      if (pdrop > 0.f) PFN_TRY(launch_dropout_scale(a.h, a.h, a.hpre, a.hpre, M, F, dseed(l, 2), pdrop, prec, s));
     }
     if (fuse_ln) {  // x2 = LN2(x1 + linear2(h))
       GemmLN g; memset(&g, 0, sizeof(g));
@@ -304,10 +331,11 @@ int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* 
       PFN_TRY(launch_gemm_ln(g, s));
       res = Resid{nullptr, a.y2, a.mean2, a.rstd2, params + p.g2, params + p.be2};
     } else {
-      {  // linear2 + residual
-        GemmNT g = nt(a.h, F, W(p.w2), F, M, E, F, EPI_BIAS | EPI_RESID | EPI_OUT_F32);
+      {  // linear2 + residual  (dropout2 as above)
+        GemmNT g = nt(a.h, F, W(p.w2), F, M, E, F, EPI_BIAS | (pdrop > 0.f ? 0 : EPI_RESID) | EPI_OUT_F32);
         g.bias = params + p.b2; g.resid = a.x1; g.ld_resid = E; g.out_f32 = a.y2; g.ld_out_f32 = E;
         PFN_TRY(launch_gemm_nt(g, prec, s));
+        if (pdrop > 0.f) PFN_TRY(launch_dropout_add(a.y2, a.x1, M, E, dseed(l, 3), pdrop, s));
       }
       PFN_TRY(launch_layernorm_fwd(a.y2, params + p.g2, params + p.be2, a.x2, a.x2_t, a.mean2, a.rstd2, M, E, d->ln_eps, prec, s));
     }
@@ -338,15 +366,17 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
                        int B, int S, int sep, void* workspace, int64_t workspace_bytes,
                        const float* dlogits, float* grads, float* dsrc_sbe, void* stream) {
   return pfn_stack_backward_split(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, B, S, sep, workspace, workspace_bytes, dlogits, grads, dsrc_sbe,
-                                  stream, 0, nullptr, nullptr);
+                                  stream, 0, nullptr, nullptr, 0, 0);
 }
 
 int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const void* shadow,
                              const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
                              int B, int S, int sep, void* workspace, int64_t workspace_bytes,
                              const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
-                             int first_group_layers, pfn_host_callback on_first_group, void* user) {
+                             int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed) {
   PFN_TRY(check_desc(d));
+  const float pdrop = use_dropout ? d->dropout : 0.f;
+  auto dseed = [&](int layer, int site) { return dropout_site_seed(dropout_seed, layer, site); };
   if (!params || !shadow || !workspace || !grads) return fail(PFN_ERR_ARGUMENT, "null pointer");
   if (!dsrc_sbe && (!x || !y)) return fail(PFN_ERR_ARGUMENT, "need x and y (or dsrc_sbe)");
   if (B < 1 || S < 1 || sep < 0 || sep > S) return fail(PFN_ERR_ARGUMENT, "bad B=%d S=%d sep=%d", B, S, sep);
@@ -419,7 +449,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   // split-K TN kernel does the rest (the register kernel it replaces streamed d(src) at 0.7 TB/s).  Custom encoders
   // (dsrc_sbe), the exact-f32 mode and wide encoders keep the f32 path.
   const bool emb_gemm = !dsrc_sbe && prec == PFN_PREC_BF16 && d->nlayers > 0 && d->num_features + 2 <= EMB_AUG && E % 8 == 0;
-  bool fuse_lnb = g_fuse_lnbwd && prec == PFN_PREC_BF16 && d->nlayers > 0;
+  bool fuse_lnb = g_fuse_lnbwd && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f;   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
   if (fuse_lnb) {
     const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
     fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1)) &&
@@ -438,9 +468,10 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
       LayerWs& a = w.layer[l];
       const char* xin_t = (l == 0) ? w.x0_t : w.layer[l - 1].x2_t;
       // (b2 / b_o: column sums of dy2 / dy1 -- from the LayerNorm-backward kernel when that ran on its own)
-      add(a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, fuse_lnb && l < d->nlayers - 1 ? grads + p.b2 : nullptr);
+      const bool drop = pdrop > 0.f;
+      add(drop ? a.dy2m_t : a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, (drop || (fuse_lnb && l < d->nlayers - 1)) ? grads + p.b2 : nullptr);
       add(a.dh_t, F, a.x1_t, E, grads + p.w1, E, F, E, grads + p.b1);
-      add(a.dy1_t, E, a.ctx, E, grads + p.w_o, E, E, E, fuse_lnb ? grads + p.b_o : nullptr);
+      add(drop ? a.dy1m_t : a.dy1_t, E, a.ctx, E, grads + p.w_o, E, E, E, (drop || fuse_lnb) ? grads + p.b_o : nullptr);
       add(a.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, 3 * E, E, grads + p.b_in);
     }
     bool grouped = prec == PFN_PREC_BF16;
@@ -467,10 +498,15 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     // LN2: the input gradient leaves only in operand precision (dy2_t); it is both the GEMM operand below and the
     // residual-branch gradient that the dx1 GEMM adds back, so no f32 copy is written or re-read.  (Fused: the layer above
     // already left dy2_t.)
+    // dropout: the gradient entering linear2 (dropout2) / out_proj (dropout1) is the LayerNorm-input gradient times that site's mask;
+    // the residual path keeps the unmasked one, and the two bias gradients become column sums of the masked operands (weight-gradient launch)
     if (!fuse_lnb || l == d->nlayers - 1)
-      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t, grads + p.g2, grads + p.be2, grads + p.b2, M, E, prec, s));
+      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t, grads + p.g2, grads + p.be2,
+                                   pdrop > 0.f ? nullptr : grads + p.b2, M, E, prec, s));
+    const char* dy2_op = a.dy2_t;
+    if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy2_t, a.dy2m_t, nullptr, nullptr, M, E, dseed(l, 3), pdrop, prec, s)); dy2_op = a.dy2m_t; }
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
-      GemmNT g = nt(a.dy2_t, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
+      GemmNT g = nt(dy2_op, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = a.hpre; g.ld_aux = F; g.out_t = a.dh_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
@@ -482,10 +518,13 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
         g.aux = a.dy2_t; g.ld_aux = E; g.out_t = w.gA_t; g.ld_out_t = E;
         PFN_TRY(launch_gemm_nt(g, prec, s));
       }
-      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, a.dy1_t, grads + p.g1, grads + p.be1, grads + p.b_o, M, E, prec, s));
+      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, a.dy1_t, grads + p.g1, grads + p.be1,
+                                   pdrop > 0.f ? nullptr : grads + p.b_o, M, E, prec, s));
     }
+    const char* dy1_op = a.dy1_t;
+    if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy1_t, a.dy1m_t, nullptr, nullptr, M, E, dseed(l, 1), pdrop, prec, s)); dy1_op = a.dy1m_t; }
     {  // d(ctx) = dy1 . Wo
-      GemmNT g = nt(a.dy1_t, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
+      GemmNT g = nt(dy1_op, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
       g.out_t = w.dctx_t; g.ld_out_t = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
@@ -493,6 +532,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
       AttnArgs at; memset(&at, 0, sizeof(at));
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
       at.dctx = w.dctx_t; at.dqkv = a.dqkv_t; at.delta = w.delta; at.ds = w.ds;
+      at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     if (fuse_lnb && l > 0) {  // dy2 of the layer below = its LN2 backward of (dqkv . Win + dy1)

@@ -24,6 +24,31 @@ struct LdsAllowance {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Dropout masks (training with dropout > 0: TransformerEncoderLayer's four sites, reference transformer.py:17 / train.py:22).
+// A mask is a pure function of (site seed, i, j) so the backward regenerates what the forward applied, in whatever register
+// layout a kernel holds the elements, with no mask tensor in HBM:
+//     keep(s, i, j)  <=>  mix32(s ^ i * 0x9E3779B1 ^ j * 0x85EBCA77) >= thr,      thr = p * 2^32
+// (mix32 = the "lowbias32" integer finaliser).  site seed = dropout_site_seed(call seed, layer, site); the attention site mixes the
+// (dataset, head) index in as well (dropout_pair_seed).  i, j = (query, key) for the attention probabilities, (token row b * S + t,
+// column) for the three element-wise sites.  oracle/pfn_oracle.py restates the same integers in numpy.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline unsigned mix32(unsigned h) {
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline unsigned dropout_site_seed(unsigned long long seed, int layer, int site) {
+  return mix32(mix32((unsigned)seed ^ (0x9E3779B1u * (unsigned)(layer * 4 + site + 1))) ^ (unsigned)(seed >> 32));
+}
+__host__ __device__ inline unsigned dropout_pair_seed(unsigned site_seed, int pair) { return mix32(site_seed ^ (0xC2B2AE35u * (unsigned)(pair + 1))); }
+__host__ __device__ inline unsigned dropout_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+}
+__host__ __device__ inline bool dropout_keep(unsigned s, unsigned i, unsigned j, unsigned thr) {
+  return mix32(s ^ (i * 0x9E3779B1u) ^ (j * 0x85EBCA77u)) >= thr;
+}
+
 // ---- GEMM -----------------------------------------------------------------------------------
 enum : int {
   EPI_BIAS = 1,      // + bias[n] (f32)
@@ -134,6 +159,9 @@ struct AttnArgs {
   int ds_rows, ds_ld;  // filled by the launcher
   int parts;  // backward launches to run, bit mask over ATTN_BWD_*; 0 = all (profiling entry point pfn_op_attention_bwd_parts)
   int pingpong;  // filled by the launcher (PFN_TUNE_ATTN_PINGPONG): bit 0 forward, bit 1 key-block pass
+  // dropout on the attention probabilities (training with dropout > 0): P' = P * keep / (1 - p), keep = dropout_keep(pair seed, query, key)
+  float p_drop;            // 0 = off (the kernels without the mask arithmetic run)
+  unsigned drop_seed;      // site seed of this layer's attention (dropout_site_seed(call seed, layer, 0)); the kernels mix (dataset, head) in
 };
 void set_attn_pingpong(int mask);
 enum : int { ATTN_BWD_DELTA = 1, ATTN_BWD_KV = 2, ATTN_BWD_DQ = 4 };
@@ -185,6 +213,11 @@ int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const floa
 int launch_colsum(const void* a_t, long lda, long rows, int cols, float* out, int precision, hipStream_t s);
 
 // gather test rows: dst[(s-sep)*B + b, :] = src[b, s, :]  (f32 in, T out)  and its transpose
+// ---- element-wise dropout (training with dropout > 0 only; masks: pfn_device.h dropout_keep with i = row, j = column) ----
+// y[r, c] = resid[r, c] + keep * y[r, c] / (1 - p)            (dropout1 / dropout2 of TransformerEncoderLayer, in place on the f32 sum)
+int launch_dropout_add(float* y, const float* resid, long rows, int cols, unsigned site_seed, float p, hipStream_t s);
+// dst[r, c] = keep * src[r, c] / (1 - p) in operand precision; src == dst allowed; a second pair shares the mask (h and gelu'(hpre))
+int launch_dropout_scale(const void* src, void* dst, const void* src2, void* dst2, long rows, int cols, unsigned site_seed, float p, int precision, hipStream_t s);
 int launch_gather_test_rows(const float* src_bse, void* dst_t, int S, int B, int E, int sep, int precision, hipStream_t s);
 // dst[b, s, :] = (s >= sep) ? src[(s-sep)*B + b, :] : 0
 int launch_scatter_test_rows(const float* src, void* dst_bse_t, int S, int B, int E, int sep, int precision, hipStream_t s);

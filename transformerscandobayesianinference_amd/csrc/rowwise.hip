@@ -340,6 +340,49 @@ template <typename T> __global__ __launch_bounds__(256) void gather_test_kernel(
     st4<T>(dst + row * E + c, *reinterpret_cast<const f32x4*>(src + (b * S + sidx) * E + c));
   }
 }
+// ---- element-wise dropout (dropout > 0 only) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_add_kernel(float* y, const float* resid, long n4, int cols4, unsigned seed, unsigned thr, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const unsigned r = (unsigned)(i / cols4), c = (unsigned)(i % cols4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(resid + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = x[e] + (dropout_keep(seed, r, c + e, thr) ? v[e] * scale : 0.f);
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+int launch_dropout_add(float* y, const float* resid, long rows, int cols, unsigned site_seed, float p, hipStream_t s) {
+  if (cols % 4) return PFN_ERR_UNSUPPORTED;
+  const long n4 = rows * cols / 4;
+  if (n4 == 0) return PFN_OK;
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, y, resid, n4, cols / 4, site_seed, dropout_threshold(p), 1.f / (1.f - p));
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+template <typename T> __global__ __launch_bounds__(256) void dropout_scale_kernel(const T* src, T* dst, const T* src2, T* dst2, long n4, int cols4, unsigned seed, unsigned thr, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const unsigned r = (unsigned)(i / cols4), c = (unsigned)(i % cols4) * 4;
+    f32x4 v = ld4<T>(src + i * 4), w = {0.f, 0.f, 0.f, 0.f};
+    if (src2) w = ld4<T>(src2 + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float k = dropout_keep(seed, r, c + e, thr) ? scale : 0.f;
+      v[e] *= k; w[e] *= k;
+    }
+    st4<T>(dst + i * 4, v);
+    if (src2) st4<T>(dst2 + i * 4, w);
+  }
+}
+int launch_dropout_scale(const void* src, void* dst, const void* src2, void* dst2, long rows, int cols, unsigned site_seed, float p, int precision, hipStream_t s) {
+  if (cols % 4) return PFN_ERR_UNSUPPORTED;
+  const long n4 = rows * cols / 4;
+  if (n4 == 0) return PFN_OK;
+  const unsigned thr = dropout_threshold(p);
+  const float scale = 1.f / (1.f - p);
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(dropout_scale_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, (const bf16*)src2, (bf16*)dst2, n4, cols / 4, site_seed, thr, scale);
+  else hipLaunchKernelGGL(dropout_scale_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, (const float*)src, (float*)dst, (const float*)src2, (float*)dst2, n4, cols / 4, site_seed, thr, scale);
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+
 int launch_gather_test_rows(const float* src, void* dst, int S, int B, int E, int sep, int precision, hipStream_t s) {
   if (E % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = (long)(S - sep) * B * E / 4;

@@ -74,11 +74,6 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     if not str(device).startswith('cuda') and getattr(TransformerModel, 'requires_gpu', False):
         raise _hip.HipExtensionError('train(): no GPU is visible; the PFN hot path runs on an MI355X through libpfn_hip.so only '
                                      '(there is no CPU fallback -- the CPU restatement lives in oracle/ and is test infrastructure)')
-    if dropout > 0:
-        # the signature keeps the reference default (train.py:22) for call compatibility, but fail HERE, before the prior
-        # and the model are built, not at the first forward
-        raise NotImplementedError(f'train(dropout={dropout}): dropout is not implemented in the HIP stack; pass dropout=0.0 '
-                                  '(every BASELINE configuration and the reference CLI default train.py:181 use 0)')
     world = dp.world_size()
     if world > 1:
         dp.seed_ranks()
