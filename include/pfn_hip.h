@@ -71,7 +71,9 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_GEMM_TN_WRAP = 1, /* profiling only: > 0 makes the grouped TN kernel re-read its first `value` token rows (wrong results, cache-resident operands) */
        PFN_TUNE_FUSE_LNBWD = 2,
        PFN_TUNE_GEMM_PERSIST = 3, /* workgroups of the persistent 256x256 NT GEMM (one per CU walking tiles); 0 = the one-tile-per-workgroup kernel */
-       PFN_TUNE_ATTN_PINGPONG = 4 /* bit 0: attention forward, bit 1: backward key-block pass -- the two waves of a SIMD run half a tile apart (default: see attention.hip) */ };
+       PFN_TUNE_ATTN_PINGPONG = 4, /* bit 0: attention forward, bit 1: backward key-block pass -- the two waves of a SIMD run half a tile apart (default: see attention.hip) */
+       PFN_TUNE_FUSE_LN_WIDE = 5   /* 1: emsize 1024 runs the LayerNorm-fused GEMMs on 64-row x 1024-column tiles (gemm_nt_ln_wide / lnbwd_wide); 0 (default): the
+                                    * 256 x 256 GEMM + LayerNorm kernels -- measured faster at that width */ };
 int pfn_set_tuning(int key, int value);
 
 /* ---- parameter packing ------------------------------------------------------------------------

@@ -207,7 +207,7 @@ def test_gemm_tn(M, P, Q, prec):
     assert relerr(C, ref) < 3e-6, relerr(C, ref)
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (77, 512, 32)])
+@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (77, 512, 32), (300, 1024, 1024), (130, 1024, 2048), (64, 1024, 96), (1, 1024, 64)])
 def test_gemm_ln_fused(M, N, K):
     """linear + bias + residual + LayerNorm in one kernel, both residual forms, against f64 PyTorch."""
     dt = torch.bfloat16
@@ -231,7 +231,8 @@ def test_gemm_ln_fused(M, N, K):
     assert relerr(x2, torch.nn.functional.layer_norm(v2, (N,), gamma.double(), beta.double(), 1e-5)) < 4e-3
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (77, 512, 1536)])
+@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (77, 512, 1536),
+                                   (200, 1024, 2048), (77, 1024, 3072), (64, 1024, 32)])      # N = 1024: the 64-row tiles (emsize 1024)
 def test_gemm_lnbwd_fused(M, N, K):
     """dgrad GEMM + residual-branch gradient + LayerNorm backward in one kernel, against f64 autograd of the LayerNorm."""
     dt = torch.bfloat16

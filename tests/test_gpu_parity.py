@@ -1136,3 +1136,36 @@ def test_dropout_vs_oracle_with_the_same_masks(precision, emsize):
     # the keep rate of a mask is 1 - p
     keep = pfn_oracle.dropout_keep_mask(pfn_oracle.dropout_site_seed(seed, 0, 1), range(400), range(64), pdrop)
     assert abs(keep.float().mean().item() - (1 - pdrop)) < 0.01
+
+
+def test_emsize_1024_fused_layernorm_gemms_in_the_stack():
+    """emsize 1024 with the LayerNorm-fused GEMMs on 64-row x 1024-column tiles switched ON (PFN_TUNE_FUSE_LN_WIDE; off by default because
+    GEMM + LayerNorm kernels measure faster at that width): forward, loss and every gradient against the f64 oracle, and against the
+    default path."""
+    cfg = dict(T=160, B=2, F=18, E=1024, H=16, nhid=2048, L=2, nbars=100)
+    lib = _hip.lib()
+    outs = {}
+    try:
+        for wide in (1, 0):
+            _hip.check(lib.pfn_set_tuning(5, wide), 'pfn_set_tuning')
+            model = random_model(cfg, 'bf16', seed=4)
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
+            model = model.to(DEV).train()
+            gen = torch.Generator().manual_seed(6)
+            x, y, _ = pfn_oracle.get_batch_fast_gp(cfg['B'], cfg['T'], cfg['F'], {'noise': 1e-4, 'outputscale': 1., 'lengthscale': .6}, gen)
+            sep = 131
+            model.zero_grad()
+            logits = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
+            loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
+            loss.backward()
+            outs[wide] = (logits.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    finally:
+        _hip.check(lib.pfn_set_tuning(5, 0), 'pfn_set_tuning')
+    loss_o, logits_o, grads_o = pfn_oracle.loss_and_grads(sd, x, y, y, sep, cfg['H'], sd['criterion.borders'])
+    for wide in (1, 0):
+        logits, grads = outs[wide]
+        within(f'fused-wide={wide} logits rel l2', relerr(logits, logits_o), 1e-2)
+        tot_err = math.sqrt(sum(((grads[k].double().cpu() - g) ** 2).sum().item() for k, g in grads_o.items()))
+        tot = math.sqrt(sum((g ** 2).sum().item() for g in grads_o.values()))
+        within(f'fused-wide={wide} global gradient rel l2', tot_err / tot, 1.2e-2)
+    assert relerr(outs[1][0], outs[0][0]) < 5e-3          # the two paths round differently, not more

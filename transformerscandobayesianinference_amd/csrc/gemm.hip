@@ -782,6 +782,230 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   }
 }
 
+// gemm_nt_ln_wide_kernel (round 3): the same kernel for emsize 1024 (BASELINE configs[4]).  The tile is MI x 32 rows by NWN waves x
+// (NJ x 32) columns; (MI, NJ) = (2, 4) gives 64 rows x 1024 columns with the same 8 accumulator blocks per wave as the 128 x 512 tile
+// above, 32-deep stages (two of them: 136 KiB).  The epilogue walks "units" of 32 rows x 64 columns (one row block, two column
+// blocks; four per wave, like the four row blocks above).  Kept as its own kernel: the generalised source costs the N <= 512
+// instantiation three spilled registers.
+template <int NWN, int MI, int NJ> struct LnEpiW {   // LDS of gemm_nt_ln_kernel's epilogue: row partial sums, column vectors, the output strips
+  static constexpr int STRIPS = MI * 32 * NWN * 4 + 5 * NWN * NJ * 32 * 4;
+  static constexpr int WAVE = 32 * 272 + 32 * 144;
+  static constexpr int BYTES = STRIPS + NWN * WAVE;
+};
+template <int NWN, bool RESID_LN, int BK, int MI, int NJ>
+__global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_wide_kernel(GemmLN g) {
+  constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
+  constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
+  constexpr int TILE_A = BM * RB, STAGE = TILE_A + BN * RB;
+  constexpr int JH = NJ / 2, NU = MI * JH;                  // units of 32 rows x 64 columns per wave
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  const int m0 = blockIdx.x * BM;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int h = lane >> 5, li = lane & 31;
+
+  const bf16* pa[PA];
+  const bf16* pb[PB];
+  constexpr int APIECES = BM / RPP;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int piece = wave + NWN * i;
+    const int row = piece * RPP + lane / CPR;
+    const int chunk = swz16<RB>(row, lane % CPR);
+    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = (wave + NWN * i) * RPP + lane / CPR;
+    const int chunk = swz16<RB>(row, lane % CPR);
+    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)row * g.ldb + chunk * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    LdsPtr ta = smem + buf * STAGE + wave * 1024;
+    LdsPtr tb = smem + buf * STAGE + TILE_A + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      if (wave + NWN * i < APIECES) __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * NWN * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * NWN * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * STAGE;
+    const lds_char* tb = ta + TILE_A;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      Frag<bf16> fa[MI], fb[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = load_frag_row<bf16, RB>(tb, wave * WN + j * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = load_frag_row<bf16, RB>(ta, i * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: v = acc + bias + residual (kept in the accumulator registers), row statistics, outputs ----
+  // The compiler never moves a global load above a global store and waits for each group of loads where it is used, so an
+  // epilogue written "load, combine, store" per 16-byte group is a chain of serialized memory round trips (measured: ~half
+  // of this kernel's time at K = 512).  So: the per-column vectors go to LDS once (their reads count on lgkmcnt, not
+  // vmcnt), the residual rows are fetched one unit ahead of their use, and the store pass issues no global load.
+  float* red = reinterpret_cast<float*>(smem_raw);          // [BM rows][NWN] partial sums; the stage buffers are dead
+  float* cvec = red + BM * NWN;                             // [5][BN]: rgamma, rbeta, bias, gamma, beta
+  for (int n = threadIdx.x; n < BN; n += NWN * 64) {
+    float c0 = 0.f, c1 = 0.f;
+    if constexpr (RESID_LN) { c0 = g.rgamma[n]; c1 = g.rbeta[n]; }
+    const float c2 = g.bias[n], c3 = g.gamma[n], c4 = g.beta[n];
+    cvec[n] = c0; cvec[BN + n] = c1; cvec[2 * BN + n] = c2; cvec[3 * BN + n] = c3; cvec[4 * BN + n] = c4;
+  }
+  const float* rsrc = RESID_LN ? g.ry : g.resid;
+  float rm[MI], rr[MI];
+  long mrow[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    mrow[i] = min((long)m0 + i * 32 + li, (long)g.M - 1);
+    rm[i] = 0.f; rr[i] = 1.f;
+    if constexpr (RESID_LN) { rm[i] = g.rmean[mrow[i]]; rr[i] = g.rrstd[mrow[i]]; }
+  }
+  f32x4 rv[2][8];
+  auto fetch_unit = [&](int u, f32x4 (&dst)[8]) {           // unit u = (row block u / JH, column blocks 2 (u % JH) and + 1)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        dst[jj * 4 + gq] = *reinterpret_cast<const f32x4*>(rsrc + mrow[u / JH] * BN + wave * WN + ((u % JH) * 2 + jj) * 32 + 8 * gq + 4 * h);
+  };
+  fetch_unit(0, rv[0]);
+  __syncthreads();                                          // cvec visible
+  float mean[MI], rstd[MI];
+  const float invN = 1.f / (float)BN;
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = u / JH, jh = u % JH;
+    if (u + 1 < NU) fetch_unit(u + 1, rv[(u + 1) & 1]);
+    if (jh == 0) s = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int j = jh * 2 + jj;
+        const int n = wave * WN + j * 32 + 8 * gq + 4 * h;
+        f32x4 r = rv[u & 1][jj * 4 + gq];
+        if constexpr (RESID_LN) {
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + n), be = *reinterpret_cast<const f32x4*>(cvec + BN + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = (r[e] - rm[i]) * rr[i] * ga[e] + be[e];
+        }
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(cvec + 2 * BN + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[i][j][4 * gq + e] + bi[e] + r[e];
+          acc[i][j][4 * gq + e] = v;
+          s += v;
+        }
+      }
+    if (jh == JH - 1) {
+      s += __shfl_xor(s, 32, 64);
+      if (h == 0) red[(i * 32 + li) * NWN + wave] = s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWN; ++w) t += red[(i * 32 + li) * NWN + w];
+    mean[i] = t * invN;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float d = acc[i][j][r] - mean[i]; sq += d * d; }
+    sq += __shfl_xor(sq, 32, 64);
+    if (h == 0) red[(i * 32 + li) * NWN + wave] = sq;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWN; ++w) t += red[(i * 32 + li) * NWN + w];
+    rstd[i] = rsqrtf(t * invN + g.eps);
+  }
+  // Outputs leave through wave-private LDS strips (one unit at a time: f32 rows of 256 B + operand-precision rows of
+  // 128 B, padded by 16 B) so that every global store instruction writes whole lines -- 4 rows x 256 B of y, 8 rows x 128 B of
+  // x_t -- instead of 32 bytes of 32 different rows (as in nt_big_epilogue).
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  bf16* x_t = reinterpret_cast<bf16*>(g.x_t);
+  LdsPtr sf = smem + LnEpiW<NWN, MI, NJ>::STRIPS + wave * LnEpiW<NWN, MI, NJ>::WAVE, st = sf + 32 * 272;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = u / JH, jh = u % JH;
+    const long m_row = (long)m0 + i * 32 + li;
+    const bool mvalid = m_row < g.M;
+    const long m = mrow[i];
+    if (jh == 0 && mvalid && wave == 0 && h == 0) { g.mean[m] = mean[i]; g.rstd[m] = rstd[i]; }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = jh * 2 + jj;
+      const int nb = wave * WN + j * 32;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = nb + 8 * gq + 4 * h;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + 3 * BN + n), be = *reinterpret_cast<const f32x4*>(cvec + 4 * BN + n);
+        f32x4 v, xo;
+        bf16x4 xt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][j][4 * gq + e];
+          xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
+          xt[e] = (bf16)xo[e];
+        }
+        lds_write16(sf + li * 272 + (jj * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
+        *reinterpret_cast<lds_bf16x4*>(st + li * 144 + (jj * 4 + gq) * 16 + h * 8) = xt;
+        if (g.x_f32 && mvalid) *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;   // (last layer only)
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const long mb = (long)m0 + i * 32;
+    const int cb = wave * WN + jh * 64;                     // first column of the unit
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rr_ = it * 4 + (lane >> 4), c = lane & 15;
+      const u32x4 q = lds_read16(sf + rr_ * 272 + c * 16);
+      if (mb + rr_ < g.M) *reinterpret_cast<u32x4*>(g.y + (mb + rr_) * BN + cb + c * 4) = q;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr_ = it * 8 + (lane >> 3), c = lane & 7;
+      const u32x4 q = lds_read16(st + rr_ * 144 + c * 16);
+      if (mb + rr_ < g.M) *reinterpret_cast<u32x4*>(x_t + (mb + rr_) * BN + cb + c * 8) = q;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // gemm_nt_lnbwd_kernel: a data-gradient GEMM whose output is the gradient w.r.t. a LayerNorm OUTPUT, with that LayerNorm's
 // backward fused into the epilogue (GemmLNB in pfn_kernels.h):
@@ -1029,6 +1253,242 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
     const int n = threadIdx.x;                              // blockDim.x == BN
     unsafeAtomicAdd(g.dbeta + n, csum[n] + csum[BN + n]);
     unsafeAtomicAdd(g.dgamma + n, csum[2 * BN + n] + csum[3 * BN + n]);
+  }
+}
+
+// gemm_nt_lnbwd_wide_kernel (round 3): the same kernel on 64-row x 1024-column tiles (emsize 1024, BASELINE configs[4]); see gemm_nt_ln_wide_kernel.
+template <int NWN, int BK, int MI, int NJ> struct LnbCfgW {
+  static constexpr int BM = MI * 32, BN = NWN * NJ * 32, NU = MI * (NJ / 2);
+  static constexpr int STAGES = 2 * (BM + BN) * (BK * 2);
+  static constexpr int RED = BM * NWN * 4;               // one [BM rows][NWN] f32 array of row partial sums
+  static constexpr int STRIP = 32 * 144;                 // a 32-row x 64-column strip in operand precision, rows padded by 16 B
+  static constexpr int CSUM = 2 * RED + BN * 4;          // [dbeta | dgamma][BN] column sums (the 128-row kernel re-uses the row-sum arrays: too small here)
+  static constexpr int STASH = CSUM + 2 * BN * 4;        // offset of the per-wave xhat / dx strips
+  static constexpr int EPI = STASH + NWN * NU * STRIP;
+  static constexpr int LDS = STAGES > EPI ? STAGES : EPI;
+};
+
+template <int NWN, int BK, int MI, int NJ>
+__global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_wide_kernel(GemmLNB g) {
+  using C = LnbCfgW<NWN, BK, MI, NJ>;
+  constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
+  constexpr int JH = NJ / 2, NU = MI * JH, NHB = MI * NJ;
+  constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
+  constexpr int TILE_A = BM * RB, STAGE = TILE_A + BN * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  const int m0 = blockIdx.x * BM;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int h = lane >> 5, li = lane & 31;
+
+  const bf16* pa[PA];
+  const bf16* pb[PB];
+  constexpr int APIECES = BM / RPP;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave + NWN * i) * RPP + lane / CPR;
+    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + swz16<RB>(row, lane % CPR) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = (wave + NWN * i) * RPP + lane / CPR;
+    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)row * g.ldb + swz16<RB>(row, lane % CPR) * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    LdsPtr ta = smem + buf * STAGE + wave * 1024;
+    LdsPtr tb = smem + buf * STAGE + TILE_A + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      if (wave + NWN * i < APIECES) __builtin_amdgcn_global_load_lds((gvoid_t*)(pa[i] + k0), (lvoid_t*)(ta + i * NWN * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) __builtin_amdgcn_global_load_lds((gvoid_t*)(pb[i] + k0), (lvoid_t*)(tb + i * NWN * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * STAGE;
+    const lds_char* tb = ta + TILE_A;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      Frag<bf16> fa[MI], fb[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) fb[j] = load_frag_row<bf16, RB>(tb, wave * WN + j * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = load_frag_row<bf16, RB>(ta, i * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  float* red1 = reinterpret_cast<float*>(smem_raw);
+  float* red2 = red1 + BM * NWN;
+  float* gam = red2 + BM * NWN;
+  LdsPtr stash = smem + C::STASH + wave * NU * C::STRIP;
+  const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
+  bf16* dx_t = reinterpret_cast<bf16*>(g.dx_t);
+  for (int n = threadIdx.x; n < BN; n += NWN * 64) gam[n] = g.gamma[n];
+  int mrow[MI];
+  bool mvalid[MI];
+  float mu[MI], rs[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + i * 32 + li;
+    mvalid[i] = m < g.M;
+    mrow[i] = mvalid[i] ? m : g.M - 1;
+    mu[i] = g.mean[mrow[i]]; rs[i] = g.rstd[mrow[i]];
+  }
+  // y rows and the residual-branch gradient: one half row block (a 32-column block of the lane's row) ahead of its use -- a whole
+  // block ahead does not fit the registers.  v = product + that gradient replaces the accumulator; rows past M hold zeros.
+  f32x4 yv[2][4];
+  bf16x4 av[2][4];
+  auto fetch_half = [&](int hb, f32x4 (&dy)[4], bf16x4 (&da)[4]) {           // hb = NJ i + j
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const long off = (long)mrow[hb / NJ] * BN + wave * WN + (hb % NJ) * 32 + 8 * gq + 4 * h;
+      dy[gq] = *reinterpret_cast<const f32x4*>(g.y + off);
+      da[gq] = *reinterpret_cast<const bf16x4*>(aux + off);
+    }
+  };
+  fetch_half(0, yv[0], av[0]);
+  __syncthreads();                                          // gam visible
+  const float invN = 1.f / (float)BN;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int hb = 0; hb < NHB; ++hb) {
+    const int i = hb / NJ, j = hb % NJ;
+    asm volatile("" ::: "memory");                          // re-read gamma from LDS per block (kept in registers across blocks it costs 32 of them)
+    if (hb + 1 < NHB) fetch_half(hb + 1, yv[(hb + 1) & 1], av[(hb + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);                      // (the scheduler would hoist the loads of every later block up here: spills)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int n = wave * WN + j * 32 + 8 * gq + 4 * h;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n);
+      bf16x4 xh_t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = mvalid[i] ? acc[i][j][4 * gq + e] + (float)av[hb & 1][gq][e] : 0.f;
+        acc[i][j][4 * gq + e] = v;
+        const float xh = (yv[hb & 1][gq][e] - mu[i]) * rs[i];
+        const float gv = ga[e] * v;
+        s1 += gv;
+        s2 += gv * xh;
+        xh_t[e] = (bf16)xh;
+      }
+      *reinterpret_cast<lds_bf16x4*>(stash + (i * JH + j / 2) * C::STRIP + li * 144 + ((j & 1) * 4 + gq) * 16 + h * 8) = xh_t;
+    }
+    if (j == NJ - 1) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) { red1[(i * 32 + li) * NWN + wave] = s1; red2[(i * 32 + li) * NWN + wave] = s2; }
+      s1 = 0.f; s2 = 0.f;
+    }
+  }
+  __syncthreads();
+  float m1[MI], m2[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWN; ++w) { t1 += red1[(i * 32 + li) * NWN + w]; t2 += red2[(i * 32 + li) * NWN + w]; }
+    m1[i] = t1 * invN; m2[i] = t2 * invN;
+  }
+  // dbeta / dgamma: column sums over this tile's rows -- the four row blocks inside the lane, the 16 lanes of a DPP row, then
+  // through LDS ([quantity][row half][column], the space of the row sums) so that the workgroup ends with ONE 64-lane atomic
+  // instruction per 64 columns (issued by the lanes that hold the sums -- 4 per instruction -- the same atomics took 270 us).
+  __syncthreads();                                          // every wave has read red1 / red2
+  float* csum = reinterpret_cast<float*>(smem_raw + C::CSUM);        // [dbeta | dgamma][BN]; the two 16-lane row halves are combined in the lanes
+  const int ccol = wave * WN + 4 * h;
+  {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * gq + e;
+          float cs = 0.f;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) cs += acc[i][j][r];
+          t[e] = row16_sum(cs);
+          t[e] += __shfl_xor(t[e], 16, 64);
+        }
+        if (li == 0) *reinterpret_cast<f32x4*>(csum + ccol + j * 32 + 8 * gq) = t;
+      }
+  }
+  float cg[NJ][16];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cg[j][r] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = u / JH, jh = u % JH;
+    LdsPtr strip = stash + u * C::STRIP;
+    asm volatile("" ::: "memory");
+    bf16x4 xh_t[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xh_t[c] = *reinterpret_cast<const lds_bf16x4*>(strip + li * 144 + c * 16 + h * 8);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int j = jh * 2 + jj;
+        const int n = wave * WN + j * 32 + 8 * gq + 4 * h;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (float)xh_t[jj * 4 + gq][e], v = acc[i][j][4 * gq + e];
+          cg[j][4 * gq + e] += v * xh;
+          o[e] = (bf16)(rs[i] * (ga[e] * v - m1[i] - xh * m2[i]));
+        }
+        *reinterpret_cast<lds_bf16x4*>(strip + li * 144 + (jj * 4 + gq) * 16 + h * 8) = o;   // (the lane's own xhat slot)
+      }
+    __builtin_amdgcn_wave_barrier();
+    const long mb = (long)m0 + i * 32;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                        // whole 128-byte lines: 8 rows x 128 B per store instruction
+      const int rr = it * 8 + (lane >> 3), c = lane & 7;
+      const u32x4 q = lds_read16(strip + rr * 144 + c * 16);
+      if (mb + rr < g.M) *reinterpret_cast<u32x4*>(dx_t + (mb + rr) * BN + wave * WN + jh * 64 + c * 8) = q;
+    }
+    // (else the dgamma additions are sunk to the end of the kernel and every block's 32 products stay in registers: spills)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(cg[j][r]));
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t[e] = row16_sum(cg[j][4 * gq + e]); t[e] += __shfl_xor(t[e], 16, 64); }
+      if (li == 0) *reinterpret_cast<f32x4*>(csum + BN + ccol + j * 32 + 8 * gq) = t;
+    }
+  __syncthreads();
+  for (int n = threadIdx.x; n < BN; n += NWN * 64) {
+    unsafeAtomicAdd(g.dbeta + n, csum[n]);
+    unsafeAtomicAdd(g.dgamma + n, csum[BN + n]);
   }
 }
 
@@ -1448,7 +1908,7 @@ int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream) {
 }
 
 bool gemm_ln_supported(const GemmLN& g) {
-  return (g.N == 128 || g.N == 256 || g.N == 512) && g.K % 32 == 0 && g.K >= 32 && (g.lda * 2) % 16 == 0 && (g.ldb * 2) % 16 == 0 &&
+  return (g.N == 128 || g.N == 256 || g.N == 512 || g.N == 1024) && g.K % 32 == 0 && g.K >= 32 && (g.lda * 2) % 16 == 0 && (g.ldb * 2) % 16 == 0 &&
          aligned16(g.A) && aligned16(g.B) && aligned16(g.bias) && aligned16(g.gamma) && aligned16(g.beta) && aligned16(g.y) && aligned16(g.x_t) &&
          (g.resid ? aligned16(g.resid) : (aligned16(g.ry) && aligned16(g.rgamma) && aligned16(g.rbeta)));
 }
@@ -1457,6 +1917,13 @@ template <int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g
   static LdsAllowance allowance;
   allowance.ensure(gemm_nt_ln_kernel<NWN, RL, BK>, lds);
   hipLaunchKernelGGL((gemm_nt_ln_kernel<NWN, RL, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
+}
+template <int NWN, bool RL, int BK, int MI, int NJ> static void launch_gemm_ln_wide_t(const GemmLN& g, hipStream_t stream) {
+  constexpr int BM = MI * 32;
+  const size_t lds = std::max<size_t>(2 * (BM + NWN * NJ * 32) * (BK * 2), LnEpiW<NWN, MI, NJ>::BYTES);
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_ln_wide_kernel<NWN, RL, BK, MI, NJ>, lds);
+  hipLaunchKernelGGL((gemm_nt_ln_wide_kernel<NWN, RL, BK, MI, NJ>), dim3((g.M + BM - 1) / BM), dim3(NWN * 64), lds, stream, g);
 }
 int launch_gemm_ln(const GemmLN& g, hipStream_t stream) {
   if (g.M <= 0) return PFN_OK;
@@ -1469,14 +1936,17 @@ int launch_gemm_ln(const GemmLN& g, hipStream_t stream) {
   switch (g.N / 64) {
     case 2: PFN_LN_CASE(2) break;
     case 4: PFN_LN_CASE(4) break;
-    default: PFN_LN_CASE(8) break;
+    case 8: PFN_LN_CASE(8) break;
+    default:   // N = 1024: 64 rows x (8 waves x 128 columns), 32-deep stages (two of them are 136 KiB)
+      if (rl) launch_gemm_ln_wide_t<8, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<8, false, 32, 2, 4>(g, stream);
+      break;
   }
 #undef PFN_LN_CASE
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 
 bool gemm_lnbwd_supported(const GemmLNB& g) {
-  return (g.N == 128 || g.N == 256 || g.N == 512) && g.K % 32 == 0 && g.K >= 32 && (g.lda * 2) % 16 == 0 && (g.ldb * 2) % 16 == 0 &&
+  return (g.N == 128 || g.N == 256 || g.N == 512 || g.N == 1024) && g.K % 32 == 0 && g.K >= 32 && (g.lda * 2) % 16 == 0 && (g.ldb * 2) % 16 == 0 &&
          aligned16(g.A) && aligned16(g.B) && aligned16(g.aux) && aligned16(g.y) && aligned16(g.gamma) && aligned16(g.dx_t) && g.dgamma && g.dbeta;
 }
 template <int NWN, int BK> static void launch_gemm_lnbwd_t(const GemmLNB& g, hipStream_t stream) {
@@ -1485,6 +1955,12 @@ template <int NWN, int BK> static void launch_gemm_lnbwd_t(const GemmLNB& g, hip
   allowance.ensure(gemm_nt_lnbwd_kernel<NWN, BK>, lds);
   hipLaunchKernelGGL((gemm_nt_lnbwd_kernel<NWN, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
 }
+template <int NWN, int BK, int MI, int NJ> static void launch_gemm_lnbwd_wide_t(const GemmLNB& g, hipStream_t stream) {
+  const size_t lds = LnbCfgW<NWN, BK, MI, NJ>::LDS;
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_lnbwd_wide_kernel<NWN, BK, MI, NJ>, lds);
+  hipLaunchKernelGGL((gemm_nt_lnbwd_wide_kernel<NWN, BK, MI, NJ>), dim3((g.M + MI * 32 - 1) / (MI * 32)), dim3(NWN * 64), lds, stream, g);
+}
 int launch_gemm_lnbwd(const GemmLNB& g, hipStream_t stream) {
   if (g.M <= 0) return PFN_OK;
   if (!gemm_lnbwd_supported(g)) return PFN_ERR_UNSUPPORTED;
@@ -1492,7 +1968,8 @@ int launch_gemm_lnbwd(const GemmLNB& g, hipStream_t stream) {
   switch (g.N / 64) {
     case 2: PFN_LNB_CASE(2) break;
     case 4: PFN_LNB_CASE(4) break;
-    default: PFN_LNB_CASE(8) break;
+    case 8: PFN_LNB_CASE(8) break;
+    default: launch_gemm_lnbwd_wide_t<8, 32, 2, 4>(g, stream); break;     // N = 1024: 64-row tiles, 32-deep stages
   }
 #undef PFN_LNB_CASE
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;

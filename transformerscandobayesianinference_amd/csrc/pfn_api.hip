@@ -159,6 +159,7 @@ GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, 
 extern "C" {
 
 static bool g_fuse_lnbwd = true;
+static bool g_fuse_ln_wide = false;   // emsize 1024: the 64-row fused kernels exist and are correct, but lose to GEMM + LayerNorm kernels (PFN_TUNE_FUSE_LN_WIDE)
 int pfn_abi_version(void) { return PFN_ABI_VERSION; }
 int pfn_set_tuning(int key, int value) {
   switch (key) {
@@ -167,6 +168,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_FUSE_LNBWD: g_fuse_lnbwd = value != 0; return PFN_OK;
     case PFN_TUNE_GEMM_PERSIST: set_gemm_nt_persist(value); return PFN_OK;
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
+    case PFN_TUNE_FUSE_LN_WIDE: g_fuse_ln_wide = value != 0; return PFN_OK;
     default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);
   }
 }
@@ -277,7 +279,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   probe.A = w.x0_t; probe.lda = E; probe.B = sh; probe.ldb = E; probe.M = M; probe.N = E; probe.K = E;
   probe.bias = params; probe.gamma = params; probe.beta = params; probe.resid = w.x0; probe.y = w.x0; probe.x_t = w.x0_t;
   // (dropout sits between the bias and the residual add: it takes the unfused GEMM / LayerNorm kernels with an element-wise pass between)
-  const bool fuse_ln = prec == PFN_PREC_BF16 && gemm_ln_supported(probe) && F % 32 == 0 && pdrop == 0.f;
+  const bool fuse_ln = prec == PFN_PREC_BF16 && gemm_ln_supported(probe) && F % 32 == 0 && pdrop == 0.f && (E <= 512 || g_fuse_ln_wide);
   struct Resid { const float* plain; const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; };
   Resid res = {w.x0, nullptr, nullptr, nullptr, nullptr, nullptr};   // where the layer input lives in f32
   auto set_resid = [](GemmLN& g, const Resid& r) {
@@ -449,7 +451,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   // split-K TN kernel does the rest (the register kernel it replaces streamed d(src) at 0.7 TB/s).  Custom encoders
   // (dsrc_sbe), the exact-f32 mode and wide encoders keep the f32 path.
   const bool emb_gemm = !dsrc_sbe && prec == PFN_PREC_BF16 && d->nlayers > 0 && d->num_features + 2 <= EMB_AUG && E % 8 == 0;
-  bool fuse_lnb = g_fuse_lnbwd && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f;   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
+  bool fuse_lnb = g_fuse_lnbwd && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || g_fuse_ln_wide);   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
   if (fuse_lnb) {
     const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
     fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1)) &&
