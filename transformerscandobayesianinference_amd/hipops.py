@@ -91,10 +91,10 @@ def gemm_lnbwd(A, B, aux, y, mean, rstd, gamma, out=None):
 ATTENTION_BWD_PARTS = [
     # (rocprofv3 prints these kernels by their mangled names: its demangler does not know the __bf16 template argument)
     ('attn_bwd: delta = rowsum(dO * O)', '_ZN3pfn17attn_delta_kernelIDF16bEEvNS_8AttnArgsEi', 1, 0.0, 0.0),
-    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', '_ZN3pfn18attn_bwd_kv_kernelIDF16bLi{D}ELi', 2, 3.0, 4.0),
-    ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', '_ZN3pfn18attn_bwd_dq_kernelIDF16bLi{D}EEEvNS_8AttnArgsE', 4, 1.0, 1.0),
+    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', '_ZN3pfn18attn_bwd_kv_kernelIDF16bLi{D}ELi0ELb0', 2, 3.0, 4.0),
+    ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', '_ZN3pfn18attn_bwd_dq_kernelIDF16bLi{D}ELb0', 4, 1.0, 1.0),      # (...ELb0: the variant without the dropout masks)
 ]
-ATTENTION_FWD_ROCPROF = '_ZN3pfn15attn_fwd_kernelIDF16bLi{D}EEEvNS_8AttnArgsE'
+ATTENTION_FWD_ROCPROF = '_ZN3pfn15attn_fwd_kernelIDF16bLi{D}ELb0'
 # (round 2: head dim 256 ran the key-block pass as two launches with one more S product -- {256: 5.0}; round 3: one pass everywhere)
 ATTENTION_BWD_KV_EXECUTED_UNITS = {}
 _bwd_scratch = {}
