@@ -155,7 +155,7 @@ def time_kernel(fn, iters=10, warm=3):
     return start.elapsed_time(stop) / 1e3 / iters
 
 
-def kernel_breakdown(batch, sep, w=WORKLOAD):
+def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False):
     """Isolated timings of the step's kernels at the workload shape (through the single-op C ABI): one entry per kernel
     symbol, with the number of launches per step, so the dominant one can be picked by in-step time."""
     from transformerscandobayesianinference_amd import _hip
@@ -192,6 +192,8 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
 
     def gemm_ln(name, k, count):
         """out_proj / linear2 with bias + residual + LayerNorm in the epilogue (the kernel the step runs when emsize allows)."""
+        if E > 512 and not fused_ln_wide:      # emsize 1024: the stack runs GEMM + LayerNorm kernels unless PFN_TUNE_FUSE_LN_WIDE is set (measured faster)
+            return False
         A, B_ = r(M, k), r(E, k)
         bias, gamma, beta, resid = f32(E), f32(E), f32(E), f32(M, E)
         bufs = (torch.empty(M + 2, E, device=dev), torch.empty(M, E, dtype=bf, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev))
@@ -205,6 +207,8 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
 
     def gemm_lnbwd(name, k, count):
         """a data-gradient GEMM with the backward of the LayerNorm it feeds in the epilogue (what the step runs when emsize allows)"""
+        if E > 512 and not fused_ln_wide:
+            return False
         A, B_, aux = r(M, k), r(E, k), r(M, E)
         y, gamma = f32(M, E), f32(E)
         mean, rstd = y.mean(1), 1 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
@@ -223,6 +227,11 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
         t = time_kernel(lambda: hipops.layernorm_bwd(gA, y, gamma, mean, rstd, Hh.PREC_BF16, want_f32=False))
         add(f'layernorm_bwd[{M}x{E}, operand-precision gradient in and out]', 'layernorm_bwd_kernel', t, 0.0, count)
 
+    def layernorm_fwd(count):
+        x, gamma, beta = f32(M, E), f32(E), f32(E)
+        t = time_kernel(lambda: hipops.layernorm_fwd(x, gamma, beta, 1e-5, Hh.PREC_BF16))
+        add(f'layernorm_fwd[{M}x{E}: f32 in, f32 + operand-precision out]', 'layernorm_fwd_kernel', t, 0.0, count, nbytes=M * E * (4 + 4 + 2))
+
     def wgrad_group():
         # every weight gradient of the stack in ONE grouped launch (pfn_stack_backward defers them)
         probs = []
@@ -238,6 +247,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD):
     gemm('qkv', 3 * E, E, Hh.EPI_BIAS | Hh.EPI_OUT_T, L)
     if not gemm_ln('out_proj', E, L):
         gemm('out_proj + residual', E, E, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
+        layernorm_fwd(2 * L)
     gemm('linear1 + GELU', F, E, Hh.EPI_BIAS | Hh.EPI_GELU | Hh.EPI_OUT_T | Hh.EPI_OUT2_T, L)
     if not gemm_ln('linear2', F, L):
         gemm('linear2 + residual', E, F, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
@@ -655,7 +665,7 @@ def main():
     if world == 1 and not args.no_kernel_breakdown:
         # kernels are launched per micro-batch (column group of the batch, streams.py): time them at THAT shape
         groups = streams if (streams > 1 and batch % streams == 0 and batch >= 2 * streams) else 1
-        ks = kernel_breakdown(batch // groups, int(round(sum(seps) / len(seps))), w)
+        ks = kernel_breakdown(batch // groups, int(round(sum(seps) / len(seps))), w, fused_ln_wide=bool(tuning.get(5)))
         for k in ks:
             k['launches_per_step'] *= groups
             k['step_seconds'] *= groups
