@@ -94,19 +94,26 @@ def gp_sample(batch_size, seq_len, num_features, device, lengthscale, outputscal
     _call_counter[0] += 1
     offset = _call_counter[0]
 
-    def run(noise_vec, y_out, info_out, gx, gz, K_ws):
-        _hip.check(lib.pfn_gp_prior_sample(x.data_ptr(), z.data_ptr(), y_out.data_ptr(), K_ws.data_ptr(), ls.data_ptr(), osc.data_ptr(),
-                                           noise_vec.data_ptr(), B, Tp, F, kernel, int(gx), int(gz), seed & (2 ** 64 - 1),
+    def run(xs, zs, lss, oscs, noise_vec, y_out, info_out, gx, gz, K_ws):
+        _hip.check(lib.pfn_gp_prior_sample(xs.data_ptr(), zs.data_ptr(), y_out.data_ptr(), K_ws.data_ptr(), lss.data_ptr(), oscs.data_ptr(),
+                                           noise_vec.data_ptr(), xs.shape[0], Tp, F, kernel, int(gx), int(gz), seed & (2 ** 64 - 1),
                                            offset, info_out.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_prior_sample')
 
-    run(nz, y, info, gen_x, gen_z, K)
+    run(x, z, ls, osc, nz, y, info, gen_x, gen_z, K)
     del K
     if check:
         def retry(noise_vec, bad):
-            # same (x, z) -- they are on the device now -- with a raised diagonal; only the failed datasets are replaced
-            y2, info2 = torch.empty_like(y), torch.zeros_like(info)
-            run(noise_vec.contiguous(), y2, info2, False, False, torch.empty(B, Tp, Tp, dtype=torch.float32, device=dev))
-            y[bad] = y2[bad]
+            # the FAILED datasets only, from the same (x, z) -- they are on the device now -- with a raised diagonal: the workspace of
+            # the retry is 4 Tp^2 bytes per failed dataset, not another full batch's
+            idx = bad.nonzero(as_tuple=True)[0]
+            n = idx.numel()
+            y2 = torch.empty(n, Tp, dtype=torch.float32, device=dev)
+            info_sub = torch.zeros(n, dtype=torch.int32, device=dev)
+            run(x[idx].contiguous(), z[idx].contiguous(), ls[idx].contiguous(), osc[idx].contiguous(), noise_vec[idx].contiguous(), y2, info_sub,
+                False, False, torch.empty(n, Tp, Tp, dtype=torch.float32, device=dev))
+            y[idx] = y2
+            info2 = torch.zeros_like(info)
+            info2[idx] = info_sub
             return info2
 
         verify = lambda: _with_jitter(retry, nz, info, 'GP prior draw')
