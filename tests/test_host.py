@@ -60,6 +60,15 @@ def test_model_state_dict_keys_match_reference():
         assert layer.linear2.weight.abs().sum() == 0 and layer.self_attn.out_proj.weight.abs().sum() == 0   # transformer.py:49-53
     with pytest.raises(_hip.HipExtensionError):   # CPU tensors never fall back to PyTorch
         m((rec['x'], rec['y']), single_eval_pos=5)
+    # the model descriptor handed to the C ABI (include/pfn_hip.h pfn_model_desc): dropout is part of it, inference defaults to f32 kernels
+    d = TransformerModel(encoders.Linear(3, 64), 8, 64, 2, 128, 2, 0.25, y_encoder=encoders.Linear(1, 64))
+    desc = d._make_desc()
+    assert (desc.num_features, desc.emsize, desc.nhead, desc.nhid, desc.nlayers, desc.n_out) == (3, 64, 2, 128, 2, 8)
+    assert abs(desc.dropout - 0.25) < 1e-7 and desc.precision == _hip.PREC_BF16 and d.eval_precision == 'f32'
+    assert d._make_desc('f32').precision == _hip.PREC_F32
+    assert _hip.lib().pfn_workspace_bytes(desc, 2, 64) > _hip.lib().pfn_workspace_bytes(m._make_desc(), 2, 64) * 0   # (host-only size query works without a GPU)
+    s1, s2 = d._next_dropout_seed(), d._next_dropout_seed()
+    assert s1 != s2 and 0 <= s1 < 2 ** 64
 
 
 def test_schedules_and_samplers_match_reference_values():
