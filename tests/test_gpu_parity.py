@@ -1033,6 +1033,19 @@ def test_custom_decoder_module_vs_oracle(precision):
     tot_err = math.sqrt(sum(((got[k].double().cpu() - v.grad) ** 2).sum().item() for k, v in leaves.items()))
     tot = math.sqrt(sum((v.grad ** 2).sum().item() for v in leaves.values()))
     within(f'{precision} global gradient rel l2', tot_err / tot, 2e-4 if tight else 1.2e-2)
+    # a custom decoder runs in PyTorch (AccumulateGrad's += on views of the shared flat buffer): such a model is NOT split over micro-batch
+    # streams, a plain one is -- and the unsplit pass through MicroBatchStreams reproduces the gradients above
+    from transformerscandobayesianinference_amd.streams import MicroBatchStreams
+    micro = MicroBatchStreams(2)
+    assert micro.groups(model, cfg['B'] * 2) == 1
+    plain = random_model(dict(cfg, nbars=12), precision, seed=41).to(DEV)
+    assert micro.groups(plain, cfg['B'] * 2) == 2
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    micro.forward_backward(model, (x.to(DEV), y.to(DEV)), y.to(DEV), sep,
+                           lambda out, tg: model.criterion(out.reshape(-1, cfg['nbars']), tg[sep:].reshape(-1)).view(out.shape[0], -1))
+    for k, p in model.named_parameters():
+        assert relerr(p.grad, ref_grads[k]) < 1e-6 or ref_grads[k].norm() < 1e-12, k
     # the optimizer's flat buffer covers the decoder module's parameters too
     opt = FusedClipAdam(model, lr=1e-3)
     before = model.decoder.mapper[0].weight.detach().clone()
