@@ -489,7 +489,7 @@ def validation_loss(model, w, device, n=8, seed=4321):
         out['trained'] = dict(source='profiles/' + os.path.basename(TRAINED),
                               notebook_recipe_5_features=dict(pick('notebook_recipe_5_features'), val_bar_nll_at_1755=tr['notebook_recipe_5_features']['val_bar_nll']['value'],
                                                               training_seconds=tr['notebook_recipe_5_features']['training_seconds']),
-                              config2_18_features=dict(pick('config2_18_features_lr3e-4_batch64'), note='still at the prior after 512 k datasets (two recipes)'))
+                              config2_18_features=dict(pick('config2_18_features_lr3e-4_batch64'), note='still at the prior after 512 k datasets under two recipes and after 2.05 M under a third'))
         if 'notebook_recipe_5_features_1M_datasets' in tr:
             k = 'notebook_recipe_5_features_1M_datasets'
             out['trained'][k] = dict(pick(k), val_bar_nll_at_1755=tr[k]['val_bar_nll']['value'], training_seconds=tr[k]['training_seconds'])
