@@ -155,6 +155,24 @@ def time_kernel(fn, iters=10, warm=3):
     return start.elapsed_time(stop) / 1e3 / iters
 
 
+def time_sequence(fns, iters=10, warm=3):
+    """Average duration (s) of each fn() of a launch SEQUENCE run back to back, `iters` times, with a HIP event between consecutive launches
+    on the launch stream: every kernel is timed in the context it runs in (the attention backward's key-block pass is always followed
+    by the query-block pass that reads what it wrote; the same launch repeated on its own queues ten 0.9 GB write bursts behind each
+    other and reads 530-660 us by box where the sequence gives 525-570)."""
+    for _ in range(warm):
+        for fn in fns:
+            fn()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(fns) + 1)] for _ in range(iters)]
+    for it in range(iters):
+        ev[it][0].record()
+        for j, fn in enumerate(fns):
+            fn()
+            ev[it][j + 1].record()
+    torch.cuda.synchronize()
+    return [sum(ev[it][j].elapsed_time(ev[it][j + 1]) for it in range(iters)) / iters / 1e3 for j in range(len(fns))]
+
+
 def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False):
     """Isolated timings of the step's kernels at the workload shape (through the single-op C ABI): one entry per kernel
     symbol, with the number of launches per step, so the dominant one can be picked by in-step time."""
@@ -270,11 +288,13 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False):
     add('attn_fwd', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit, L)
     ctx, lse = hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16)
     dctx = r(batch, S, E)
-    for name, rocprof, part, alg_units, exec_units in hipops.ATTENTION_BWD_PARTS:
+    # the backward's three launches, each timed inside their sequence (delta, key-block pass, query-block pass back to back)
+    seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=part))
+                         for _, _, part, _, _ in hipops.ATTENTION_BWD_PARTS])
+    for (name, rocprof, part, alg_units, exec_units), t in zip(hipops.ATTENTION_BWD_PARTS, seq):
         rocprof = rocprof.format(D=D)
         if part == 2:
             exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
-        t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=part))
         add(name, rocprof, t, alg_units * unit, L, exec_units * unit)
     t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=7))
     out.append(dict(kernel='attn_bwd (whole launch set, for reference)', rocprof_name='attn_bwd_* + attn_delta_kernel', launches_per_step=0,
@@ -696,8 +716,9 @@ def main():
                               'executed_flops_per_launch': dom['executed_flops'], 'executed_frac': dom['executed_tflops'] * 1e12 / MFMA_BF16_PEAK,
                               'avg_launch_us': dom['seconds'] * 1e6, 'launches_per_step': dom['launches_per_step'],
                               'in_step_ms': dom['step_seconds'] * 1e3,
-                              'note': 'dominant kernel by launches x duration; each launch timed alone with HIP events on its stream (inside the step the '
-                                      'micro-batch streams and the sampler stream share the GPU and stretch it by a few percent)'}
+                              'note': 'dominant kernel by launches x duration; every launch timed with HIP events on its stream, without co-runners -- GEMMs and the '
+                                      'attention forward repeated on their own, the attention backward\'s three launches inside their sequence (time_sequence); '
+                                      'in_step_avg_launch_us = the same symbol inside the step, where two micro-batch streams and the sampler share the chip'}
         result['kernels'] = [{k: (round(v, 6) if isinstance(v, float) else v) for k, v in kk.items()} for kk in ks]
     if world == 1 and not args.no_parity:
         result['parity'], inputs = parity_check(model, w, device, args.precision)
