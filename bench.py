@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK = 2.5e15     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 KERNEL_STATS = os.path.join(ROOT, 'profiles', 'r03_bench_kernel_stats.csv')      # rocprofv3 --kernel-trace --stats of the default command
+IN_STEP_ATTENTION = os.path.join(ROOT, 'profiles', 'r03_in_step_attention.json')   # tools/pmc_summary.py: the attention kernels inside the step, from that run's kernel trace
 TRAINED = os.path.join(ROOT, 'profiles', 'r03_trained_config2.json')
 
 # BASELINE.json configs (index = position in the list; 3 is configs[1] on 8 GPUs)
@@ -78,16 +79,20 @@ def pairs(S, sep):
     return S * sep + (S - sep)
 
 
-def fwd_flops(S, sep, nf, E, F, L, n_out):
+def fwd_flops(S, sep, nf, E, F, L, n_out, top_rows_only=False):
     """Algorithmic forward FLOPs of one dataset: embeddings, L layers with mask-aware
-    attention, decoder on the test rows only."""
-    return (2 * S * nf * E + 2 * sep * E
-            + L * (6 * S * E * E + 4 * E * pairs(S, sep) + 2 * S * E * E + 4 * S * E * F)
+    attention, decoder on the test rows only.  top_rows_only: the top layer's train rows feed nothing (the reference returns
+    output[single_eval_pos:]) and the stack does not compute them -- that layer then counts its K / V projection on every row and
+    everything else (Q projection, attention, out_proj, FFN) on the S - sep test rows."""
+    layer = 6 * S * E * E + 4 * E * pairs(S, sep) + 2 * S * E * E + 4 * S * E * F
+    T = S - sep
+    top = (4 * S * E * E + 2 * T * E * E + 4 * E * (T * sep + T) + 2 * T * E * E + 4 * T * E * F) if (top_rows_only and L > 0) else layer
+    return (2 * S * nf * E + 2 * sep * E + max(L - 1, 0) * layer + (top if L > 0 else 0)
             + (S - sep) * (2 * E * F + 2 * F * n_out))
 
 
-def train_flops(S, sep, nf, E, F, L, n_out):
-    return 3 * fwd_flops(S, sep, nf, E, F, L, n_out)
+def train_flops(S, sep, nf, E, F, L, n_out, top_rows_only=False):
+    return 3 * fwd_flops(S, sep, nf, E, F, L, n_out, top_rows_only)
 
 
 def quiet():
@@ -173,14 +178,19 @@ def time_sequence(fns, iters=10, warm=3):
     return [sum(ev[it][j].elapsed_time(ev[it][j + 1]) for it in range(iters)) / iters / 1e3 for j in range(len(fns))]
 
 
-def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False):
+def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None):
     """Isolated timings of the step's kernels at the workload shape (through the single-op C ABI): one entry per kernel
-    symbol, with the number of launches per step, so the dominant one can be picked by in-step time."""
+    symbol, with the number of launches per step, so the dominant one can be picked by in-step time.  top_rows (pfn_top_layer_rows): the rows
+    the top layer runs on behind its K / V projection -- when that is the (S - sep) * batch test rows, L - 1 launches of every row-wise kernel
+    run on all rows and one on those (separate entries)."""
     from transformerscandobayesianinference_amd import _hip
     from transformerscandobayesianinference_amd import hipops
     dev = torch.device('cuda')
     S, E, F, H, L = w['bptt'], w['emsize'], w['nhid'], w['nhead'], w['nlayers']
     M = batch * S
+    Mt = M if top_rows is None else int(top_rows)
+    top = Mt != M                      # the top layer on the test rows only
+    Lf = L - 1 if top else L           # launches of a per-layer kernel on all rows
     bf = torch.bfloat16
     r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(bf)
     f32 = lambda *s: torch.randn(*s, device=dev)
@@ -194,8 +204,10 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False):
                         executed_flops=executed if executed is not None else flops, bytes=nbytes,
                         hbm_floor_us=None if nbytes is None else nbytes / 6.3e12 * 1e6, mfma_floor_us=flops / MFMA_BF16_PEAK * 1e6))
 
-    def gemm(name, n, k, flags, count):
+    def gemm(name, n, k, flags, count, M=M):
         """One encoder GEMM with its REAL epilogue (bias / GELU / residual / output streams), M = batch * bptt rows."""
+        if count <= 0 or M <= 0:
+            return
         A, B_ = r(M, k), r(n, k)
         kw = {}
         if flags & Hh.EPI_BIAS: kw['bias'] = f32(n)
@@ -208,10 +220,12 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False):
         nbytes = sum(v.numel() * v.element_size() for v in [A, B_] + list(kw.values()))
         add(f'gemm_nt[{name} {M}x{n}x{k}]', f'gemm_nt_big_kernel<{flags}, ', t, 2.0 * M * n * k, count, nbytes=nbytes)
 
-    def gemm_ln(name, k, count):
+    def gemm_ln(name, k, count, M=M):
         """out_proj / linear2 with bias + residual + LayerNorm in the epilogue (the kernel the step runs when emsize allows)."""
         if E > 512 and not fused_ln_wide:      # emsize 1024: the stack runs GEMM + LayerNorm kernels unless PFN_TUNE_FUSE_LN_WIDE is set (measured faster)
             return False
+        if count <= 0 or M <= 0:
+            return True
         A, B_ = r(M, k), r(E, k)
         bias, gamma, beta, resid = f32(E), f32(E), f32(E), f32(M, E)
         bufs = (torch.empty(M + 2, E, device=dev), torch.empty(M, E, dtype=bf, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev))
@@ -223,10 +237,12 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False):
         add(f'gemm_nt_ln[{name} + residual + LayerNorm {M}x{E}x{k}]', 'gemm_nt_ln_kernel', t, 2.0 * M * E * k, count, nbytes=nbytes)
         return True
 
-    def gemm_lnbwd(name, k, count):
+    def gemm_lnbwd(name, k, count, M=M):
         """a data-gradient GEMM with the backward of the LayerNorm it feeds in the epilogue (what the step runs when emsize allows)"""
         if E > 512 and not fused_ln_wide:
             return False
+        if count <= 0 or M <= 0:
+            return True
         A, B_, aux = r(M, k), r(E, k), r(M, E)
         y, gamma = f32(M, E), f32(E)
         mean, rstd = y.mean(1), 1 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
@@ -239,63 +255,106 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False):
         add(f'gemm_nt_lnbwd[{name} {M}x{E}x{k}]', 'gemm_nt_lnbwd_kernel', t, 2.0 * M * E * k, count, nbytes=nbytes)
         return True
 
-    def layernorm_bwd(count):
+    def layernorm_bwd(count, M=M):
+        if count <= 0 or M <= 0:
+            return
         gA, y, gamma = r(M, E), f32(M, E), f32(E)
         mean, rstd = y.mean(1), 1 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
         t = time_kernel(lambda: hipops.layernorm_bwd(gA, y, gamma, mean, rstd, Hh.PREC_BF16, want_f32=False))
         add(f'layernorm_bwd[{M}x{E}, operand-precision gradient in and out]', 'layernorm_bwd_kernel', t, 0.0, count)
 
-    def layernorm_fwd(count):
+    def layernorm_fwd(count, M=M):
+        if count <= 0 or M <= 0:
+            return
         x, gamma, beta = f32(M, E), f32(E), f32(E)
         t = time_kernel(lambda: hipops.layernorm_fwd(x, gamma, beta, 1e-5, Hh.PREC_BF16))
         add(f'layernorm_fwd[{M}x{E}: f32 in, f32 + operand-precision out]', 'layernorm_fwd_kernel', t, 0.0, count, nbytes=M * E * (4 + 4 + 2))
 
     def wgrad_group():
-        # every weight gradient of the stack in ONE grouped launch (pfn_stack_backward defers them)
+        # every weight gradient of the stack in ONE grouped launch (pfn_stack_backward defers them); a top layer on the test rows contributes its
+        # K / V / Q projection's gradient there and its other three as a second, short launch over the test rows
         probs = []
-        for _ in range(L):
-            probs += [(r(M, E), r(M, F), torch.zeros(E, F, device=dev), None), (r(M, F), r(M, E), torch.zeros(F, E, device=dev), torch.zeros(F, device=dev)),
-                      (r(M, E), r(M, E), torch.zeros(E, E, device=dev), None), (r(M, 3 * E), r(M, E), torch.zeros(3 * E, E, device=dev), torch.zeros(3 * E, device=dev))]
+        for l in range(L):
+            if not (top and l == L - 1):
+                probs += [(r(M, E), r(M, F), torch.zeros(E, F, device=dev), None), (r(M, F), r(M, E), torch.zeros(F, E, device=dev), torch.zeros(F, device=dev)),
+                          (r(M, E), r(M, E), torch.zeros(E, E, device=dev), None)]
+            probs += [(r(M, 3 * E), r(M, E), torch.zeros(3 * E, E, device=dev), torch.zeros(3 * E, device=dev))]
         nmax = 26
         launches = [probs[i:i + nmax] for i in range(0, len(probs), nmax)]
         t = time_kernel(lambda: [hipops.gemm_tn_group(g, 0) for g in launches], iters=5, warm=2)
-        add(f'gemm_tn_group[{4 * L} weight gradients, {M} tokens, {len(launches)} launch(es)]', 'gemm_tn_big_kernel', t / len(launches),
-            2.0 * M * L * (2 * E * F + 4 * E * E) / len(launches), len(launches))
+        add(f'gemm_tn_group[{len(probs)} weight gradients, {M} tokens, {len(launches)} launch(es)]', 'gemm_tn_big_kernel', t / len(launches),
+            2.0 * M * (Lf * (2 * E * F + E * E) + L * 3 * E * E) / len(launches), len(launches))
+        if top:
+            tp = [(r(Mt, E), r(Mt, F), torch.zeros(E, F, device=dev), None), (r(Mt, F), r(Mt, E), torch.zeros(F, E, device=dev), torch.zeros(F, device=dev)),
+                  (r(Mt, E), r(Mt, E), torch.zeros(E, E, device=dev), None)]
+            t = time_kernel(lambda: hipops.gemm_tn_group(tp, 0), iters=5, warm=2)
+            add(f'gemm_tn_group[top layer: 3 weight gradients, {Mt} test rows]', 'gemm_tn_big_kernel', t, 2.0 * Mt * (2 * E * F + E * E), 1)
 
-    gemm('qkv', 3 * E, E, Hh.EPI_BIAS | Hh.EPI_OUT_T, L)
-    if not gemm_ln('out_proj', E, L):
-        gemm('out_proj + residual', E, E, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
-        layernorm_fwd(2 * L)
-    gemm('linear1 + GELU', F, E, Hh.EPI_BIAS | Hh.EPI_GELU | Hh.EPI_OUT_T | Hh.EPI_OUT2_T, L)
-    if not gemm_ln('linear2', F, L):
-        gemm('linear2 + residual', E, F, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, L)
-    gemm('d(hpre) = dy2.W2 * gelu\'', F, E, Hh.EPI_GELU_BWD | Hh.EPI_OUT_T, L)
-    if gemm_lnbwd('dy1 = LN1 backward of dh.W1 + dy2', F, L):
-        if L > 1:
-            gemm_lnbwd('dy2 = LN2 backward (layer below) of dqkv.Win + dy1', 3 * E, L - 1)
-        gemm('dx = dqkv.Win + dy1 (first layer: gradient of the embedding output)', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, 1)
-        layernorm_bwd(1)
-    else:
-        gemm('dx1 = dh.W1 + dy2', E, F, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
-        gemm('dx = dqkv.Win + dy1', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
-        layernorm_bwd(2 * L)
-    gemm('d(ctx) = dy1.Wo', E, E, Hh.EPI_OUT_T, L)
+    # (`rows`: every per-layer kernel runs Lf times on all rows and, with the top layer on the test rows, once more on those)
+    for rows, cnt, tag in ([(M, Lf, '')] + ([(Mt, 1, 'top layer, test rows: ')] if top else [])):
+        if rows == M:
+            gemm('qkv', 3 * E, E, Hh.EPI_BIAS | Hh.EPI_OUT_T, L)
+        if not gemm_ln(tag + 'out_proj', E, cnt, rows):
+            gemm(tag + 'out_proj + residual', E, E, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, cnt, rows)
+            layernorm_fwd(2 * cnt, rows)
+        gemm(tag + 'linear1 + GELU', F, E, Hh.EPI_BIAS | Hh.EPI_GELU | Hh.EPI_OUT_T | Hh.EPI_OUT2_T, cnt, rows)
+        if not gemm_ln(tag + 'linear2', F, cnt, rows):
+            gemm(tag + 'linear2 + residual', E, F, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, cnt, rows)
+        gemm(tag + 'd(hpre) = dy2.W2 * gelu\'', F, E, Hh.EPI_GELU_BWD | Hh.EPI_OUT_T, cnt, rows)
+        if gemm_lnbwd(tag + 'dy1 = LN1 backward of dh.W1 + dy2', F, cnt, rows):
+            if rows == M:
+                if L > 1:
+                    gemm_lnbwd('dy2 = LN2 backward (layer below) of dqkv.Win + dy1', 3 * E, L - 1)
+                gemm('dx = dqkv.Win + dy1 (first layer: gradient of the embedding output)', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, 1)
+            if rows == Mt:
+                layernorm_bwd(1, rows)          # the top LayerNorm's backward (its gradient comes from the decoder)
+        else:
+            gemm(tag + 'dx1 = dh.W1 + dy2', E, F, Hh.EPI_RESID_T | Hh.EPI_OUT_T, cnt, rows)
+            if rows == M:
+                gemm('dx = dqkv.Win + dy1', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
+            layernorm_bwd(2 * cnt, rows)
+        gemm(tag + 'd(ctx) = dy1.Wo', E, E, Hh.EPI_OUT_T, cnt, rows)
     wgrad_group()
     qkv = r(batch, S, 3 * E)
     D = E // H
-    t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16))
     unit = 2.0 * E * pairs(S, sep) * batch          # one S x keys x head-dim product over all heads
-    add('attn_fwd', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit, L)
     ctx, lse = hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16)
     dctx = r(batch, S, E)
-    # the backward's three launches, each timed inside their sequence (delta, key-block pass, query-block pass back to back)
-    seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=part))
-                         for _, _, part, _, _ in hipops.ATTENTION_BWD_PARTS])
-    for (name, rocprof, part, alg_units, exec_units), t in zip(hipops.ATTENTION_BWD_PARTS, seq):
-        rocprof = rocprof.format(D=D)
-        if part == 2:
-            exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
-        add(name, rocprof, t, alg_units * unit, L, exec_units * unit)
+    if Lf > 0:
+        t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16))
+        add('attn_fwd', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit, Lf)
+        # the backward's three launches, each timed inside their sequence (delta, key-block pass, query-block pass back to back)
+        seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=part))
+                             for _, _, part, _, _ in hipops.ATTENTION_BWD_PARTS])
+        for (name, rocprof, part, alg_units, exec_units), t in zip(hipops.ATTENTION_BWD_PARTS, seq):
+            rocprof = rocprof.format(D=D)
+            if part == 2:
+                exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
+            add(name, rocprof, t, alg_units * unit, Lf, exec_units * unit)
+    if top:
+        # the top layer's attention: the queries >= sep only (q_begin; the kernels start at the query block that holds sep)
+        unit_t = 2.0 * E * ((S - sep) * sep + (S - sep)) * batch
+        q0 = sep // 256 * 256
+        unit_x = 2.0 * E * ((S - q0) * sep + (S - sep)) * batch          # executed: whole query blocks
+        dctx_t = dctx.clone()
+        dctx_t[:, :sep] = 0
+        bufs_t = (torch.empty_like(ctx), torch.empty_like(lse))
+        t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16, q_begin=sep, out=bufs_t))
+        add('top layer: attn_fwd for the queries >= sep', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit_t, 1, 2 * unit_x)
+        seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx_t, H, sep, _hip.PREC_BF16, parts=part, q_begin=sep))
+                             for _, _, part, _, _ in hipops.ATTENTION_BWD_PARTS])
+        for (name, rocprof, part, alg_units, exec_units), t in zip(hipops.ATTENTION_BWD_PARTS, seq):
+            if part == 2:
+                exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
+            add('top layer, queries >= sep: ' + name, rocprof.format(D=D), t, alg_units * unit_t, 1, exec_units * unit_x)
+        # ... and its row moves: attention output / layer input gathered, d(attention output) / LayerNorm-input gradient scattered back
+        c_t, y32 = r(batch, S, E), f32(batch, S, E)
+        g_t = r(Mt, E)
+        o1, o2, o3 = torch.empty(Mt, E, dtype=bf, device=dev), torch.empty(Mt, E, device=dev), torch.empty(batch, S, E, dtype=bf, device=dev)
+        t = time_kernel(lambda: (hipops.gather_rows(c_t, sep, out=o1), hipops.gather_rows(y32, sep, out=o2), hipops.scatter_rows(g_t, batch, S, sep, q0, out=o3),
+                                 hipops.scatter_rows(g_t, batch, S, sep, 0, out=o3)))
+        add('top layer: test rows gathered (attention output, layer input) and scattered back (2 gradients)', 'gather_rows_kernel / scatter_rows_kernel', t, 0.0, 1,
+            nbytes=(S - sep) * batch * E * (2 * 2 + 4 * 2 + 2 + 2) + M * E * 2)
     t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=7))
     out.append(dict(kernel='attn_bwd (whole launch set, for reference)', rocprof_name='attn_bwd_* + attn_delta_kernel', launches_per_step=0,
                     seconds=t, flops=4 * unit, executed_flops=(hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, 4.0) + 1.0) * unit))
@@ -562,8 +621,8 @@ def main():
     torch.cuda.set_device(device)
     w = CONFIGS[args.config]
     tuning = {int(k): int(v) for k, v in (kv.split('=') for kv in args.tune.split(',') if kv)}
+    from transformerscandobayesianinference_amd import _hip
     for k, v in tuning.items():
-        from transformerscandobayesianinference_amd import _hip
         _hip.check(_hip.lib().pfn_set_tuning(k, v), 'pfn_set_tuning')
     batch = args.batch or w['batch']
     streams = args.streams or w['streams']
@@ -658,7 +717,11 @@ def main():
     if rank != 0:
         return
     total = batch * world * args.steps
-    step_flops = sum(train_flops(S, s, nf, E, F, L, O) for s in seps) * batch * world
+    import ctypes
+    lib, desc = _hip.lib(), model._make_desc()
+    top_rows_of = lambda rows, s: int(lib.pfn_top_layer_rows(ctypes.byref(desc), rows, S, s, 0))     # rows the top layer runs on (all, or the test rows only)
+    step_flops = sum(train_flops(S, s, nf, E, F, L, O) for s in seps) * batch * world               # the reference's graph
+    needed_flops = sum(train_flops(S, s, nf, E, F, L, O, top_rows_of(1, s) != S) for s in seps) * batch * world
     result = {
         'metric': w['metric'], 'value': total / elapsed, 'unit': 'datasets/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -668,8 +731,12 @@ def main():
                    'per_gpu_batch': batch, 'global_batch': batch * world, 'seq_len': S, 'parallelism': f'dp{world}', 'micro_batch_streams': streams,
                    'eval_pos': f"{w['eval_pos']} sampler({S})" if args.fixed_sep is None else args.fixed_sep, 'mean_sep': sum(seps) / len(seps),
                    'sampler_group_steps': group, 'final_loss': final_loss},
-        'step_roofline': {'bound': 'mfma', 'achieved': step_flops / elapsed / 1e12 / world, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                          'frac': step_flops / elapsed / world / MFMA_BF16_PEAK, 'note': 'whole step per GPU, algorithmic mask-aware FLOPs 3*fwd(S,sep)'},
+        'step_roofline': {'bound': 'mfma', 'achieved': needed_flops / elapsed / 1e12 / world, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                          'frac': needed_flops / elapsed / world / MFMA_BF16_PEAK,
+                          'reference_graph_frac': step_flops / elapsed / world / MFMA_BF16_PEAK,
+                          'note': 'whole step per GPU, algorithmic mask-aware FLOPs 3*fwd(S,sep).  `frac` counts what the result needs: the top encoder layer\'s train '
+                                  'rows feed nothing (the reference returns output[single_eval_pos:]) and are not computed (pfn_top_layer_rows); '
+                                  '`reference_graph_frac` counts the reference\'s graph, which computes and discards them (the figure of rounds 1-2)'},
     }
     if tuning:
         result['config']['tuning'] = tuning
@@ -688,7 +755,8 @@ def main():
     if world == 1 and not args.no_kernel_breakdown:
         # kernels are launched per micro-batch (column group of the batch, streams.py): time them at THAT shape
         groups = streams if (streams > 1 and batch % streams == 0 and batch >= 2 * streams) else 1
-        ks = kernel_breakdown(batch // groups, int(round(sum(seps) / len(seps))), w, fused_ln_wide=bool(tuning.get(5)))
+        mean_sep = int(round(sum(seps) / len(seps)))
+        ks = kernel_breakdown(batch // groups, mean_sep, w, fused_ln_wide=bool(tuning.get(5)), top_rows=top_rows_of(batch // groups, mean_sep))
         for k in ks:
             k['launches_per_step'] *= groups
             k['step_seconds'] *= groups
@@ -696,12 +764,19 @@ def main():
         traffic, traffic_src = None, None
         pmc = json.load(open(PMC_TRAFFIC)) if os.path.exists(PMC_TRAFFIC) else {}
         if pmc.get('config', 2) == args.config and pmc.get('batch') == batch and pmc.get('streams', 1) == streams:   # PMC passes of this command
-            hit = [v for name, v in pmc.get('kernels', {}).items() if name.startswith(dom['rocprof_name'])]
+            hit = [v for name, v in pmc.get('kernels', {}).items() if name.startswith(dom['rocprof_name']) and 'top layer' not in name]   # (the top layer's short launches are listed apart)
             if hit:
                 traffic = hit[0].get('read_bytes', 0) + hit[0].get('write_bytes', 0)
                 traffic_src = f"profiles/{os.path.basename(PMC_TRAFFIC)} ({pmc.get('note', '')})"
         in_step_us, in_step_src = None, None
-        if os.path.exists(KERNEL_STATS) and args.config == 2 and batch == w['batch'] and streams == w['streams']:
+        if os.path.exists(IN_STEP_ATTENTION) and args.config == 2 and batch == w['batch'] and streams == w['streams']:
+            # the kernel trace of THIS command, the top layer's short launches (queries >= sep only) apart from the full ones (tools/pmc_summary.py)
+            for name, v in json.load(open(IN_STEP_ATTENTION)).get('kernels', {}).items():
+                if name.startswith(dom['rocprof_name']) and 'top layer' not in name:
+                    in_step_us = v['avg_us']
+                    in_step_src = (f'profiles/{os.path.basename(IN_STEP_ATTENTION)} (rocprofv3 --kernel-trace of this command: two micro-batch streams + the sampler share '
+                                   f'the chip; {v["calls"]} launches on every query, the top layer\'s short launches listed apart)')
+        if in_step_us is None and os.path.exists(KERNEL_STATS) and args.config == 2 and batch == w['batch'] and streams == w['streams']:
             import csv
             for row in csv.DictReader(open(KERNEL_STATS)):      # the committed rocprofv3 trace of THIS command: the same symbol inside the step
                 if row.get('Name', '').startswith(dom['rocprof_name']):

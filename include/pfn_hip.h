@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 4
+#define PFN_ABI_VERSION 5
 
 enum {
   PFN_OK = 0,
@@ -72,8 +72,10 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_FUSE_LNBWD = 2,
        PFN_TUNE_GEMM_PERSIST = 3, /* workgroups of the persistent 256x256 NT GEMM (one per CU walking tiles); 0 = the one-tile-per-workgroup kernel */
        PFN_TUNE_ATTN_PINGPONG = 4, /* bit 0: attention forward, bit 1: backward key-block pass -- the two waves of a SIMD run half a tile apart (default: see attention.hip) */
-       PFN_TUNE_FUSE_LN_WIDE = 5   /* 1: emsize 1024 runs the LayerNorm-fused GEMMs on 64-row x 1024-column tiles (gemm_nt_ln_wide / lnbwd_wide); 0 (default): the
-                                    * 256 x 256 GEMM + LayerNorm kernels -- measured faster at that width */ };
+       PFN_TUNE_FUSE_LN_WIDE = 5,  /* 1: emsize 1024 runs the LayerNorm-fused GEMMs on 64-row x 1024-column tiles (gemm_nt_ln_wide / lnbwd_wide); 0 (default): the
+                                    * 256 x 256 GEMM + LayerNorm kernels -- measured faster at that width */
+       PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
+                                    * returns output[single_eval_pos:] (transformer.py:91), so that layer's train rows feed nothing; 0: every layer on every row */ };
 int pfn_set_tuning(int key, int value);
 
 /* ---- parameter packing ------------------------------------------------------------------------
@@ -99,6 +101,10 @@ int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shado
  * src_sbe: optional [T,B,E] f32 pre-embedded input (custom encoders / positional encodings run
  * in PyTorch); when non-NULL x/y are ignored and pfn_stack_backward returns d(src) in dsrc_sbe. */
 int64_t pfn_workspace_bytes(const pfn_model_desc* d, int B, int S);
+/* Rows the TOP encoder layer runs on behind its K / V projection for this call shape: (S - sep) * B when the stack drops that layer's train rows
+ * (they feed nothing: the reference returns output[single_eval_pos:], transformer.py:91 -- PFN_TUNE_TOP_LAYER_TEST_ROWS, on by default; not with live
+ * dropout, not when sep < S / 4), else B * S.  Same results either way; bench.py counts FLOPs and launches with it. */
+int64_t pfn_top_layer_rows(const pfn_model_desc* d, int B, int S, int sep, int use_dropout);
 int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* shadow,
                       const float* x, int64_t x_st, int64_t x_sb,
                       const float* y, int64_t y_st, int64_t y_sb,
@@ -246,6 +252,19 @@ int64_t pfn_op_attention_bwd_ws_bytes(int B, int S, int H, int prec);
 int pfn_op_attention_bwd(const void* qkv, const void* ctx, const float* lse, const void* dctx,
                          void* dqkv, float* delta_ws, void* ds_ws, int B, int S, int E, int H, int sep,
                          int prec, int parts, void* stream);
+/* The same two with the queries below q_begin skipped (q_begin is rounded DOWN to a multiple of 256 = whole query blocks of every kernel): their
+ * ctx / lse rows are not written; in the backward they add nothing to dK / dV and their dQ rows are zeros.  dctx must be zero in
+ * [q_begin rounded down, first row that carries a gradient).  This is how the stack runs its TOP layer, whose train rows feed nothing
+ * (the reference returns output[single_eval_pos:], transformer.py:91): q_begin = sep. */
+int pfn_op_attention_fwd_from(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep, int q_begin,
+                              int prec, void* stream);
+int pfn_op_attention_bwd_from(const void* qkv, const void* ctx, const float* lse, const void* dctx,
+                              void* dqkv, float* delta_ws, void* ds_ws, int B, int S, int E, int H, int sep, int q_begin,
+                              int prec, int parts, void* stream);
+/* Rows of [B, S] token order <-> the decoder's compact test-row order [(S - sep), B] (row bytes a multiple of 4); the scatter
+ * writes zeros into rows [zero_from, sep) and leaves rows below zero_from alone. */
+int pfn_op_gather_rows(const void* src_bs, void* dst_tb, int B, int S, int64_t row_bytes, int sep, void* stream);
+int pfn_op_scatter_rows(const void* src_tb, void* dst_bs, int B, int S, int64_t row_bytes, int sep, int zero_from, void* stream);
 int pfn_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
                          float* mean, float* rstd, int64_t rows, int E, float eps, int prec, void* stream);
 /* dy: f32 when dy_is_t == 0, operand precision (prec) otherwise -- the form the backward schedule feeds it;

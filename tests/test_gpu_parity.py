@@ -13,6 +13,7 @@ Tolerances (north_star: NLL and posterior-predictive means within 1e-3 relative)
     in profiles/r03_parity_measured.json (`within`, tests/bounds.py); the gradient at the BENCHMARKED shapes against the f64 oracle is
     in profiles/r03_grad_parity.json (tools/grad_parity.py: 6.1e-3 at configs[1], 5.0e-3 at the configs[4] slice).
 """
+import ctypes
 import math
 import os
 import random
@@ -1051,6 +1052,62 @@ def test_custom_decoder_module_vs_oracle(precision):
     before = model.decoder.mapper[0].weight.detach().clone()
     opt.step(zero_grad=True)
     assert not torch.equal(before, model.decoder.mapper[0].weight.detach())
+
+
+@pytest.mark.parametrize('decoder', ['built-in', 'module'])
+@pytest.mark.parametrize('L', [1, 3])
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_top_layer_on_the_test_rows_equals_every_layer_on_every_row(precision, L, decoder):
+    """The reference returns output[single_eval_pos:] (transformer.py:91): the top encoder layer's train rows feed nothing, and the stack runs that
+    layer on the test rows only (PFN_TUNE_TOP_LAYER_TEST_ROWS, include/pfn_hip.h).  Same logits and the same gradient of every parameter as the
+    schedule that runs every layer on every row (the oracle comparisons of this file all run with the default, i.e. the shortened schedule)."""
+    from transformerscandobayesianinference_amd import decoders
+    cfg = dict(T=600, B=3, F=5, E=128, H=2, nhid=256, L=L, nbars=20)
+    sep = 437                                                      # first query block the attention kernels touch: 256
+    desc = None
+    results = {}
+    try:
+        for mode in (1, 0):
+            _hip.check(_hip.lib().pfn_set_tuning(6, mode), 'tuning')
+            if decoder == 'module':
+                torch.manual_seed(7)
+                borders = torch.sort(torch.randn(cfg['nbars'] + 1) * 1.5)[0]
+                model = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], 0.0,
+                                         y_encoder=encoders.Linear(1, cfg['E']), decoder=decoders.FixedScaledDecoder, precision=precision, eval_precision=precision)
+                model.criterion = bar_distribution.FullSupportBarDistribution(borders)
+                with torch.no_grad():
+                    for layer in model.transformer_encoder.layers:
+                        for t in (layer.linear2.weight, layer.self_attn.out_proj.weight):
+                            t.normal_(0, 0.03)
+            else:
+                model = random_model(cfg, precision, seed=7)
+            model = model.to(DEV).train()
+            desc = model._make_desc()
+            rows = _hip.lib().pfn_top_layer_rows(ctypes.byref(desc), cfg['B'], cfg['T'], sep, 0)
+            assert rows == ((cfg['T'] - sep) * cfg['B'] if mode else cfg['T'] * cfg['B'])
+            g = torch.Generator().manual_seed(9)
+            x, y = torch.rand(cfg['T'], cfg['B'], cfg['F'], generator=g).to(DEV), torch.randn(cfg['T'], cfg['B'], generator=g).to(DEV)
+            logits = model((x, y), single_eval_pos=sep)
+            model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].flatten()).mean().backward()
+            with torch.no_grad():
+                model.eval()
+                infer = model((x, y), single_eval_pos=sep)
+            results[mode] = (logits.detach().clone(), infer.clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    finally:
+        _hip.check(_hip.lib().pfn_set_tuning(6, 1), 'tuning')
+    tight = precision == 'f32'
+    # (bf16: the row-wise products are the same instructions on the same rows; what differs is the f32 decoder gradient entering the top LayerNorm's
+    # backward unrounded, and the summation order of the weight gradients over fewer rows)
+    within(f'{precision} top-layer schedules: logits rel l2', relerr(results[1][0], results[0][0]), 1e-6 if tight else 1e-5)
+    within(f'{precision} top-layer schedules: inference logits rel l2', relerr(results[1][1], results[0][1]), 1e-6 if tight else 1e-5)
+    for k, g0 in results[0][2].items():
+        if g0.norm() < 1e-12:
+            assert results[1][2][k].norm() < 1e-9, k
+            continue
+        within(f'{precision} top-layer schedules: gradient rel l2', relerr(results[1][2][k], g0), 1e-5 if tight else 6e-3)
+    # short train parts keep every row (nothing to gain) and dropout does too (its masks are indexed by the full-layout row)
+    assert _hip.lib().pfn_top_layer_rows(ctypes.byref(desc), cfg['B'], cfg['T'], cfg['T'] // 4 - 1, 0) == cfg['T'] * cfg['B']
+    assert _hip.lib().pfn_top_layer_rows(ctypes.byref(desc), cfg['B'], cfg['T'], cfg['T'], 0) == cfg['T'] * cfg['B']
 
 
 def test_trained_checkpoint_parity():

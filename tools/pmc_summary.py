@@ -16,6 +16,34 @@ def short(n):
     return n.replace('void ', '').replace('pfn::', '')[:64]
 
 
+TOP = ' [top layer: queries >= sep]'
+
+
+def top_layer_dispatches(rows, grid_key):
+    """The attention launches of the TOP encoder layer skip the queries below sep (pfn_api.hip): the forward and the query-block pass then run a
+    smaller grid, the delta kernel and the key-block pass the usual one.  Returns the Dispatch_Ids of a top-layer launch set: per queue (= HIP
+    stream) in dispatch order, a forward / query-block launch with less than the largest grid of its symbol, and the delta and key-block launches
+    in front of such a query-block launch."""
+    full = {}
+    for r in rows:
+        n = r['Kernel_Name']
+        if 'attn_fwd_kernel' in n or 'attn_bwd_dq_kernel' in n:
+            full[n] = max(full.get(n, 0), int(r[grid_key]))
+    top, pending = set(), {}
+    for r in sorted(rows, key=lambda r: int(r['Dispatch_Id'])):
+        n, q = r['Kernel_Name'], r['Queue_Id']
+        if 'attn_fwd_kernel' in n and int(r[grid_key]) < full[n]:
+            top.add(r['Dispatch_Id'])
+        elif 'attn_delta_kernel' in n or 'attn_bwd_kv_kernel' in n:
+            pending.setdefault(q, []).append(r['Dispatch_Id'])
+        elif 'attn_bwd_dq_kernel' in n:
+            if int(r[grid_key]) < full[n]:
+                top.add(r['Dispatch_Id'])
+                top.update(pending.get(q, []))
+            pending[q] = []
+    return top
+
+
 def main():
     import json
     out = sys.argv[1]
@@ -27,6 +55,24 @@ def main():
         print(f'{"kernel":66s} {"calls":>7s} {"total_ms":>10s} {"avg_us":>10s} {"pct":>6s}')
         for r in rows[:28]:
             print(f'{short(r["Name"]):66s} {int(r["Calls"]):7d} {float(r["TotalDurationNs"]) / 1e6:10.3f} {float(r["AverageNs"]) / 1e3:10.2f} {float(r["Percentage"]):6.2f}')
+    tr = find(os.path.join(out, 'stats'), '*kernel_trace.csv')
+    if tr:
+        # the attention kernels' in-step durations, the top layer's short launches (queries >= sep only) apart from the others
+        rows = [r for r in csv.DictReader(open(tr)) if 'attn_' in r['Kernel_Name']]
+        top = top_layer_dispatches(rows, 'Grid_Size_X')
+        agg = {}
+        for r in rows:
+            a = agg.setdefault((r['Kernel_Name'], r['Dispatch_Id'] in top), [0, 0.0])
+            a[0] += 1
+            a[1] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+        print('== attention kernels inside the step (kernel trace of the same run), top-layer launches apart ==')
+        in_step = {}
+        for (name, is_top), (n, ns) in sorted(agg.items()):
+            print(f'{short(name) + (TOP if is_top else ""):96s} n={n:5d} avg_us={ns / n / 1e3:10.2f}')
+            in_step[name + (TOP if is_top else '')] = {'calls': n, 'avg_us': ns / n / 1e3}
+        json.dump({'note': 'rocprofv3 --kernel-trace of bench.py --steps 10 --warmup 3 (tools/profile_bench.sh): average in-step duration per attention kernel; the top '
+                           'encoder layer\'s launches (queries >= sep only, told by the grid of the forward / query-block pass) are listed apart', 'kernels': in_step},
+                  open(os.path.join(out, 'in_step_attention.json'), 'w'), indent=1)
     for d in sorted(glob.glob(os.path.join(out, 'pmc_*'))):
         if not os.path.isdir(d):
             continue
@@ -35,13 +81,15 @@ def main():
             print('no counter csv under', d)
             continue
         agg = {}
-        for r in csv.DictReader(open(cc)):
-            k = (short(r['Kernel_Name']), r['Counter_Name'])
+        crow = list(csv.DictReader(open(cc)))
+        top = top_layer_dispatches([r for r in crow if 'attn_' in r['Kernel_Name']], 'Grid_Size')
+        for r in crow:
+            k = (short(r['Kernel_Name']) + (TOP if r['Dispatch_Id'] in top else ''), r['Counter_Name'])
             a = agg.setdefault(k, [0, 0.0])
             a[0] += 1
             a[1] += float(r['Counter_Value'])
         print(f'== PMC pass {os.path.basename(d)} (average per launch) ==')
-        for (k, c), (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+        for (k, c), (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
             avg = v / n
             extra = ''
             if c == 'FETCH_SIZE':

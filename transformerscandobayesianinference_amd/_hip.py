@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpfn_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 PREC_BF16 = 0
 PREC_F32 = 1
@@ -54,6 +54,7 @@ SIGNATURES = {
     'pfn_shadow_bytes': (_L, [_D]),
     'pfn_prepare_params': (_I, [_D, _P, _P, _P]),
     'pfn_workspace_bytes': (_L, [_D, _I, _I]),
+    'pfn_top_layer_rows': (_L, [_D, _I, _I, _I, _I]),
     'pfn_stack_forward': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P, _L, _P, _P]),
     'pfn_stack_backward': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P]),
     'pfn_stack_forward_dropout': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P, _L, _P, _P, _U64]),
@@ -72,6 +73,10 @@ SIGNATURES = {
     'pfn_op_gemm_lnbwd': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pfn_op_attention_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_attention_bwd_ws_bytes': (_L, [_I, _I, _I, _I]),
+    'pfn_op_attention_fwd_from': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'pfn_op_attention_bwd_from': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'pfn_op_gather_rows': (_I, [_P, _P, _I, _I, _L, _I, _P]),
+    'pfn_op_scatter_rows': (_I, [_P, _P, _I, _I, _L, _I, _I, _P]),
     'pfn_op_attention_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_layernorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
     'pfn_op_layernorm_bwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),

@@ -189,7 +189,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   auto Vt = [&](int buf) { return smem + 2 * C::RIMG + buf * C::CIMG; };
   constexpr int NVB = 4;
 
-  const AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
+  AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK, a.H);
+  wg.blk += a.q_begin / C::QBLK;      // (q_begin: a multiple of 256, i.e. whole query blocks)
   const int b = wg.b, hd = wg.hd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
   // PING-PONG (8-wave configurations): a SIMD holds waves w and w + 4.  With one barrier at the end of every tile all eight waves
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, int D) {
   for (long pr = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pr < pairs; pr += (long)gridDim.x * 16) {
     const long tok = pr / a.H;
     const int hd = (int)(pr % a.H);
+    if ((int)(tok % a.S) < a.q_begin) continue;      // (uniform over the 16-lane group; no wave-wide operation below)
     const T* o = reinterpret_cast<const T*>(a.ctx) + tok * a.E + hd * D;
     const T* d = reinterpret_cast<const T*>(a.dctx) + tok * a.E + hd * D;
     float s = 0.f;
@@ -622,13 +624,14 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     if (wave == 0) { if (lane < QB) dma4(rl, St(buf), (lane + q0) * 4); }
     else if (wave == 1) { if (lane < QB) dma4(rdl, St(buf) + QB * 4, (lane + q0) * 4); }
   };
-  dma(0, 0);
-  stage_stats(0, 0);
+  const int t0 = a.q_begin / QB;      // first query tile (0 unless the caller skips the queries below q_begin: AttnArgs)
+  dma(0, t0);
+  stage_stats(0, t0 * QB);
   dma_wait_all();
   __syncthreads();
-  if (!(ABL & 1) && ntiles > 1) {     // tile 1 -> the second buffer; from here on a tile's successor-but-one is requested at its end
-    dma(1, 1);
-    stage_stats(1, QB);
+  if (!(ABL & 1) && t0 + 1 < ntiles) {     // the second tile -> the second buffer; from here on a tile's successor-but-one is requested at its end
+    dma(1, t0 + 1);
+    stage_stats(1, (t0 + 1) * QB);
   }
   constexpr int DS_STORES = DO_DK && !(KVABL & 1) ? (sizeof(T) == 2 ? 2 : 4) : 0;   // store instructions of one tile's dS^T per wave
   bool stored = false;                // this wave's dS^T stores of the previous tile may still be in flight
@@ -797,7 +800,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  for (int t = 0; t < ntiles; t += 2) {
+  for (int t = t0; t < ntiles; t += 2) {
     tile(I0{}, t);
     if (t + 1 < ntiles) tile(I1{}, t + 1);
   }
@@ -889,7 +892,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   LdsPtr smem = lds_cast(smem_raw);
   auto Kc = [&](int slot) { return smem + C::NW * Q::NDS * Q::DSW + slot * C::CIMG; };
 
-  AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK, a.H);
+  AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK, a.H);
+  wg.blk += a.q_begin / C::QBLK;    // (q_begin: AttnArgs; the launcher zero-fills the dQ rows below it)
   wg.b = a.B - 1 - wg.b;            // most recently written dS^T first (see above)
   wg.hd = a.H - 1 - wg.hd;
   const int b = wg.b, hd = wg.hd;
@@ -1104,7 +1108,8 @@ template <typename T, int D, bool DROP> static int launch_fwd_k(const AttnArgs& 
   const size_t lds = 2 * C::RIMG + 4 * C::CIMG;
   static LdsAllowance allowance;
   allowance.ensure(attn_fwd_kernel<T, D, DROP>, lds);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
+  if ((a.S + C::QBLK - 1) / C::QBLK <= a.q_begin / C::QBLK) return PFN_OK;      // no query at or above q_begin
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
@@ -1135,8 +1140,13 @@ template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& 
     }
   }
   if (parts & ATTN_BWD_DQ) {
+    if (a.q_begin > 0) {      // dQ of the skipped queries: zeros (every row of dqkv is read by the GEMMs behind this launch)
+      const int rc = launch_zero_row_prefix(a.dqkv, a.S, a.B, a.q_begin, 3L * a.E * (long)sizeof(T), (long)a.E * (long)sizeof(T), s);
+      if (rc != PFN_OK) return rc;
+    }
+    if ((a.S + C::QBLK - 1) / C::QBLK <= a.q_begin / C::QBLK) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
     allow_dq.ensure(attn_bwd_dq_kernel<T, D, DROP>, lds_dq);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK) * a.H * a.B), dim3(C::NT), lds_dq, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK) * a.H * a.B), dim3(C::NT), lds_dq, s, a);
   }
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
@@ -1146,7 +1156,7 @@ template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStrea
 
 static int check_attn(const AttnArgs& a, int precision) {
   if (a.B <= 0 || a.S <= 0 || a.H <= 0 || a.E % a.H) return PFN_ERR_ARGUMENT;
-  if (a.sep < 0 || a.sep > a.S) return PFN_ERR_ARGUMENT;
+  if (a.sep < 0 || a.sep > a.S || a.q_begin < 0 || a.q_begin > a.S) return PFN_ERR_ARGUMENT;
   const int es = precision == PFN_PREC_BF16 ? 2 : 4;
   if ((a.E * es) % 16) return PFN_ERR_ALIGNMENT;
   return PFN_OK;
@@ -1178,6 +1188,7 @@ int launch_attn_fwd(const AttnArgs& a_in, int precision, hipStream_t s) {
   if (rc != PFN_OK) return rc;
   AttnArgs a = a_in;
   a.pingpong = g_attn_pingpong;
+  a.q_begin = a.q_begin / 256 * 256;
   PFN_ATTN_DISPATCH(launch_fwd_t)
 }
 void attn_bwd_ds_dims(int S, int sep, int* rows, int* ld) {
@@ -1195,6 +1206,7 @@ int launch_attn_bwd(const AttnArgs& a_in, int precision, hipStream_t s) {
   if (!a_in.ds) return PFN_ERR_ARGUMENT;
   AttnArgs a = a_in;
   attn_bwd_ds_dims(a.S, a.sep, &a.ds_rows, &a.ds_ld);
+  a.q_begin = a.q_begin / 256 * 256;
   PFN_ATTN_DISPATCH(launch_bwd_t)
 }
 

@@ -108,6 +108,9 @@ struct Ws {
   float *dxt, *gA, *delta;   // gA: f32 gradient of the embedding output (the last dx of the backward)
   char* ds;                  // dS^T of the attention backward (key-block pass -> query-block pass), one layer at a time
   char* gA_t;                // gradient w.r.t. a layer's output between layers, operand precision
+  // the top layer on the test rows only (top_layer_on_test_rows below): compact [S - sep, B] row order
+  char *top_ctx_t, *top_dy1_t, *top_dctx_t;   // attention output / LN1-input gradient / d(attention output) of the test rows
+  float *top_ry, *top_rmean, *top_rrstd;      // the layer input (the residual of its first LayerNorm) of the test rows
   int64_t bytes;
 };
 
@@ -137,6 +140,8 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   w.dctx_t = take(M * E * es);
   w.delta = (float*)take(2 * (int64_t)B * d.nhead * S * 4);      // [delta | lse in log2 units], both [B,H,S] (attn_delta_kernel)
   w.ds = take(attn_bwd_ds_bytes(B, S, d.nhead, d.precision));
+  w.top_ctx_t = take(M * E * es); w.top_dy1_t = take(M * E * es); w.top_dctx_t = take(M * E * es);
+  w.top_ry = (float*)take(M * E * 4); w.top_rmean = (float*)take(M * 4); w.top_rrstd = (float*)take(M * 4);
   w.bytes = cur;
   return w;
 }
@@ -159,6 +164,15 @@ GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, 
 extern "C" {
 
 static bool g_fuse_lnbwd = true;
+// The reference returns output[single_eval_pos:] (transformer.py:91): the TOP encoder layer's train rows feed nothing -- no later layer reads
+// them as keys, the decoder and the loss never see them, their gradient is zero.  So everything of that layer behind its K / V projection runs on
+// the test rows only, in the decoder's compact row order: the attention for the queries >= sep, out_proj / LayerNorm / FFN on (S - sep) B rows,
+// and the same in the backward (zero rows dropped from every product).  Same results row for row; at the north star (sep ~ 0.8 S) it removes
+// ~80 % of one layer in six.  Off with dropout (the masks are indexed by the full-layout row) and when fewer than a quarter of the rows are train rows.
+static bool g_top_test_rows = true;
+static bool top_layer_on_test_rows(const pfn_model_desc& d, int S, int sep, float pdrop) {
+  return g_top_test_rows && d.nlayers > 0 && pdrop == 0.f && sep < S && 4L * sep >= S;
+}
 static bool g_fuse_ln_wide = false;   // emsize 1024: the 64-row fused kernels exist and are correct, but lose to GEMM + LayerNorm kernels (PFN_TUNE_FUSE_LN_WIDE)
 int pfn_abi_version(void) { return PFN_ABI_VERSION; }
 int pfn_set_tuning(int key, int value) {
@@ -169,6 +183,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_GEMM_PERSIST: set_gemm_nt_persist(value); return PFN_OK;
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
     case PFN_TUNE_FUSE_LN_WIDE: g_fuse_ln_wide = value != 0; return PFN_OK;
+    case PFN_TUNE_TOP_LAYER_TEST_ROWS: g_top_test_rows = value != 0; return PFN_OK;
     default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);
   }
 }
@@ -197,6 +212,11 @@ int64_t pfn_shadow_bytes(const pfn_model_desc* d) {
 int64_t pfn_workspace_bytes(const pfn_model_desc* d, int B, int S) {
   if (check_desc(d) != PFN_OK || B < 1 || S < 1) return -1;
   return carve(*d, B, S, nullptr).bytes;
+}
+
+int64_t pfn_top_layer_rows(const pfn_model_desc* d, int B, int S, int sep, int use_dropout) {
+  if (check_desc(d) != PFN_OK || B < 1 || S < 1 || sep < 0 || sep > S) return -1;
+  return top_layer_on_test_rows(*d, S, sep, use_dropout ? d->dropout : 0.f) ? (int64_t)(S - sep) * B : (int64_t)B * S;
 }
 
 int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shadow, void* stream) {
@@ -285,9 +305,12 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   auto set_resid = [](GemmLN& g, const Resid& r) {
     g.resid = r.plain; g.ry = r.y; g.rmean = r.mean; g.rrstd = r.rstd; g.rgamma = r.gamma; g.rbeta = r.beta;
   };
+  const bool top_mode = top_layer_on_test_rows(*d, S, sep, pdrop);
   for (int l = 0; l < d->nlayers; ++l) {
     const LayerP& p = L.layer[l];
     LayerWs& a = w.layer[l];
+    const bool top = top_mode && l == d->nlayers - 1;     // this layer's rows behind the K / V projection: the test rows only (compact order)
+    const int Ml = top ? Mt : M;
     {  // packed q/k/v projection
       GemmNT g = nt(xin_t, E, W(p.w_in), E, M, 3 * E, E, EPI_BIAS | EPI_OUT_T);
       g.bias = params + p.b_in; g.out_t = a.qkv; g.ld_out_t = 3 * E;
@@ -297,11 +320,28 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       AttnArgs at; memset(&at, 0, sizeof(at));
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
       at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
+      at.q_begin = top ? sep : 0;
       PFN_TRY(launch_attn_fwd(at, prec, s));
     }
+    const char* ctx_in = a.ctx;
+    if (top) {      // the test rows of the attention output and of the layer input, gathered
+      PFN_TRY(launch_gather_rows(a.ctx, w.top_ctx_t, S, B, (long)E * es, sep, s));
+      ctx_in = w.top_ctx_t;
+      if (fuse_ln && !res.plain) {
+        PFN_TRY(launch_gather_rows(res.y, w.top_ry, S, B, (long)E * 4, sep, s));
+        PFN_TRY(launch_gather_rows(res.mean, w.top_rmean, S, B, 4, sep, s));
+        PFN_TRY(launch_gather_rows(res.rstd, w.top_rrstd, S, B, 4, sep, s));
+        res = Resid{nullptr, w.top_ry, w.top_rmean, w.top_rrstd, res.gamma, res.beta};
+      } else {
+        PFN_TRY(launch_gather_rows(fuse_ln ? res.plain : xin, w.top_ry, S, B, (long)E * 4, sep, s));
+        res = Resid{w.top_ry, nullptr, nullptr, nullptr, nullptr, nullptr};
+        xin = w.top_ry;
+      }
+    }
+    float* x2_f32 = top ? (O == 0 ? logits : nullptr) : a.x2;     // the stack's f32 output rows: only what the decoder gather (or the caller) reads
     if (fuse_ln) {  // x1 = LN1(x + out_proj(ctx))
       GemmLN g; memset(&g, 0, sizeof(g));
-      g.A = a.ctx; g.lda = E; g.B = W(p.w_o); g.ldb = E; g.M = M; g.N = E; g.K = E; g.bias = params + p.b_o;
+      g.A = ctx_in; g.lda = E; g.B = W(p.w_o); g.ldb = E; g.M = Ml; g.N = E; g.K = E; g.bias = params + p.b_o;
       set_resid(g, res);
       g.gamma = params + p.g1; g.beta = params + p.be1; g.eps = d->ln_eps;
       g.y = a.y1; g.mean = a.mean1; g.rstd = a.rstd1; g.x_t = a.x1_t;
@@ -309,15 +349,15 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       res = Resid{nullptr, a.y1, a.mean1, a.rstd1, params + p.g1, params + p.be1};
     } else {
       {  // out_proj + residual  (dropout1: the product leaves alone and the element-wise pass adds the residual)
-        GemmNT g = nt(a.ctx, E, W(p.w_o), E, M, E, E, EPI_BIAS | (pdrop > 0.f ? 0 : EPI_RESID) | EPI_OUT_F32);
+        GemmNT g = nt(ctx_in, E, W(p.w_o), E, Ml, E, E, EPI_BIAS | (pdrop > 0.f ? 0 : EPI_RESID) | EPI_OUT_F32);
         g.bias = params + p.b_o; g.resid = xin; g.ld_resid = E; g.out_f32 = a.y1; g.ld_out_f32 = E;
         PFN_TRY(launch_gemm_nt(g, prec, s));
         if (pdrop > 0.f) PFN_TRY(launch_dropout_add(a.y1, xin, M, E, dseed(l, 1), pdrop, s));
       }
-      PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, a.x1, a.x1_t, a.mean1, a.rstd1, M, E, d->ln_eps, prec, s));
+      PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, a.x1, a.x1_t, a.mean1, a.rstd1, Ml, E, d->ln_eps, prec, s));
     }
     {  // linear1 + GELU (pre-activation kept for the backward)
-      GemmNT g = nt(a.x1_t, E, W(p.w1), E, M, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
+      GemmNT g = nt(a.x1_t, E, W(p.w1), E, Ml, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
       g.bias = params + p.b1; g.out_t = a.h; g.ld_out_t = F; g.out2_t = a.hpre; g.ld_out2 = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
       // FFN dropout: h and the stored GELU derivative take the same mask, so linear2, its weight gradient and d(hpre) need nothing more
@@ -325,32 +365,35 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
     }
     if (fuse_ln) {  // x2 = LN2(x1 + linear2(h))
       GemmLN g; memset(&g, 0, sizeof(g));
-      g.A = a.h; g.lda = F; g.B = W(p.w2); g.ldb = F; g.M = M; g.N = E; g.K = F; g.bias = params + p.b2;
+      g.A = a.h; g.lda = F; g.B = W(p.w2); g.ldb = F; g.M = Ml; g.N = E; g.K = F; g.bias = params + p.b2;
       set_resid(g, res);
       g.gamma = params + p.g2; g.beta = params + p.be2; g.eps = d->ln_eps;
       g.y = a.y2; g.mean = a.mean2; g.rstd = a.rstd2; g.x_t = a.x2_t;
-      g.x_f32 = (l == d->nlayers - 1) ? a.x2 : nullptr;
+      g.x_f32 = (l == d->nlayers - 1) ? x2_f32 : nullptr;
       PFN_TRY(launch_gemm_ln(g, s));
       res = Resid{nullptr, a.y2, a.mean2, a.rstd2, params + p.g2, params + p.be2};
     } else {
       {  // linear2 + residual  (dropout2 as above)
-        GemmNT g = nt(a.h, F, W(p.w2), F, M, E, F, EPI_BIAS | (pdrop > 0.f ? 0 : EPI_RESID) | EPI_OUT_F32);
+        GemmNT g = nt(a.h, F, W(p.w2), F, Ml, E, F, EPI_BIAS | (pdrop > 0.f ? 0 : EPI_RESID) | EPI_OUT_F32);
         g.bias = params + p.b2; g.resid = a.x1; g.ld_resid = E; g.out_f32 = a.y2; g.ld_out_f32 = E;
         PFN_TRY(launch_gemm_nt(g, prec, s));
         if (pdrop > 0.f) PFN_TRY(launch_dropout_add(a.y2, a.x1, M, E, dseed(l, 3), pdrop, s));
       }
-      PFN_TRY(launch_layernorm_fwd(a.y2, params + p.g2, params + p.be2, a.x2, a.x2_t, a.mean2, a.rstd2, M, E, d->ln_eps, prec, s));
+      PFN_TRY(launch_layernorm_fwd(a.y2, params + p.g2, params + p.be2, top ? x2_f32 : a.x2, a.x2_t, a.mean2, a.rstd2, Ml, E, d->ln_eps, prec, s));
     }
     xin = a.x2; xin_t = a.x2_t;
   }
   // decoder on the test rows only (the reference decodes all rows, then slices: transformer.py:85,91)
+  // (top_mode: the top layer already ran on exactly these rows, in this order -- its operand-precision output IS the decoder's input, its f32
+  // output went straight to the caller when there is no decoder)
   if (Mt > 0 && O == 0) {
     // no decoder (a custom decoder module runs in PyTorch, reference transformer.py:23): hand out the test rows [Mt, E] in f32
-    PFN_TRY(launch_gather_test_rows(xin, logits, S, B, E, sep, PFN_PREC_F32, s));
+    if (!top_mode) PFN_TRY(launch_gather_test_rows(xin, logits, S, B, E, sep, PFN_PREC_F32, s));
   } else if (Mt > 0) {
-    PFN_TRY(launch_gather_test_rows(xin, w.xt_t, S, B, E, sep, prec, s));
+    if (!top_mode) PFN_TRY(launch_gather_test_rows(xin, w.xt_t, S, B, E, sep, prec, s));
+    const char* xt_t = top_mode ? w.layer[d->nlayers - 1].x2_t : w.xt_t;
     {
-      GemmNT g = nt(w.xt_t, E, W(L.dec0_w), E, Mt, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
+      GemmNT g = nt(xt_t, E, W(L.dec0_w), E, Mt, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
       g.bias = params + L.dec0_b; g.out_t = w.dt; g.ld_out_t = F; g.out2_t = w.dpre; g.ld_out2 = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
@@ -378,6 +421,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
                              int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed) {
   PFN_TRY(check_desc(d));
   const float pdrop = use_dropout ? d->dropout : 0.f;
+  const bool top_mode = top_layer_on_test_rows(*d, S, sep, pdrop);       // (the forward took the same decision: same descriptor, shape, dropout)
   auto dseed = [&](int layer, int site) { return dropout_site_seed(dropout_seed, layer, site); };
   if (!params || !shadow || !workspace || !grads) return fail(PFN_ERR_ARGUMENT, "null pointer");
   if (!dsrc_sbe && (!x || !y)) return fail(PFN_ERR_ARGUMENT, "need x and y (or dsrc_sbe)");
@@ -395,6 +439,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
 
   // ---- decoder ----
   const float* dxt = w.dxt;
+  const char* xt_t = top_mode ? w.layer[d->nlayers - 1].x2_t : w.xt_t;      // the decoder's input rows (forward)
   if (Mt > 0 && O == 0) {
     if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
     dxt = dlogits;   // no decoder: the incoming gradient already is d(test rows) [Mt, E]
@@ -407,7 +452,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     dp2.A = w.dlog_t; dp2.lda = npad; dp2.B = w.dt; dp2.ldb = F; dp2.C = grads + L.dec2_w; dp2.ldc = F; dp2.P = npad; dp2.Q = F; dp2.Pv = O;
     dp2.colsum = grads + L.dec2_b;
     TnProblem dp0; memset(&dp0, 0, sizeof(dp0));
-    dp0.A = w.dd_t; dp0.lda = F; dp0.B = w.xt_t; dp0.ldb = E; dp0.C = grads + L.dec0_w; dp0.ldc = E; dp0.P = F; dp0.Q = E; dp0.colsum = grads + L.dec0_b;
+    dp0.A = w.dd_t; dp0.lda = F; dp0.B = xt_t; dp0.ldb = E; dp0.C = grads + L.dec0_w; dp0.ldc = E; dp0.P = F; dp0.Q = E; dp0.colsum = grads + L.dec0_b;
     const bool dec_grouped = prec == PFN_PREC_BF16 && gemm_tn_group_supported(dp2) && gemm_tn_group_supported(dp0);
     if (!dec_grouped) PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b), prec, s));
     {
@@ -421,7 +466,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
       g.n = 2; g.M = Mt; g.p[0] = dp2; g.p[1] = dp0;
       PFN_TRY(launch_gemm_tn_group(g, s));
     } else {
-      PFN_TRY(launch_gemm_tn(tn(w.dd_t, F, w.xt_t, E, grads + L.dec0_w, E, Mt, F, E, grads + L.dec0_b), prec, s));
+      PFN_TRY(launch_gemm_tn(tn(w.dd_t, F, xt_t, E, grads + L.dec0_w, E, Mt, F, E, grads + L.dec0_b), prec, s));
     }
     {
       GemmNT g = nt(w.dd_t, F, WT(L.dec0_wt), F, Mt, E, F, EPI_OUT_F32);
@@ -429,7 +474,8 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
   }
-  PFN_TRY(launch_scatter_test_rows(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
+  // (top_mode: the top layer's backward runs on the compact test rows and takes dxt as it is)
+  if (!top_mode) PFN_TRY(launch_scatter_test_rows(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
 
   // ---- encoder layers, last to first; gA holds d(loss)/d(layer output) ----
   // Only the data-gradient chain runs here.  Each layer leaves the output-gradient operands of its four
@@ -440,9 +486,9 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   // LayerNorm's backward in their epilogue (gemm_nt_lnbwd_kernel) when the shape allows: the sum never reaches HBM, and the
   // bias gradient of the Linear in front of the LayerNorm moves to the weight-gradient GEMM that reads the same operand.
   auto lnb = [&](const void* A, long lda, const void* Bw, long ldb, int K, const void* aux, const float* y, const float* mean, const float* rstd,
-                 const float* gamma, void* dx_t, float* dgamma, float* dbeta) {
+                 const float* gamma, void* dx_t, float* dgamma, float* dbeta, int rows) {
     GemmLNB g; memset(&g, 0, sizeof(g));
-    g.A = A; g.lda = lda; g.B = Bw; g.ldb = ldb; g.M = M; g.N = E; g.K = K; g.aux = aux;
+    g.A = A; g.lda = lda; g.B = Bw; g.ldb = ldb; g.M = rows; g.N = E; g.K = K; g.aux = aux;
     g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta;
     return g;
   };
@@ -454,16 +500,16 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   bool fuse_lnb = g_fuse_lnbwd && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || g_fuse_ln_wide);   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
   if (fuse_lnb) {
     const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
-    fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1)) &&
-               gemm_lnbwd_supported(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, a.y2, a.mean2, a.rstd2, params + p.g2, a.dy2_t, grads + p.g2, grads + p.be2));
+    fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1, M)) &&
+               gemm_lnbwd_supported(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, a.y2, a.mean2, a.rstd2, params + p.g2, a.dy2_t, grads + p.g2, grads + p.be2, M));
   }
   // ---- weight gradients of the layers [l_lo, l_hi] as one grouped launch (called once after the chain, or -- data-parallel runs,
   // pfn_stack_backward_split -- once for the top layers in the middle of the chain and once for the rest) ----
   auto launch_weight_gradients = [&](int l_hi, int l_lo) -> int {
-    std::vector<TnProblem> probs;
-    auto add = [&](const void* A, long lda, const void* Bm, long ldb, float* C, long ldc, int P, int Q, float* colsum) {
+    std::vector<TnProblem> probs, probs_top;      // contraction over all B S tokens / over the test rows (a top layer on the test rows)
+    auto add = [&](const void* A, long lda, const void* Bm, long ldb, float* C, long ldc, int P, int Q, float* colsum, bool compact = false) {
       TnProblem t; memset(&t, 0, sizeof(t)); t.A = A; t.lda = lda; t.B = Bm; t.ldb = ldb; t.C = C; t.ldc = ldc; t.P = P; t.Q = Q; t.colsum = colsum;
-      probs.push_back(t);
+      (compact ? probs_top : probs).push_back(t);
     };
     for (int l = l_hi; l >= l_lo; --l) {
       const LayerP& p = L.layer[l];
@@ -471,10 +517,26 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
       const char* xin_t = (l == 0) ? w.x0_t : w.layer[l - 1].x2_t;
       // (b2 / b_o: column sums of dy2 / dy1 -- from the LayerNorm-backward kernel when that ran on its own)
       const bool drop = pdrop > 0.f;
-      add(drop ? a.dy2m_t : a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, (drop || (fuse_lnb && l < d->nlayers - 1)) ? grads + p.b2 : nullptr);
-      add(a.dh_t, F, a.x1_t, E, grads + p.w1, E, F, E, grads + p.b1);
-      add(drop ? a.dy1m_t : a.dy1_t, E, a.ctx, E, grads + p.w_o, E, E, E, (drop || fuse_lnb) ? grads + p.b_o : nullptr);
+      const bool top = top_mode && l == d->nlayers - 1;      // its FFN / out_proj operands hold the test rows only
+      add(drop ? a.dy2m_t : a.dy2_t, E, a.h, F, grads + p.w2, F, E, F, (drop || (fuse_lnb && l < d->nlayers - 1)) ? grads + p.b2 : nullptr, top);
+      add(a.dh_t, F, a.x1_t, E, grads + p.w1, E, F, E, grads + p.b1, top);
+      add(drop ? a.dy1m_t : (top ? w.top_dy1_t : a.dy1_t), E, top ? w.top_ctx_t : a.ctx, E, grads + p.w_o, E, E, E, (drop || fuse_lnb) ? grads + p.b_o : nullptr, top);
       add(a.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, 3 * E, E, grads + p.b_in);
+    }
+    if (!probs_top.empty()) {
+      bool grouped_top = prec == PFN_PREC_BF16;
+      for (const TnProblem& t : probs_top) grouped_top = grouped_top && gemm_tn_group_supported(t);
+      if (grouped_top) {
+        GemmTNGroup g;
+        memset(&g, 0, sizeof(g));
+        g.n = (int)probs_top.size();
+        g.M = Mt;
+        for (int i = 0; i < g.n; ++i) g.p[i] = probs_top[i];
+        PFN_TRY(launch_gemm_tn_group(g, s));
+      } else {
+        for (const TnProblem& t : probs_top)
+          PFN_TRY(launch_gemm_tn(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, Mt, t.P, t.Q, t.colsum), prec, s));
+      }
     }
     bool grouped = prec == PFN_PREC_BF16;
     for (const TnProblem& t : probs) grouped = grouped && gemm_tn_group_supported(t);
@@ -497,51 +559,61 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   for (int l = d->nlayers - 1; l >= 0; --l) {
     const LayerP &p = L.layer[l], &t = L.layer_t[l];
     LayerWs& a = w.layer[l];
+    const bool top = top_mode && l == d->nlayers - 1;      // the chain of this layer down to d(attention output) runs on the test rows (compact order)
+    const int Ml = top ? Mt : M;
+    char* dy1_t = top ? w.top_dy1_t : a.dy1_t;
     // LN2: the input gradient leaves only in operand precision (dy2_t); it is both the GEMM operand below and the
     // residual-branch gradient that the dx1 GEMM adds back, so no f32 copy is written or re-read.  (Fused: the layer above
     // already left dy2_t.)
     // dropout: the gradient entering linear2 (dropout2) / out_proj (dropout1) is the LayerNorm-input gradient times that site's mask;
     // the residual path keeps the unmasked one, and the two bias gradients become column sums of the masked operands (weight-gradient launch)
     if (!fuse_lnb || l == d->nlayers - 1)
-      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t, grads + p.g2, grads + p.be2,
-                                   pdrop > 0.f ? nullptr : grads + p.b2, M, E, prec, s));
+      PFN_TRY(launch_layernorm_bwd(top ? (const void*)dxt : (const void*)w.gA_t, top ? 0 : 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t,
+                                   grads + p.g2, grads + p.be2, pdrop > 0.f ? nullptr : grads + p.b2, Ml, E, prec, s));
     const char* dy2_op = a.dy2_t;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy2_t, a.dy2m_t, nullptr, nullptr, M, E, dseed(l, 3), pdrop, prec, s)); dy2_op = a.dy2m_t; }
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
-      GemmNT g = nt(dy2_op, E, WT(t.w2), E, M, F, E, EPI_GELU_BWD | EPI_OUT_T);
+      GemmNT g = nt(dy2_op, E, WT(t.w2), E, Ml, F, E, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = a.hpre; g.ld_aux = F; g.out_t = a.dh_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     if (fuse_lnb) {  // dy1 = LN1 backward of (dh . W1 + dy2)
-      PFN_TRY(launch_gemm_lnbwd(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1), s));
+      PFN_TRY(launch_gemm_lnbwd(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, dy1_t, grads + p.g1, grads + p.be1, Ml), s));
     } else {
       {  // dx1 = dh . W1 + dy2
-        GemmNT g = nt(a.dh_t, F, WT(t.w1), F, M, E, F, EPI_RESID_T | EPI_OUT_T);
+        GemmNT g = nt(a.dh_t, F, WT(t.w1), F, Ml, E, F, EPI_RESID_T | EPI_OUT_T);
         g.aux = a.dy2_t; g.ld_aux = E; g.out_t = w.gA_t; g.ld_out_t = E;
         PFN_TRY(launch_gemm_nt(g, prec, s));
       }
-      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, a.dy1_t, grads + p.g1, grads + p.be1,
-                                   pdrop > 0.f ? nullptr : grads + p.b_o, M, E, prec, s));
+      PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, dy1_t, grads + p.g1, grads + p.be1,
+                                   pdrop > 0.f ? nullptr : grads + p.b_o, Ml, E, prec, s));
     }
-    const char* dy1_op = a.dy1_t;
+    const char* dy1_op = dy1_t;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy1_t, a.dy1m_t, nullptr, nullptr, M, E, dseed(l, 1), pdrop, prec, s)); dy1_op = a.dy1m_t; }
     {  // d(ctx) = dy1 . Wo
-      GemmNT g = nt(dy1_op, E, WT(t.w_o), E, M, E, E, EPI_OUT_T);
-      g.out_t = w.dctx_t; g.ld_out_t = E;
+      GemmNT g = nt(dy1_op, E, WT(t.w_o), E, Ml, E, E, EPI_OUT_T);
+      g.out_t = top ? w.top_dctx_t : w.dctx_t; g.ld_out_t = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
+    }
+    if (top) {
+      // back to the token order for the attention backward and for the dx product of the K / V projection: d(attention output) is needed from the first
+      // query block the attention kernels touch (AttnArgs::q_begin: zeros up to sep), the LayerNorm-input gradient as the residual term of every row
+      PFN_TRY(launch_scatter_rows(w.top_dctx_t, w.dctx_t, S, B, (long)E * es, sep, sep / 256 * 256, s));
+      PFN_TRY(launch_scatter_rows(w.top_dy1_t, a.dy1_t, S, B, (long)E * es, sep, 0, s));
     }
     {
       AttnArgs at; memset(&at, 0, sizeof(at));
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
       at.dctx = w.dctx_t; at.dqkv = a.dqkv_t; at.delta = w.delta; at.ds = w.ds;
       at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
+      at.q_begin = top ? sep : 0;
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     if (fuse_lnb && l > 0) {  // dy2 of the layer below = its LN2 backward of (dqkv . Win + dy1)
       const LayerP& pb = L.layer[l - 1];
       LayerWs& ab = w.layer[l - 1];
       PFN_TRY(launch_gemm_lnbwd(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, ab.y2, ab.mean2, ab.rstd2, params + pb.g2, ab.dy2_t,
-                                    grads + pb.g2, grads + pb.be2), s));
+                                    grads + pb.g2, grads + pb.be2, M), s));
     } else {  // dx = dqkv . Win + dy1
       // the gradient stays in operand precision between layers; the embedding's gradient (layer 0) too when its weight
       // gradients are computed as a GEMM (emb_gemm below), else it leaves in f32
@@ -706,6 +778,30 @@ int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, i
   AttnArgs at; memset(&at, 0, sizeof(at));
   at.qkv = qkv; at.ctx = ctx; at.lse = lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
   PFN_TRY(launch_attn_fwd(at, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_attention_fwd_from(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep, int q_begin, int prec, void* stream) {
+  AttnArgs at; memset(&at, 0, sizeof(at));
+  at.qkv = qkv; at.ctx = ctx; at.lse = lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep; at.q_begin = q_begin;
+  PFN_TRY(launch_attn_fwd(at, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_attention_bwd_from(const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv, float* delta_ws, void* ds_ws,
+                              int B, int S, int E, int H, int sep, int q_begin, int prec, int parts, void* stream) {
+  AttnArgs at; memset(&at, 0, sizeof(at));
+  at.qkv = qkv; at.ctx = const_cast<void*>(ctx); at.lse = const_cast<float*>(lse); at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
+  at.dctx = dctx; at.dqkv = dqkv; at.delta = delta_ws; at.ds = ds_ws; at.parts = parts; at.q_begin = q_begin;
+  PFN_TRY(launch_attn_bwd(at, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_gather_rows(const void* src_bs, void* dst_tb, int B, int S, int64_t row_bytes, int sep, void* stream) {
+  if (!src_bs || !dst_tb || B < 1 || S < 1 || sep < 0 || sep > S) return fail(PFN_ERR_ARGUMENT, "bad gather_rows arguments");
+  PFN_TRY(launch_gather_rows(src_bs, dst_tb, S, B, row_bytes, sep, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_scatter_rows(const void* src_tb, void* dst_bs, int B, int S, int64_t row_bytes, int sep, int zero_from, void* stream) {
+  if (!src_tb || !dst_bs || B < 1 || S < 1 || sep < 0 || sep > S) return fail(PFN_ERR_ARGUMENT, "bad scatter_rows arguments");
+  PFN_TRY(launch_scatter_rows(src_tb, dst_bs, S, B, row_bytes, sep, zero_from, (hipStream_t)stream));
   return PFN_OK;
 }
 int64_t pfn_op_attention_bwd_ws_bytes(int B, int S, int H, int prec) {

@@ -159,6 +159,10 @@ struct AttnArgs {
   int ds_rows, ds_ld;  // filled by the launcher
   int parts;  // backward launches to run, bit mask over ATTN_BWD_*; 0 = all (profiling entry point pfn_op_attention_bwd_parts)
   int pingpong;  // filled by the launcher (PFN_TUNE_ATTN_PINGPONG): bit 0 forward, bit 1 key-block pass
+  // Queries below q_begin are skipped: their context rows / dQ rows are not written and they add nothing to dK and dV (the top encoder
+  // layer, whose train rows feed nothing: pfn_api.hip).  The launcher rounds it down to a multiple of 256 (whole query blocks / tiles of every
+  // kernel); the caller hands in dctx rows that are ZERO in [that multiple, its own first live row).
+  int q_begin;
   // dropout on the attention probabilities (training with dropout > 0): P' = P * keep / (1 - p), keep = dropout_keep(pair seed, query, key)
   float p_drop;            // 0 = off (the kernels without the mask arithmetic run)
   unsigned drop_seed;      // site seed of this layer's attention (dropout_site_seed(call seed, layer, 0)); the kernels mix (dataset, head) in
@@ -221,6 +225,12 @@ int launch_dropout_scale(const void* src, void* dst, const void* src2, void* dst
 int launch_gather_test_rows(const float* src_bse, void* dst_t, int S, int B, int E, int sep, int precision, hipStream_t s);
 // dst[b, s, :] = (s >= sep) ? src[(s-sep)*B + b, :] : 0
 int launch_scatter_test_rows(const float* src, void* dst_bse_t, int S, int B, int E, int sep, int precision, hipStream_t s);
+// the same row moves for any operand, as bytes (the top encoder layer runs on the test rows only, pfn_api.hip): compact order [S - sep, B]
+int launch_gather_rows(const void* src_bs, void* dst_tb, int S, int B, long row_bytes, int sep, hipStream_t s);
+// rows >= sep take the compact rows, rows in [zero_from, sep) zeros, rows below zero_from are not touched
+int launch_scatter_rows(const void* src_tb, void* dst_bs, int S, int B, long row_bytes, int sep, int zero_from, hipStream_t s);
+// base[b, s, 0 : width_bytes] = 0 for s < nrows
+int launch_zero_row_prefix(void* base, int S, int B, int nrows, long row_bytes, long width_bytes, hipStream_t s);
 
 // ---- bar distribution (bar.hip) ----------------------------------------------------------------
 struct BarArgs {

@@ -410,6 +410,68 @@ int launch_scatter_test_rows(const float* src, void* dst, int S, int B, int E, i
   return PFN_LAUNCH_OK();
 }
 
+// The top encoder layer runs on the test rows only (pfn_api.hip): rows of any operand move between the [B, S] token order and the
+// compact [S - sep, B] order of the decoder's rows as bytes (W = 16 or 4 bytes per unit; a row is row_units units).
+template <typename U> __global__ __launch_bounds__(256) void gather_rows_kernel(const U* src, U* dst, int S, int B, int row_units, int sep) {
+  const long n = (long)(S - sep) * B * row_units;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i / row_units; const int c = (int)(i % row_units);
+    const long t = row / B, b = row % B;
+    dst[i] = src[(b * S + sep + t) * row_units + c];
+  }
+}
+int launch_gather_rows(const void* src_bs, void* dst_tb, int S, int B, long row_bytes, int sep, hipStream_t s) {
+  if (row_bytes % 4) return PFN_ERR_ALIGNMENT;
+  if ((long)(S - sep) * B * row_bytes == 0) return PFN_OK;
+  if (row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(src_bs) | reinterpret_cast<uintptr_t>(dst_tb)) % 16 == 0) {
+    const int ru = (int)(row_bytes / 16);
+    hipLaunchKernelGGL(gather_rows_kernel<u32x4>, dim3(grid_for((long)(S - sep) * B * ru, 256)), dim3(256), 0, s, (const u32x4*)src_bs, (u32x4*)dst_tb, S, B, ru, sep);
+  } else {
+    const int ru = (int)(row_bytes / 4);
+    hipLaunchKernelGGL(gather_rows_kernel<unsigned>, dim3(grid_for((long)(S - sep) * B * ru, 256)), dim3(256), 0, s, (const unsigned*)src_bs, (unsigned*)dst_tb, S, B, ru, sep);
+  }
+  return PFN_LAUNCH_OK();
+}
+// dst[b, s, :] = src[(s - sep) * B + b, :] for s >= sep, zeros for zero_from <= s < sep; rows below zero_from are not touched
+template <typename U> __global__ __launch_bounds__(256) void scatter_rows_kernel(const U* src, U* dst, int S, int B, int row_units, int sep, int zero_from) {
+  const long per_b = (long)(S - zero_from) * row_units, n = per_b * B;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / per_b, r = i % per_b;
+    const long sidx = zero_from + r / row_units; const int c = (int)(r % row_units);
+    U v = {};
+    if (sidx >= sep) v = src[((sidx - sep) * B + b) * row_units + c];
+    dst[(b * S + sidx) * row_units + c] = v;
+  }
+}
+int launch_scatter_rows(const void* src_tb, void* dst_bs, int S, int B, long row_bytes, int sep, int zero_from, hipStream_t s) {
+  if (row_bytes % 4) return PFN_ERR_ALIGNMENT;
+  if (zero_from < 0 || zero_from > sep) return PFN_ERR_ARGUMENT;
+  if ((long)(S - zero_from) * B * row_bytes == 0) return PFN_OK;
+  if (row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(src_tb) | reinterpret_cast<uintptr_t>(dst_bs)) % 16 == 0) {
+    const int ru = (int)(row_bytes / 16);
+    hipLaunchKernelGGL(scatter_rows_kernel<u32x4>, dim3(grid_for((long)(S - zero_from) * B * ru, 256)), dim3(256), 0, s, (const u32x4*)src_tb, (u32x4*)dst_bs, S, B, ru, sep, zero_from);
+  } else {
+    const int ru = (int)(row_bytes / 4);
+    hipLaunchKernelGGL(scatter_rows_kernel<unsigned>, dim3(grid_for((long)(S - zero_from) * B * ru, 256)), dim3(256), 0, s, (const unsigned*)src_tb, (unsigned*)dst_bs, S, B, ru, sep, zero_from);
+  }
+  return PFN_LAUNCH_OK();
+}
+// base[b, s, 0 : width] = 0 for s < nrows (rows of row_bytes bytes; width_bytes, row_bytes multiples of 16)
+__global__ __launch_bounds__(256) void zero_row_prefix_kernel(u32x4* base, int S, int B, int nrows, int row_units, int width_units) {
+  const long per_b = (long)nrows * width_units, n = per_b * B;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / per_b, r = i % per_b;
+    base[(b * S + r / width_units) * row_units + r % width_units] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+int launch_zero_row_prefix(void* base, int S, int B, int nrows, long row_bytes, long width_bytes, hipStream_t s) {
+  if (row_bytes % 16 || width_bytes % 16 || reinterpret_cast<uintptr_t>(base) % 16) return PFN_ERR_ALIGNMENT;
+  if ((long)nrows * B * width_bytes == 0) return PFN_OK;
+  hipLaunchKernelGGL(zero_row_prefix_kernel, dim3(grid_for((long)nrows * B * (width_bytes / 16), 256)), dim3(256), 0, s, (u32x4*)base, S, B, nrows,
+                     (int)(row_bytes / 16), (int)(width_bytes / 16));
+  return PFN_LAUNCH_OK();
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, the row lives in registers (NV float4 per lane, E <= 256*NV)
 // ---------------------------------------------------------------------------------------------
@@ -447,7 +509,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, cons
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu) * rstd * g[e] + bb[e];
-        *reinterpret_cast<f32x4*>(y32 + row * E + c) = o;
+        if (y32) *reinterpret_cast<f32x4*>(y32 + row * E + c) = o;
         if (yt) st4<T>(yt + row * E + c, o);
       }
     }

@@ -63,13 +63,39 @@ def gemm_ln(A, B, bias, gamma, beta, eps, resid=None, prev=None, out=None):
     return y[:M], x_t, mean, rstd
 
 
-def attention_fwd(qkv, H, sep, prec):
+def attention_fwd(qkv, H, sep, prec, q_begin=0, out=None):
+    """q_begin > 0: the queries below it (rounded down to a multiple of 256) are skipped -- their ctx / lse rows keep the NaN fill
+    (or whatever `out` = (ctx, lse) held: timing loops pass buffers so that no fill kernel runs between the launches)."""
     B, S, E3 = qkv.shape
     E = E3 // 3
+    if q_begin:
+        if out is not None:
+            ctx, lse = out
+        else:
+            ctx = torch.full((B, S, E), float('nan'), dtype=qkv.dtype, device=qkv.device)
+            lse = torch.full((B, H, S), float('nan'), dtype=torch.float32, device=qkv.device)
+        _hip.check(_hip.lib().pfn_op_attention_fwd_from(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, S, E, H, sep, q_begin, prec, sp()), 'attn fwd')
+        return ctx, lse
     ctx = torch.empty(B, S, E, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
     _hip.check(_hip.lib().pfn_op_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, S, E, H, sep, prec, sp()), 'attn fwd')
     return ctx, lse
+
+
+def gather_rows(src, sep, out=None):
+    """[B, S, W] -> the compact test rows [(S - sep) * B, W] in the decoder's order (row (t - sep) * B + b)."""
+    B, S, W = src.shape
+    dst = out if out is not None else torch.empty((S - sep) * B, W, dtype=src.dtype, device=src.device)
+    _hip.check(_hip.lib().pfn_op_gather_rows(src.data_ptr(), dst.data_ptr(), B, S, W * src.element_size(), sep, sp()), 'gather rows')
+    return dst
+
+
+def scatter_rows(src, B, S, sep, zero_from, fill=float('nan'), out=None):
+    """the inverse: rows >= sep from the compact rows, zeros in [zero_from, sep), `fill` (untouched) below"""
+    W = src.shape[1]
+    dst = out if out is not None else torch.full((B, S, W), fill, dtype=src.dtype, device=src.device)
+    _hip.check(_hip.lib().pfn_op_scatter_rows(src.data_ptr(), dst.data_ptr(), B, S, W * src.element_size(), sep, zero_from, sp()), 'scatter rows')
+    return dst
 
 
 def gemm_lnbwd(A, B, aux, y, mean, rstd, gamma, out=None):
@@ -100,7 +126,7 @@ ATTENTION_BWD_KV_EXECUTED_UNITS = {}
 _bwd_scratch = {}
 
 
-def attention_bwd(qkv, ctx, lse, dctx, H, sep, prec, parts=0):
+def attention_bwd(qkv, ctx, lse, dctx, H, sep, prec, parts=0, q_begin=0):
     """parts = 0: the whole backward (outputs start as NaN so a skipped element shows).  parts != 0 (timing): only the selected
     launches, into cached scratch buffers (the skipped launches' products must exist from an earlier full call with the same
     shapes for the numbers to mean anything)."""
@@ -116,6 +142,10 @@ def attention_bwd(qkv, ctx, lse, dctx, H, sep, prec, parts=0):
     if not parts:
         dqkv = torch.full_like(qkv, float('nan'))
         ds.fill_(0xff)                                 # NaN patterns: a dS^T element the key-block pass skipped would show in dQ
+    if q_begin:
+        _hip.check(_hip.lib().pfn_op_attention_bwd_from(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(),
+                                                        delta.data_ptr(), ds.data_ptr(), B, S, E, H, sep, q_begin, prec, parts, sp()), 'attn bwd')
+        return dqkv
     _hip.check(_hip.lib().pfn_op_attention_bwd(qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(),
                                                delta.data_ptr(), ds.data_ptr(), B, S, E, H, sep, prec, parts, sp()), 'attn bwd')
     return dqkv
