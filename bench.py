@@ -147,11 +147,32 @@ def build_model(device, precision, w=WORKLOAD, criterion=None):
     return model.to(device)
 
 
+_spin = {}
+
+
+def run_ahead(ms=1.5):
+    """Keeps the GPU busy for ~`ms` (a spin kernel, calibrated once) so that the host enqueues the launches and events that follow while it runs:
+    they then execute back to back, and an event-to-event interval holds the kernel between the two events and no host gap.  (Without it a slow
+    host shows up inside the intervals of short sequences: the key-block pass behind the 30-us delta kernel read 526 us on one box and 646 on
+    another whose whole step was FASTER; the three launches enqueued as one call took 793 us on both.)"""
+    if 'cycles_per_ms' not in _spin:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(10000)
+        torch.cuda.synchronize()
+        a.record()
+        torch.cuda._sleep(1000000)
+        b.record()
+        b.synchronize()
+        _spin['cycles_per_ms'] = 1000000 / max(a.elapsed_time(b), 1e-3)
+    torch.cuda._sleep(int(ms * _spin['cycles_per_ms']))
+
+
 def time_kernel(fn, iters=10, warm=3):
     """Average duration (s) of fn() with HIP events recorded on the stream the kernels run on."""
     for _ in range(warm):
         fn()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    run_ahead()
     start.record()
     for _ in range(iters):
         fn()
@@ -170,6 +191,7 @@ def time_sequence(fns, iters=10, warm=3):
             fn()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(fns) + 1)] for _ in range(iters)]
     for it in range(iters):
+        run_ahead()
         ev[it][0].record()
         for j, fn in enumerate(fns):
             fn()

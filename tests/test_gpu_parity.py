@@ -1104,7 +1104,7 @@ def test_top_layer_on_the_test_rows_equals_every_layer_on_every_row(precision, L
         if g0.norm() < 1e-12:
             assert results[1][2][k].norm() < 1e-9, k
             continue
-        within(f'{precision} top-layer schedules: gradient rel l2', relerr(results[1][2][k], g0), 1e-5 if tight else 6e-3)
+        within(f'{precision} top-layer schedules: gradient rel l2', relerr(results[1][2][k], g0), 1e-5 if tight else 3.5e-3)
     # short train parts keep every row (nothing to gain) and dropout does too (its masks are indexed by the full-layout row)
     assert _hip.lib().pfn_top_layer_rows(ctypes.byref(desc), cfg['B'], cfg['T'], cfg['T'] // 4 - 1, 0) == cfg['T'] * cfg['B']
     assert _hip.lib().pfn_top_layer_rows(ctypes.byref(desc), cfg['B'], cfg['T'], cfg['T'], 0) == cfg['T'] * cfg['B']
