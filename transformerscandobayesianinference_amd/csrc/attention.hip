@@ -148,7 +148,8 @@ PFN_DEV AttnBlock attn_block_ragged_last(int nblk, int nfull, int H) {
 #endif
 constexpr int ABL = PFN_ATTN_ABLATE;
 // ... and -DPFN_KV_ABLATE=<bits> in the backward key-block pass: no dS^T store (1), the transposed fragments of the dV / dK
-// products read once instead of four times (2), V row fragments not read (4), exponentials replaced by a multiply (8)
+// products read once instead of four times (2), V row fragments not read (4), exponentials replaced by a multiply (8), the Q / dO row
+// fragments read for the first k-steps only (16)
 #ifndef PFN_KV_ABLATE
 #define PFN_KV_ABLATE 0
 #endif
@@ -668,7 +669,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       if constexpr (PRIO & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < C::NKK; ++kk) {
-        if (kk + PD < C::NKK) qfr[kk + PD] = load_frag_row_p<T, C::RS>(qr, li, (kk + PD) * 16);
+        if (kk + PD < C::NKK) qfr[kk + PD] = (KVABL & 16) ? qfr[0] : load_frag_row_p<T, C::RS>(qr, li, (kk + PD) * 16);
         s = mma32(qfr[kk], kf[kk], s);
         PFN_PIN_LDS_MFMA();
       }
@@ -710,7 +711,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 #pragma unroll
       for (int kk = 0; kk < C::NKK; ++kk) {
         if (kk + PD2 < C::NKK) {
-          ofr[kk + PD2] = load_frag_row_p<T, C::RS>(orow, li, (kk + PD2) * 16);
+          ofr[kk + PD2] = (KVABL & 16) ? ofr[0] : load_frag_row_p<T, C::RS>(orow, li, (kk + PD2) * 16);
           if constexpr (K::VLDS && !(KVABL & 4)) vfr[kk + PD2] = load_frag_row_p<T, C::RS>(Vimg(), wave * 32 + li, (kk + PD2) * 16);
         }
         if constexpr (K::VLDS && (KVABL & 4)) dp = mma32(ofr[kk], ofr[kk], dp);
