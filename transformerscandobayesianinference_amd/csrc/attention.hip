@@ -164,6 +164,10 @@ constexpr int PRIO = PFN_ATTN_PRIO;
 #ifndef PFN_KV_SPLIT_D256
 #define PFN_KV_SPLIT_D256 0
 #endif
+// key-block pass (operand precision 2 bytes): ONE LDS image per Q / dO tile instead of a row image and a column image (BwdKvCfg)
+#ifndef PFN_KV_ONE_IMAGE
+#define PFN_KV_ONE_IMAGE 1
+#endif
 #ifndef PFN_KV_PD_S
 #define PFN_KV_PD_S 2
 #endif
@@ -457,14 +461,38 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, int D) {
 // Keys >= sep in the last key block run on clamped data: never stored (dK, dV) and never read (the dQ pass
 // zero-fills dS^T rows >= sep when it stages them).
 // =============================================================================================
+// LDS row of query q of a 32-query tile in the one-image layout of the key-block pass (BwdKvCfg::ONE): the two 2-bit fields of the row index swapped
+__host__ __device__ constexpr int kv_row_perm(int q) { return 4 * (q & 3) + ((q >> 2) & 3) + (q & ~15); }
+// The transposed fragment (MAP 2 of load_frag_tr_p: k = query rows k0 + 4h + {0..3} and k0 + 8 + 4h + {0..3}, the accumulator's row order) from that
+// image: kv_row_perm(k0 + 4h + j) = 4 j + h + k0 and kv_row_perm(k0 + 8 + 4h + j) = 4 j + h + 2 + k0 for k0 in {0, 16} -- one lane base, immediate offsets
+template <typename T, int STRIDE> PFN_DEV Frag<T> load_frag_tr_perm(const lds_char* tile, int k0, int col0) {
+  static_assert(sizeof(T) == 2, "one-image layout: 2-byte operands");
+  const int l = lane_id(), h = l >> 5, i = l & 15, g = (l >> 4) & 1;
+  const int colb = (col0 + 16 * g + 4 * (i & 3)) * 2;
+  const int row = 4 * (i >> 2) + h + k0;
+  Frag<T> f;
+  bf16x4 lo = ds_read_tr16_b64(tile + row * STRIDE + colb);
+  bf16x4 hi = ds_read_tr16_b64(tile + (row + 2) * STRIDE + colb);
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+
 template <typename T, int D> struct BwdKvCfg {
   using C = AttnCfg<T, D>;
   static constexpr int QB = 32;                         // queries per tile
   static constexpr bool VLDS = C::NW == 8;              // V rows of the workgroup's keys in LDS instead of registers
   static constexpr int VIMG = VLDS ? C::QBLK * C::RS : 0;
+  // A Q / dO tile is read twice per wave: along its rows (ds_read_b128, A operand of S = Q K^T / dP = dO V^T) and transposed (ds_read_b64_tr_b16, A
+  // operand of dV^T += dO^T P / dK^T += Q^T dS).  The two patterns want different paddings (PadStride: row stride = 4 x odd dwords for the
+  // first, 16 x odd for the second), so rounds 1-3 kept every tile twice -- and paid for it in LDS-DMA instructions, the largest single item of
+  // the pass (profiles/r03_attention_experiments.txt: 36 one-KiB pieces per tile, -75 us of 523 without them).  ONE image serves both when query
+  // q sits in LDS row perm(q) = 4 (q & 3) + ((q >> 2) & 3) + 16 (q >> 4) (the two 2-bit fields of the row index swapped) under the ROW padding:
+  // the transposed read's four consecutive queries are then rows 4 apart = 16 x odd dwords apart, and the row read's 16-lane groups
+  // ({0-3, 12-15, 20-27}, ...) still cover every residue mod 16.  Both stay conflict-free; the tile costs half the DMA pieces and half the LDS.
+  static constexpr bool ONE = PFN_KV_ONE_IMAGE && sizeof(T) == 2;
   // Q / dO tiles go global -> LDS by LDS-DMA in 1-KiB pieces (64 lanes x 16 bytes, lane-linear in LDS): every image is
   // allocated in whole pieces; piece p of an image holds its bytes [1024 p, 1024 p + 1024)
-  static constexpr int NPR = (QB * C::RS + 1023) / 1024, NPC = (QB * C::CS + 1023) / 1024;   // pieces of a row / col image
+  static constexpr int NPR = (QB * C::RS + 1023) / 1024, NPC = ONE ? 0 : (QB * C::CS + 1023) / 1024;   // pieces of a row / col image
   static constexpr int RIMG = NPR * 1024, CIMG = NPC * 1024;
   static constexpr int NP = 2 * (NPR + NPC);                  // Q rows, Q cols, dO rows, dO cols
   static constexpr int NI = (NP + C::NW - 1) / C::NW;         // pieces per wave
@@ -496,9 +524,9 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   LdsPtr smem = lds_cast(smem_raw);
   auto Vimg = [&]() { return smem; };
   auto Qr = [&](int buf) { return smem + K::VIMG + buf * K::BUF; };
-  auto Qc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::RIMG; };
+  auto Qc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + (K::ONE ? 0 : K::RIMG); };      // (ONE: the one image of the tile)
   auto Or = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::RIMG + K::CIMG; };
-  auto Oc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + 2 * K::RIMG + K::CIMG; };
+  auto Oc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + (K::ONE ? K::RIMG : 2 * K::RIMG + K::CIMG); };
   auto St = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::IMG; };   // [lse x QB][delta x QB]
 
   const AttnBlock wg = attn_block_ragged_last((a.sep + C::QBLK - 1) / C::QBLK, a.sep / C::QBLK, a.H);
@@ -512,6 +540,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   const T* dOp = reinterpret_cast<const T*>(a.dctx) + (long)b * a.S * a.E + hd * D;
   T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
   const int sep = a.sep;
+  const int lip = K::ONE ? kv_row_perm(li) : li;      // the LDS row of the Q / dO tiles this lane reads along (query li of the tile)
   const int key0 = wg.blk * C::QBLK;
   const int key = key0 + wave * 32 + li;
   const bool kvalid = key < sep;
@@ -583,6 +612,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     int row, col;
     if (img & 1) { row = c / (C::CS / 16); col = c % (C::CS / 16); }
     else { row = c / (C::RS / 16); col = c % (C::RS / 16); }
+    if constexpr (K::ONE) row = row < QB ? kv_row_perm(row) : row;      // LDS row r holds query perm(r) (an involution)
     return (row < QB && col < C::RB / 16) ? row * (img >= 2 ? ldo : ldq) + col * 16 : BUF_OOB;
   };
   LdsPtr pvtab = smem + K::VIMG + 2 * K::BUF;   // [NI][NT] ints
@@ -664,12 +694,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
       Frag<T> qfr[C::NKK];
 #pragma unroll
-      for (int kk = 0; kk < PD; ++kk) qfr[kk] = load_frag_row_p<T, C::RS>(qr, li, kk * 16);
+      for (int kk = 0; kk < PD; ++kk) qfr[kk] = load_frag_row_p<T, C::RS>(qr, lip, kk * 16);
       PFN_PIN_LDS_MFMA();
       if constexpr (PRIO & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < C::NKK; ++kk) {
-        if (kk + PD < C::NKK) qfr[kk + PD] = (KVABL & 16) ? qfr[0] : load_frag_row_p<T, C::RS>(qr, li, (kk + PD) * 16);
+        if (kk + PD < C::NKK) qfr[kk + PD] = (KVABL & 16) ? qfr[0] : load_frag_row_p<T, C::RS>(qr, lip, (kk + PD) * 16);
         s = mma32(qfr[kk], kf[kk], s);
         PFN_PIN_LDS_MFMA();
       }
@@ -704,14 +734,14 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       Frag<T> ofr[C::NKK], vfr[K::VLDS ? C::NKK : 1];
 #pragma unroll
       for (int kk = 0; kk < PD2; ++kk) {
-        ofr[kk] = load_frag_row_p<T, C::RS>(orow, li, kk * 16);
+        ofr[kk] = load_frag_row_p<T, C::RS>(orow, lip, kk * 16);
         if constexpr (K::VLDS && !(KVABL & 4)) vfr[kk] = load_frag_row_p<T, C::RS>(Vimg(), wave * 32 + li, kk * 16);
       }
       PFN_PIN_LDS_MFMA();
 #pragma unroll
       for (int kk = 0; kk < C::NKK; ++kk) {
         if (kk + PD2 < C::NKK) {
-          ofr[kk + PD2] = (KVABL & 16) ? ofr[0] : load_frag_row_p<T, C::RS>(orow, li, (kk + PD2) * 16);
+          ofr[kk + PD2] = (KVABL & 16) ? ofr[0] : load_frag_row_p<T, C::RS>(orow, lip, (kk + PD2) * 16);
           if constexpr (K::VLDS && !(KVABL & 4)) vfr[kk + PD2] = load_frag_row_p<T, C::RS>(Vimg(), wave * 32 + li, (kk + PD2) * 16);
         }
         if constexpr (K::VLDS && (KVABL & 4)) dp = mma32(ofr[kk], ofr[kk], dp);
@@ -753,7 +783,10 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       const int prod = P0 + step / NG, grp = step % NG;
       const lds_char* img = prod < 2 ? oc : qc;
 #pragma unroll
-      for (int c = 0; c < CG; ++c) cf[c] = load_frag_tr_p<T, C::CS, 2>(img, (prod & 1) * 16, (grp * CG + c) * 32);
+      for (int c = 0; c < CG; ++c) {
+        if constexpr (K::ONE) cf[c] = load_frag_tr_perm<T, C::RS>(img, (prod & 1) * 16, (grp * CG + c) * 32);
+        else cf[c] = load_frag_tr_p<T, C::CS, 2>(img, (prod & 1) * 16, (grp * CG + c) * 32);
+      }
     };
     request(0);
     PFN_PIN_LDS_MFMA();
