@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """PFN_TEST_TUNE="key=value,..." applies pfn_set_tuning keys (include/pfn_hip.h) to the whole session: the same parity suite then runs over a
+    non-default kernel schedule (e.g. 4=3: the ping-pong barrier placement in the key-block pass too)."""
+    spec = os.environ.get('PFN_TEST_TUNE', '')
+    if spec:
+        import torch  # noqa: F401  (libamdhip64 resident before the library loads)
+        from transformerscandobayesianinference_amd import _hip
+        for kv in spec.split(','):
+            k, v = kv.split('=')
+            _hip.check(_hip.lib().pfn_set_tuning(int(k), int(v)), 'pfn_set_tuning')
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

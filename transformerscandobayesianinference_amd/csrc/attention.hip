@@ -168,6 +168,9 @@ constexpr int PRIO = PFN_ATTN_PRIO;
 #ifndef PFN_KV_ONE_IMAGE
 #define PFN_KV_ONE_IMAGE 1
 #endif
+#ifndef PFN_KV_THREE_BUFFERS
+#define PFN_KV_THREE_BUFFERS 1
+#endif
 #ifndef PFN_KV_PD_S
 #define PFN_KV_PD_S 2
 #endif
@@ -498,6 +501,12 @@ template <typename T, int D> struct BwdKvCfg {
   static constexpr int NI = (NP + C::NW - 1) / C::NW;         // pieces per wave
   static constexpr int IMG = 2 * (RIMG + CIMG);
   static constexpr int BUF = IMG + 2 * QB * 4;                // + lse2[QB], delta[QB]
+  // Tile buffers: two (tile t is computed while tile t+1 lands) -- three in the 8-wave one-image configurations, where the LDS has the room and the
+  // PING-PONG schedule needs it: waves 4..7 take their one barrier per tile BETWEEN the S / dP half (row reads, exponentials) and the dV / dK half
+  // (transposed reads, 16 MFMAs) instead of at the tile's end, so the two waves of a SIMD run half a tile apart and one's vector-heavy half overlaps the
+  // other's matrix-heavy half (the forward's schedule, attn_fwd_kernel).  The lagging waves still read tile t's buffer while the leading ones request
+  // tile t+2: that request goes to the THIRD buffer (last read in tile t-1, which every wave has left at the barrier in front of the request).
+  static constexpr int NBUF = (PFN_KV_THREE_BUFFERS && ONE && C::NW == 8) ? 3 : 2;
   // the lanes' DMA source offsets (one per piece of the wave) live in an LDS table when there is room (every shipped shape):
   // recomputing them per tile costs ~20 vector instructions per piece, keeping them in registers costs registers this kernel
   // does not have
@@ -506,9 +515,9 @@ template <typename T, int D> struct BwdKvCfg {
   // P unpacked from its packed registers the single pass fits the register file (508 VGPRs, no scratch) -- 64 MFMAs per tile instead
   // of 80, one sweep over the Q / dO tiles instead of two.  -DPFN_KV_SPLIT_D256=1 restores the two passes (A/B builds).
   static constexpr bool SPLIT = PFN_KV_SPLIT_D256 && C::NW == 4 && D > 128;
-  static constexpr bool PVLDS = VIMG + 2 * BUF + NI * C::NT * 4 <= 160 * 1024;
+  static constexpr bool PVLDS = VIMG + NBUF * BUF + NI * C::NT * 4 <= 160 * 1024;
   static constexpr int PVTAB = PVLDS ? NI * C::NT * 4 : 0;
-  static constexpr int LDS = VIMG + 2 * BUF + PVTAB;
+  static constexpr int LDS = VIMG + NBUF * BUF + PVTAB;
 };
 
 // MODE 0: dK and dV in one pass.  Head dim 256 cannot hold both accumulators beside the K and V fragments even in the whole
@@ -541,6 +550,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
   const int sep = a.sep;
   const int lip = K::ONE ? kv_row_perm(li) : li;      // the LDS row of the Q / dO tiles this lane reads along (query li of the tile)
+  const bool lag = K::NBUF == 3 && (a.pingpong & 2) && wave >= 4;      // ping-pong (BwdKvCfg::NBUF): this wave takes its barrier in the middle of the tile
   const int key0 = wg.blk * C::QBLK;
   const int key = key0 + wave * 32 + li;
   const bool kvalid = key < sep;
@@ -615,7 +625,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     if constexpr (K::ONE) row = row < QB ? kv_row_perm(row) : row;      // LDS row r holds query perm(r) (an involution)
     return (row < QB && col < C::RB / 16) ? row * (img >= 2 ? ldo : ldq) + col * 16 : BUF_OOB;
   };
-  LdsPtr pvtab = smem + K::VIMG + 2 * K::BUF;   // [NI][NT] ints
+  LdsPtr pvtab = smem + K::VIMG + K::NBUF * K::BUF;   // [NI][NT] ints
   if constexpr (K::PVLDS) {
 #pragma unroll
     for (int i = 0; i < K::NI; ++i)
@@ -687,6 +697,13 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     // DMA pieces and keeps the barriers, and leaves the matrix pipe, the vector ALU and the LDS ports of its SIMD to its partner.
     // The workgroup of a ragged last block therefore finishes early and frees its CU for the next one (sep mod 256 is uniform:
     // on average half of that block's waves are dead).
+    // one barrier per tile and wave: at the tile's end, or (lagging waves of the ping-pong schedule) between its two halves.  Either way it is passed
+    // with this wave's LDS reads done and its pieces of tile t+1 landed (vmcnt = the dS^T stores issued behind them: loads and stores retire in order)
+    auto sync_tile = [&]() __attribute__((always_inline)) {
+      if (ABL & 4) dma_wait_all();
+      else if (stored) wait_vm_barrier<DS_STORES>();
+      else wait_vm_barrier<0>();
+    };
     if (wave_live) {
     {
       f32x16 s;
@@ -765,6 +782,9 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
       df0 = acc_to_frag<T>(dp, 0);
       df1 = acc_to_frag<T>(dp, 1);
     }
+    }
+    if (lag) sync_tile();
+    if (wave_live) {
     if constexpr (DROP) {     // the dV product sees the masked probabilities (the dS stage above wanted the unmasked ones)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -813,12 +833,11 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     // behind the barrier), THEN this tile's dS^T stores (block (key / 32, t), operand precision: exactly what the dK product
     // consumed) -- and the wait for tile t+1 one tile earlier is vmcnt(stores of the previous tile), which leaves those stores two
     // tile times to be acknowledged instead of stalling every tile on them (with them in front of the DMA: 70 us of 372).
-    if (ABL & 4) dma_wait_all();
-    else if (stored) wait_vm_barrier<DS_STORES>();
-    else wait_vm_barrier<0>();
+    if (!lag) sync_tile();
     if (!(ABL & 1) && t + 2 < ntiles) {
-      dma(BUF, t + 2);
-      stage_stats(BUF, (t + 2) * QB);
+      constexpr int NXT = (BUF + 2) % K::NBUF;      // two buffers: this tile's own (free behind the barrier); three: the one tile t-1 used
+      dma(NXT, t + 2);
+      stage_stats(NXT, (t + 2) * QB);
     }
     // keys >= sep of a block row the dQ pass reads (rows < ds_rows) leave as zeros: that pass does not mask rows
     if constexpr (DS_STORES > 0) {
@@ -834,9 +853,11 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  for (int t = t0; t < ntiles; t += 2) {
+  using I2 = std::integral_constant<int, 2 % K::NBUF>;
+  for (int t = t0; t < ntiles; t += K::NBUF) {
     tile(I0{}, t);
     if (t + 1 < ntiles) tile(I1{}, t + 1);
+    if (K::NBUF == 3 && t + 2 < ntiles) tile(I2{}, t + 2);
   }
 
   {
