@@ -203,6 +203,54 @@ def test_torch_modules_model_matches_the_port():
     assert set(m.state_dict()) == {k for k in sd if not k.startswith('criterion.')}
 
 
+def test_top_layer_train_rows_feed_nothing_in_the_reference_stack():
+    """What licenses the HIP stack to run its top encoder layer on the test rows only (pfn_api.hip top_layer_on_test_rows): in the module stack the
+    reference instantiates, everything the TOP layer computes for its train rows behind the K / V projection -- attention output, out_proj, both
+    LayerNorms, FFN -- reaches neither the returned logits (output[single_eval_pos:], transformer.py:91) nor any parameter gradient.  Checked on the
+    torch modules themselves: the top layer's train-row outputs are replaced by garbage (so is their gradient path), the train-row queries of its
+    attention see garbage too; logits and every gradient stay what they were.  The K / V projection of the train rows IS needed -- removing it
+    changes the result."""
+    from oracle import torch_modules
+    rec = torch.load(os.path.join(GOLD, 'model_small_h32.pt'))
+    cfg, sd = rec['config'], rec['state_dict']
+    x, y = rec['x'], rec['y']
+    sep = sorted(rec['per_sep'])[len(rec['per_sep']) // 2]
+    assert 0 < sep < len(x)
+
+    def run(mangle):
+        m = torch_modules.from_state_dict(sd, cfg['H']).train()
+        top = m.transformer_encoder.layers[-1]
+        handles = []
+        if mangle in ('outputs', 'queries'):
+            # the top layer's train-row outputs replaced by garbage without a gradient path
+            handles.append(top.register_forward_hook(lambda mod, inp, out: torch.cat([torch.full_like(out[:sep], 1e3).detach(), out[sep:]], 0)))
+        if mangle == 'queries':
+            # ... and its attention's train-row QUERIES too (keys and values untouched): the self-attention module is called as attn(x, x, x)
+            def pre(mod, args, kwargs):
+                q, k, v = args[:3]
+                return (torch.cat([torch.full_like(q[:sep], -7.0), q[sep:]], 0), k, v) + tuple(args[3:]), kwargs
+            handles.append(top.self_attn.register_forward_pre_hook(pre, with_kwargs=True))
+        if mangle == 'keys':
+            def pre(mod, args, kwargs):
+                q, k, v = args[:3]
+                return (q, torch.cat([torch.zeros_like(k[:sep]), k[sep:]], 0), v) + tuple(args[3:]), kwargs
+            handles.append(top.self_attn.register_forward_pre_hook(pre, with_kwargs=True))
+        out = m((x, y), sep)
+        out.square().mean().backward()
+        for h in handles:
+            h.remove()
+        return out.detach(), {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+
+    base_out, base_grads = run(None)
+    for mangle in ('outputs', 'queries'):
+        out, grads = run(mangle)
+        assert torch.equal(out, base_out), mangle
+        for k, g in base_grads.items():
+            assert torch.allclose(grads[k], g, rtol=1e-5, atol=1e-7 * float(g.abs().max() + 1e-30)), (mangle, k)
+    out, _ = run('keys')
+    assert relerr(out, base_out) > 1e-3
+
+
 def test_oracle_mlp_prior_causal_matches_reference():
     """The remaining branches of the reference's priors.mlp forward -- causal graph with pre-sampled causes, categorical features,
     per-unit pre-sampled noise scales -- re-built by the oracle from the tensors the reference drew (tests/golden/mlp_prior_causal.pt,
