@@ -1,7 +1,8 @@
 #!/bin/bash
 # Ablation / experiment builds of libpfn_hip.so: [SRC=gemm.hip] tools/build_variants.sh name "<extra hipcc flags for $SRC>" [name flags ...]
 # (SRC defaults to attention.hip) -> transformerscandobayesianinference_amd/_variants/libpfn_<name>.so (travels to the GPU box;
-# select with PFN_LIB=<path> in the tools/ scripts)
+# select with PFN_LIB=<path> in the tools/ scripts, or by name in tools/bench_kv_variants.py).  Every build is ~3 MB of snapshot per gpurun call:
+# rm -rf transformerscandobayesianinference_amd/_variants when the experiment is over.
 set -e
 cd "$(dirname "$0")/../transformerscandobayesianinference_amd/csrc"
 mkdir -p ../_variants
