@@ -30,6 +30,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.pfn_abi_version() == _hip.ABI_VERSION
 
 
+def test_c_client_of_the_abi(tmp_path):
+    """The boundary is a C ABI: include/pfn_hip.h compiles as C99, and a C program (tests/cabi_check.c) dlopens the library, resolves every declared entry point
+    and runs the host-side ones -- no Python, no torch types anywhere in the signatures."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    header = open(os.path.join(ROOT, 'include', 'pfn_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(pfn_[a-z0-9_]+)\s*\(', header)))
+    exe = str(tmp_path / 'cabi_check')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'cabi_check.c'), '-ldl', '-o', exe], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH='/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', ''))
+    res = subprocess.run([exe, _hip.LIB_PATH] + declared, capture_output=True, text=True, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert 'cabi_check ok' in res.stdout
+
+
 def test_param_layout_matches_reference_state_dict_order():
     lib = _hip.lib()
     d = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5)
