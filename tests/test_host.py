@@ -47,6 +47,36 @@ def test_c_client_of_the_abi(tmp_path):
     assert 'cabi_check ok' in res.stdout
 
 
+def test_attention_kernels_keep_their_register_and_lds_budgets(tmp_path):
+    """The attention kernels are written against hard budgets: no scratch in any operand-precision variant, at most 256 VGPRs where two
+    waves share a SIMD (8-wave configurations: head dims 32 / 64 / 128) and at most 512 where one wave has it (head dim 256); the LDS budget (160 KiB) is a
+    static_assert in the launchers, so it holds whenever this compiles.  Read off
+    the compiler's own kernel descriptors (hipcc -S of attention.hip with the flags of csrc/build.sh) -- a change that starts spilling fails here, not in a profile."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = os.path.join(ROOT, 'transformerscandobayesianinference_amd', 'csrc', 'attention.hip')
+    asm = str(tmp_path / 'attention.s')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-S', '--cuda-device-only', src, '-o', asm], check=True,
+                   capture_output=True)
+    text = open(asm).read()
+    seen = 0
+    for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', text, re.S):
+        name, body = m.group(1), m.group(2)
+        if 'DF16b' not in name or 'attn_' not in name:          # the bf16 (operand precision) instantiations
+            continue
+        vgpr = int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1))
+        scratch = int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', body).group(1))
+        assert scratch == 0, (name, scratch)
+        head_dim = re.search(r'Li(\d+)E', name)
+        if head_dim:                                              # (the delta kernel has no head-dim parameter)
+            assert vgpr <= (512 if int(head_dim.group(1)) == 256 else 256), (name, vgpr)
+        seen += 1
+    assert seen >= 4 * 2 * 3 + 1          # forward / key-block pass / query-block pass x 4 head dims x {plain, dropout}, + delta
+
+
 def test_param_layout_matches_reference_state_dict_order():
     lib = _hip.lib()
     d = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5)

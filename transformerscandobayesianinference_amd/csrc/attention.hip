@@ -1160,7 +1160,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 // =============================================================================================
 template <typename T, int D, bool DROP> static int launch_fwd_k(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
-  const size_t lds = 2 * C::RIMG + 4 * C::CIMG;
+  constexpr size_t lds = 2 * C::RIMG + 4 * C::CIMG;
+  static_assert(lds <= 160 * 1024, "attention forward: tile buffers exceed the CU's LDS");
   static LdsAllowance allowance;
   allowance.ensure(attn_fwd_kernel<T, D, DROP>, lds);
   if ((a.S + C::QBLK - 1) / C::QBLK <= a.q_begin / C::QBLK) return PFN_OK;      // no query at or above q_begin
@@ -1178,7 +1179,8 @@ template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& 
     int grid = (int)std::min<long>((pairs + 15) / 16, 4096);
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, s, a, D);
   }
-  const size_t lds_kv = BwdKvCfg<T, D>::LDS, lds_dq = BwdDqCfg<T, D>::LDS;
+  constexpr size_t lds_kv = BwdKvCfg<T, D>::LDS, lds_dq = BwdDqCfg<T, D>::LDS;
+  static_assert(lds_kv <= 160 * 1024 && lds_dq <= 160 * 1024, "attention backward: tile buffers exceed the CU's LDS");
   static LdsAllowance allow_kv[3], allow_dq;      // (per device; hipFuncSetAttribute costs tens of microseconds of host time per call)
   auto run_kv = [&](auto kernel, LdsAllowance& allow, const AttnArgs& ac) {
     allow.ensure(kernel, lds_kv);
