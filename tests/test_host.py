@@ -77,6 +77,30 @@ def test_attention_kernels_keep_their_register_and_lds_budgets(tmp_path):
     assert seen >= 4 * 2 * 3 + 1          # forward / key-block pass / query-block pass x 4 head dims x {plain, dropout}, + delta
 
 
+def test_step_gemm_kernels_have_no_scratch(tmp_path):
+    """The same for the GEMMs the training step launches (bench.py's kernel table names them): the 256 x 256 NT kernel in its default tile mode <flags, 2, 64>, the
+    LayerNorm-fused forms at 8 waves (emsize 512) and their wide variants, the grouped weight-gradient kernel -- no scratch, at most 256 VGPRs (two waves per SIMD).
+    (Alternative tile modes and the persistent kernel are tuning options outside the step and are not held to it.)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = os.path.join(ROOT, 'transformerscandobayesianinference_amd', 'csrc', 'gemm.hip')
+    asm = str(tmp_path / 'gemm.s')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', src, '-o', asm], check=True, capture_output=True)
+    step = re.compile(r'gemm_nt_big_kernelILi\d+ELi2ELi64E|gemm_nt_ln_kernelILi8E|gemm_nt_lnbwd_kernelILi8E|gemm_nt_ln_wide_kernel|gemm_nt_lnbwd_wide_kernel|gemm_tn_big_kernel')
+    seen = 0
+    for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', open(asm).read(), re.S):
+        name, body = m.group(1), m.group(2)
+        if not step.search(name):
+            continue
+        assert int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', body).group(1)) == 0, name
+        assert int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1)) <= 256, name
+        seen += 1
+    assert seen >= 10 + 4 + 2 + 3 + 1
+
+
 def test_param_layout_matches_reference_state_dict_order():
     lib = _hip.lib()
     d = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5)
