@@ -1239,3 +1239,34 @@ def test_emsize_1024_fused_layernorm_gemms_in_the_stack():
         tot = math.sqrt(sum((g ** 2).sum().item() for g in grads_o.values()))
         within(f'fused-wide={wide} global gradient rel l2', tot_err / tot, 1.2e-2)
     assert relerr(outs[1][0], outs[0][0]) < 5e-3          # the two paths round differently, not more
+
+
+def test_eval_mode_forward_then_backward_uses_the_training_kernels():
+    """with the DEFAULT eval_precision='f32' on a bf16 model, an eval()-mode forward that is differentiated afterwards
+    (fine-tuning under eval(), input gradients) must run the training-precision kernels -- its backward reads that workspace layout.
+    eval() + backward == train() + backward at dropout 0, bit for bit; under no_grad eval() still takes the exact-f32 inference kernels."""
+    cfg = dict(T=96, B=3, F=4, E=64, H=2, nhid=128, L=2, nbars=20)
+    model = random_model(cfg, 'bf16', seed=31)
+    model.eval_precision = 'f32'                                # the constructor default (random_model pins it to the training precision)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g = torch.Generator().manual_seed(2)
+    x, y = torch.rand(cfg['T'], cfg['B'], cfg['F'], generator=g).to(DEV), torch.randn(cfg['T'], cfg['B'], generator=g).to(DEV)
+    sep = 70
+    grads, outs = {}, {}
+    for mode in ('train', 'eval'):
+        getattr(model, mode)()
+        model.flat_parameters()[1].zero_()
+        out = model((x, y), single_eval_pos=sep)
+        model.criterion(out.reshape(-1, cfg['nbars']), y[sep:].flatten()).mean().backward()
+        grads[mode], outs[mode] = model.flat_parameters()[1].clone(), out.detach().clone()
+    assert model._eval_desc is not None                          # a separate inference precision IS configured
+    assert torch.isfinite(grads['eval']).all()
+    assert torch.equal(outs['eval'], outs['train']) and torch.equal(grads['eval'], grads['train'])
+    _, _, grads_o = pfn_oracle.loss_and_grads(sd, x.cpu(), y.cpu(), y.cpu(), sep, cfg['H'], sd['criterion.borders'])
+    tot_err = math.sqrt(sum(((p.grad.double().cpu() - grads_o[k]) ** 2).sum().item() for k, p in model.named_parameters()))
+    within('eval-mode backward, global gradient rel l2', tot_err / math.sqrt(sum((v ** 2).sum().item() for v in grads_o.values())), 1.2e-2)
+    with torch.no_grad():
+        inf = model((x, y), single_eval_pos=sep)                 # inference pass: exact-f32 kernels
+    want = pfn_oracle.forward(sd, x.cpu(), y.cpu(), sep, cfg['H'])
+    assert relerr(inf, want) < 1e-4 < relerr(outs['eval'], want)
