@@ -13,7 +13,11 @@
  *   - work is enqueued asynchronously on `stream` (a hipStream_t; NULL = the legacy default stream);
  *   - return value: PFN_OK (0) or a negative PFN_ERR_* code; pfn_last_error_string() gives detail;
  *     no C++ exception crosses the boundary;
- *   - re-entrant for distinct streams; no global mutable state besides the per-thread error string.
+ *   - re-entrant for distinct streams.  Everything that decides what a call computes or how its workspace is laid out travels IN the call
+ *     (pfn_model_desc incl. its `schedule` bits, shapes, pointers).  The only process-wide mutable state is (a) the per-thread error
+ *     string, (b) the TEST / PROFILING hooks pfn_set_tuning and pfn_profile_* below -- kernel-selection and instrumentation switches that
+ *     never change a result beyond rounding order or a buffer layout; they are not synchronised and are meant to be set while no call is
+ *     in flight (tests, bench.py --tune); production callers never touch them.
  *
  * Internal activation layout is batch-major [B, S, E] (one synthetic dataset = one contiguous
  * block); the reference layout [S, B, ...] is converted at the boundary kernels.
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 5
+#define PFN_ABI_VERSION 6
 
 enum {
   PFN_OK = 0,
@@ -57,12 +61,25 @@ typedef struct pfn_model_desc {
                          * buffers are carved.  > 0: pfn_stack_forward_dropout / pfn_stack_backward_split(use_dropout = 1) apply it at the
                          * layer's four sites (attention probabilities, after out_proj, after the FFN activation, after linear2);
                          * pfn_stack_forward is the inference pass (model.eval()) and applies none. */
+  int32_t schedule;     /* PFN_SCHED_* bits, 0 = the measured defaults.  The schedule is part of the descriptor because it decides the row
+                         * layout of some workspace buffers: a forward and the backward that reads its workspace must see the same bits, and
+                         * they do when both are given the same descriptor (ABI 6; it was process-global state before). */
 } pfn_model_desc;
+enum { PFN_SCHED_TOP_LAYER_ALL_ROWS = 1, /* run the TOP encoder layer on every row like the others.  Default (bit clear): everything behind its K / V
+                                          * projection runs on the test rows only -- the reference returns output[single_eval_pos:] (transformer.py:91),
+                                          * so that layer's train rows feed nothing (not with live dropout, not when sep < S / 4) */
+       PFN_SCHED_FUSE_LN_WIDE = 2,       /* emsize 1024: LayerNorm-fused GEMMs on 64-row x 1024-column tiles (correct, measured slower: default off) */
+       PFN_SCHED_SEPARATE_LNBWD = 4      /* LayerNorm backward as its own kernels instead of inside the data-gradient GEMMs that feed it */ };
+/* schedule bits a binding should put into new descriptors: 0 unless a test / profiling run changed the defaults through pfn_set_tuning
+ * (PFN_TUNE_FUSE_LNBWD, PFN_TUNE_FUSE_LN_WIDE, PFN_TUNE_TOP_LAYER_TEST_ROWS) */
+int pfn_default_schedule(void);
 
 int pfn_abi_version(void);
 const char* pfn_last_error_string(void);
-/* Process-wide kernel-selection knobs for tests and profiling (results are identical up to rounding
- * order).  PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
+/* TEST / PROFILING ONLY: process-wide kernel-selection knobs (results are identical up to rounding order; not synchronised -- set them
+ * while no call is in flight).  Keys 2, 5 and 6 do not act on calls directly: they change what pfn_default_schedule() hands to NEW
+ * descriptors (pfn_model_desc::schedule), so a forward / backward pair can never disagree about them.
+ * PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
  * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one.
  * PFN_TUNE_FUSE_LNBWD: 1 (default) the stack backward runs LayerNorm backward inside the data-gradient GEMMs that feed it
  * (pfn_op_gemm_lnbwd), 0 as separate kernels.  PFN_TUNE_GEMM_PERSIST: > 0 runs the 256x256 NT GEMM as that many persistent
@@ -77,6 +94,16 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
                                     * returns output[single_eval_pos:] (transformer.py:91), so that layer's train rows feed nothing; 0: every layer on every row */ };
 int pfn_set_tuning(int key, int value);
+/* TEST / PROFILING ONLY: in-step kernel timing.  pfn_profile_enable(1) makes the stack entry points (and pfn_op_attention_*) bracket every
+ * launch of the kernel classes below with a pair of HIP events ON THE LAUNCH STREAM; pfn_profile_read(slot, &ms, &n) waits for the pairs
+ * recorded for that class so far, returns their summed duration and count and forgets them.  bench.py uses it to report how long the
+ * dominant kernel runs INSIDE the step (two micro-batch streams and the prior sampler share the chip), next to its duration on an idle chip.
+ * Slots with +1 = the same kernel launched for the top encoder layer's test rows only. */
+enum { PFN_PROF_ATTN_FWD = 0, PFN_PROF_ATTN_BWD_DELTA = 2, PFN_PROF_ATTN_BWD_KV = 4, PFN_PROF_ATTN_BWD_DQ = 6, PFN_PROF_GEMM_QKV = 8,
+       PFN_PROF_GEMM_OUT_LN = 10, PFN_PROF_GEMM_LIN1 = 12, PFN_PROF_GEMM_LIN2_LN = 14, PFN_PROF_GEMM_DHPRE = 16, PFN_PROF_GEMM_DY1 = 18,
+       PFN_PROF_GEMM_DCTX = 20, PFN_PROF_GEMM_DX = 22, PFN_PROF_WGRAD = 24, PFN_PROF_SLOTS = 26 };
+int pfn_profile_enable(int on);
+int pfn_profile_read(int slot, double* total_ms, int64_t* launches);
 
 /* ---- parameter packing ------------------------------------------------------------------------
  * All parameters live in ONE flat f32 buffer (and one flat f32 gradient buffer) in state-dict
@@ -102,7 +129,7 @@ int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shado
  * in PyTorch); when non-NULL x/y are ignored and pfn_stack_backward returns d(src) in dsrc_sbe. */
 int64_t pfn_workspace_bytes(const pfn_model_desc* d, int B, int S);
 /* Rows the TOP encoder layer runs on behind its K / V projection for this call shape: (S - sep) * B when the stack drops that layer's train rows
- * (they feed nothing: the reference returns output[single_eval_pos:], transformer.py:91 -- PFN_TUNE_TOP_LAYER_TEST_ROWS, on by default; not with live
+ * (they feed nothing: the reference returns output[single_eval_pos:], transformer.py:91 -- the default; not with PFN_SCHED_TOP_LAYER_ALL_ROWS, not with live
  * dropout, not when sep < S / 4), else B * S.  Same results either way; bench.py counts FLOPs and launches with it. */
 int64_t pfn_top_layer_rows(const pfn_model_desc* d, int B, int S, int sep, int use_dropout);
 int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* shadow,

@@ -273,6 +273,88 @@ def gp_case(ref):
     print('gp cases', [(c['B'], c['T'], c['F'], c['length_scale'], [round(float(v), 4) for v in c['evaluate_nll'][:4]]) for c in rec['cases']])
 
 
+class ReplayLoader:
+    """PriorDataLoader protocol (reference priors/prior.py:4-12, priors/utils.py:14-42) over RECORDED batches: what `train.train` iterates
+    once per epoch.  The cursor runs on across epochs, so epoch e sees batches [e * num_steps, (e + 1) * num_steps).  tests/ holds the same
+    class (tests/replay.py) so the HIP `train()` replays the identical stream."""
+    num_outputs = 1
+    fuse_x_y = False
+
+    def __init__(self, num_steps, batch_size=None, seq_len=None, batches=None, **_):
+        self.num_steps, self.batches, self.cursor = num_steps, batches, 0
+        self.num_features = batches[0][0].shape[-1]
+
+    def __len__(self):
+        return self.num_steps
+
+    def __iter__(self):
+        for _ in range(self.num_steps):
+            x, y, target = self.batches[self.cursor % len(self.batches)]
+            self.cursor += 1
+            yield (x, y), target
+
+
+def train_loop_case(ref, name='train_loop_small', T=60, B=3, F=5, E=64, H=2, nhid=128, L=2, nbars=50, epochs=4, steps_per_epoch=8, aggregate_k=2,
+                    warmup_epochs=1, lr=1e-3, seed=17):
+    """Pins the TRAINING LOOP to the reference's own `train.train` (train.py:22-135): recorded batches and a recorded
+    eval-position stream are replayed through it on the CPU -- `aggregate_k_gradients` micro-batches summed per optimizer step (:92-97),
+    clip-to-1 + Adam, the per-EPOCH cosine schedule with warm-up whose first epoch runs at lr = 0 (utils.py:10-22: LambdaLR(step 0) = 0 / warmup)
+    -- and every batch loss, the learning rate of every batch, the per-epoch mean losses and the final state dict are recorded.  Dropout 0
+    (torch's dropout stream cannot be replayed)."""
+    gen = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    nb = epochs * steps_per_epoch
+    batches = []
+    for _ in range(nb):
+        x, y, _ = gp_draw(B, T, F, gen)
+        batches.append((x, y, y.clone()))
+    random.seed(seed)
+    sampler = ref['utils'].get_weighted_single_eval_pos_sampler(T)
+    seps = [sampler() for _ in range(nb)]
+    borders = ref['bar_distribution'].get_bucket_limits(nbars, ys=gp_draw(200, 20, F, gen)[1])
+    log = dict(loss=[], lr=[])
+    state = {}
+
+    class RecordingFullSupportBarDistribution(ref['bar_distribution'].FullSupportBarDistribution):      # ("BarDistribution" stays in the class name: train.py:37)
+        def forward(self, logits, y):
+            losses = super().forward(logits, y)
+            log['loss'].append(float(losses.detach().mean()))
+            log['lr'].append(state['opt'].param_groups[0]['lr'])
+            return losses
+
+    criterion = RecordingFullSupportBarDistribution(borders)
+    # initial weights: built the way train() builds the model, with the residual branches un-zeroed (transformer.py:49-53 zeroes them)
+    init = ref['transformer'].TransformerModel(ref['encoders'].Linear(F, E), nbars, E, H, nhid, L, 0.0, y_encoder=ref['encoders'].Linear(1, E),
+                                               pos_encoder=ref['positional_encodings'].NoPositionalEncoding(E, T * 2))
+    init.criterion = ref['bar_distribution'].FullSupportBarDistribution(borders)
+    with torch.no_grad():
+        for layer in init.transformer_encoder.layers:
+            for t in (layer.linear2.weight, layer.self_attn.out_proj.weight):
+                t.normal_(0, 0.05)
+    init_sd = {k: v.clone() for k, v in init.state_dict().items()}
+    it = iter(seps)
+
+    def scheduler(optimizer, warmup, total):
+        state['opt'] = optimizer
+        return ref['utils'].get_cosine_schedule_with_warmup(optimizer, warmup, total)
+
+    total_loss, positional, model = ref['train'].train(
+        ReplayLoader, criterion, ref['encoders'].Linear, emsize=E, nhid=nhid, nlayers=L, nhead=H, dropout=0.0, epochs=epochs,
+        steps_per_epoch=steps_per_epoch, batch_size=B, bptt=T, lr=lr, warmup_epochs=warmup_epochs, y_encoder_generator=ref['encoders'].Linear,
+        extra_prior_kwargs_dict=dict(batches=batches), scheduler=scheduler, load_weights_from_this_state_dict=init_sd,
+        single_eval_pos_gen=lambda: next(it), aggregate_k_gradients=aggregate_k, verbose=False)
+    assert len(log['loss']) == nb
+    epoch_losses = [sum(log['loss'][e * steps_per_epoch:(e + 1) * steps_per_epoch]) / steps_per_epoch for e in range(epochs)]
+    assert abs(epoch_losses[-1] - total_loss) < 1e-6
+    rec = dict(config=dict(T=T, B=B, F=F, E=E, H=H, nhid=nhid, L=L, nbars=nbars, epochs=epochs, steps_per_epoch=steps_per_epoch,
+                           aggregate_k_gradients=aggregate_k, warmup_epochs=warmup_epochs, lr=lr),
+               batches=[(x, y) for x, y, _ in batches], seps=seps, borders=borders, init_state_dict=init_sd,
+               batch_losses=log['loss'], batch_lr=log['lr'], epoch_losses=epoch_losses, returned_total_loss=total_loss,
+               returned_positional_losses=positional, final_state_dict={k: v.clone() for k, v in model.state_dict().items()})
+    torch.save(rec, os.path.join(OUT, f'{name}.pt'))
+    print(name, 'epoch losses', [round(v, 5) for v in epoch_losses], 'lr per epoch', log['lr'][::steps_per_epoch], 'seps', seps[:8])
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -284,3 +366,4 @@ if __name__ == '__main__':
     mlp_prior_case(ref)
     mlp_prior_causal_case(ref)
     gp_case(ref)
+    train_loop_case(ref)

@@ -42,8 +42,16 @@ int main(int argc, char** argv) {
   CHECK(workspace_bytes(&d, 32, 2000) > 0 && workspace_bytes(&d, 64, 2000) > workspace_bytes(&d, 32, 2000));
   CHECK(top_rows(&d, 32, 2000, 1604, 0) == (int64_t)(2000 - 1604) * 32);
   CHECK(top_rows(&d, 32, 2000, 100, 0) == (int64_t)2000 * 32);
-  CHECK(set_tuning(PFN_TUNE_TOP_LAYER_TEST_ROWS, 0) == PFN_OK && top_rows(&d, 32, 2000, 1604, 0) == (int64_t)2000 * 32);
-  CHECK(set_tuning(PFN_TUNE_TOP_LAYER_TEST_ROWS, 1) == PFN_OK);
+  /* the schedule is part of the descriptor (ABI 6): the same bits reach a forward and the backward that reads its workspace */
+  d.schedule = PFN_SCHED_TOP_LAYER_ALL_ROWS;
+  CHECK(top_rows(&d, 32, 2000, 1604, 0) == (int64_t)2000 * 32);
+  d.schedule = 0;
+  /* the test / profiling knob only changes the default for NEW descriptors */
+  int (*default_schedule)(void) = (int (*)(void))dlsym(lib, "pfn_default_schedule");
+  CHECK(default_schedule() == 0);
+  CHECK(set_tuning(PFN_TUNE_TOP_LAYER_TEST_ROWS, 0) == PFN_OK && default_schedule() == PFN_SCHED_TOP_LAYER_ALL_ROWS);
+  CHECK(top_rows(&d, 32, 2000, 1604, 0) == (int64_t)(2000 - 1604) * 32);
+  CHECK(set_tuning(PFN_TUNE_TOP_LAYER_TEST_ROWS, 1) == PFN_OK && default_schedule() == 0);
   CHECK(set_tuning(12345, 0) < 0);
   /* error path: head dim 100 (the reference's train() default emsize 200 / nhead 2) is refused with a message, not computed wrongly */
   d.emsize = 200; d.nhead = 2; d.nhid = 200;

@@ -127,12 +127,27 @@ def test_top_layer_row_rule_and_flop_accounting():
     rows = lambda sep, drop=0, desc=d: lib.pfn_top_layer_rows(ctypes.byref(desc), B, S, sep, drop)
     assert rows(1604) == (S - 1604) * B and rows(500) == (S - 500) * B          # test rows only
     assert rows(499) == B * S and rows(0) == B * S and rows(S) == B * S          # short train part / no test row: every row
-    try:
-        assert lib.pfn_set_tuning(6, 0) == 0 and rows(1604) == B * S             # PFN_TUNE_TOP_LAYER_TEST_ROWS = 0
+    # the schedule travels in the descriptor (ABI 6): a forward and its backward cannot disagree about the row layout
+    all_rows = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5, 0.0, _hip.SCHED_TOP_LAYER_ALL_ROWS)
+    assert rows(1604, 0, all_rows) == B * S
+    ws = lambda desc: lib.pfn_workspace_bytes(ctypes.byref(desc), B, S)
+    assert ws(all_rows) < ws(d)                                                  # ... and the compact-row buffers are only carved when they can be used
+    try:      # the test / profiling knob changes the DEFAULT handed to new descriptors, not calls on existing ones
+        assert lib.pfn_default_schedule() == 0
+        assert lib.pfn_set_tuning(6, 0) == 0 and lib.pfn_default_schedule() == _hip.SCHED_TOP_LAYER_ALL_ROWS and rows(1604) == (S - 1604) * B
     finally:
         lib.pfn_set_tuning(6, 1)
+    assert lib.pfn_default_schedule() == 0
+    bad_bits = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5, 0.0, 64)
+    assert rows(1604, 0, bad_bits) < 0
     with_dropout = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5, 0.2)
-    assert rows(1604, 1, with_dropout) == B * S and rows(1604, 0, with_dropout) == (S - 1604) * B   # live dropout keeps the full-layout row indices
+    assert rows(1604, 1, with_dropout) == B * S and rows(1604, 0, with_dropout) == B * S   # dropout keeps the full-layout row indices (the compact-row buffers are not carved)
+    assert ws(with_dropout) > 0
+    # profiling hook: nothing recorded unless enabled; reading an empty slot is fine without a GPU
+    import ctypes as _c
+    ms, n = _c.c_double(-1), _c.c_int64(-1)
+    assert lib.pfn_profile_read(4, _c.byref(ms), _c.byref(n)) == 0 and ms.value == 0.0 and n.value == 0
+    assert lib.pfn_profile_read(999, _c.byref(ms), _c.byref(n)) < 0
     no_layers = _hip.ModelDesc(18, 512, 4, 1024, 0, 1000, _hip.PREC_BF16, 1e-5)
     assert rows(1604, 0, no_layers) == B * S
     assert rows(S + 1) < 0
@@ -343,6 +358,33 @@ def test_train_loop_plumbing_on_cpu(monkeypatch):
     assert next(model.parameters()).device.type == 'cpu'
     with pytest.raises(AssertionError):
         _cpu_train(monkeypatch, epochs=1, steps_per_epoch=3, batch_size=4, aggregate_k_gradients=2)
+
+
+def test_train_loop_replays_the_reference_train_golden_on_cpu(monkeypatch):
+    """The training LOOP pinned to the reference's own `train.train` (train.py:58-110,134; utils.py:10-22):
+    tests/golden/train_loop_small.pt holds recorded batches, a recorded eval-position stream and what the reference's loop made of them --
+    4 epochs x 8 batches, aggregate_k_gradients = 2 (micro-batch gradients SUMMED per optimizer step), cosine schedule with one
+    warm-up epoch stepped per EPOCH whose first epoch runs at lr = 0 (Q5).  This repo's train() replays the same stream here with the f32
+    oracle standing in for the HIP model (the GPU suite runs the real stack on the same fixture): every batch loss, every learning rate
+    and the final weights must come out as the reference's did."""
+    import replay
+    from transformerscandobayesianinference_amd import bar_distribution, encoders, train as train_mod
+    rec = torch.load(os.path.join(GOLD, 'train_loop_small.pt'))
+    monkeypatch.setattr(train_mod, 'TransformerModel', _OracleModel)
+    monkeypatch.setattr(train_mod, 'FusedClipAdam', _TorchAdam)
+
+    class CpuBar(bar_distribution.FullSupportBarDistribution):
+        def forward(self, logits, y):
+            return pfn_oracle.bar_nll(logits, y, self.borders, True)
+
+    losses, lrs, total, final = replay.replay(train_mod.train, rec, CpuBar, encoders, utils.get_cosine_schedule_with_warmup)
+    cfg = rec['config']
+    assert len(losses) == cfg['epochs'] * cfg['steps_per_epoch']
+    assert lrs == pytest.approx(rec['batch_lr'], rel=1e-12, abs=0)
+    assert lrs[0] == 0.0 and lrs[cfg['steps_per_epoch']] == cfg['lr']                   # epoch 1 trains at lr = 0 (reference quirk Q5)
+    assert max(abs(a - b) / abs(b) for a, b in zip(losses, rec['batch_losses'])) < 2e-5
+    assert abs(total - rec['returned_total_loss']) < 2e-5 * abs(rec['returned_total_loss'])
+    assert replay.update_error(final, rec) < 1e-3
 
 
 _DP_SCRIPT = r'''

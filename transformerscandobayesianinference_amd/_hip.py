@@ -13,10 +13,11 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpfn_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 PREC_BF16 = 0
 PREC_F32 = 1
+SCHED_TOP_LAYER_ALL_ROWS, SCHED_FUSE_LN_WIDE, SCHED_SEPARATE_LNBWD = 1, 2, 4     # pfn_model_desc.schedule bits (include/pfn_hip.h)
 
 # GEMM epilogue flags (csrc/pfn_kernels.h)
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_OUT_F32, EPI_OUT_T, EPI_OUT2_T, EPI_ACCUM, EPI_RESID_T = 1, 2, 4, 8, 16, 32, 64, 128, 256
@@ -29,10 +30,10 @@ class HipExtensionError(RuntimeError):
 class ModelDesc(ctypes.Structure):
     _fields_ = [('num_features', ctypes.c_int32), ('emsize', ctypes.c_int32), ('nhead', ctypes.c_int32),
                 ('nhid', ctypes.c_int32), ('nlayers', ctypes.c_int32), ('n_out', ctypes.c_int32),
-                ('precision', ctypes.c_int32), ('ln_eps', ctypes.c_float), ('dropout', ctypes.c_float)]
+                ('precision', ctypes.c_int32), ('ln_eps', ctypes.c_float), ('dropout', ctypes.c_float), ('schedule', ctypes.c_int32)]
 
     def key(self):
-        return (self.num_features, self.emsize, self.nhead, self.nhid, self.nlayers, self.n_out, self.precision, self.ln_eps, self.dropout)
+        return (self.num_features, self.emsize, self.nhead, self.nhid, self.nlayers, self.n_out, self.precision, self.ln_eps, self.dropout, self.schedule)
 
 
 HOST_CALLBACK = ctypes.CFUNCTYPE(None, ctypes.c_void_p)     # pfn_host_callback
@@ -49,6 +50,9 @@ SIGNATURES = {
     'pfn_abi_version': (_I, []),
     'pfn_last_error_string': (_c.c_char_p, []),
     'pfn_set_tuning': (_I, [_I, _I]),
+    'pfn_default_schedule': (_I, []),
+    'pfn_profile_enable': (_I, [_I]),
+    'pfn_profile_read': (_I, [_I, _c.POINTER(_c.c_double), _c.POINTER(_L)]),
     'pfn_param_layout': (_I, [_D, _c.POINTER(_L), _c.POINTER(_L), _I]),
     'pfn_param_count': (_L, [_D]),
     'pfn_shadow_bytes': (_L, [_D]),

@@ -186,16 +186,24 @@ constexpr float RESCALE_THR = 6.f;  // log2 units: lazily raised running max of 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <typename T, int D, bool DROP = false>
+// DV < D (exact-f32 kernels at head dim 256, inference): the head dimension of V / O is split over gridDim.y workgroups, each of which
+// forms the whole score row (Q.K over all D columns) and the D / gridDim.y output columns [blockIdx.y * DV, + DV) -- a full f32 K tile
+// and a full V tile of 256 columns do not fit the LDS side by side (2 x 33 KB + 4 x 34 KB), a K tile and a half V tile do.  The softmax
+// statistics are recomputed per slice (identical values; slice 0 writes lse).  1.5 x the matrix work of an unsplit kernel, for a pass
+// that is not the throughput path (reference transformer.py:55-91 under model.eval(), priors/fast_gp_mix.py:139-153 validate).
+template <typename T, int D, bool DROP = false, int DV = D>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
+  using CV = AttnCfg<T, DV>;      // the V / O side: CV::NDB column blocks, CV::CIMG bytes per tile image
+  static_assert(C::KVB == CV::KVB && D % DV == 0, "V slices share the K tile's key count");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
   // two K buffers (row images) followed by four V buffers (col images): P.V runs one tile behind Q.K (below), and with the
   // ping-pong schedule half of the waves run another half tile behind the others
   auto Kt = [&](int buf) { return smem + buf * C::RIMG; };
-  auto Vt = [&](int buf) { return smem + 2 * C::RIMG + buf * C::CIMG; };
+  auto Vt = [&](int buf) { return smem + 2 * C::RIMG + buf * CV::CIMG; };
   constexpr int NVB = 4;
+  const int vcol0 = DV == D ? 0 : (int)blockIdx.y * DV;      // first V / O column of this workgroup inside the head
 
   AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK, a.H);
   wg.blk += a.q_begin / C::QBLK;      // (q_begin: a multiple of 256, i.e. whole query blocks)
@@ -212,7 +220,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
   const T* Qp = base + hd * D;
   const T* Kp = base + a.E + hd * D;
-  const T* Vp = base + 2 * a.E + hd * D;
+  const T* Vp = base + 2 * a.E + hd * D + vcol0;
   const int qi = wg.blk * C::QBLK + wave * 32 + li;
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
@@ -233,9 +241,9 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   const bool is_test = qc >= sep;
   const bool wave_has_test = !(ABL & 8) && wg.blk * C::QBLK + wave * 32 + 31 >= sep;   // ABL 8: profiling without the self-key work
   float m = -1e30f, lsum = 0.f;
-  f32x16 o[C::NDB];
+  f32x16 o[CV::NDB];
 #pragma unroll
-  for (int db = 0; db < C::NDB; ++db)
+  for (int db = 0; db < CV::NDB; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   if (wave_has_test) {
@@ -246,7 +254,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
     m = is_test ? part * scale_log2 : -1e30f;
     lsum = (is_test && h == 0) ? 1.f : 0.f;
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db)
+    for (int db = 0; db < CV::NDB; ++db)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         f32x4 v = load4<T>(Vp + (long)qc * rs + db * 32 + 8 * rg + 4 * h);
@@ -257,15 +265,16 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
 
   const int nfull = sep / C::KVB;
   const int ntiles = (sep + C::KVB - 1) / C::KVB;
-  TileStage<T, C::KVB, C::RB, C::NT> sk, sv;
+  TileStage<T, C::KVB, C::RB, C::NT> sk;
+  TileStage<T, C::KVB, CV::RB, C::NT> sv;
   if (ntiles > 0) {
     sk.issue(Kp, rs, sep, D);
-    sv.issue(Vp, rs, sep, D);
+    sv.issue(Vp, rs, sep, DV);
     sk.template commit_p<C::RS>(Kt(0));
-    sv.template commit_p<C::CS>(Vt(0));
+    sv.template commit_p<CV::CS>(Vt(0));
     if (ntiles > 1) {   // tile 1 stays in flight across the barrier (see the loop)
       sk.issue(Kp + (long)C::KVB * rs, rs, sep - C::KVB, D);
-      sv.issue(Vp + (long)C::KVB * rs, rs, sep - C::KVB, D);
+      sv.issue(Vp + (long)C::KVB * rs, rs, sep - C::KVB, DV);
     }
   }
   __syncthreads();
@@ -287,8 +296,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
 #pragma unroll
     for (int c = 0; c < NPF; ++c)
 #pragma unroll
-      for (int db = 0; db < C::NDB; ++db)
-        o[db] = mma32(load_frag_tr_p<T, C::CS, 2>(vt, c * 16, db * 32), pf[c], o[db]);
+      for (int db = 0; db < CV::NDB; ++db)
+        o[db] = mma32(load_frag_tr_p<T, CV::CS, 2>(vt, c * 16, db * 32), pf[c], o[db]);
   };
   int vb_prev = 0, vb_cur = 0;           // V buffer of tile t-1 / tile t
   if constexpr (PRIO & 2) { if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1); }
@@ -323,12 +332,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
     const int vb_next = vb_cur == NVB - 1 ? 0 : vb_cur + 1;   // the slot tile t-3 has released
     if (!(ABL & 2)) {
       sk.template commit_p<C::RS>(Kt((t + 1) & 1));
-      sv.template commit_p<C::CS>(Vt(vb_next));
+      sv.template commit_p<CV::CS>(Vt(vb_next));
     }
     if (!(ABL & 1) && t + 2 < ntiles) {
       const long k2 = k0 + 2 * C::KVB;
       sk.issue(Kp + k2 * rs, rs, sep - (int)k2, D);
-      sv.issue(Vp + k2 * rs, rs, sep - (int)k2, D);
+      sv.issue(Vp + k2 * rs, rs, sep - (int)k2, DV);
     }
     if (t == nfull) {   // ragged last tile: keys >= sep do not exist
 #pragma unroll
@@ -350,7 +359,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
       m = m_new;
       lsum *= alpha;
 #pragma unroll
-      for (int db = 0; db < C::NDB; ++db)
+      for (int db = 0; db < CV::NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       if (t > 0) {     // P_{t-1} is still at the old maximum
@@ -404,15 +413,15 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   lsum += __shfl_xor(lsum, 32, 64);
   const float inv = DROP ? 1.f / (lsum * (1.f - a.p_drop)) : 1.f / lsum;
   {
-    T* out = reinterpret_cast<T*>(a.ctx) + ((long)b * a.S + qc) * a.E + hd * D;
+    T* out = reinterpret_cast<T*>(a.ctx) + ((long)b * a.S + qc) * a.E + hd * D + vcol0;
 #pragma unroll
-    for (int db = 0; db < C::NDB; ++db) {
+    for (int db = 0; db < CV::NDB; ++db) {
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = o[db][r] * inv;
       store_row_block<T>(out + db * 32, v, h, qvalid);
     }
-    if (qvalid && h == 0) a.lse[((long)b * a.H + hd) * a.S + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;
+    if (qvalid && h == 0 && vcol0 == 0) a.lse[((long)b * a.H + hd) * a.S + qi] = (m + __builtin_amdgcn_logf(lsum)) * LN2;
   }
 }
 
@@ -1160,12 +1169,15 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 // =============================================================================================
 template <typename T, int D, bool DROP> static int launch_fwd_k(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
-  constexpr size_t lds = 2 * C::RIMG + 4 * C::CIMG;
+  // exact-f32 at head dim 256: the V / O columns in two slices of 128 (attn_fwd_kernel, DV)
+  constexpr int DV = (sizeof(T) == 4 && D == 256) ? 128 : D;
+  constexpr size_t lds = 2 * C::RIMG + 4 * AttnCfg<T, DV>::CIMG;
   static_assert(lds <= 160 * 1024, "attention forward: tile buffers exceed the CU's LDS");
   static LdsAllowance allowance;
-  allowance.ensure(attn_fwd_kernel<T, D, DROP>, lds);
+  allowance.ensure(attn_fwd_kernel<T, D, DROP, DV>, lds);
   if ((a.S + C::QBLK - 1) / C::QBLK <= a.q_begin / C::QBLK) return PFN_OK;      // no query at or above q_begin
-  hipLaunchKernelGGL((attn_fwd_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK) * a.H * a.B), dim3(C::NT), lds, s, a);
+  ProfScope ps(PFN_PROF_ATTN_FWD + (a.q_begin > 0 ? 1 : 0), s);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D, DROP, DV>), dim3(((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK) * a.H * a.B, D / DV), dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
@@ -1177,6 +1189,7 @@ template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& 
   if (parts & ATTN_BWD_DELTA) {
     const long pairs = (long)a.B * a.S * a.H;
     int grid = (int)std::min<long>((pairs + 15) / 16, 4096);
+    ProfScope ps(PFN_PROF_ATTN_BWD_DELTA + (a.q_begin > 0 ? 1 : 0), s);
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(grid), dim3(256), 0, s, a, D);
   }
   constexpr size_t lds_kv = BwdKvCfg<T, D>::LDS, lds_dq = BwdDqCfg<T, D>::LDS;
@@ -1189,6 +1202,7 @@ template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& 
   // (Launching the pair for a few datasets at a time into one scratch, so that dS^T -- 436 MB per 16 datasets -- stays in the
   // 256 MB memory-side cache, was measured: 432 vs 436 us with two chunks, slower with more: each launch ends in a partial round.)
   if ((parts & ATTN_BWD_KV) && a.sep > 0) {
+    ProfScope ps(PFN_PROF_ATTN_BWD_KV + (a.q_begin > 0 ? 1 : 0), s);
     if constexpr (BwdKvCfg<T, D>::SPLIT && !DROP) {      // (A/B builds only: -DPFN_KV_SPLIT_D256=1)
       run_kv(attn_bwd_kv_kernel<T, D, 2, false>, allow_kv[2], a);
       run_kv(attn_bwd_kv_kernel<T, D, 1, false>, allow_kv[1], a);
@@ -1203,6 +1217,7 @@ template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& 
     }
     if ((a.S + C::QBLK - 1) / C::QBLK <= a.q_begin / C::QBLK) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
     allow_dq.ensure(attn_bwd_dq_kernel<T, D, DROP>, lds_dq);
+    ProfScope ps(PFN_PROF_ATTN_BWD_DQ + (a.q_begin > 0 ? 1 : 0), s);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK) * a.H * a.B), dim3(C::NT), lds_dq, s, a);
   }
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
@@ -1219,7 +1234,9 @@ static int check_attn(const AttnArgs& a, int precision) {
   return PFN_OK;
 }
 
-#define PFN_ATTN_DISPATCH(FN)                                                             \
+// F32_256: what the exact-f32 mode does at head dim 256 -- the forward has a kernel (V / O columns in two slices), the backward has none
+// (its tiles do not fit the LDS in f32): training at that head dim runs in the product precision, inference in either
+#define PFN_ATTN_DISPATCH(FN, F32_256)                                                    \
   const int D = a.E / a.H;                                                                 \
   if (precision == PFN_PREC_BF16) {                                                        \
     switch (D) {                                                                           \
@@ -1234,6 +1251,7 @@ static int check_attn(const AttnArgs& a, int precision) {
       case 32: return FN<float, 32>(a, s);                                                 \
       case 64: return FN<float, 64>(a, s);                                                 \
       case 128: return FN<float, 128>(a, s);                                               \
+      case 256: F32_256;                                                                   \
       default: return PFN_ERR_UNSUPPORTED;                                                 \
     }                                                                                      \
   }
@@ -1246,7 +1264,7 @@ int launch_attn_fwd(const AttnArgs& a_in, int precision, hipStream_t s) {
   AttnArgs a = a_in;
   a.pingpong = g_attn_pingpong;
   a.q_begin = a.q_begin / 256 * 256;
-  PFN_ATTN_DISPATCH(launch_fwd_t)
+  PFN_ATTN_DISPATCH(launch_fwd_t, return (launch_fwd_t<float, 256>(a, s)))
 }
 void attn_bwd_ds_dims(int S, int sep, int* rows, int* ld) {
   *rows = (sep + 63) / 64 * 64;       // whole key tiles of the dQ pass
@@ -1264,7 +1282,7 @@ int launch_attn_bwd(const AttnArgs& a_in, int precision, hipStream_t s) {
   AttnArgs a = a_in;
   attn_bwd_ds_dims(a.S, a.sep, &a.ds_rows, &a.ds_ld);
   a.q_begin = a.q_begin / 256 * 256;
-  PFN_ATTN_DISPATCH(launch_bwd_t)
+  PFN_ATTN_DISPATCH(launch_bwd_t, return PFN_ERR_UNSUPPORTED)
 }
 
 }  // namespace pfn

@@ -9,10 +9,38 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "pfn_kernels.h"
 
 using namespace pfn;
+
+// ---- in-step kernel timing (test / profiling hook, include/pfn_hip.h pfn_profile_*) -------------------------------------------------
+// Event pairs on the launch stream around the launches of a kernel class; nothing is recorded unless enabled.
+namespace pfn {
+namespace {
+struct ProfPair { hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::vector<ProfPair> g_prof[PFN_PROF_SLOTS];
+std::atomic<int> g_prof_on{0};
+}  // namespace
+bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed) != 0; }
+void* prof_begin(int slot, hipStream_t s) {
+  if (!prof_enabled() || slot < 0 || slot >= PFN_PROF_SLOTS) return nullptr;
+  ProfPair* p = new ProfPair;
+  if (hipEventCreate(&p->a) != hipSuccess || hipEventCreate(&p->b) != hipSuccess) { delete p; return nullptr; }
+  (void)hipEventRecord(p->a, s);
+  return p;
+}
+void prof_end(void* token, int slot, hipStream_t s) {
+  if (!token) return;
+  ProfPair* p = (ProfPair*)token;
+  (void)hipEventRecord(p->b, s);
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  g_prof[slot].push_back(*p);
+  delete p;
+}
+}  // namespace pfn
 
 namespace {
 
@@ -42,9 +70,11 @@ int check_desc(const pfn_model_desc* d) {
   if (d->emsize % d->nhead) return fail(PFN_ERR_ARGUMENT, "emsize %d not divisible by nhead %d", d->emsize, d->nhead);
   if (d->emsize % 8 || d->nhid % 8) return fail(PFN_ERR_UNSUPPORTED, "emsize and nhid must be multiples of 8 (16-byte operand rows)");
   const int dh = d->emsize / d->nhead;
-  const bool ok = dh == 32 || dh == 64 || dh == 128 || (dh == 256 && d->precision == PFN_PREC_BF16);
-  if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128, 256 in bf16)", dh);
+  // (head dim 256 in the exact-f32 mode: forward only -- pfn_stack_backward refuses it; inference passes of a bf16-trained model run there)
+  const bool ok = dh == 32 || dh == 64 || dh == 128 || dh == 256;
+  if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128/256)", dh);
   if (d->emsize > 2048) return fail(PFN_ERR_UNSUPPORTED, "emsize > 2048 unsupported by the LayerNorm kernels");
+  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
   if (!(d->dropout >= 0.f && d->dropout < 1.f)) return fail(PFN_ERR_ARGUMENT, "dropout %g outside [0, 1)", (double)d->dropout);
   return PFN_OK;
 }
@@ -140,8 +170,11 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   w.dctx_t = take(M * E * es);
   w.delta = (float*)take(2 * (int64_t)B * d.nhead * S * 4);      // [delta | lse in log2 units], both [B,H,S] (attn_delta_kernel)
   w.ds = take(attn_bwd_ds_bytes(B, S, d.nhead, d.precision));
-  w.top_ctx_t = take(M * E * es); w.top_dy1_t = take(M * E * es); w.top_dctx_t = take(M * E * es);
-  w.top_ry = (float*)take(M * E * 4); w.top_rmean = (float*)take(M * 4); w.top_rrstd = (float*)take(M * 4);
+  // the top layer on the test rows only: used when the schedule allows it (no dropout, PFN_SCHED_TOP_LAYER_ALL_ROWS clear) and then for at most the
+  // (S - sep) B <= 3/4 S B rows that 4 sep >= S leaves (top_layer_on_test_rows below) -- not carved otherwise
+  const int64_t Mtop = (d.nlayers > 0 && d.dropout == 0.f && !(d.schedule & PFN_SCHED_TOP_LAYER_ALL_ROWS)) ? (int64_t)B * (S - (S + 3) / 4) : 0;
+  w.top_ctx_t = take(Mtop * E * es); w.top_dy1_t = take(Mtop * E * es); w.top_dctx_t = take(Mtop * E * es);
+  w.top_ry = (float*)take(Mtop * E * 4); w.top_rmean = (float*)take(Mtop * 4); w.top_rrstd = (float*)take(Mtop * 4);
   w.bytes = cur;
   return w;
 }
@@ -163,27 +196,48 @@ GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, 
 
 extern "C" {
 
-static bool g_fuse_lnbwd = true;
+// Defaults handed to NEW descriptors by pfn_default_schedule() (test / profiling hook); the entry points read pfn_model_desc::schedule only.
+static int g_default_schedule = 0;
 // The reference returns output[single_eval_pos:] (transformer.py:91): the TOP encoder layer's train rows feed nothing -- no later layer reads
 // them as keys, the decoder and the loss never see them, their gradient is zero.  So everything of that layer behind its K / V projection runs on
 // the test rows only, in the decoder's compact row order: the attention for the queries >= sep, out_proj / LayerNorm / FFN on (S - sep) B rows,
 // and the same in the backward (zero rows dropped from every product).  Same results row for row; at the north star (sep ~ 0.8 S) it removes
 // ~80 % of one layer in six.  Off with dropout (the masks are indexed by the full-layout row) and when fewer than a quarter of the rows are train rows.
-static bool g_top_test_rows = true;
+// (d.dropout, not the live probability: with dropout configured the top_* buffers are not carved -- an inference pass of such a model keeps every row)
 static bool top_layer_on_test_rows(const pfn_model_desc& d, int S, int sep, float pdrop) {
-  return g_top_test_rows && d.nlayers > 0 && pdrop == 0.f && sep < S && 4L * sep >= S;
+  return !(d.schedule & PFN_SCHED_TOP_LAYER_ALL_ROWS) && d.nlayers > 0 && pdrop == 0.f && d.dropout == 0.f && sep < S && 4L * sep >= S;
 }
-static bool g_fuse_ln_wide = false;   // emsize 1024: the 64-row fused kernels exist and are correct, but lose to GEMM + LayerNorm kernels (PFN_TUNE_FUSE_LN_WIDE)
+// emsize 1024: the 64-row fused kernels exist and are correct, but lose to GEMM + LayerNorm kernels (PFN_SCHED_FUSE_LN_WIDE)
 int pfn_abi_version(void) { return PFN_ABI_VERSION; }
+int pfn_default_schedule(void) { return g_default_schedule; }
+int pfn_profile_enable(int on) { g_prof_on.store(on ? 1 : 0); return PFN_OK; }
+int pfn_profile_read(int slot, double* total_ms, int64_t* launches) {
+  if (slot < 0 || slot >= PFN_PROF_SLOTS) return fail(PFN_ERR_ARGUMENT, "bad profile slot %d", slot);
+  std::vector<ProfPair> pairs;
+  {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    pairs.swap(g_prof[slot]);
+  }
+  double ms = 0.0;
+  for (ProfPair& p : pairs) {
+    float t = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) ms += t;
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = (int64_t)pairs.size();
+  return PFN_OK;
+}
 int pfn_set_tuning(int key, int value) {
   switch (key) {
     case PFN_TUNE_GEMM_NT_KERNEL: set_gemm_nt_big_mode(value); return PFN_OK;
     case PFN_TUNE_GEMM_TN_WRAP: set_gemm_tn_debug_wrap(value); return PFN_OK;
-    case PFN_TUNE_FUSE_LNBWD: g_fuse_lnbwd = value != 0; return PFN_OK;
+    case PFN_TUNE_FUSE_LNBWD: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_SEPARATE_LNBWD) : (g_default_schedule | PFN_SCHED_SEPARATE_LNBWD); return PFN_OK;
     case PFN_TUNE_GEMM_PERSIST: set_gemm_nt_persist(value); return PFN_OK;
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
-    case PFN_TUNE_FUSE_LN_WIDE: g_fuse_ln_wide = value != 0; return PFN_OK;
-    case PFN_TUNE_TOP_LAYER_TEST_ROWS: g_top_test_rows = value != 0; return PFN_OK;
+    case PFN_TUNE_FUSE_LN_WIDE: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_LN_WIDE) : (g_default_schedule & ~PFN_SCHED_FUSE_LN_WIDE); return PFN_OK;
+    case PFN_TUNE_TOP_LAYER_TEST_ROWS: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_TOP_LAYER_ALL_ROWS) : (g_default_schedule | PFN_SCHED_TOP_LAYER_ALL_ROWS); return PFN_OK;
     default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);
   }
 }
@@ -299,7 +353,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   probe.A = w.x0_t; probe.lda = E; probe.B = sh; probe.ldb = E; probe.M = M; probe.N = E; probe.K = E;
   probe.bias = params; probe.gamma = params; probe.beta = params; probe.resid = w.x0; probe.y = w.x0; probe.x_t = w.x0_t;
   // (dropout sits between the bias and the residual add: it takes the unfused GEMM / LayerNorm kernels with an element-wise pass between)
-  const bool fuse_ln = prec == PFN_PREC_BF16 && gemm_ln_supported(probe) && F % 32 == 0 && pdrop == 0.f && (E <= 512 || g_fuse_ln_wide);
+  const bool fuse_ln = prec == PFN_PREC_BF16 && gemm_ln_supported(probe) && F % 32 == 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));
   struct Resid { const float* plain; const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; };
   Resid res = {w.x0, nullptr, nullptr, nullptr, nullptr, nullptr};   // where the layer input lives in f32
   auto set_resid = [](GemmLN& g, const Resid& r) {
@@ -312,6 +366,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
     const bool top = top_mode && l == d->nlayers - 1;     // this layer's rows behind the K / V projection: the test rows only (compact order)
     const int Ml = top ? Mt : M;
     {  // packed q/k/v projection
+      ProfScope ps(PFN_PROF_GEMM_QKV, s);
       GemmNT g = nt(xin_t, E, W(p.w_in), E, M, 3 * E, E, EPI_BIAS | EPI_OUT_T);
       g.bias = params + p.b_in; g.out_t = a.qkv; g.ld_out_t = 3 * E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
@@ -340,6 +395,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
     }
     float* x2_f32 = top ? (O == 0 ? logits : nullptr) : a.x2;     // the stack's f32 output rows: only what the decoder gather (or the caller) reads
     if (fuse_ln) {  // x1 = LN1(x + out_proj(ctx))
+      ProfScope ps(PFN_PROF_GEMM_OUT_LN + (top ? 1 : 0), s);
       GemmLN g; memset(&g, 0, sizeof(g));
       g.A = ctx_in; g.lda = E; g.B = W(p.w_o); g.ldb = E; g.M = Ml; g.N = E; g.K = E; g.bias = params + p.b_o;
       set_resid(g, res);
@@ -357,6 +413,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, a.x1, a.x1_t, a.mean1, a.rstd1, Ml, E, d->ln_eps, prec, s));
     }
     {  // linear1 + GELU (pre-activation kept for the backward)
+      ProfScope ps(PFN_PROF_GEMM_LIN1 + (top ? 1 : 0), s);
       GemmNT g = nt(a.x1_t, E, W(p.w1), E, Ml, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
       g.bias = params + p.b1; g.out_t = a.h; g.ld_out_t = F; g.out2_t = a.hpre; g.ld_out2 = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
@@ -364,6 +421,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       if (pdrop > 0.f) PFN_TRY(launch_dropout_scale(a.h, a.h, a.hpre, a.hpre, M, F, dseed(l, 2), pdrop, prec, s));
     }
     if (fuse_ln) {  // x2 = LN2(x1 + linear2(h))
+      ProfScope ps(PFN_PROF_GEMM_LIN2_LN + (top ? 1 : 0), s);
       GemmLN g; memset(&g, 0, sizeof(g));
       g.A = a.h; g.lda = F; g.B = W(p.w2); g.ldb = F; g.M = Ml; g.N = E; g.K = F; g.bias = params + p.b2;
       set_resid(g, res);
@@ -420,6 +478,8 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
                              const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
                              int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed) {
   PFN_TRY(check_desc(d));
+  if (d->precision == PFN_PREC_F32 && d->emsize / d->nhead == 256)
+    return fail(PFN_ERR_UNSUPPORTED, "the exact-f32 mode has no attention backward at head dim 256 (forward / inference only): train in PFN_PREC_BF16");
   const float pdrop = use_dropout ? d->dropout : 0.f;
   const bool top_mode = top_layer_on_test_rows(*d, S, sep, pdrop);       // (the forward took the same decision: same descriptor, shape, dropout)
   auto dseed = [&](int layer, int site) { return dropout_site_seed(dropout_seed, layer, site); };
@@ -497,7 +557,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   // split-K TN kernel does the rest (the register kernel it replaces streamed d(src) at 0.7 TB/s).  Custom encoders
   // (dsrc_sbe), the exact-f32 mode and wide encoders keep the f32 path.
   const bool emb_gemm = !dsrc_sbe && prec == PFN_PREC_BF16 && d->nlayers > 0 && d->num_features + 2 <= EMB_AUG && E % 8 == 0;
-  bool fuse_lnb = g_fuse_lnbwd && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || g_fuse_ln_wide);   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
+  bool fuse_lnb = !(d->schedule & PFN_SCHED_SEPARATE_LNBWD) && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
   if (fuse_lnb) {
     const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
     fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1, M)) &&
@@ -527,6 +587,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
       bool grouped_top = prec == PFN_PREC_BF16;
       for (const TnProblem& t : probs_top) grouped_top = grouped_top && gemm_tn_group_supported(t);
       if (grouped_top) {
+        ProfScope ps(PFN_PROF_WGRAD + 1, s);
         GemmTNGroup g;
         memset(&g, 0, sizeof(g));
         g.n = (int)probs_top.size();
@@ -542,6 +603,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     for (const TnProblem& t : probs) grouped = grouped && gemm_tn_group_supported(t);
     if (grouped) {
       for (size_t i0 = 0; i0 < probs.size(); i0 += TN_GROUP_MAX) {
+        ProfScope ps(PFN_PROF_WGRAD, s);
         GemmTNGroup g;
         memset(&g, 0, sizeof(g));
         g.n = (int)std::min<size_t>(TN_GROUP_MAX, probs.size() - i0);
@@ -573,11 +635,13 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     const char* dy2_op = a.dy2_t;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy2_t, a.dy2m_t, nullptr, nullptr, M, E, dseed(l, 3), pdrop, prec, s)); dy2_op = a.dy2m_t; }
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
+      ProfScope ps(PFN_PROF_GEMM_DHPRE + (top ? 1 : 0), s);
       GemmNT g = nt(dy2_op, E, WT(t.w2), E, Ml, F, E, EPI_GELU_BWD | EPI_OUT_T);
       g.aux = a.hpre; g.ld_aux = F; g.out_t = a.dh_t; g.ld_out_t = F;
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     if (fuse_lnb) {  // dy1 = LN1 backward of (dh . W1 + dy2)
+      ProfScope ps(PFN_PROF_GEMM_DY1 + (top ? 1 : 0), s);
       PFN_TRY(launch_gemm_lnbwd(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, dy1_t, grads + p.g1, grads + p.be1, Ml), s));
     } else {
       {  // dx1 = dh . W1 + dy2
@@ -591,6 +655,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     const char* dy1_op = dy1_t;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy1_t, a.dy1m_t, nullptr, nullptr, M, E, dseed(l, 1), pdrop, prec, s)); dy1_op = a.dy1m_t; }
     {  // d(ctx) = dy1 . Wo
+      ProfScope ps(PFN_PROF_GEMM_DCTX + (top ? 1 : 0), s);
       GemmNT g = nt(dy1_op, E, WT(t.w_o), E, Ml, E, E, EPI_OUT_T);
       g.out_t = top ? w.top_dctx_t : w.dctx_t; g.ld_out_t = E;
       PFN_TRY(launch_gemm_nt(g, prec, s));
@@ -610,6 +675,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     if (fuse_lnb && l > 0) {  // dy2 of the layer below = its LN2 backward of (dqkv . Win + dy1)
+      ProfScope ps(PFN_PROF_GEMM_DX, s);
       const LayerP& pb = L.layer[l - 1];
       LayerWs& ab = w.layer[l - 1];
       PFN_TRY(launch_gemm_lnbwd(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, ab.y2, ab.mean2, ab.rstd2, params + pb.g2, ab.dy2_t,

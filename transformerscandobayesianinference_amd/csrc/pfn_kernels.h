@@ -24,6 +24,19 @@ struct LdsAllowance {
   }
 };
 
+// In-step kernel timing (test / profiling hook pfn_profile_*, pfn_api.hip): an event pair on the launch stream around the launches inside the scope;
+// a no-op unless profiling is enabled.
+bool prof_enabled();
+void* prof_begin(int slot, hipStream_t s);
+void prof_end(void* token, int slot, hipStream_t s);
+struct ProfScope {
+  void* token; int slot; hipStream_t s;
+  ProfScope(int slot_, hipStream_t s_) : token(prof_begin(slot_, s_)), slot(slot_), s(s_) {}
+  ~ProfScope() { prof_end(token, slot, s); }
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Dropout masks (training with dropout > 0: TransformerEncoderLayer's four sites, reference transformer.py:17 / train.py:22).
 // A mask is a pure function of (site seed, i, j) so the backward regenerates what the forward applied, in whatever register

@@ -101,6 +101,8 @@ class OverlappedGradientReducer:
         self.model = model
         self.events, self._armed, self.expected = [], False, 0
         self.overlapped_last_step = False
+        self.fallbacks = 0            # armed steps whose early collective could NOT be overlapped (the hook fired fewer times than armed for)
+        self._callback_error = None   # an exception raised inside the ctypes host callback (ctypes swallows it): re-raised by finish()
         if model is not None:
             _, flat_grad = model.flat_parameters()
             L = model.nlayers
@@ -119,9 +121,12 @@ class OverlappedGradientReducer:
 
     def first_group_launched(self):
         """Host callback of pfn_stack_backward_split, on the thread and stream that run the backward."""
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.grad.device))
-        self.events.append(ev)
+        try:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.grad.device))
+            self.events.append(ev)
+        except BaseException as e:      # (we are inside a ctypes callback: an exception would be printed and dropped)
+            self._callback_error = e
 
     # ---- called by the training loop ----
     def arm(self, passes=1):
@@ -130,12 +135,23 @@ class OverlappedGradientReducer:
 
     def finish(self):
         """All-reduce (sum) the whole buffer; returns after the collectives are ordered before further work of the current stream."""
-        self._armed = False
+        was_armed, self._armed = self._armed, False
+        if self._callback_error is not None:
+            err, self._callback_error = self._callback_error, None
+            raise RuntimeError('the first-group host callback of pfn_stack_backward_split failed') from err
         if not is_distributed():
             self.events = []
             return self.grad
         works = []
         overlapped = self.split is not None and self.comm is not None and len(self.events) == self.expected and self.expected > 0
+        if was_armed and self.split is not None and self.comm is not None and not overlapped:
+            # same collectives, nothing hidden: say so instead of degrading silently (bench.py reports the count; every rank takes the same branch
+            # because `expected` and the number of backward passes are rank-uniform)
+            self.fallbacks += 1
+            if self.fallbacks == 1:
+                import warnings
+                warnings.warn(f'OverlappedGradientReducer: armed for {self.expected} backward pass(es) but the early weight-gradient launch called back '
+                              f'{len(self.events)} time(s); the gradient all-reduce of this step is not overlapped')
         if overlapped:
             with torch.cuda.stream(self.comm):
                 for ev in self.events:
@@ -154,6 +170,13 @@ class OverlappedGradientReducer:
         self.events = []
         self.overlapped_last_step = overlapped
         return self.grad
+
+    def detach(self):
+        """Unhook from the model (end of train()): the model then holds no reference to this object, its stream or its events -- it can be
+        pickled / deep-copied / moved, and a later re-flattening cannot leave `self.grad` pointing at a stale buffer."""
+        if self.model is not None and getattr(self.model, '_first_group_hook', None) is self:
+            self.model._first_group_hook = None
+        self.events, self._armed = [], False
 
     def layout(self):
         n = self.grad.numel()

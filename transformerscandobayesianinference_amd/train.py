@@ -191,6 +191,8 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
         if epoch_callback is not None:      # (model, epoch, mean loss, learning rate of the epoch, seconds): loss curves / checkpoints
             epoch_callback(model, epoch, total_loss, scheduler.get_last_lr()[0], time.time() - epoch_start_time)
         scheduler.step()
+    if reducer is not None:
+        reducer.detach()      # the returned model carries no reference to the reducer, its stream or the GPU gradient buffer
     return total_loss, total_positional_losses, model.to('cpu')
 
 
