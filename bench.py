@@ -11,13 +11,18 @@ all-reduce of the flat gradient], clip + Adam (HIP).  The metric is synthetic da
 scaling: per-GPU batch fixed).  The default is configs[1] (the configuration the metric is quoted on).
 
 The JSON line also carries
-  roofline     : the step's dominant kernel BY IN-STEP TIME (launches x duration; every kernel symbol timed on its own
-                 with HIP events on the launch stream), algorithmic FLOPs (mask-aware) / duration vs
-                 the dense bf16 MFMA peak, and the FLOPs it executes when that differs (recomputation);
+  roofline     : the step's dominant kernel (picked by launches x isolated duration): `frac` / `achieved` = algorithmic FLOPs (mask-aware,
+                 SURVEY.md 8(d)) / its average launch duration INSIDE the running step -- HIP event pairs around the launches on their
+                 launch stream (pfn_profile_*), two micro-batch streams + the sampler sharing the chip -- vs the dense bf16 MFMA peak;
+                 `isolated_*` = the same launch timed on an idle chip; `kernels` carries both for every kernel class of the step;
+  other_configs: short runs (5 steps) of BASELINE configs[3] and configs[4] in the same process: datasets/s, ms per step, whole-step
+                 roofline fraction, parity of inference outputs and of the timed path;
+  batch_sweep  : configs[1] at per-GPU batch 4 x aggregate_k_gradients 25 (the notebook's recipe), 8, 16, 32;
   step_roofline: the same accounting for the whole step (train(S,sep) = 3 * fwd(S,sep) per dataset);
-  parity       : the benchmarked model (its weights after the timed steps) against the f64 CPU oracle on the SAME fixed-seed
-                 draw, weights and eval position: loss and posterior-predictive means of its inference outputs (eval mode:
-                 exact-f32 kernels by default) and, as `training_forward`, of the timed path's bf16 forward (rank 0, N = 1);
+  parity_inference / parity_timed_path : the benchmarked model (its weights after the timed steps) against the f64 CPU oracle on the SAME
+                 fixed-seed draw, weights and eval position, one block per PATH: inference outputs (eval mode under no_grad: exact-f32 kernels
+                 by default -- what the north star's 1e-3 is asserted on; with the latency and memory that pass costs) and the forward of the
+                 TIMED bf16 training path (rank 0, N = 1).  `parity` keeps the combined layout of rounds 2-3;
   val_bar_nll  : the loss of the benchmarked model on a fixed-seed validation draw (second half of BASELINE.json's metric);
   cpu_baseline : the reference's CPU path timed on the host cores on a bounded sample of the same workload from the same
                  weights and inputs (rank 0, N = 1 only): the torch nn.TransformerEncoder stack the reference instantiates
@@ -219,14 +224,15 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
     Hh = _hip
     out = []
 
-    def add(kernel, rocprof, seconds, flops, count, executed=None, nbytes=None):
+    def add(kernel, rocprof, seconds, flops, count, executed=None, nbytes=None, prof=None):
         # nbytes: ALGORITHMIC HBM bytes of one launch (every operand read once, every output written once); its floor at the 6.3 TB/s
         # a stream achieves on this part (MI355X_MICROARCH.md) next to the MFMA floor says which of the two bounds the launch
-        out.append(dict(kernel=kernel, rocprof_name=rocprof, launches_per_step=count, seconds=seconds, flops=flops,
+        # prof: the library's in-step timing class of this launch (PROF_SLOTS; main() adds `in_step_us` from the profiled steps)
+        out.append(dict(kernel=kernel, rocprof_name=rocprof, prof_class=prof, launches_per_step=count, seconds=seconds, flops=flops,
                         executed_flops=executed if executed is not None else flops, bytes=nbytes,
                         hbm_floor_us=None if nbytes is None else nbytes / 6.3e12 * 1e6, mfma_floor_us=flops / MFMA_BF16_PEAK * 1e6))
 
-    def gemm(name, n, k, flags, count, M=M):
+    def gemm(name, n, k, flags, count, M=M, prof=None):
         """One encoder GEMM with its REAL epilogue (bias / GELU / residual / output streams), M = batch * bptt rows."""
         if count <= 0 or M <= 0:
             return
@@ -240,9 +246,9 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
         if flags & Hh.EPI_OUT2_T: kw['out2_t'] = torch.empty(M, n, dtype=bf, device=dev)
         t = time_kernel(lambda: hipops.gemm_nt(A, B_, flags, Hh.PREC_BF16, **kw))
         nbytes = sum(v.numel() * v.element_size() for v in [A, B_] + list(kw.values()))
-        add(f'gemm_nt[{name} {M}x{n}x{k}]', f'gemm_nt_big_kernel<{flags}, ', t, 2.0 * M * n * k, count, nbytes=nbytes)
+        add(f'gemm_nt[{name} {M}x{n}x{k}]', f'gemm_nt_big_kernel<{flags}, ', t, 2.0 * M * n * k, count, nbytes=nbytes, prof=prof)
 
-    def gemm_ln(name, k, count, M=M):
+    def gemm_ln(name, k, count, M=M, prof=None):
         """out_proj / linear2 with bias + residual + LayerNorm in the epilogue (the kernel the step runs when emsize allows)."""
         if E > 512 and not fused_ln_wide:      # emsize 1024: the stack runs GEMM + LayerNorm kernels unless PFN_TUNE_FUSE_LN_WIDE is set (measured faster)
             return False
@@ -256,10 +262,10 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
         except _hip.HipExtensionError:   # shape outside the fused kernel (emsize 1024): the step runs GEMM + LayerNorm kernels there
             return False
         nbytes = sum(v.numel() * v.element_size() for v in (A, B_, resid) + bufs)     # operands, f32 residual in, f32 sum + bf16 LN output + statistics out
-        add(f'gemm_nt_ln[{name} + residual + LayerNorm {M}x{E}x{k}]', 'gemm_nt_ln_kernel', t, 2.0 * M * E * k, count, nbytes=nbytes)
+        add(f'gemm_nt_ln[{name} + residual + LayerNorm {M}x{E}x{k}]', 'gemm_nt_ln_kernel', t, 2.0 * M * E * k, count, nbytes=nbytes, prof=prof)
         return True
 
-    def gemm_lnbwd(name, k, count, M=M):
+    def gemm_lnbwd(name, k, count, M=M, prof=None):
         """a data-gradient GEMM with the backward of the LayerNorm it feeds in the epilogue (what the step runs when emsize allows)"""
         if E > 512 and not fused_ln_wide:
             return False
@@ -274,7 +280,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
         except _hip.HipExtensionError:
             return False
         nbytes = sum(v.numel() * v.element_size() for v in (A, B_, aux, y, mean, rstd, bufs[0]))
-        add(f'gemm_nt_lnbwd[{name} {M}x{E}x{k}]', 'gemm_nt_lnbwd_kernel', t, 2.0 * M * E * k, count, nbytes=nbytes)
+        add(f'gemm_nt_lnbwd[{name} {M}x{E}x{k}]', 'gemm_nt_lnbwd_kernel', t, 2.0 * M * E * k, count, nbytes=nbytes, prof=prof)
         return True
 
     def layernorm_bwd(count, M=M):
@@ -305,28 +311,29 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
         launches = [probs[i:i + nmax] for i in range(0, len(probs), nmax)]
         t = time_kernel(lambda: [hipops.gemm_tn_group(g, 0) for g in launches], iters=5, warm=2)
         add(f'gemm_tn_group[{len(probs)} weight gradients, {M} tokens, {len(launches)} launch(es)]', 'gemm_tn_big_kernel', t / len(launches),
-            2.0 * M * (Lf * (2 * E * F + E * E) + L * 3 * E * E) / len(launches), len(launches))
+            2.0 * M * (Lf * (2 * E * F + E * E) + L * 3 * E * E) / len(launches), len(launches), prof='gemm_tn_group')
         if top:
             tp = [(r(Mt, E), r(Mt, F), torch.zeros(E, F, device=dev), None), (r(Mt, F), r(Mt, E), torch.zeros(F, E, device=dev), torch.zeros(F, device=dev)),
                   (r(Mt, E), r(Mt, E), torch.zeros(E, E, device=dev), None)]
             t = time_kernel(lambda: hipops.gemm_tn_group(tp, 0), iters=5, warm=2)
-            add(f'gemm_tn_group[top layer: 3 weight gradients, {Mt} test rows]', 'gemm_tn_big_kernel', t, 2.0 * Mt * (2 * E * F + E * E), 1)
+            add(f'gemm_tn_group[top layer: 3 weight gradients, {Mt} test rows]', 'gemm_tn_big_kernel', t, 2.0 * Mt * (2 * E * F + E * E), 1, prof='gemm_tn_group [top layer: test rows]')
 
     # (`rows`: every per-layer kernel runs Lf times on all rows and, with the top layer on the test rows, once more on those)
     for rows, cnt, tag in ([(M, Lf, '')] + ([(Mt, 1, 'top layer, test rows: ')] if top else [])):
+        sfx = ' [top layer: test rows]' if tag else ''       # the library's in-step timing class of the compact-row launches (PROF_SLOTS + 1)
         if rows == M:
-            gemm('qkv', 3 * E, E, Hh.EPI_BIAS | Hh.EPI_OUT_T, L)
-        if not gemm_ln(tag + 'out_proj', E, cnt, rows):
+            gemm('qkv', 3 * E, E, Hh.EPI_BIAS | Hh.EPI_OUT_T, L, prof='gemm_qkv')
+        if not gemm_ln(tag + 'out_proj', E, cnt, rows, prof='gemm_out_proj_ln' + sfx):
             gemm(tag + 'out_proj + residual', E, E, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, cnt, rows)
             layernorm_fwd(2 * cnt, rows)
-        gemm(tag + 'linear1 + GELU', F, E, Hh.EPI_BIAS | Hh.EPI_GELU | Hh.EPI_OUT_T | Hh.EPI_OUT2_T, cnt, rows)
-        if not gemm_ln(tag + 'linear2', F, cnt, rows):
+        gemm(tag + 'linear1 + GELU', F, E, Hh.EPI_BIAS | Hh.EPI_GELU | Hh.EPI_OUT_T | Hh.EPI_OUT2_T, cnt, rows, prof='gemm_linear1_gelu' + sfx)
+        if not gemm_ln(tag + 'linear2', F, cnt, rows, prof='gemm_linear2_ln' + sfx):
             gemm(tag + 'linear2 + residual', E, F, Hh.EPI_BIAS | Hh.EPI_RESID | Hh.EPI_OUT_F32, cnt, rows)
-        gemm(tag + 'd(hpre) = dy2.W2 * gelu\'', F, E, Hh.EPI_GELU_BWD | Hh.EPI_OUT_T, cnt, rows)
-        if gemm_lnbwd(tag + 'dy1 = LN1 backward of dh.W1 + dy2', F, cnt, rows):
+        gemm(tag + 'd(hpre) = dy2.W2 * gelu\'', F, E, Hh.EPI_GELU_BWD | Hh.EPI_OUT_T, cnt, rows, prof='gemm_dhpre' + sfx)
+        if gemm_lnbwd(tag + 'dy1 = LN1 backward of dh.W1 + dy2', F, cnt, rows, prof='gemm_dy1_lnbwd' + sfx):
             if rows == M:
                 if L > 1:
-                    gemm_lnbwd('dy2 = LN2 backward (layer below) of dqkv.Win + dy1', 3 * E, L - 1)
+                    gemm_lnbwd('dy2 = LN2 backward (layer below) of dqkv.Win + dy1', 3 * E, L - 1, prof='gemm_dx_lnbwd')
                 gemm('dx = dqkv.Win + dy1 (first layer: gradient of the embedding output)', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, 1)
             if rows == Mt:
                 layernorm_bwd(1, rows)          # the top LayerNorm's backward (its gradient comes from the decoder)
@@ -335,7 +342,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
             if rows == M:
                 gemm('dx = dqkv.Win + dy1', E, 3 * E, Hh.EPI_RESID_T | Hh.EPI_OUT_T, L)
             layernorm_bwd(2 * cnt, rows)
-        gemm(tag + 'd(ctx) = dy1.Wo', E, E, Hh.EPI_OUT_T, cnt, rows)
+        gemm(tag + 'd(ctx) = dy1.Wo', E, E, Hh.EPI_OUT_T, cnt, rows, prof='gemm_dctx' + sfx)
     wgrad_group()
     qkv = r(batch, S, 3 * E)
     D = E // H
@@ -344,7 +351,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
     dctx = r(batch, S, E)
     if Lf > 0:
         t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16))
-        add('attn_fwd', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit, Lf)
+        add('attn_fwd', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit, Lf, prof='attn_fwd')
         # the backward's three launches, each timed inside their sequence (delta, key-block pass, query-block pass back to back)
         seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=part))
                              for _, _, part, _, _ in hipops.ATTENTION_BWD_PARTS])
@@ -352,7 +359,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
             rocprof = rocprof.format(D=D)
             if part == 2:
                 exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
-            add(name, rocprof, t, alg_units * unit, Lf, exec_units * unit)
+            add(name, rocprof, t, alg_units * unit, Lf, exec_units * unit, prof={1: 'attn_bwd_delta', 2: 'attn_bwd_kv', 4: 'attn_bwd_dq'}[part])
     if top:
         # the top layer's attention: the queries >= sep only (q_begin; the kernels start at the query block that holds sep)
         unit_t = 2.0 * E * ((S - sep) * sep + (S - sep)) * batch
@@ -362,13 +369,14 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
         dctx_t[:, :sep] = 0
         bufs_t = (torch.empty_like(ctx), torch.empty_like(lse))
         t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16, q_begin=sep, out=bufs_t))
-        add('top layer: attn_fwd for the queries >= sep', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit_t, 1, 2 * unit_x)
+        add('top layer: attn_fwd for the queries >= sep', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit_t, 1, 2 * unit_x, prof='attn_fwd [top layer: test rows]')
         seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx_t, H, sep, _hip.PREC_BF16, parts=part, q_begin=sep))
                              for _, _, part, _, _ in hipops.ATTENTION_BWD_PARTS])
         for (name, rocprof, part, alg_units, exec_units), t in zip(hipops.ATTENTION_BWD_PARTS, seq):
             if part == 2:
                 exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
-            add('top layer, queries >= sep: ' + name, rocprof.format(D=D), t, alg_units * unit_t, 1, exec_units * unit_x)
+            add('top layer, queries >= sep: ' + name, rocprof.format(D=D), t, alg_units * unit_t, 1, exec_units * unit_x,
+                prof={1: 'attn_bwd_delta', 2: 'attn_bwd_kv', 4: 'attn_bwd_dq'}[part] + ' [top layer: test rows]')
         # ... and its row moves: attention output / layer input gathered, d(attention output) / LayerNorm-input gradient scattered back
         c_t, y32 = r(batch, S, E), f32(batch, S, E)
         g_t = r(Mt, E)
@@ -614,46 +622,43 @@ def self_launch(args):
     raise SystemExit(res.returncode)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='BASELINE.json configuration (2 = configs[1], the metric\'s; 4 = BNN prior; 5 = GP mixture, bptt 4000)')
-    ap.add_argument('--batch', type=int, default=None, help='datasets per GPU per step (default: per configuration)')
-    ap.add_argument('--streams', type=int, default=None, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-parity', action='store_true')
-    ap.add_argument('--no-kernel-breakdown', action='store_true')
-    ap.add_argument('--fixed-sep', type=int, default=None, help='use one eval position instead of the sampler')
-    ap.add_argument('--prefetch-group', type=int, default=None, help='steps of datasets per sampler call (default: the loader class\'s; the bench uses its gcd with --steps)')
-    ap.add_argument('--tune', default='', help='experiments: comma-separated key=value pairs for pfn_set_tuning (include/pfn_hip.h); recorded in config')
-    args = ap.parse_args()
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        self_launch(args)
+# kernel classes the library can time INSIDE the step (include/pfn_hip.h PFN_PROF_*; slot + 1 = the top layer's launch on the test rows)
+PROF_SLOTS = {'attn_fwd': 0, 'attn_bwd_delta': 2, 'attn_bwd_kv': 4, 'attn_bwd_dq': 6, 'gemm_qkv': 8, 'gemm_out_proj_ln': 10, 'gemm_linear1_gelu': 12,
+              'gemm_linear2_ln': 14, 'gemm_dhpre': 16, 'gemm_dy1_lnbwd': 18, 'gemm_dctx': 20, 'gemm_dx_lnbwd': 22, 'gemm_tn_group': 24}
 
-    from transformerscandobayesianinference_amd import dp
+
+def read_profile():
+    """{class: {avg_us, launches}} of the event pairs the library recorded since the last read (pfn_profile_read)."""
+    import ctypes
+    from transformerscandobayesianinference_amd import _hip
+    out = {}
+    for name, slot in PROF_SLOTS.items():
+        for top in (0, 1):
+            ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+            _hip.check(_hip.lib().pfn_profile_read(slot + top, ctypes.byref(ms), ctypes.byref(n)), 'pfn_profile_read')
+            if n.value:
+                out[name + (' [top layer: test rows]' if top else '')] = dict(avg_us=ms.value * 1e3 / n.value, launches=n.value)
+    return out
+
+
+def run_config(config, device, rank, world, precision, batch=None, streams=None, steps=20, warmup=5, aggregate_k=1, fixed_sep=None, prefetch_group=None,
+               profile_steps=0):
+    """One benchmark run of a BASELINE.json configuration: builds criterion, model, optimizer and the prior's loader, runs `warmup` untimed and
+    `steps` timed OPTIMIZER steps (each = `aggregate_k` batches of `batch` datasets per rank: forward + loss + backward per batch, gradients
+    summed, then [all-reduce +] clip + Adam -- reference train.py:66-97) between barrier + synchronize on both sides, max over ranks.
+    profile_steps > 0: that many further steps with the library's in-step kernel timing on (not part of the timed window)."""
+    from transformerscandobayesianinference_amd import _hip, dp
     from transformerscandobayesianinference_amd.optim import FusedClipAdam
     from transformerscandobayesianinference_amd.streams import MicroBatchStreams
     from transformerscandobayesianinference_amd.utils import get_uniform_single_eval_pos_sampler, get_weighted_single_eval_pos_sampler
-    rank, world, local = dp.init_from_env()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    device = torch.device('cuda', local)
-    torch.cuda.set_device(device)
-    w = CONFIGS[args.config]
-    tuning = {int(k): int(v) for k, v in (kv.split('=') for kv in args.tune.split(',') if kv)}
-    from transformerscandobayesianinference_amd import _hip
-    for k, v in tuning.items():
-        _hip.check(_hip.lib().pfn_set_tuning(k, v), 'pfn_set_tuning')
-    batch = args.batch or w['batch']
-    streams = args.streams or w['streams']
-    S, nf, E, F, L, O = w['bptt'], w['num_features'], w['emsize'], w['nhid'], w['nlayers'], w['num_bars']
-
     import numpy as np
+    w = CONFIGS[config]
+    batch = batch or w['batch']
+    streams = streams or w['streams']
+    S = w['bptt']
     torch.manual_seed(0); np.random.seed(0)
     criterion = make_criterion(w, device)
-    model = build_model(device, args.precision, w, criterion)
+    model = build_model(device, precision, w, criterion)
     if world > 1:
         torch.distributed.broadcast(model.flat_parameters()[0], 0)
         if criterion is not None and hasattr(criterion, 'borders'):
@@ -678,13 +683,14 @@ def main():
         reducer = dp.OverlappedGradientReducer(model)
 
     def step(batches):
-        sep = args.fixed_sep if args.fixed_sep is not None else sampler()
-        seps.append(sep)
-        (x, y), target = next(batches)
-        # forward + loss + backward of the batch, as `--streams` concurrent column groups (streams.py)
-        if reducer is not None:
-            reducer.arm(micro.groups(model, x.shape[1]))
-        losses = micro.forward_backward(model, (x, y), target, sep, lambda out, tg: loss_fn(out, tg[sep:]))
+        for k in range(aggregate_k):       # reference train.py:92-97: micro-batch gradients are summed, one optimizer step per aggregate_k batches
+            sep = fixed_sep if fixed_sep is not None else sampler()
+            seps.append(sep)
+            (x, y), target = next(batches)
+            if reducer is not None and k == aggregate_k - 1:
+                reducer.arm(micro.groups(model, x.shape[1]))
+            # forward + loss + backward of the batch, as `streams` concurrent column groups (streams.py)
+            losses = micro.forward_backward(model, (x, y), target, sep, lambda out, tg: loss_fn(out, tg[sep:]))
         if reducer is not None:
             reducer.finish()       # two collectives: the upper layers' half was enqueued behind their weight gradients, under the backward
         opt.step(zero_grad=True)
@@ -695,67 +701,161 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # ONE loader across warm-up and timed steps: a continuous training run.  The sampler works one look-ahead group of G steps
+    # ONE loader across warm-up and timed steps: a continuous training run.  The sampler works one look-ahead group of G batches
     # ahead on a side stream (priors/utils.py): the draw for group g + 1 is enqueued when the first batch of group g is handed
-    # out.  With G dividing `steps` the groups enqueued inside the timed window are exactly steps / G full groups wherever the
-    # window starts (one per multiple of G among the window's step indices) -- as much sampler work as the window's steps
-    # consume -- and the synchronisations on both sides of the window make the executed work equal the enqueued work.  The
-    # loader is a whole number of groups long and extends one group past the window so that every one of those groups exists
-    # and is full.
+    # out.  With G dividing the timed batches the groups enqueued inside the timed window are exactly that many / G full groups wherever the
+    # window starts -- as much sampler work as the window's steps consume -- and the synchronisations on both sides of the window make the
+    # executed work equal the enqueued work.  The loader is a whole number of groups long and extends one group past the window.
     loader_cls = prior_module(w).DataLoader
-    group = math.gcd(args.steps, int(args.prefetch_group or getattr(loader_cls, 'prefetch_group', 1))) if getattr(loader_cls, 'prefetch', False) else 1
-    num_steps = (args.warmup + args.steps + group + group - 1) // group * group
+    nb = steps * aggregate_k
+    group = math.gcd(nb, int(prefetch_group or getattr(loader_cls, 'prefetch_group', 1))) if getattr(loader_cls, 'prefetch', False) else 1
+    num_batches = ((warmup + steps + profile_steps) * aggregate_k + group + group - 1) // group * group
     with quiet():   # DataLoader.__init__ prints its kwargs (reference behaviour)
-        dl = loader_cls(num_steps=num_steps, batch_size=batch, seq_len=S, device=device, **prior_kwargs(w))
+        dl = loader_cls(num_steps=num_batches, batch_size=batch, seq_len=S, device=device, **prior_kwargs(w))
     dl.prefetch_group = group
     batches = iter(dl)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(batches)
     barrier()
     seps.clear()
     t0 = time.time()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step(batches)
     barrier()
-    elapsed = time.time() - t0
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    ranks_seen = torch.ones(1, device=device, dtype=torch.float64)
-    allreduce_ms = None
+    local_elapsed = elapsed = time.time() - t0
+    timed_seps = list(seps)
+    out = dict(config=config, w=w, model=model, batch=batch, streams=streams, steps=steps, warmup=warmup, aggregate_k=aggregate_k, group=group, seps=timed_seps,
+               micro_groups=micro.groups(model, batch))
     if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        out['per_rank_elapsed'] = [e.item() for e in every]
+        elapsed = max(out['per_rank_elapsed'])
+        ranks_seen = torch.ones(1, device=device, dtype=torch.float64)
         torch.distributed.all_reduce(ranks_seen)
+        out['ranks_seen'] = int(ranks_seen.item())
         grad = model.flat_parameters()[1]
-        overlapped_in_steps = reducer.overlapped_last_step
+        out['overlapped_in_steps'] = bool(reducer.overlapped_last_step)
+        out['fallback_steps'] = reducer.fallbacks
         barrier()
         t1 = time.time()
         for _ in range(5):
             reducer.finish()           # not armed: both collectives back to back, nothing to hide behind = the exposed cost
         torch.cuda.synchronize()
-        allreduce_ms = (time.time() - t1) / 5 * 1e3
+        out['allreduce_ms'] = (time.time() - t1) / 5 * 1e3
+        out['reducer_layout'] = reducer.layout()
         grad.zero_()
-    elapsed = t.item()
-    final_loss = loss.item()
+    out['elapsed'], out['local_elapsed'], out['final_loss'] = elapsed, local_elapsed, loss.item()
+    if profile_steps > 0 and world == 1:
+        # the same steps once more with an event pair around every launch of the step's kernel classes, ON their launch streams: how long each
+        # kernel runs INSIDE the step, where two micro-batch streams and the prior sampler share the chip
+        lib = _hip.lib()
+        _hip.check(lib.pfn_profile_enable(1), 'pfn_profile_enable')
+        read_profile()
+        for _ in range(profile_steps):
+            step(batches)
+        torch.cuda.synchronize()
+        _hip.check(lib.pfn_profile_enable(0), 'pfn_profile_enable')
+        out['in_step'] = read_profile()
+        out['profile_seps'] = seps[len(timed_seps):]
+    if reducer is not None:
+        reducer.detach()
+    return out
 
+
+def throughput_fields(r, world):
+    """datasets/s, ms per optimizer step and the whole-step roofline fraction of a run_config() result."""
+    import ctypes
+    from transformerscandobayesianinference_amd import _hip
+    w = r['w']
+    S, nf, E, F, L, O = w['bptt'], w['num_features'], w['emsize'], w['nhid'], w['nlayers'], w['num_bars']
+    lib, desc = _hip.lib(), r['model']._make_desc()
+    top_rows_of = lambda rows, s: int(lib.pfn_top_layer_rows(ctypes.byref(desc), rows, S, s, 0))     # rows the top layer runs on (all, or the test rows only)
+    step_flops = sum(train_flops(S, s, nf, E, F, L, O) for s in r['seps']) * r['batch'] * world               # the reference's graph (SURVEY.md 8(d))
+    needed_flops = sum(train_flops(S, s, nf, E, F, L, O, top_rows_of(1, s) != S) for s in r['seps']) * r['batch'] * world
+    total = r['batch'] * world * r['steps'] * r['aggregate_k']
+    return dict(value=total / r['elapsed'], ms_per_step=r['elapsed'] / r['steps'] * 1e3, frac=needed_flops / r['elapsed'] / world / MFMA_BF16_PEAK,
+                reference_graph_frac=step_flops / r['elapsed'] / world / MFMA_BF16_PEAK, needed_flops=needed_flops, top_rows_of=top_rows_of)
+
+
+def inference_cost(model, w, device, sep):
+    """Latency of one inference pass (eval mode, no_grad -> model.eval_precision kernels) and of the same forward in the training precision,
+    at the parity batch, plus the extra device memory the separate inference precision holds (its operand copy of the weights)."""
+    B, S, nf = w['parity_batch'], w['bptt'], w['num_features']
+    x, y = torch.rand(S, B, nf, device=device), torch.randn(S, B, device=device)
+    was = model.training
+    out = {}
+    with torch.no_grad():
+        for name, mode in (('inference_ms', False), ('training_precision_forward_ms', True)):
+            model.train(mode)
+            out[name] = time_kernel(lambda: model((x, y), single_eval_pos=sep), iters=3, warm=1) * 1e3
+    model.train(was)
+    out['batch'] = B
+    out['inference_extra_weight_bytes'] = int(model._eval_shadow.numel()) if getattr(model, '_eval_shadow', None) is not None else 0
+    return out
+
+
+def release(r):
+    r.pop('model', None)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='BASELINE.json configuration (2 = configs[1], the metric\'s; 4 = BNN prior; 5 = GP mixture, bptt 4000)')
+    ap.add_argument('--batch', type=int, default=None, help='datasets per GPU per batch (default: per configuration)')
+    ap.add_argument('--aggregate-k', type=int, default=1, help='batches per optimizer step (train()\'s aggregate_k_gradients)')
+    ap.add_argument('--streams', type=int, default=None, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-kernel-breakdown', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip `other_configs` (short runs of configs 4 and 5) and `batch_sweep` (configs[1] at per-GPU batch 4 x 25, 8, 16, 32)')
+    ap.add_argument('--fixed-sep', type=int, default=None, help='use one eval position instead of the sampler')
+    ap.add_argument('--prefetch-group', type=int, default=None, help='steps of datasets per sampler call (default: the loader class\'s; the bench uses its gcd with --steps)')
+    ap.add_argument('--tune', default='', help='experiments: comma-separated key=value pairs for pfn_set_tuning (include/pfn_hip.h); recorded in config')
+    args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
+
+    from transformerscandobayesianinference_amd import dp
+    rank, world, local = dp.init_from_env()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    w = CONFIGS[args.config]
+    tuning = {int(k): int(v) for k, v in (kv.split('=') for kv in args.tune.split(',') if kv)}
+    from transformerscandobayesianinference_amd import _hip
+    for k, v in tuning.items():
+        _hip.check(_hip.lib().pfn_set_tuning(k, v), 'pfn_set_tuning')
+    t_start = time.time()
+    r = run_config(args.config, device, rank, world, args.precision, batch=args.batch, streams=args.streams, steps=args.steps, warmup=args.warmup,
+                   aggregate_k=args.aggregate_k, fixed_sep=args.fixed_sep, prefetch_group=args.prefetch_group,
+                   profile_steps=0 if (world > 1 or args.no_kernel_breakdown) else 5)
     if rank != 0:
         return
-    total = batch * world * args.steps
-    import ctypes
-    lib, desc = _hip.lib(), model._make_desc()
-    top_rows_of = lambda rows, s: int(lib.pfn_top_layer_rows(ctypes.byref(desc), rows, S, s, 0))     # rows the top layer runs on (all, or the test rows only)
-    step_flops = sum(train_flops(S, s, nf, E, F, L, O) for s in seps) * batch * world               # the reference's graph
-    needed_flops = sum(train_flops(S, s, nf, E, F, L, O, top_rows_of(1, s) != S) for s in seps) * batch * world
+    model, batch, streams, seps = r['model'], r['batch'], r['streams'], r['seps']
+    S, nf, E, F, L, O = w['bptt'], w['num_features'], w['emsize'], w['nhid'], w['nlayers'], w['num_bars']
+    tp = throughput_fields(r, world)
+    top_rows_of = tp['top_rows_of']
     result = {
-        'metric': w['metric'], 'value': total / elapsed, 'unit': 'datasets/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'metric': w['metric'], 'value': tp['value'], 'unit': 'datasets/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': tp['ms_per_step'],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
         'config': {'workload': w['workload'], 'baseline_config': args.config,
-                   'per_gpu_batch': batch, 'global_batch': batch * world, 'seq_len': S, 'parallelism': f'dp{world}', 'micro_batch_streams': streams,
+                   'per_gpu_batch': batch, 'global_batch': batch * world, 'aggregate_k_gradients': args.aggregate_k, 'seq_len': S, 'parallelism': f'dp{world}',
+                   'micro_batch_streams': streams,
                    'eval_pos': f"{w['eval_pos']} sampler({S})" if args.fixed_sep is None else args.fixed_sep, 'mean_sep': sum(seps) / len(seps),
-                   'sampler_group_steps': group, 'final_loss': final_loss},
-        'step_roofline': {'bound': 'mfma', 'achieved': needed_flops / elapsed / 1e12 / world, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
-                          'frac': needed_flops / elapsed / world / MFMA_BF16_PEAK,
-                          'reference_graph_frac': step_flops / elapsed / world / MFMA_BF16_PEAK,
+                   'sampler_group_steps': r['group'], 'final_loss': r['final_loss']},
+        'step_roofline': {'bound': 'mfma', 'achieved': tp['needed_flops'] / r['elapsed'] / 1e12 / world, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                          'frac': tp['frac'], 'reference_graph_frac': tp['reference_graph_frac'],
                           'note': 'whole step per GPU, algorithmic mask-aware FLOPs 3*fwd(S,sep).  `frac` counts what the result needs: the top encoder layer\'s train '
                                   'rows feed nothing (the reference returns output[single_eval_pos:]) and are not computed (pfn_top_layer_rows); '
                                   '`reference_graph_frac` counts the reference\'s graph, which computes and discards them (the figure of rounds 1-2)'},
@@ -763,25 +863,32 @@ def main():
     if tuning:
         result['config']['tuning'] = tuning
     if world > 1:
-        result['ranks_seen'] = int(ranks_seen.item())
-        result['allreduce_ms'] = allreduce_ms
+        result['ranks_seen'] = r['ranks_seen']
+        result['per_rank_ms_per_step'] = [e / args.steps * 1e3 for e in r['per_rank_elapsed']]      # spread = load imbalance / stragglers at the all-reduce
+        result['allreduce_ms'] = r['allreduce_ms']
         result['allreduce_bytes'] = model.flat_parameters()[1].numel() * 4
-        result['allreduce_overlapped'] = dict(reducer.layout(), in_timed_steps=bool(overlapped_in_steps),
+        result['allreduce_overlapped'] = dict(r['reducer_layout'], in_timed_steps=r['overlapped_in_steps'], fallback_steps=r['fallback_steps'],
                                               note='the gradient buffer is reduced as two collectives; `overlapped_bytes` (upper half of the layers + '
                                                    'decoder) start behind those layers\' weight gradients and run under the rest of the backward, '
-                                                   '`exposed_bytes` after it; allreduce_ms = both collectives timed alone, back to back')
+                                                   '`exposed_bytes` after it; allreduce_ms = both collectives timed alone, back to back (an upper bound on what a step '
+                                                   'can lose to communication); fallback_steps = armed steps whose early collective could not be overlapped')
         result['collective_backend'] = torch.distributed.get_backend()
         result['devices_visible'] = torch.cuda.device_count()
         if os.environ.get('PFN_DP_SINGLE_DEVICE') == '1':
             result['ranks_share_device'] = True    # one-GPU test hook: NOT a scaling measurement
     if world == 1 and not args.no_kernel_breakdown:
         # kernels are launched per micro-batch (column group of the batch, streams.py): time them at THAT shape
-        groups = streams if (streams > 1 and batch % streams == 0 and batch >= 2 * streams) else 1
+        groups = r['micro_groups']
         mean_sep = int(round(sum(seps) / len(seps)))
         ks = kernel_breakdown(batch // groups, mean_sep, w, fused_ln_wide=bool(tuning.get(5)), top_rows=top_rows_of(batch // groups, mean_sep))
+        in_step = r.get('in_step', {})
         for k in ks:
-            k['launches_per_step'] *= groups
-            k['step_seconds'] *= groups
+            k['launches_per_step'] *= groups * args.aggregate_k
+            k['step_seconds'] *= groups * args.aggregate_k
+            cls = k.get('prof_class')
+            if cls and cls in in_step:
+                k['in_step_us'] = in_step[cls]['avg_us']
+                k['in_step_launches_timed'] = in_step[cls]['launches']
         dom = max(ks, key=lambda k: k['step_seconds'])   # the kernel the step spends most time in
         traffic, traffic_src = None, None
         pmc = json.load(open(PMC_TRAFFIC)) if os.path.exists(PMC_TRAFFIC) else {}
@@ -790,38 +897,77 @@ def main():
             if hit:
                 traffic = hit[0].get('read_bytes', 0) + hit[0].get('write_bytes', 0)
                 traffic_src = f"profiles/{os.path.basename(PMC_TRAFFIC)} ({pmc.get('note', '')})"
-        in_step_us, in_step_src = None, None
-        if os.path.exists(IN_STEP_ATTENTION) and args.config == 2 and batch == w['batch'] and streams == w['streams']:
-            # the kernel trace of THIS command, the top layer's short launches (queries >= sep only) apart from the full ones (tools/pmc_summary.py)
-            for name, v in json.load(open(IN_STEP_ATTENTION)).get('kernels', {}).items():
-                if name.startswith(dom['rocprof_name']) and 'top layer' not in name:
-                    in_step_us = v['avg_us']
-                    in_step_src = (f'profiles/{os.path.basename(IN_STEP_ATTENTION)} (rocprofv3 --kernel-trace of this command: two micro-batch streams + the sampler share '
-                                   f'the chip; {v["calls"]} launches on every query, the top layer\'s short launches listed apart)')
-        if in_step_us is None and os.path.exists(KERNEL_STATS) and args.config == 2 and batch == w['batch'] and streams == w['streams']:
-            import csv
-            for row in csv.DictReader(open(KERNEL_STATS)):      # the committed rocprofv3 trace of THIS command: the same symbol inside the step
-                if row.get('Name', '').startswith(dom['rocprof_name']):
-                    in_step_us = float(row['AverageNs']) / 1e3
-                    in_step_src = f'profiles/{os.path.basename(KERNEL_STATS)} (rocprofv3 --kernel-trace --stats of this command: two micro-batch streams + the sampler share the chip)'
-                    break
-        result['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'rocprof_kernel': dom['rocprof_name'], 'achieved': dom['tflops'],
-                              'in_step_avg_launch_us': in_step_us, 'in_step_source': in_step_src,
-                              'in_step_frac': None if in_step_us is None else dom['flops'] / (in_step_us * 1e-6) / MFMA_BF16_PEAK,
-                              'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': dom['tflops'] * 1e12 / MFMA_BF16_PEAK,
+        in_us = dom.get('in_step_us')
+        iso_frac = dom['tflops'] * 1e12 / MFMA_BF16_PEAK
+        in_frac = None if in_us is None else dom['flops'] / (in_us * 1e-6) / MFMA_BF16_PEAK
+        # (the in-step launches run at the eval positions of the profiled steps; the isolated ones at the mean position -- FLOPs per launch taken at the mean)
+        result['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'rocprof_kernel': dom['rocprof_name'],
+                              'achieved': dom['tflops'] if in_us is None else dom['flops'] / (in_us * 1e-6) / 1e12,
+                              'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s', 'frac': iso_frac if in_frac is None else in_frac,
+                              'frac_is': 'isolated (no in-step timing for this kernel class)' if in_frac is None else
+                                         'IN-STEP: average launch duration inside the running step (HIP event pairs on the launch stream, pfn_profile_*; two micro-batch '
+                                         'streams + the sampler share the chip)',
+                              'in_step_avg_launch_us': in_us, 'in_step_launches_timed': dom.get('in_step_launches_timed'),
+                              'isolated_frac': iso_frac, 'isolated_avg_launch_us': dom['seconds'] * 1e6, 'isolated_achieved': dom['tflops'],
                               'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_flops_per_launch': dom['flops'],
                               'executed_flops_per_launch': dom['executed_flops'], 'executed_frac': dom['executed_tflops'] * 1e12 / MFMA_BF16_PEAK,
-                              'avg_launch_us': dom['seconds'] * 1e6, 'launches_per_step': dom['launches_per_step'],
+                              'avg_launch_us': dom['seconds'] * 1e6 if in_us is None else in_us, 'launches_per_step': dom['launches_per_step'],
                               'in_step_ms': dom['step_seconds'] * 1e3,
-                              'note': 'dominant kernel by launches x duration; every launch timed with HIP events on its stream, without co-runners -- GEMMs and the '
-                                      'attention forward repeated on their own, the attention backward\'s three launches inside their sequence (time_sequence); '
-                                      'in_step_avg_launch_us = the same symbol inside the step, where two micro-batch streams and the sampler share the chip'}
+                              'note': 'dominant kernel by launches x isolated duration.  isolated_* = every launch timed with HIP events on its stream without co-runners '
+                                      '(GEMMs and the attention forward repeated on their own, the attention backward\'s three launches inside their sequence); `frac` / '
+                                      '`achieved` / `avg_launch_us` = the same kernel class timed inside the step'}
         result['kernels'] = [{k: (round(v, 6) if isinstance(v, float) else v) for k, v in kk.items()} for kk in ks]
+        result['in_step_kernel_us'] = {k: dict(avg_us=round(v['avg_us'], 2), launches=v['launches']) for k, v in in_step.items()}
     if world == 1 and not args.no_parity:
-        result['parity'], inputs = parity_check(model, w, device, args.precision)
+        parity, inputs = parity_check(model, w, device, args.precision)
+        timed = parity.pop('training_forward')
+        cost = inference_cost(model, w, device, w['parity_sep'])
+        # two blocks, each saying which path it covers: the north star's 1e-3 is a statement about OUTPUTS (inference passes: eval mode ->
+        # model.eval_precision kernels); the throughput above is the bf16 training path, whose forward is measured beside it on the same inputs
+        result['parity_inference'] = dict(parity, covers='inference outputs: model.eval() under no_grad (validate / run_test / criterion.mean); NOT the timed path',
+                                          gate='north_star 1e-3 on nll_rel and mean_rel_l2', passed=bool(parity['nll_rel'] < 1e-3 and parity['mean_rel_l2'] < 1e-3), cost=cost)
+        result['parity_timed_path'] = dict(timed, covers=f'forward of the TIMED path (train mode, {args.precision} operands) on the same inputs and weights',
+                                           gate='reported; nll_rel < 1e-3 holds on these (untrained) weights, trained weights: DESIGN.md section 4',
+                                           nll_within_1e3=bool(timed['nll_rel'] < 1e-3), mean_within_1e3_of_own_norm=bool(timed['mean_rel_l2'] < 1e-3))
+        result['parity'] = dict(parity, training_forward=timed)      # (the layout of rounds 2-3, kept for tools/)
         result['val_bar_nll'] = validation_loss(model, w, device)
         if not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(w, inputs)
+    result['seconds_main_line'] = time.time() - t_start
+    if world == 1 and not args.no_extras and args.config == 2 and args.batch is None and args.aggregate_k == 1:
+        release(r)
+        del model
+        result['other_configs'] = {}
+        for cfg in (4, 5):
+            t0 = time.time()
+            rc = run_config(cfg, device, 0, 1, args.precision, steps=5, warmup=2)
+            tc = throughput_fields(rc, 1)
+            entry = dict(workload=CONFIGS[cfg]['workload'], value=tc['value'], unit='datasets/s', ms_per_step=tc['ms_per_step'], steps=5, warmup=2,
+                         per_gpu_batch=rc['batch'], micro_batch_streams=rc['streams'], mean_sep=sum(rc['seps']) / len(rc['seps']),
+                         step_roofline=dict(frac=tc['frac'], reference_graph_frac=tc['reference_graph_frac']))
+            if not args.no_parity:
+                par, _ = parity_check(rc['model'], CONFIGS[cfg], device, args.precision)
+                tf = par['training_forward']
+                entry['parity'] = dict(precision=par['precision'], nll_rel=par['nll_rel'], mean_rel_l2=par['mean_rel_l2'], mean_max_over_y_range=par['mean_max_over_y_range'],
+                                       logits_rel_l2=par['logits_rel_l2'], oracle_forward_s=par['oracle_forward_s'],
+                                       timed_path=dict(precision=tf['precision'], nll_rel=tf['nll_rel'], mean_rel_l2=tf['mean_rel_l2'], logits_rel_l2=tf['logits_rel_l2']))
+            entry['seconds'] = time.time() - t0
+            result['other_configs'][f'configs[{cfg - 1}]'] = entry
+            release(rc)
+            del rc
+        # the small-batch regime of the reference's notebooks (SetupForGPFittingExperiments.ipynb:143-149 trains configs[1] at batch_size 4 with
+        # aggregate_k_gradients 25): per-GPU batch 4 x 25 batches per optimizer step, then 8 / 16 / 32 with one batch per step
+        result['batch_sweep'] = []
+        for b, k, st in ((4, 25, 2), (8, 1, 10), (16, 1, 10), (32, 1, 10)):
+            t0 = time.time()
+            rb = run_config(2, device, 0, 1, args.precision, batch=b, aggregate_k=k, steps=st, warmup=2)
+            tb = throughput_fields(rb, 1)
+            result['batch_sweep'].append(dict(per_gpu_batch=b, aggregate_k_gradients=k, datasets_per_optimizer_step=b * k, value=tb['value'], unit='datasets/s',
+                                              ms_per_optimizer_step=tb['ms_per_step'], steps=st, micro_batch_groups=rb['micro_groups'],
+                                              step_roofline_frac=tb['frac'], seconds=time.time() - t0))
+            release(rb)
+            del rb
+    result['seconds_total'] = time.time() - t_start
     print(json.dumps(result))
 
 

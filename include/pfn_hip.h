@@ -91,6 +91,7 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_ATTN_PINGPONG = 4, /* bit 0: attention forward, bit 1: backward key-block pass -- the two waves of a SIMD run half a tile apart (default: see attention.hip) */
        PFN_TUNE_FUSE_LN_WIDE = 5,  /* 1: emsize 1024 runs the LayerNorm-fused GEMMs on 64-row x 1024-column tiles (gemm_nt_ln_wide / lnbwd_wide); 0 (default): the
                                     * 256 x 256 GEMM + LayerNorm kernels -- measured faster at that width */
+       PFN_TUNE_GEMM_LN_ROWS = 7,  /* 1: the LayerNorm-fused GEMMs at emsize 512 run on 64-row tiles, two workgroups per CU (gemm.hip g_ln_rows64); 0 (default): 128-row tiles */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
                                     * returns output[single_eval_pos:] (transformer.py:91), so that layer's train rows feed nothing; 0: every layer on every row */ };
 int pfn_set_tuning(int key, int value);

@@ -207,9 +207,19 @@ def test_gemm_tn(M, P, Q, prec):
     assert relerr(C, ref) < 3e-6, relerr(C, ref)
 
 
+@pytest.fixture(params=[0, 1], ids=['128-row-tiles', '64-row-tiles'])
+def ln_tile_rows(request):
+    """PFN_TUNE_GEMM_LN_ROWS: the LayerNorm-fused GEMMs at N = 512 on 128-row tiles (default) or on 64-row tiles, two workgroups per CU."""
+    _hip.check(_hip.lib().pfn_set_tuning(7, request.param), 'pfn_set_tuning')
+    yield request.param
+    _hip.check(_hip.lib().pfn_set_tuning(7, 0), 'pfn_set_tuning')
+
+
 @pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (77, 512, 32), (300, 1024, 1024), (130, 1024, 2048), (64, 1024, 96), (1, 1024, 64)])
-def test_gemm_ln_fused(M, N, K):
+def test_gemm_ln_fused(M, N, K, ln_tile_rows):
     """linear + bias + residual + LayerNorm in one kernel, both residual forms, against f64 PyTorch."""
+    if ln_tile_rows and N != 512:
+        pytest.skip('the 64-row tiles exist at N = 512 only')
     dt = torch.bfloat16
     A, B = rnd(M, K, dtype=dt, seed=40), rnd(N, K, dtype=dt, seed=41, scale=0.1)
     bias, gamma, beta = rnd(N, seed=42), rnd(N, seed=43) + 1, rnd(N, seed=44)
@@ -233,8 +243,10 @@ def test_gemm_ln_fused(M, N, K):
 
 @pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (77, 512, 1536),
                                    (200, 1024, 2048), (77, 1024, 3072), (64, 1024, 32)])      # N = 1024: the 64-row tiles (emsize 1024)
-def test_gemm_lnbwd_fused(M, N, K):
+def test_gemm_lnbwd_fused(M, N, K, ln_tile_rows):
     """dgrad GEMM + residual-branch gradient + LayerNorm backward in one kernel, against f64 autograd of the LayerNorm."""
+    if ln_tile_rows and N != 512:
+        pytest.skip('the 64-row tiles exist at N = 512 only')
     dt = torch.bfloat16
     A, B = rnd(M, K, dtype=dt, seed=50), rnd(N, K, dtype=dt, seed=51, scale=0.1)
     aux = rnd(M, N, dtype=dt, seed=52)

@@ -1256,7 +1256,9 @@ static int check_attn(const AttnArgs& a, int precision) {
     }                                                                                      \
   }
 
-static int g_attn_pingpong = 1;      // measured default: see DESIGN.md section 3 (round 3)
+// both bits since round 4: the key-block pass's ping-pong placement measures -2.5 % on the pass alone (profiles/r03_attention_experiments.txt), the whole GPU
+// suite is green under it (gpurun call 1 of round 4), and the step is neutral to it (2411 / 2409 vs 2399 / 2414 datasets/s, same box)
+static int g_attn_pingpong = 3;
 void set_attn_pingpong(int mask) { g_attn_pingpong = mask; }
 int launch_attn_fwd(const AttnArgs& a_in, int precision, hipStream_t s) {
   int rc = check_attn(a_in, precision);

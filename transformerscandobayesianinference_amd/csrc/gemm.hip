@@ -793,7 +793,7 @@ template <int NWN, int MI, int NJ> struct LnEpiW {   // LDS of gemm_nt_ln_kernel
   static constexpr int BYTES = STRIPS + NWN * WAVE;
 };
 template <int NWN, bool RESID_LN, int BK, int MI, int NJ>
-__global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_wide_kernel(GemmLN g) {
+__global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_kernel(GemmLN g) {      // (4-wave tiles: two workgroups per CU, 256 registers per wave)
   constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
   constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
   constexpr int TILE_A = BM * RB, STAGE = TILE_A + BN * RB;
@@ -1269,7 +1269,7 @@ template <int NWN, int BK, int MI, int NJ> struct LnbCfgW {
 };
 
 template <int NWN, int BK, int MI, int NJ>
-__global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_wide_kernel(GemmLNB g) {
+__global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wide_kernel(GemmLNB g) {
   using C = LnbCfgW<NWN, BK, MI, NJ>;
   constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
   constexpr int JH = NJ / 2, NU = MI * JH, NHB = MI * NJ;
@@ -1918,6 +1918,11 @@ template <int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g
   allowance.ensure(gemm_nt_ln_kernel<NWN, RL, BK>, lds);
   hipLaunchKernelGGL((gemm_nt_ln_kernel<NWN, RL, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
 }
+// PFN_TUNE_GEMM_LN_ROWS (test / profiling knob): 1 = the LayerNorm-fused GEMMs at N = 512 run on 64-ROW tiles (4 waves x (2 x 4) blocks, 32-deep stages:
+// 72 KiB of LDS, 256 registers per wave) so that TWO workgroups share a CU and one's HBM-bound epilogue can run under the other's MFMA loop; 0 = the
+// 128-row tiles that fill the CU's LDS alone
+static int g_ln_rows64 = 0;
+void set_gemm_ln_rows64(int on) { g_ln_rows64 = on; }
 template <int NWN, bool RL, int BK, int MI, int NJ> static void launch_gemm_ln_wide_t(const GemmLN& g, hipStream_t stream) {
   constexpr int BM = MI * 32;
   const size_t lds = std::max<size_t>(2 * (BM + NWN * NJ * 32) * (BK * 2), LnEpiW<NWN, MI, NJ>::BYTES);
@@ -1933,6 +1938,10 @@ int launch_gemm_ln(const GemmLN& g, hipStream_t stream) {
 #define PFN_LN_CASE(NWN) \
   if (g.K % 64 == 0) { if (rl) launch_gemm_ln_t<NWN, true, 64>(g, stream); else launch_gemm_ln_t<NWN, false, 64>(g, stream); } \
   else { if (rl) launch_gemm_ln_t<NWN, true, 32>(g, stream); else launch_gemm_ln_t<NWN, false, 32>(g, stream); }
+  if (g.N == 512 && g_ln_rows64) {
+    if (rl) launch_gemm_ln_wide_t<4, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<4, false, 32, 2, 4>(g, stream);
+    return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+  }
   switch (g.N / 64) {
     case 2: PFN_LN_CASE(2) break;
     case 4: PFN_LN_CASE(4) break;
@@ -1965,6 +1974,10 @@ int launch_gemm_lnbwd(const GemmLNB& g, hipStream_t stream) {
   if (g.M <= 0) return PFN_OK;
   if (!gemm_lnbwd_supported(g)) return PFN_ERR_UNSUPPORTED;
 #define PFN_LNB_CASE(NWN) if (g.K % 64 == 0) launch_gemm_lnbwd_t<NWN, 64>(g, stream); else launch_gemm_lnbwd_t<NWN, 32>(g, stream);
+  if (g.N == 512 && g_ln_rows64) {
+    launch_gemm_lnbwd_wide_t<4, 32, 2, 4>(g, stream);
+    return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+  }
   switch (g.N / 64) {
     case 2: PFN_LNB_CASE(2) break;
     case 4: PFN_LNB_CASE(4) break;

@@ -236,6 +236,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_FUSE_LNBWD: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_SEPARATE_LNBWD) : (g_default_schedule | PFN_SCHED_SEPARATE_LNBWD); return PFN_OK;
     case PFN_TUNE_GEMM_PERSIST: set_gemm_nt_persist(value); return PFN_OK;
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
+    case PFN_TUNE_GEMM_LN_ROWS: set_gemm_ln_rows64(value); return PFN_OK;
     case PFN_TUNE_FUSE_LN_WIDE: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_LN_WIDE) : (g_default_schedule & ~PFN_SCHED_FUSE_LN_WIDE); return PFN_OK;
     case PFN_TUNE_TOP_LAYER_TEST_ROWS: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_TOP_LAYER_ALL_ROWS) : (g_default_schedule | PFN_SCHED_TOP_LAYER_ALL_ROWS); return PFN_OK;
     default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);

@@ -93,6 +93,7 @@ int launch_gemm_nt(const GemmNT& g, int precision, hipStream_t stream);
 // kernel selection knob (tests / profiling): 0 automatic, 1 only the 128x128 kernel, 2 the 256x256 kernel whenever legal
 void set_gemm_nt_big_mode(int mode);
 void set_gemm_nt_persist(int wgs);
+void set_gemm_ln_rows64(int on);
 
 struct GemmTN {
   const void* A; long lda;  // [M,P] T

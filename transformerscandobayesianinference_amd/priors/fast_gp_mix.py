@@ -121,6 +121,63 @@ class DataLoader(get_batch_to_dataloader(get_batch)):
         return 123.
 
 
-def get_model(*args, **kwargs):
-    raise NotImplementedError('priors.fast_gp_mix.get_model builds a botorch SingleTaskGP (reference :24-55); fitting / MCMC baselines '
-                              'are outside the MI355X hot path (SURVEY.md 2). Use sample_hyperparameters() + fast_gp.gp_sample().')
+class _PriorDraw:
+    """What `likelihood(model(x))` is in the reference's sampling path (:96-99): the prior-predictive distribution of y at x under ONE draw of
+    the hyper-parameters per dataset.  `.sample()` is the HIP sampler (Gram -> blocked Cholesky -> L z, csrc/gp_prior.hip)."""
+
+    def __init__(self, model, x, with_noise):
+        self.model, self.x, self.with_noise = model, x, with_noise
+
+    @torch.no_grad()
+    def sample(self):
+        m = self.model
+        x = self.x if self.x.dim() == 3 else self.x.unsqueeze(0)
+        noise = m.noise if self.with_noise else torch.full_like(m.noise, 1e-9)      # the latent f: no observation noise (a jitter keeps f32 positive definite)
+        _, y, _, _ = fast_gp.gp_sample(x.shape[0], x.shape[1], x.shape[2], x.device, m.lengthscale, m.outputscale, noise, m.kernel, x=x.float(), check='sync')
+        return y
+
+
+class _SampledLikelihood:
+    """GaussianLikelihood of a sampled model: adds the sampled observation noise to the prior at x."""
+
+    def __init__(self, model):
+        self.model = model
+        self.noise = model.noise
+
+    def __call__(self, prior):
+        return _PriorDraw(prior.model, prior.x, with_noise=True)
+
+
+class SampledGP:
+    """`get_model(x, y, hyperparameters, sample=True)[0]` (reference :24-55: `SingleTaskGP(...).pyro_sample_from_prior()`): a GP whose kernel
+    hyper-parameters were DRAWN from the Gamma hyper-priors, one independent draw per dataset of the batch.  Exposes the sampled
+    `lengthscale [n, F]` (ARD), `outputscale [n]`, `noise [n]` (floored at botorch's MIN_INFERRED_NOISE_LEVEL) and `nu`; `model(x)` is the
+    prior at x, `likelihood(model(x)).sample()` the draw `get_batch` takes ([n, T], :96-99)."""
+
+    def __init__(self, x, hyperparameters):
+        hp = hyperparameters or {}
+        x = x if x.dim() == 3 else x.unsqueeze(0)
+        self.nu = float(hp.get('nu', 2.5))
+        if self.nu not in fast_gp.MATERN_KERNEL_OF_NU:
+            raise ValueError(f'priors.fast_gp_mix: Matern nu must be 0.5, 1.5 or 2.5 (gpytorch MaternKernel, reference :40), got {self.nu}')
+        self.kernel = fast_gp.MATERN_KERNEL_OF_NU[self.nu]
+        self.lengthscale, self.outputscale, self.noise = sample_hyperparameters(x.shape[0], x.shape[-1], hp, x.device)
+        self.likelihood = _SampledLikelihood(self)
+
+    def __call__(self, x):
+        return _PriorDraw(self, x, with_noise=False)
+
+    def to(self, device):
+        self.lengthscale, self.outputscale, self.noise = self.lengthscale.to(device), self.outputscale.to(device), self.noise.to(device)
+        return self
+
+
+def get_model(x, y, hyperparameters: dict, sample=True):
+    """Reference :24-55.  sample=True (the only form `get_batch` uses, :95): (sampled model, its likelihood), hyper-parameters drawn per dataset of the
+    batched x [n, T, F]; `y` is ignored as in the reference's prior mode (it passes an empty tensor).  sample=False builds the botorch model for
+    FITTING (get_fitted_model, :156-171), which needs gpytorch / botorch and is outside this path."""
+    if not sample:
+        raise NotImplementedError('priors.fast_gp_mix.get_model(sample=False) is the botorch SingleTaskGP for hyper-parameter FITTING (reference :156-171); '
+                                  'fitting / MCMC baselines need gpytorch / botorch and are outside the MI355X hot path (SURVEY.md 2)')
+    model = SampledGP(x, hyperparameters)
+    return model, model.likelihood
