@@ -642,7 +642,7 @@ def read_profile():
 
 
 def run_config(config, device, rank, world, precision, batch=None, streams=None, steps=20, warmup=5, aggregate_k=1, fixed_sep=None, prefetch_group=None,
-               profile_steps=0):
+               profile_steps=0, aggregate_streams=0):
     """One benchmark run of a BASELINE.json configuration: builds criterion, model, optimizer and the prior's loader, runs `warmup` untimed and
     `steps` timed OPTIMIZER steps (each = `aggregate_k` batches of `batch` datasets per rank: forward + loss + backward per batch, gradients
     summed, then [all-reduce +] clip + Adam -- reference train.py:66-97) between barrier + synchronize on both sides, max over ranks.
@@ -674,6 +674,11 @@ def run_config(config, device, rank, world, precision, batch=None, streams=None,
     seps = []
     loss_fn = loss_of(w, criterion)
     micro = MicroBatchStreams(streams)
+    # aggregate_streams > 1: the batches of one optimizer step run whole, round-robin on that many streams (streams.py forward_backward_on; train()'s
+    # automatic choice for small batches) instead of each being split into column groups
+    alt = MicroBatchStreams(aggregate_streams) if (aggregate_streams > 1 and aggregate_k > 1) else None
+    if alt is not None and not alt.can_alternate(model):
+        alt = None
     reducer = None
     if world > 1:
         backend = torch.distributed.get_backend()
@@ -687,10 +692,15 @@ def run_config(config, device, rank, world, precision, batch=None, streams=None,
             sep = fixed_sep if fixed_sep is not None else sampler()
             seps.append(sep)
             (x, y), target = next(batches)
+            if alt is not None:
+                losses = alt.forward_backward_on(k, model, (x, y), target, sep, lambda out, tg, sep=sep: loss_fn(out, tg[sep:]))
+                continue
             if reducer is not None and k == aggregate_k - 1:
                 reducer.arm(micro.groups(model, x.shape[1]))
             # forward + loss + backward of the batch, as `streams` concurrent column groups (streams.py)
             losses = micro.forward_backward(model, (x, y), target, sep, lambda out, tg: loss_fn(out, tg[sep:]))
+        if alt is not None:
+            alt.join()
         if reducer is not None:
             reducer.finish()       # two collectives: the upper layers' half was enqueued behind their weight gradients, under the backward
         opt.step(zero_grad=True)
@@ -811,6 +821,7 @@ def main():
     ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='BASELINE.json configuration (2 = configs[1], the metric\'s; 4 = BNN prior; 5 = GP mixture, bptt 4000)')
     ap.add_argument('--batch', type=int, default=None, help='datasets per GPU per batch (default: per configuration)')
     ap.add_argument('--aggregate-k', type=int, default=1, help='batches per optimizer step (train()\'s aggregate_k_gradients)')
+    ap.add_argument('--aggregate-streams', type=int, default=0, help='> 1: the aggregate_k batches of a step run whole, round-robin on that many streams (small batches)')
     ap.add_argument('--streams', type=int, default=None, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -836,7 +847,7 @@ def main():
         _hip.check(_hip.lib().pfn_set_tuning(k, v), 'pfn_set_tuning')
     t_start = time.time()
     r = run_config(args.config, device, rank, world, args.precision, batch=args.batch, streams=args.streams, steps=args.steps, warmup=args.warmup,
-                   aggregate_k=args.aggregate_k, fixed_sep=args.fixed_sep, prefetch_group=args.prefetch_group,
+                   aggregate_k=args.aggregate_k, fixed_sep=args.fixed_sep, prefetch_group=args.prefetch_group, aggregate_streams=args.aggregate_streams,
                    profile_steps=0 if (world > 1 or args.no_kernel_breakdown) else 5)
     if rank != 0:
         return
@@ -850,7 +861,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
         'config': {'workload': w['workload'], 'baseline_config': args.config,
-                   'per_gpu_batch': batch, 'global_batch': batch * world, 'aggregate_k_gradients': args.aggregate_k, 'seq_len': S, 'parallelism': f'dp{world}',
+                   'per_gpu_batch': batch, 'global_batch': batch * world, 'aggregate_k_gradients': args.aggregate_k, 'aggregate_streams': args.aggregate_streams, 'seq_len': S, 'parallelism': f'dp{world}',
                    'micro_batch_streams': streams,
                    'eval_pos': f"{w['eval_pos']} sampler({S})" if args.fixed_sep is None else args.fixed_sep, 'mean_sep': sum(seps) / len(seps),
                    'sampler_group_steps': r['group'], 'final_loss': r['final_loss']},

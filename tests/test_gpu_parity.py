@@ -1324,8 +1324,8 @@ def test_trained_head_dim_256_inference_parity():
             within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 0.12)
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16'])
-def test_training_loop_vs_reference_train_golden(precision):
+@pytest.mark.parametrize('precision,aggregate_streams', [('f32', 0), ('bf16', 0), ('f32', 2)])
+def test_training_loop_vs_reference_train_golden(precision, aggregate_streams):
     """The training loop pinned to the reference's OWN `train.train` (train.py:58-110,134; utils.py:10-22):
     tests/golden/train_loop_small.pt = recorded batches + recorded eval positions + what the reference's loop made of them (4 epochs x 8
     batches, aggregate_k_gradients 2, per-epoch cosine schedule whose first epoch runs at lr 0; oracle/make_golden.py::train_loop_case).
@@ -1335,7 +1335,9 @@ def test_training_loop_vs_reference_train_golden(precision):
     from transformerscandobayesianinference_amd import train as train_mod, utils
     rec = torch.load(os.path.join(GOLD, 'train_loop_small.pt'))
     losses, lrs, total, final = replay.replay(train_mod.train, rec, bar_distribution.FullSupportBarDistribution, encoders, utils.get_cosine_schedule_with_warmup,
-                                              gpu_device=DEV, precision=precision, micro_streams=1)
+                                              gpu_device=DEV, precision=precision, micro_streams=1, aggregate_streams=aggregate_streams)
+    # (aggregate_streams = 2: the two batches of every optimizer step run whole on alternating HIP streams -- streams.py forward_backward_on, train()'s
+    # choice for small batches -- and must reproduce the reference's sequential accumulation just the same)
     cfg = rec['config']
     assert lrs == pytest.approx(rec['batch_lr'], rel=1e-12, abs=0) and lrs[0] == 0.0
     tight = precision == 'f32'

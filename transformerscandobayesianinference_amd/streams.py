@@ -59,3 +59,35 @@ class MicroBatchStreams:
         for o in outs:
             o.record_stream(main)
         return torch.cat(outs, 1)
+
+    # ---- whole batches on alternating streams (gradient accumulation over small batches) -------------------------------------------
+    # train(aggregate_k_gradients = k) sums the gradients of k consecutive batches before one optimizer step (reference train.py:92-97); the
+    # notebooks train BASELINE configs[1] that way at batch_size 4 (SetupForGPFittingExperiments.ipynb:143-149).  A batch of 4 datasets is 8000
+    # tokens -- a fraction of one round of tiles on 256 CUs -- and splitting it into column groups makes the launches smaller still.  The k
+    # batches of one optimizer step are independent given the weights, so they run WHOLE, round-robin on the streams: up to `n` batches in flight,
+    # their gradients accumulated atomically into the shared flat buffer, joined before the optimizer step.
+    def can_alternate(self, model):
+        fused = getattr(model, '_fused_embedding', lambda: False)() and not getattr(model, '_custom_decoder', False)
+        return bool(self.streams) and fused
+
+    def forward_backward_on(self, slot, model, data, targets, single_eval_pos, loss_fn):
+        """The whole batch on stream `slot % n`; returns the detached per-(position, dataset) losses, valid on the caller's stream after join()."""
+        x, y = data
+        main = torch.cuda.current_stream()
+        model.flat_parameters()
+        model._refresh_shadow(_hip.stream_ptr(x.device))      # operand copies of the weights: on the caller's stream, before any batch of the step reads them
+        s = self.streams[slot % self.n]
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            output = model(data, single_eval_pos=single_eval_pos)
+            losses = loss_fn(output, targets)
+            losses.mean().backward()
+            out = losses.detach()
+        for t in (x, y, targets):
+            t.record_stream(s)
+        return out
+
+    def join(self):
+        main = torch.cuda.current_stream()
+        for s in self.streams:
+            main.wait_stream(s)

@@ -68,7 +68,8 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
           epochs=10, steps_per_epoch=100, batch_size=200, bptt=10, lr=None, warmup_epochs=10, input_normalization=False,
           y_encoder_generator=None, pos_encoder_generator=None, decoder=None, extra_prior_kwargs_dict={},
           scheduler=get_cosine_schedule_with_warmup, load_weights_from_this_state_dict=None, validation_period=10,
-          single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16', micro_streams=2, epoch_callback=None):
+          single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16', micro_streams=2, epoch_callback=None,
+          aggregate_streams=None):
     device = gpu_device if torch.cuda.is_available() else 'cpu:0'
     print(f'Using {device} device')
     if not str(device).startswith('cuda') and getattr(TransformerModel, 'requires_gpu', False):
@@ -111,6 +112,11 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     optimizer.grad_multiplier = 1.0 / world
     scheduler = scheduler(optimizer, warmup_epochs, epochs)
     micro = MicroBatchStreams(micro_streams if str(device).startswith('cuda') else 1)   # concurrent half-batches (streams.py)
+    # gradient accumulation over SMALL batches (the notebooks' batch_size 4 x aggregate_k_gradients 25): the batches of one optimizer step run whole, round-robin on
+    # `aggregate_streams` HIP streams, instead of each being split into column groups (streams.py; measured in bench.py's batch_sweep).  None = automatic.
+    if aggregate_streams is None:
+        aggregate_streams = 4 if (aggregate_k_gradients >= 4 and dp.local_batch_size(batch_size) * bptt <= 16 * 2048) else 0
+    alt = MicroBatchStreams(aggregate_streams) if (aggregate_streams and aggregate_streams > 1 and aggregate_k_gradients > 1 and str(device).startswith('cuda')) else None
     # data-parallel runs: the flat gradient buffer is all-reduced as two collectives, the upper layers' half under the backward
     reducer = dp.OverlappedGradientReducer(model) if world > 1 and hasattr(model, 'flat_parameters') else None
 
@@ -122,13 +128,21 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
         before_get_batch = time.time()
         time_to_get_batch = forward_time = step_time = 0.
         assert len(dl) % aggregate_k_gradients == 0, 'Please set the number of steps per epoch s.t. `aggregate_k_gradients` divides it.'
+        pending = []      # (eval position, losses) of batches still running on the alternating streams
         for batch, (data, targets) in enumerate(dl):
             time_to_get_batch = time.time() - before_get_batch
             before_forward = time.time()
             single_eval_pos = single_eval_pos_gen() if callable(single_eval_pos_gen) else single_eval_pos_gen
             data = tuple(e.to(device) for e in data) if isinstance(data, tuple) else data.to(device)
             last_micro_step = batch % aggregate_k_gradients == aggregate_k_gradients - 1
-            if isinstance(data, tuple) and single_eval_pos is not None:
+            if isinstance(data, tuple) and single_eval_pos is not None and alt is not None and alt.can_alternate(model):
+                targets = targets.to(device)
+                losses = alt.forward_backward_on(batch, model, data, targets, single_eval_pos,
+                                                 lambda out, tg, sep=single_eval_pos: compute_losses(criterion, out, tg[sep:], n_out))
+                pending.append((single_eval_pos, losses))
+                loss = None
+                forward_time = time.time() - before_forward
+            elif isinstance(data, tuple) and single_eval_pos is not None:
                 targets = targets.to(device)
                 if reducer is not None and last_micro_step:
                     reducer.arm(micro.groups(model, data[0].shape[1]))
@@ -147,6 +161,8 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
                 loss = losses.mean()
                 loss.backward()
             if last_micro_step:
+                if alt is not None:
+                    alt.join()       # every batch of this optimizer step has finished its backward (in stream order)
                 if reducer is not None:
                     reducer.finish()
                 elif world > 1:
@@ -155,13 +171,22 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
             step_time = time.time() - before_forward
 
             with torch.no_grad():
-                total_loss += loss.detach()
-                if single_eval_pos is None:
-                    positional_sum += losses.detach().mean(1)
-                    positional_cnt += 1
+                if loss is None:     # alternating streams: the losses are folded in at the join (their streams have been waited for)
+                    if last_micro_step:
+                        for sep_k, losses_k in pending:
+                            lk = losses_k.mean()
+                            total_loss += lk
+                            positional_sum[sep_k] += lk
+                            positional_cnt[sep_k] += 1
+                        pending = []
                 else:
-                    positional_sum[single_eval_pos] += loss.detach()
-                    positional_cnt[single_eval_pos] += 1
+                    total_loss += loss.detach()
+                    if single_eval_pos is None:
+                        positional_sum += losses.detach().mean(1)
+                        positional_cnt += 1
+                    else:
+                        positional_sum[single_eval_pos] += loss.detach()
+                        positional_cnt[single_eval_pos] += 1
             before_get_batch = time.time()
         if world > 1:
             torch.distributed.all_reduce(total_loss)
