@@ -969,12 +969,15 @@ def main():
         # the small-batch regime of the reference's notebooks (SetupForGPFittingExperiments.ipynb:143-149 trains configs[1] at batch_size 4 with
         # aggregate_k_gradients 25): per-GPU batch 4 x 25 batches per optimizer step, then 8 / 16 / 32 with one batch per step
         result['batch_sweep'] = []
-        for b, k, st in ((4, 25, 2), (8, 1, 10), (16, 1, 10), (32, 1, 10)):
+        # (schedule: `alternating` = the batches of one optimizer step whole, round-robin on that many streams -- what train() picks for small batches;
+        # `column groups` = every batch split over the two micro-batch streams, what the large batches use)
+        for b, k, st, alt_streams in ((4, 25, 2, 8), (4, 25, 2, 0), (8, 1, 10, 0), (16, 1, 10, 0), (32, 1, 10, 0)):
             t0 = time.time()
-            rb = run_config(2, device, 0, 1, args.precision, batch=b, aggregate_k=k, steps=st, warmup=2)
+            rb = run_config(2, device, 0, 1, args.precision, batch=b, aggregate_k=k, steps=st, warmup=2, aggregate_streams=alt_streams)
             tb = throughput_fields(rb, 1)
-            result['batch_sweep'].append(dict(per_gpu_batch=b, aggregate_k_gradients=k, datasets_per_optimizer_step=b * k, value=tb['value'], unit='datasets/s',
-                                              ms_per_optimizer_step=tb['ms_per_step'], steps=st, micro_batch_groups=rb['micro_groups'],
+            result['batch_sweep'].append(dict(per_gpu_batch=b, aggregate_k_gradients=k, datasets_per_optimizer_step=b * k,
+                                              schedule=f'alternating x {alt_streams}' if alt_streams else f"column groups x {rb['micro_groups']}",
+                                              value=tb['value'], unit='datasets/s', ms_per_optimizer_step=tb['ms_per_step'], steps=st,
                                               step_roofline_frac=tb['frac'], seconds=time.time() - t0))
             release(rb)
             del rb

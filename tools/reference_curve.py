@@ -97,6 +97,7 @@ def main():
             rec['runs'].setdefault(f'{F}_features', {})['reference_cpu_f32'] = r
             print(F, 'features, reference:', [round(v, 3) for v in r['epoch_losses']], f"{r['seconds']:.0f} s")
     if a.hip:
+        torch.set_num_threads(4)       # (the per-batch 200 x 200 f64 Cholesky on the host: a many-core box thrashes with its default thread count)
         sys.path.insert(0, ROOT)
         from transformerscandobayesianinference_amd import bar_distribution, encoders, train as train_mod, utils
         for F in (5, 18):
@@ -116,6 +117,8 @@ def main():
                    'distributions (torch.manual_seed(7): the reference and this repo construct the same parameter tensors in the same order, so the draws coincide '
                    'where the construction order does); epoch_losses = mean training loss per epoch (bar NLL, nats); the prior level is the first epoch (lr 0)')
     json.dump(rec, open(OUT, 'w'), indent=1)
+    if a.hip and os.path.isdir(os.path.join(ROOT, 'gpurun_out')):
+        json.dump(rec, open(os.path.join(ROOT, 'gpurun_out', os.path.basename(OUT)), 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -115,7 +115,9 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     # gradient accumulation over SMALL batches (the notebooks' batch_size 4 x aggregate_k_gradients 25): the batches of one optimizer step run whole, round-robin on
     # `aggregate_streams` HIP streams, instead of each being split into column groups (streams.py; measured in bench.py's batch_sweep).  None = automatic.
     if aggregate_streams is None:
-        aggregate_streams = 4 if (aggregate_k_gradients >= 4 and dp.local_batch_size(batch_size) * bptt <= 16 * 2048) else 0
+        # (one MI355X, configs[1]: batch 4 x 25 batches 956 datasets/s as column groups, 1680 / 1688 / 1927 on 2 / 4 / 8 alternating streams; batch 8 x 4:
+        # 1637 -> 2066; batch 16 x 4: 2175 -> 2346 -- gpurun call 3 of round 4, profiles/r04_small_batch_streams.txt)
+        aggregate_streams = min(8, aggregate_k_gradients) if (aggregate_k_gradients >= 2 and dp.local_batch_size(batch_size) * bptt <= 16 * 2048) else 0
     alt = MicroBatchStreams(aggregate_streams) if (aggregate_streams and aggregate_streams > 1 and aggregate_k_gradients > 1 and str(device).startswith('cuda')) else None
     # data-parallel runs: the flat gradient buffer is all-reduced as two collectives, the upper layers' half under the backward
     reducer = dp.OverlappedGradientReducer(model) if world > 1 and hasattr(model, 'flat_parameters') else None
