@@ -91,6 +91,7 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_ATTN_PINGPONG = 4, /* bit 0: attention forward, bit 1: backward key-block pass -- the two waves of a SIMD run half a tile apart (default: see attention.hip) */
        PFN_TUNE_FUSE_LN_WIDE = 5,  /* 1: emsize 1024 runs the LayerNorm-fused GEMMs on 64-row x 1024-column tiles (gemm_nt_ln_wide / lnbwd_wide); 0 (default): the
                                     * 256 x 256 GEMM + LayerNorm kernels -- measured faster at that width */
+       PFN_TUNE_GP_PLANES = 8,     /* 1 (default): the GP sampler's rank-256 trailing update reads pre-split bf16 planes by LDS-DMA; 0: it splits the f32 panel per tile (rounds 2-3) */
        PFN_TUNE_GEMM_LN_ROWS = 7,  /* 1: the LayerNorm-fused GEMMs at emsize 512 run on 64-row tiles, two workgroups per CU (gemm.hip g_ln_rows64); 0 (default): 128-row tiles */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
                                     * returns output[single_eval_pos:] (transformer.py:91), so that layer's train rows feed nothing; 0: every layer on every row */ };
@@ -203,7 +204,9 @@ int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
  * x [B,S,nf] f32: filled with U[0,1) from the counter-based generator when gen_x != 0, else input.
  * z [B,S] f32 base normals: generated when gen_z != 0 (and written back), else input.
  * lengthscale [B,nf], outputscale [B], noise [B].  kernel: 0 = RBF, 1 / 2 / 3 = Matern nu = 2.5 / 1.5 / 0.5 (gpytorch MaternKernel's three closed forms).
- * K_ws: [B,S,S] f32 workspace.  info [B]: 0 or (index+1) of the first non-positive pivot. */
+ * K_ws: workspace of pfn_gp_workspace_bytes(B, S) bytes: the [B,S,S] f32 matrix, factored in place, followed by the scratch of the trailing update
+ * (the three bf16 planes of the current outer block's solved panel: + 19 % at S = 2000).  info [B]: 0 or (index+1) of the first non-positive pivot. */
+int64_t pfn_gp_workspace_bytes(int B, int S);
 int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws,
                         const float* lengthscale, const float* outputscale, const float* noise,
                         int B, int S, int nf, int kernel, int gen_x, int gen_z,
@@ -214,7 +217,7 @@ int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws,
  * the full covariance gives all of them (gp_prior.hip): for every dataset b and position t, the posterior at x[b,t]
  * given (x[b,:t], y[b,:t]) under the GP with the given hyper-parameters:
  *   mean[b,t], var[b,t] (predictive, observation noise included), nll[b,t] = -log N(y[b,t]; mean, var).
- * Position 0 is the prior.  x [B,S,nf], y [B,S]; K_ws [B,S,S], resid_ws / w_ws [B,S] scratch; nll / mean / var may be
+ * Position 0 is the prior.  x [B,S,nf], y [B,S]; K_ws: pfn_gp_workspace_bytes(B, S) bytes; resid_ws / w_ws [B,S] scratch; nll / mean / var may be
  * null.  S % 4 == 0.  info as in pfn_gp_prior_sample. */
 int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_ws, float* w_ws,
                      const float* lengthscale, const float* outputscale, const float* noise,

@@ -67,6 +67,7 @@ SIGNATURES = {
     'pfn_bar_nll_backward': (_I, [_P, _L, _P, _P, _P, _L, _I, _P, _P]),
     'pfn_bar_mean': (_I, [_P, _L, _P, _L, _I, _I, _P, _P]),
     'pfn_clip_adam_step': (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
+    'pfn_gp_workspace_bytes': (_L, [_I, _I]),
     'pfn_gp_prior_sample': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P, _P]),
     'pfn_gp_posterior': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'pfn_mlp_prior_forward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P]),

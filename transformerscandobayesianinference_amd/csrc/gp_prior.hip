@@ -382,6 +382,120 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r
 }
 
 // ---------------------------------------------------------------------------------------------
+// The rank-256 trailing update from PRE-SPLIT panels (round 4).  gp_syrk_kernel above re-reads its two f32 panels for every tile and
+// splits every value into its three bf16 terms again as the chunk goes to LDS -- for the trailing update of an outer block that is ~10x
+// redundant vector work (one split per tile that touches the row) staged through 64 registers per lane.  Here gp_trsm_wide_kernel, which
+// produces the solved panel anyway, ALSO leaves its three bf16 planes in a scratch behind K_ws (GpArgs::planes), laid out for the consumer:
+//     slab (plane p, k-chunk kc of PL_KC columns)  =  [rows below the outer block][PL_KC] bf16, contiguous (32 bytes per row),
+//     the two 16-byte halves of a row swapped when (row >> 3) & 1 -- the bank swizzle of load_frag_row<bf16, 32>.
+// A 128-row operand chunk of one plane is then 4 contiguous KiB: the update's tiles fetch them by LDS-DMA (dma16, no staging registers, no
+// vector work), two stages of 6 slabs x 4 KiB each, and multiply exactly as before (six bf16 MFMAs per block product).  L2 traffic per tile
+// goes up 1.5x (6 instead of 4 bytes per panel value); the split and the register staging are gone.
+// ---------------------------------------------------------------------------------------------
+constexpr int PL_KC = 16;                           // panel columns per slab / per LDS stage
+constexpr int PL_NKC = 256 / PL_KC;                 // slabs per plane of a 256-wide panel
+constexpr int PL_ROWB = PL_KC * 2;                  // bytes per slab row
+PFN_DEV long plane_slab_bytes(long rows_alloc) { return rows_alloc * PL_ROWB; }
+// byte offset of (plane, chunk, row) inside one dataset's plane scratch of `rows_alloc` rows
+PFN_DEV long plane_offset(long rows_alloc, int plane, int kc, long row) { return ((long)(plane * PL_NKC + kc) * rows_alloc + row) * PL_ROWB; }
+
+constexpr int SYP_SLAB = 128 * PL_ROWB;             // one plane of one 128-row operand chunk in LDS: 4 KiB
+constexpr int SYP_STAGE = 2 * 3 * SYP_SLAB;         // A and B, three planes each: 24 KiB
+constexpr int SYP_LDS = 2 * SYP_STAGE;              // two stages: 48 KiB, three workgroups per CU
+
+__global__ __launch_bounds__(256, 3) void gp_syrk_planes_kernel(GpArgs a, int r0, int r1) {
+  // C[i][j] -= sum_k X[i][k] X[j][k] for rows / columns >= r0 (lower triangle, 128 x 128 tiles), X = the 256-wide solved panel of the outer
+  // block that ends at r0, read from its planes (row index in the planes: global row - r0)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  const int S = a.S, T = gridDim.x * gridDim.y;
+  int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  int b, t;
+  if (a.B % 8 == 0) { const int xcd = lin & 7, j = lin >> 3; b = xcd + 8 * (j / T); t = j % T; }     // a dataset's tiles on one XCD: its planes stay in that L2
+  else { b = lin / T; t = lin % T; }
+  const int i0 = r0 + (t / gridDim.x) * 128, j0 = r0 + (t % gridDim.x) * 128;
+  if (j0 > i0 + 127) return;          // tile entirely above the diagonal
+  float* Kb = a.K + (long)b * S * S;
+  const char* pl = reinterpret_cast<const char*>(a.planes) + (long)b * 3 * PL_NKC * plane_slab_bytes(a.plane_rows);
+  const DmaRsrc rp = make_dma_rsrc(pl, 3L * PL_NKC * plane_slab_bytes(a.plane_rows));
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // a stage = 24 one-KiB pieces: piece q = (operand o = q / 12, plane p = (q / 4) % 3, quarter qq = q % 4) -> LDS (o * 3 + p) * SYP_SLAB + qq * 1024; wave w
+  // moves pieces w, w + 4, ...  Source: 32 consecutive slab rows = one contiguous KiB (the swizzle is already in the slab).
+  auto stage = [&](int buf, int kc) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int q = wave + 4 * i;
+      const int o = q / 12, p = (q / 4) % 3, qq = q % 4;
+      const long row = (long)((o ? j0 : i0) - r0) + qq * 32;
+      const long off = plane_offset(a.plane_rows, p, kc, row) + lane * 16;
+      dma16(rp, smem + buf * SYP_STAGE + (o * 3 + p) * SYP_SLAB + qq * 1024, (int)off);
+    }
+  };
+  stage(0, 0);
+  for (int kc = 0; kc < PL_NKC; ++kc) {
+    const int cur = kc & 1;
+    dma_wait_all();
+    __syncthreads();                   // stage kc has landed for everyone; the other buffer's readers (stage kc - 1) are done
+    if (kc + 1 < PL_NKC) stage(cur ^ 1, kc + 1);
+    const lds_char* tA = smem + cur * SYP_STAGE;
+    const lds_char* tB = tA + 3 * SYP_SLAB;
+    Frag<bf16> fa[2][3], fb[2][3];     // [block][hi, mid, lo]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[i][p] = load_frag_row<bf16, PL_ROWB>(tA + p * SYP_SLAB, wm * 64 + i * 32 + (lane & 31), 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fb[j][p] = load_frag_row<bf16, PL_ROWB>(tB + p * SYP_SLAB, wn * 64 + j * 32 + (lane & 31), 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {   // swapped operands: a lane owns one ROW of the tile; smallest terms first (as gp_syrk_kernel)
+        f32x16 c = acc[i][j];
+        c = mma32(fb[j][2], fa[i][0], c);
+        c = mma32(fb[j][0], fa[i][2], c);
+        c = mma32(fb[j][1], fa[i][1], c);
+        c = mma32(fb[j][1], fa[i][0], c);
+        c = mma32(fb[j][0], fa[i][1], c);
+        acc[i][j] = mma32(fb[j][0], fa[i][0], c);
+      }
+  }
+  // read-modify-write of C in 16-byte pieces: lane = row, accumulator group g = 4 consecutive columns
+  const int h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gi = i0 + wm * 64 + i * 32 + (lane & 31);
+    if (gi >= r1) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int gj = j0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
+        if (gj > gi || gj >= r1) continue;
+        float* cp = Kb + (long)gi * S + gj;
+        if (gj + 3 <= gi && gj + 3 < r1) {
+          f32x4 c = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c[e] -= acc[i][j][4 * gq + e];
+          *reinterpret_cast<f32x4*>(cp) = c;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gj + e <= gi && gj + e < r1) cp[e] -= acc[i][j][4 * gq + e];
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // wide trsm: all rows below a finished 256-wide outer block.  X = A[rows, kout:kout+256] . L_d^-T with L_d the
 // factored 256x256 diagonal block, as a blocked forward substitution over its four 64-column blocks:
 //   V_j -= sum_{i<j} X_i L_ji^T   exact-f32 MFMA, one 32x32 tile per wave
@@ -475,6 +589,42 @@ __global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
     const int r = id / (OBW / 4), c = id % (OBW / 4);
     if (r < rows_valid) *reinterpret_cast<u32x4*>(Kb + (long)(row0 + r) * S + kout + c * 4) = lds_read16(V + r * TW_STRIDE + c * 16);
   }
+  if (a.planes) {
+    // the solved rows once more, as the three bf16 planes the trailing update multiplies (gp_syrk_planes_kernel: layout and why).  A task = 8 consecutive
+    // columns of a row (two 16-byte reads of V) -> one 16-byte half row in each plane; a = hi + mid + lo to 2^-27 |a|, each residual exact in f32.
+    char* pl = reinterpret_cast<char*>(a.planes) + (long)b * 3 * PL_NKC * plane_slab_bytes(a.plane_rows);
+    const long prow0 = (long)row0 - (kout + OBW);                      // row index inside the planes: rows below the outer block
+    for (int id = threadIdx.x; id < 64 * (OBW / 8); id += 256) {
+      const int r = id / (OBW / 8), c8 = id % (OBW / 8);                 // columns 8 c8 .. 8 c8 + 7
+      if (r >= rows_valid) continue;
+      const f32x4 v0 = __builtin_bit_cast(f32x4, lds_read16(V + r * TW_STRIDE + c8 * 32));
+      const f32x4 v1 = __builtin_bit_cast(f32x4, lds_read16(V + r * TW_STRIDE + c8 * 32 + 16));
+      bf16x8 hi, mid, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? v0[e] : v1[e - 4];
+        hi[e] = (bf16)v;
+        const float r1 = v - (float)hi[e];
+        mid[e] = (bf16)r1;
+        lo[e] = (bf16)(r1 - (float)mid[e]);
+      }
+      const int kc = c8 / 2;
+      const long prow = prow0 + r;
+      const int half = (c8 & 1) ^ (int)((prow >> 3) & 1);                // the consumer's bank swizzle (load_frag_row<bf16, 32>), applied at the source
+      *reinterpret_cast<bf16x8*>(pl + plane_offset(a.plane_rows, 0, kc, prow) + half * 16) = hi;
+      *reinterpret_cast<bf16x8*>(pl + plane_offset(a.plane_rows, 1, kc, prow) + half * 16) = mid;
+      *reinterpret_cast<bf16x8*>(pl + plane_offset(a.plane_rows, 2, kc, prow) + half * 16) = lo;
+    }
+  }
+}
+
+// K_ws of the C ABI: K [B, S, S] f32, then (256-byte aligned) the plane scratch of gp_syrk_planes_kernel
+static long gp_plane_rows(int S) { return S > OBW ? ((long)(S - OBW + 127) / 128) * 128 : 0; }
+static int64_t gp_k_bytes(int B, int S) { return ((int64_t)B * S * S * 4 + 255) / 256 * 256; }
+int64_t gp_workspace_bytes(int B, int S) { return gp_k_bytes(B, S) + (int64_t)B * 3 * PL_NKC * gp_plane_rows(S) * PL_ROWB; }
+void gp_attach_planes(GpArgs& a) {      // a.K = the caller's K_ws of gp_workspace_bytes(B, S) bytes
+  a.plane_rows = gp_plane_rows(a.S);
+  a.planes = a.plane_rows > 0 ? reinterpret_cast<char*>(a.K) + gp_k_bytes(a.B, a.S) : nullptr;
 }
 
 int launch_gp_sample(const GpArgs& a, hipStream_t s) {
@@ -514,7 +664,12 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
     }
     if (kend < S) {
       hipLaunchKernelGGL(gp_trsm_wide_kernel, dim3((S - kend + 63) / 64, B), dim3(256), tw_lds, s, a, kout);
-      syrk(kend, S, kend, S, kout, OBW);
+      if (a.planes) {      // the trailing update from the pre-split planes gp_trsm_wide_kernel just wrote (every full 256-wide outer block)
+        const int tn = (S - kend + 127) / 128;
+        hipLaunchKernelGGL(gp_syrk_planes_kernel, dim3(tn, tn, B), dim3(256), SYP_LDS, s, a, kend, S);
+      } else {
+        syrk(kend, S, kend, S, kout, OBW);
+      }
     }
   }
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;

@@ -196,6 +196,7 @@ GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, 
 
 extern "C" {
 
+static bool g_gp_planes = true;      // PFN_TUNE_GP_PLANES (see pfn_gp_prior_sample)
 // Defaults handed to NEW descriptors by pfn_default_schedule() (test / profiling hook); the entry points read pfn_model_desc::schedule only.
 static int g_default_schedule = 0;
 // The reference returns output[single_eval_pos:] (transformer.py:91): the TOP encoder layer's train rows feed nothing -- no later layer reads
@@ -237,6 +238,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_GEMM_PERSIST: set_gemm_nt_persist(value); return PFN_OK;
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
     case PFN_TUNE_GEMM_LN_ROWS: set_gemm_ln_rows64(value); return PFN_OK;
+    case PFN_TUNE_GP_PLANES: g_gp_planes = value != 0; return PFN_OK;
     case PFN_TUNE_FUSE_LN_WIDE: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_LN_WIDE) : (g_default_schedule & ~PFN_SCHED_FUSE_LN_WIDE); return PFN_OK;
     case PFN_TUNE_TOP_LAYER_TEST_ROWS: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_TOP_LAYER_ALL_ROWS) : (g_default_schedule | PFN_SCHED_TOP_LAYER_ALL_ROWS); return PFN_OK;
     default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);
@@ -751,6 +753,12 @@ int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
   return PFN_OK;
 }
 
+// PFN_TUNE_GP_PLANES (test / profiling knob): 1 (default) = the rank-256 trailing update of the blocked Cholesky multiplies the pre-split bf16 planes the wide
+// triangular solve leaves behind K (gp_syrk_planes_kernel); 0 = it re-reads and re-splits the f32 panel per tile (gp_syrk_kernel, rounds 2-3).  Same arithmetic.
+int64_t pfn_gp_workspace_bytes(int B, int S) {
+  if (B < 1 || S < 1) return -1;
+  return gp_workspace_bytes(B, S);
+}
 int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws, const float* lengthscale, const float* outputscale,
                         const float* noise, int B, int S, int nf, int kernel, int gen_x, int gen_z, uint64_t seed, uint64_t offset,
                         int32_t* info, void* stream) {
@@ -760,6 +768,8 @@ int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws, const float* 
   a.x = x; a.z = z; a.y = y; a.K = K_ws; a.lengthscale = lengthscale; a.outputscale = outputscale; a.noise = noise;
   a.B = B; a.S = S; a.nf = nf; a.kernel = kernel; a.seed = seed; a.offset = offset; a.gen_x = gen_x; a.gen_z = gen_z; a.info = info;
   a.w = nullptr;
+  a.planes = nullptr; a.plane_rows = 0;
+  if (g_gp_planes) gp_attach_planes(a);
   PFN_TRY(launch_gp_sample(a, (hipStream_t)stream));
   return PFN_OK;
 }
@@ -774,6 +784,8 @@ int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_w
   a.x = const_cast<float*>(x); a.z = nullptr; a.y = resid_ws; a.K = K_ws; a.lengthscale = lengthscale; a.outputscale = outputscale;
   a.noise = noise; a.B = B; a.S = S; a.nf = nf; a.kernel = kernel; a.seed = 0; a.offset = 0; a.gen_x = 0; a.gen_z = 0; a.info = info;
   a.w = w_ws;
+  a.planes = nullptr; a.plane_rows = 0;
+  if (g_gp_planes) gp_attach_planes(a);
   PFN_TRY(launch_gp_posterior(a, y, nll, mean, var, (hipStream_t)stream));
   return PFN_OK;
 }

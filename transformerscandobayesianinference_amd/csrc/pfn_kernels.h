@@ -291,7 +291,13 @@ struct GpArgs {
   // running residual (y_data on entry), w the solution, and every panel subtracts L[rows, panel] w[panel] from the
   // residual below it where the sampler adds L[rows, panel] z[panel] to the draw
   float* w;                  // [B,S]; null = sampler mode
+  // scratch behind K (gp_workspace_bytes): the three bf16 planes of the current outer block's solved panel, written by gp_trsm_wide_kernel and read by
+  // gp_syrk_planes_kernel -- [B][3 planes][16 k-chunks][plane_rows][16] bf16.  null = the trailing update splits the f32 panel itself (gp_syrk_kernel)
+  void* planes;
+  long plane_rows;           // rows allocated per slab (>= S - 256, a multiple of 128)
 };
+int64_t gp_workspace_bytes(int B, int S);      // K [B,S,S] f32 + the plane scratch
+void gp_attach_planes(GpArgs& a);               // points a.planes behind a.K (a workspace of gp_workspace_bytes)
 int launch_gp_sample(const GpArgs& a, hipStream_t s);
 // Sequential exact-GP predictions from ONE factorisation: for every t, the posterior at x_t given points 0..t-1.
 //   mean[b,t], var[b,t] (with observation noise), nll[b,t] = -log N(y_t; mean, var);  resid_ws / w_ws: [B,S] scratch

@@ -87,7 +87,7 @@ def gp_sample(batch_size, seq_len, num_features, device, lengthscale, outputscal
     x = torch.empty(B, Tp, F, dtype=torch.float32, device=dev) if gen_x else x.to(dev).float().contiguous()
     z = torch.empty(B, Tp, dtype=torch.float32, device=dev) if gen_z else z.to(dev).float().contiguous()
     y = torch.empty(B, Tp, dtype=torch.float32, device=dev)
-    K = torch.empty(B, Tp, Tp, dtype=torch.float32, device=dev)
+    K = torch.empty(lib.pfn_gp_workspace_bytes(B, Tp), dtype=torch.uint8, device=dev)      # the [B, Tp, Tp] f32 matrix + the trailing update's plane scratch
     info = torch.zeros(B, dtype=torch.int32, device=dev)
     if seed is None:
         seed = torch.initial_seed()
@@ -110,7 +110,7 @@ def gp_sample(batch_size, seq_len, num_features, device, lengthscale, outputscal
             y2 = torch.empty(n, Tp, dtype=torch.float32, device=dev)
             info_sub = torch.zeros(n, dtype=torch.int32, device=dev)
             run(x[idx].contiguous(), z[idx].contiguous(), ls[idx].contiguous(), osc[idx].contiguous(), noise_vec[idx].contiguous(), y2, info_sub,
-                False, False, torch.empty(n, Tp, Tp, dtype=torch.float32, device=dev))
+                False, False, torch.empty(lib.pfn_gp_workspace_bytes(n, Tp), dtype=torch.uint8, device=dev))
             y[idx] = y2
             info2 = torch.zeros_like(info)
             info2[idx] = info_sub
@@ -173,7 +173,7 @@ def gp_posterior(x, y, lengthscale, outputscale, noise, kernel=KERNEL_RBF, check
         xp = torch.cat([xp, torch.rand(B, Tp - T, F, device=dev)], 1)
         yp = torch.cat([yp, torch.zeros(B, Tp - T, device=dev)], 1)
     xp, yp = xp.contiguous(), yp.contiguous()
-    K = torch.empty(B, Tp, Tp, dtype=torch.float32, device=dev)
+    K = torch.empty(lib.pfn_gp_workspace_bytes(B, Tp), dtype=torch.uint8, device=dev)
     resid, w = torch.empty_like(yp), torch.empty_like(yp)
 
     def run(noise_vec):
@@ -234,4 +234,4 @@ DataLoader.prefetch = True        # draws run ahead of the training steps on a s
 DataLoader.prefetch_group = 10    # ... ten steps' worth of datasets per sampler call (MI355X, bptt 2000: 64 us per dataset at 4 x 32, 54 us at 10 x 32;
                                   # 16 MB of factorisation workspace per dataset: 5 GB of the 288)
 DataLoader.prefetch_memory_share = 0.125    # ... but never more than an eighth of the free device memory per group (two groups are alive at a time)
-DataLoader.prefetch_bytes_per_dataset = staticmethod(lambda kw: 4 * ((kw.get('seq_len', 0) + 3) // 4 * 4) ** 2)   # K_ws[Tp, Tp] f32
+DataLoader.prefetch_bytes_per_dataset = staticmethod(lambda kw: int(1.2 * 4 * ((kw.get('seq_len', 0) + 3) // 4 * 4) ** 2))   # K_ws[Tp, Tp] f32 + the plane scratch (pfn_gp_workspace_bytes)
