@@ -284,6 +284,81 @@ PFN_DEV void syrk_commit_split(LdsPtr tile, int r, int c, u32x4 raw) {
   *reinterpret_cast<lds_bf16x4*>(tile + 2 * SYRK_PLANE + off) = lo;
 }
 
+
+// C -= acc for one 128 x 128 tile of the trailing update (lower triangle, rows < r1, columns < cend): read-modify-write in 16-byte pieces, lane = row,
+// accumulator group g = 4 consecutive columns.  EVERY load is issued before the first store: the compiler never moves a load above a store (they may alias),
+// so the natural "load, subtract, store" loop is a chain of sixteen dependent HBM round trips per wave -- ~2 us each, i.e. most of a tile's time (rocprofv3,
+// round 4: 18 us per tile and CU against 5 us of MFMA work).  Tiles strictly below the diagonal and inside the matrix (three quarters of them) take a
+// BRANCH-FREE path: sixteen loads, one wait, sixteen stores back to back -- with a branch around every piece hipcc's wait-count pass puts vmcnt(0) at the head
+// of every block, and since gfx9 counts stores in the same counter each store then waits for the previous one's acknowledgement.
+PFN_DEV void syrk_rmw(float* Kb, int S, const f32x16 (&acc)[2][2], int i0, int j0, int r1, int cend, int wm, int wn, int lane) {
+  const int h = lane >> 5;
+  const bool interior = __builtin_amdgcn_readfirstlane((j0 + 127 < i0 && i0 + 127 < r1 && j0 + 127 < cend) ? 1 : 0) != 0;
+  if (interior) {
+    f32x4 c[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          c[i][j][gq] = *reinterpret_cast<const f32x4*>(Kb + (long)(i0 + wm * 64 + i * 32 + (lane & 31)) * S + j0 + wn * 64 + j * 32 + 8 * gq + 4 * h);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          f32x4 v = c[i][j][gq];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] -= acc[i][j][4 * gq + e];
+          // (non-temporal loads / stores here were measured and are SLOWER: the rank-256 update of the first outer block 1958 vs 1632 us per 320 datasets)
+          *reinterpret_cast<f32x4*>(Kb + (long)(i0 + wm * 64 + i * 32 + (lane & 31)) * S + j0 + wn * 64 + j * 32 + 8 * gq + 4 * h) = v;
+        }
+    return;
+  }
+  // diagonal tiles and the last tile row / column: pieces cut by the diagonal or the matrix edge go element by element
+  f32x4 cold[2][2][4];
+  unsigned whole = 0;                  // bit (i * 8 + j * 4 + gq): the piece lies inside the lower triangle and the matrix as a whole 16-byte vector
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gi = i0 + wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int gj = j0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
+        if (gi < r1 && gj + 3 <= gi && gj + 3 < cend) {
+          cold[i][j][gq] = *reinterpret_cast<const f32x4*>(Kb + (long)gi * S + gj);
+          whole |= 1u << (i * 8 + j * 4 + gq);
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gi = i0 + wm * 64 + i * 32 + (lane & 31);
+    if (gi >= r1) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int gj = j0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
+        if (gj > gi || gj >= cend) continue;
+        float* cp = Kb + (long)gi * S + gj;
+        if (whole & (1u << (i * 8 + j * 4 + gq))) {
+          f32x4 v = cold[i][j][gq];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] -= acc[i][j][4 * gq + e];
+          *reinterpret_cast<f32x4*>(cp) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gj + e <= gi && gj + e < cend) cp[e] -= acc[i][j][4 * gq + e];
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r1, int c0, int c1, int kp0, int K) {
   constexpr int RB = SYRK_KC * 4;  // 128-byte chunk rows in global memory (f32)
   constexpr int RBT = SYRK_KC * 2; // 64-byte rows of a bf16 plane in LDS
@@ -354,31 +429,7 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r
         }
     }
   }
-  // read-modify-write of C in 16-byte pieces: lane = row, accumulator group g = 4 consecutive columns
-  const int h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int gi = i0 + wm * 64 + i * 32 + (lane & 31);
-    if (gi >= r1) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int gj = j0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
-        if (gj > gi || gj >= c1) continue;
-        float* cp = Kb + (long)gi * S + gj;
-        if (gj + 3 <= gi && gj + 3 < c1) {
-          f32x4 c = *reinterpret_cast<const f32x4*>(cp);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c[e] -= acc[i][j][4 * gq + e];
-          *reinterpret_cast<f32x4*>(cp) = c;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gj + e <= gi && gj + e < c1) cp[e] -= acc[i][j][4 * gq + e];
-        }
-      }
-  }
+  syrk_rmw(Kb, S, acc, i0, j0, r1, c1, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,31 +519,7 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_planes_kernel(GpArgs a, int r0
         acc[i][j] = mma32(fb[j][0], fa[i][0], c);
       }
   }
-  // read-modify-write of C in 16-byte pieces: lane = row, accumulator group g = 4 consecutive columns
-  const int h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int gi = i0 + wm * 64 + i * 32 + (lane & 31);
-    if (gi >= r1) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int gj = j0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
-        if (gj > gi || gj >= r1) continue;
-        float* cp = Kb + (long)gi * S + gj;
-        if (gj + 3 <= gi && gj + 3 < r1) {
-          f32x4 c = *reinterpret_cast<const f32x4*>(cp);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c[e] -= acc[i][j][4 * gq + e];
-          *reinterpret_cast<f32x4*>(cp) = c;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gj + e <= gi && gj + e < r1) cp[e] -= acc[i][j][4 * gq + e];
-        }
-      }
-  }
+  syrk_rmw(Kb, S, acc, i0, j0, r1, r1, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -517,19 +544,22 @@ __global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
   const int rows_valid = min(64, S - row0);
   float* Kb = a.K + (long)b * S * S;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31;
+  // row block jb of L_d reaches LDS through registers; the request for block jb + 1 is issued as soon as block jb has been committed, so its round trip
+  // (L2 / HBM, one workgroup per CU: nothing else hides it) runs under block jb's MFMA phases instead of in front of block jb + 1's -- and block 0 travels
+  // together with the workgroup's own rows
+  TileStage<float, 64, OBW * 4, 256> sl;
   {
     TileStage<float, 64, OBW * 4, 256> sv;
     sv.issue(Kb + (long)row0 * S + kout, S, rows_valid, OBW);
+    sl.issue(Kb + (long)kout * S + kout, S, NB, NB);
+    const float zv = (a.w ? a.w : a.z)[(long)b * S + kout + threadIdx.x];
     sv.template commit_p<TW_STRIDE>(V);
-    zs[threadIdx.x] = (a.w ? a.w : a.z)[(long)b * S + kout + threadIdx.x];
+    zs[threadIdx.x] = zv;
   }
   for (int jb = 0; jb < 4; ++jb) {
     __syncthreads();   // V current (initial load / previous block's solution), Lr free
-    {
-      TileStage<float, 64, OBW * 4, 256> sl;
-      sl.issue(Kb + (long)(kout + jb * NB) * S + kout, S, NB, (jb + 1) * NB);
-      sl.template commit_p<TW_STRIDE>(Lr);
-    }
+    sl.template commit_p<TW_STRIDE>(Lr);
+    if (jb + 1 < 4) sl.issue(Kb + (long)(kout + (jb + 1) * NB) * S + kout, S, NB, (jb + 2) * NB);
     __syncthreads();
     if (jb > 0) {
       const int rt = wave >> 1, ct = wave & 1;
