@@ -15,7 +15,7 @@ The JSON line also carries
                  SURVEY.md 8(d)) / its average launch duration INSIDE the running step -- HIP event pairs around the launches on their
                  launch stream (pfn_profile_*), two micro-batch streams + the sampler sharing the chip -- vs the dense bf16 MFMA peak;
                  `isolated_*` = the same launch timed on an idle chip; `kernels` carries both for every kernel class of the step;
-  other_configs: short runs (5 steps) of BASELINE configs[3] and configs[4] in the same process: datasets/s, ms per step, whole-step
+  other_configs: short runs (10 steps) of BASELINE configs[3] and configs[4] in the same process: datasets/s, ms per step, whole-step
                  roofline fraction, parity of inference outputs and of the timed path;
   batch_sweep  : configs[1] at per-GPU batch 4 x aggregate_k_gradients 25 (the notebook's recipe), 8, 16, 32;
   step_roofline: the same accounting for the whole step (train(S,sep) = 3 * fwd(S,sep) per dataset);
@@ -949,9 +949,9 @@ def main():
         result['other_configs'] = {}
         for cfg in (4, 5):
             t0 = time.time()
-            rc = run_config(cfg, device, 0, 1, args.precision, steps=5, warmup=2)
+            rc = run_config(cfg, device, 0, 1, args.precision, steps=10, warmup=3)
             tc = throughput_fields(rc, 1)
-            entry = dict(workload=CONFIGS[cfg]['workload'], value=tc['value'], unit='datasets/s', ms_per_step=tc['ms_per_step'], steps=5, warmup=2,
+            entry = dict(workload=CONFIGS[cfg]['workload'], value=tc['value'], unit='datasets/s', ms_per_step=tc['ms_per_step'], steps=10, warmup=3,
                          per_gpu_batch=rc['batch'], micro_batch_streams=rc['streams'], mean_sep=sum(rc['seps']) / len(rc['seps']),
                          step_roofline=dict(frac=tc['frac'], reference_graph_frac=tc['reference_graph_frac']))
             if not args.no_parity:
@@ -969,7 +969,7 @@ def main():
         result['batch_sweep'] = []
         # (schedule: `alternating` = the batches of one optimizer step whole, round-robin on that many streams -- what train() picks for small batches;
         # `column groups` = every batch split over the two micro-batch streams, what the large batches use)
-        for b, k, st, alt_streams in ((4, 25, 2, 8), (4, 25, 2, 0), (8, 1, 10, 0), (16, 1, 10, 0), (32, 1, 10, 0)):
+        for b, k, st, alt_streams in ((4, 25, 3, 8), (4, 25, 3, 0), (8, 1, 10, 0), (16, 1, 10, 0), (32, 1, 10, 0)):
             t0 = time.time()
             rb = run_config(2, device, 0, 1, args.precision, batch=b, aggregate_k=k, steps=st, warmup=2, aggregate_streams=alt_streams)
             tb = throughput_fields(rb, 1)
