@@ -1319,9 +1319,11 @@ def test_trained_head_dim_256_inference_parity():
                 nll = model.criterion(lg.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean().item()
                 mean = model.criterion.mean(lg)
             tight = not train_mode
-            within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3 if tight else 6e-2)
-            within(f'{mode}: means rel l2 (own norm)', relerr(mean, mean_o), 1e-3 if tight else 0.12)
-            within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 0.12)
+            # (measured, profiles/r04_parity_measured.json: inference 7e-7 / 8e-7 / 9e-7; the bf16 training forward on these weights -- 2500 optimizer steps, the
+            # loss 2.7 nats below its start -- 7.5e-4 / 9.3e-4 / 1.4e-3: bounds = 2 x measured)
+            within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3 if tight else 2e-3)
+            within(f'{mode}: means rel l2 (own norm)', relerr(mean, mean_o), 1e-3 if tight else 2e-3)
+            within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 3e-3)
 
 
 @pytest.mark.parametrize('precision,aggregate_streams', [('f32', 0), ('bf16', 0), ('f32', 2)])
@@ -1341,11 +1343,12 @@ def test_training_loop_vs_reference_train_golden(precision, aggregate_streams):
     cfg = rec['config']
     assert lrs == pytest.approx(rec['batch_lr'], rel=1e-12, abs=0) and lrs[0] == 0.0
     tight = precision == 'f32'
-    within(f'{precision} batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses, rec['batch_losses'])), 1e-4 if tight else 1e-2)
+    # (measured: f32 5.4e-7 / 2.4e-7 / 2.6e-4, bf16 7.5e-4 / 1.3e-4 / 4.2e-2 -- profiles/r04_parity_measured.json)
+    within(f'{precision} batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses, rec['batch_losses'])), 1e-4 if tight else 2e-3)
     epoch = [sum(losses[e * cfg['steps_per_epoch']:(e + 1) * cfg['steps_per_epoch']]) / cfg['steps_per_epoch'] for e in range(cfg['epochs'])]
     within(f'{precision} epoch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(epoch, rec['epoch_losses'])), 1e-4 if tight else 2e-3)
     assert abs(total - rec['returned_total_loss']) < (1e-4 if tight else 2e-3) * abs(rec['returned_total_loss'])
-    within(f'{precision} parameter update over the run, rel l2', replay.update_error(final, rec), 1e-3 if tight else 0.2)
+    within(f'{precision} parameter update over the run, rel l2', replay.update_error(final, rec), 1e-3 if tight else 0.1)
 
 
 def _two_gpus():
