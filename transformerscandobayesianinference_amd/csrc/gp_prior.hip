@@ -291,9 +291,9 @@ PFN_DEV void syrk_commit_split(LdsPtr tile, int r, int c, u32x4 raw) {
 // round 4: 18 us per tile and CU against 5 us of MFMA work).  Tiles strictly below the diagonal and inside the matrix (three quarters of them) take a
 // BRANCH-FREE path: sixteen loads, one wait, sixteen stores back to back -- with a branch around every piece hipcc's wait-count pass puts vmcnt(0) at the head
 // of every block, and since gfx9 counts stores in the same counter each store then waits for the previous one's acknowledgement.
-PFN_DEV void syrk_rmw(float* Kb, int S, const f32x16 (&acc)[2][2], int i0, int j0, int r1, int cend, int wm, int wn, int lane) {
+// (row0, col0) = first row / column of the wave's 64 x 64 sub-tile; `interior` (wave-uniform) = the whole workgroup tile lies strictly below the diagonal and inside the matrix
+PFN_DEV void syrk_rmw(float* Kb, int S, const f32x16 (&acc)[2][2], int row0, int col0, bool interior, int r1, int cend, int lane) {
   const int h = lane >> 5;
-  const bool interior = __builtin_amdgcn_readfirstlane((j0 + 127 < i0 && i0 + 127 < r1 && j0 + 127 < cend) ? 1 : 0) != 0;
   if (interior) {
     f32x4 c[2][2][4];
 #pragma unroll
@@ -302,7 +302,7 @@ PFN_DEV void syrk_rmw(float* Kb, int S, const f32x16 (&acc)[2][2], int i0, int j
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
-          c[i][j][gq] = *reinterpret_cast<const f32x4*>(Kb + (long)(i0 + wm * 64 + i * 32 + (lane & 31)) * S + j0 + wn * 64 + j * 32 + 8 * gq + 4 * h);
+          c[i][j][gq] = *reinterpret_cast<const f32x4*>(Kb + (long)(row0 + i * 32 + (lane & 31)) * S + col0 + j * 32 + 8 * gq + 4 * h);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -313,7 +313,7 @@ PFN_DEV void syrk_rmw(float* Kb, int S, const f32x16 (&acc)[2][2], int i0, int j
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] -= acc[i][j][4 * gq + e];
           // (non-temporal loads / stores here were measured and are SLOWER: the rank-256 update of the first outer block 1958 vs 1632 us per 320 datasets)
-          *reinterpret_cast<f32x4*>(Kb + (long)(i0 + wm * 64 + i * 32 + (lane & 31)) * S + j0 + wn * 64 + j * 32 + 8 * gq + 4 * h) = v;
+          *reinterpret_cast<f32x4*>(Kb + (long)(row0 + i * 32 + (lane & 31)) * S + col0 + j * 32 + 8 * gq + 4 * h) = v;
         }
     return;
   }
@@ -322,12 +322,12 @@ PFN_DEV void syrk_rmw(float* Kb, int S, const f32x16 (&acc)[2][2], int i0, int j
   unsigned whole = 0;                  // bit (i * 8 + j * 4 + gq): the piece lies inside the lower triangle and the matrix as a whole 16-byte vector
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int gi = i0 + wm * 64 + i * 32 + (lane & 31);
+    const int gi = row0 + i * 32 + (lane & 31);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int gj = j0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
+        const int gj = col0 + j * 32 + 8 * gq + 4 * h;
         if (gi < r1 && gj + 3 <= gi && gj + 3 < cend) {
           cold[i][j][gq] = *reinterpret_cast<const f32x4*>(Kb + (long)gi * S + gj);
           whole |= 1u << (i * 8 + j * 4 + gq);
@@ -336,13 +336,13 @@ PFN_DEV void syrk_rmw(float* Kb, int S, const f32x16 (&acc)[2][2], int i0, int j
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int gi = i0 + wm * 64 + i * 32 + (lane & 31);
+    const int gi = row0 + i * 32 + (lane & 31);
     if (gi >= r1) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int gj = j0 + wn * 64 + j * 32 + 8 * gq + 4 * h;
+        const int gj = col0 + j * 32 + 8 * gq + 4 * h;
         if (gj > gi || gj >= cend) continue;
         float* cp = Kb + (long)gi * S + gj;
         if (whole & (1u << (i * 8 + j * 4 + gq))) {
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r
         }
     }
   }
-  syrk_rmw(Kb, S, acc, i0, j0, r1, c1, wm, wn, lane);
+  syrk_rmw(Kb, S, acc, i0 + wm * 64, j0 + wn * 64, __builtin_amdgcn_readfirstlane((j0 + 127 < i0 && i0 + 127 < r1 && j0 + 127 < c1) ? 1 : 0) != 0, r1, c1, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -519,8 +519,12 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_planes_kernel(GpArgs a, int r0
         acc[i][j] = mma32(fb[j][0], fa[i][0], c);
       }
   }
-  syrk_rmw(Kb, S, acc, i0, j0, r1, r1, wm, wn, lane);
+  syrk_rmw(Kb, S, acc, i0 + wm * 64, j0 + wn * 64, __builtin_amdgcn_readfirstlane((j0 + 127 < i0 && i0 + 127 < r1) ? 1 : 0) != 0, r1, r1, lane);
 }
+
+// (A 256 x 256-tile form of this kernel -- 8 waves, three 48-KiB stages in a ring, one workgroup per CU -- was built and measured in round 4: the update of the first
+// outer block 2013 us per 320 datasets against 1632 here.  The C read-modify-write of a tile costs the HBM as long as its products cost the matrix pipe (512 KiB against
+// 20 us per 256 x 256 tile), and with one workgroup per CU the two no longer overlap; three co-resident 128 x 128 workgroups do overlap them.  profiles/r04_gp_sampler_experiments.txt)
 
 // ---------------------------------------------------------------------------------------------
 // wide trsm: all rows below a finished 256-wide outer block.  X = A[rows, kout:kout+256] . L_d^-T with L_d the
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
 }
 
 // K_ws of the C ABI: K [B, S, S] f32, then (256-byte aligned) the plane scratch of gp_syrk_planes_kernel
-static long gp_plane_rows(int S) { return S > OBW ? ((long)(S - OBW + 127) / 128) * 128 : 0; }
+static long gp_plane_rows(int S) { return S > OBW ? ((long)(S - OBW + 127) / 128) * 128 : 0; }      // whole 128-row tiles of the trailing update
 static int64_t gp_k_bytes(int B, int S) { return ((int64_t)B * S * S * 4 + 255) / 256 * 256; }
 int64_t gp_workspace_bytes(int B, int S) { return gp_k_bytes(B, S) + (int64_t)B * 3 * PL_NKC * gp_plane_rows(S) * PL_ROWB; }
 void gp_attach_planes(GpArgs& a) {      // a.K = the caller's K_ws of gp_workspace_bytes(B, S) bytes
