@@ -159,6 +159,28 @@ def test_top_layer_row_rule_and_flop_accounting():
     assert bench.fwd_flops(S, sep, nf, E, F, 0, O, True) == bench.fwd_flops(S, sep, nf, E, F, 0, O)
 
 
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under the package imports, opens or executes anything under oracle/ or /root/reference, and bench.py
+    reaches the oracle only inside parity_check / cpu_baseline / parity_inputs / oracle_loss_and_means (after the timed window)."""
+    import ast
+    pkg = os.path.join(ROOT, 'transformerscandobayesianinference_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.sh')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert '/root/reference' not in text, f
+                if f.endswith('.py'):
+                    for node in ast.walk(ast.parse(text)):
+                        names = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ''] if isinstance(node, ast.ImportFrom) else []
+                        assert not any(n == 'oracle' or n.startswith('oracle.') for n in names), (f, names)
+    tree = ast.parse(open(os.path.join(ROOT, 'bench.py')).read())
+    allowed = {'parity_check', 'cpu_baseline', 'parity_inputs', 'oracle_loss_and_means'}
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or '').split('.')[0] == 'oracle' for n in ast.walk(fn))
+        assert not uses or fn.name in allowed, fn.name
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and 'oracle' in ast.dump(n) for n in tree.body)      # no module-level import either
+
+
 def test_bench_profile_classes_match_the_header():
     """bench.py reads the library's in-step kernel timings by slot number (pfn_profile_read): its table must be the header's PFN_PROF_* enum, and every
     kernel class the step launches must have a slot (include/pfn_hip.h)."""
