@@ -565,7 +565,8 @@ def cpu_baseline(w, inputs, steps=3, warm=1):
     legs = [leg('torch-modules'), leg('port')]
     note = ' (BNN prior draw not included: the reference sampler is per-dataset Python, 57 datasets/s in BASELINE.md)' if w['prior'] == 'mlp' else ''
     best = max(legs, key=lambda l: l['value'])     # the faster leg is the honest baseline (torch-modules on every box seen so far)
-    return dict(value=best['value'], unit='datasets/s', cores=threads, kind=best['kind'],
+    return dict(value=best['value'], unit='datasets/s', cores=threads, kind='port', port=best['kind'],
+                sample_short=f'{steps} full training steps (draw+fwd+loss+bwd+clip+Adam), batch {B}, bptt {S}, sep {sep}, torch f32, leg {best["kind"]}',
                 sample=f'{steps} full training step(s) (prior draw + fwd + loss + bwd + clip + Adam), batch {B}, bptt {S}, eval position {sep}, torch f32 on the '
                        f'host cores from the benchmarked weights; step 0 reads the parity inputs.  kind "torch-modules" = the nn.TransformerEncoder stack the '
                        f'reference instantiates (transformer.py:17-18) with its dense mask and all-row decoder; the explicit-math port (the parity checker) is '
@@ -811,6 +812,82 @@ def release(r):
     torch.cuda.empty_cache()
 
 
+DETAIL_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bench_detail.json')
+LINE_LIMIT = 6000     # the driver keeps an 8 KB tail of stdout: the line it parses must fit in it whole (round 4's 26 KB line lost its head)
+
+
+def _num(v, digits=6):
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return float(f'{v:.{digits}g}')
+    if isinstance(v, (list, tuple)):
+        return [_num(x, digits) for x in v]
+    if isinstance(v, dict):
+        return {k: _num(x, digits) for k, x in v.items()}
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_line(result):
+    """The ONE line the driver parses: the contract keys + one number per side measurement.  Everything else (kernel table, notes, legs of the
+    CPU baseline, parity details) lives in `bench_detail.json` next to this script, whose path the line names."""
+    line = _pick(result, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'))
+    cfg = result['config']
+    line['config'] = _pick(cfg, ('workload', 'baseline_config', 'per_gpu_batch', 'global_batch', 'aggregate_k_gradients', 'aggregate_streams', 'seq_len', 'parallelism',
+                                 'micro_batch_streams', 'eval_pos', 'mean_sep', 'final_loss', 'tuning'))
+    line['step_roofline'] = _pick(result['step_roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'reference_graph_frac'))
+    if 'roofline' in result:
+        line['roofline'] = _pick(result['roofline'], ('bound', 'kernel', 'rocprof_kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_is', 'avg_launch_us', 'isolated_frac',
+                                                      'isolated_avg_launch_us', 'algorithmic_flops_per_launch', 'executed_frac', 'launches_per_step', 'traffic', 'traffic_source'))
+        line['roofline']['frac_is'] = 'in-step' if str(line['roofline'].get('frac_is', '')).startswith('IN-STEP') else 'isolated'
+    if 'cpu_baseline' in result:
+        c = result['cpu_baseline']
+        line['cpu_baseline'] = dict(_pick(c, ('value', 'unit', 'cores', 'kind', 'port')), sample=c.get('sample_short', c.get('sample', ''))[:200])
+    if 'parity_inference' in result:
+        line['parity_inference'] = _pick(result['parity_inference'], ('precision', 'nll_rel', 'mean_rel_l2', 'logits_rel_l2', 'passed'))
+        line['parity_timed_path'] = _pick(result['parity_timed_path'], ('precision', 'nll_rel', 'mean_rel_l2', 'logits_rel_l2', 'nll_within_1e3', 'mean_within_1e3_of_own_norm'))
+    if 'val_bar_nll' in result:
+        v = result['val_bar_nll']
+        line['val_bar_nll'] = v if not isinstance(v, dict) else _pick(v, ('bar_nll', 'value', 'n', 'sep'))
+    for name, e in result.get('other_configs', {}).items():
+        line.setdefault('other_configs', {})[name] = dict(value=e['value'], ms_per_step=e['ms_per_step'], per_gpu_batch=e['per_gpu_batch'], frac=e['step_roofline']['frac'])
+    if 'batch_sweep' in result:
+        line['batch_sweep'] = [dict(b=e['per_gpu_batch'], k=e['aggregate_k_gradients'], schedule=e['schedule'], value=e['value']) for e in result['batch_sweep']]
+    for k in ('ranks_seen', 'per_rank_ms_per_step', 'allreduce_ms', 'allreduce_bytes', 'collective_backend', 'devices_visible', 'ranks_share_device'):
+        if k in result:
+            line[k] = result[k]
+    if 'allreduce_overlapped' in result:
+        line['allreduce_overlapped'] = _pick(result['allreduce_overlapped'], ('overlapped_bytes', 'exposed_bytes', 'in_timed_steps', 'fallback_steps'))
+    line['seconds_total'] = result['seconds_total']
+    line['detail'] = os.path.basename(DETAIL_FILE)
+    line = _num(line)
+    text = json.dumps(line, separators=(',', ':'))
+    for drop in ('batch_sweep', 'other_configs', 'val_bar_nll', 'allreduce_overlapped', 'per_rank_ms_per_step'):    # never reached at the sizes above; the limit is a hard one
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(',', ':'))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def emit(result):
+    """Full record -> bench_detail.json (and stderr when PFN_BENCH_VERBOSE=1); compact line -> the LAST line of stdout."""
+    try:
+        with open(DETAIL_FILE, 'w') as f:
+            json.dump(result, f, indent=1)
+    except OSError as e:
+        print(f'bench.py: could not write {DETAIL_FILE}: {e}', file=sys.stderr)
+    if os.environ.get('PFN_BENCH_VERBOSE') == '1':
+        print(json.dumps(result), file=sys.stderr)
+    sys.stdout.flush()
+    print(compact_line(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -906,6 +983,8 @@ def main():
             if hit:
                 traffic = hit[0].get('read_bytes', 0) + hit[0].get('write_bytes', 0)
                 traffic_src = f"profiles/{os.path.basename(PMC_TRAFFIC)} ({pmc.get('note', '')})"
+        else:
+            traffic_src = f"none: the committed PMC passes ({os.path.basename(PMC_TRAFFIC)}) are of config {pmc.get('config', 2)} / batch {pmc.get('batch')} / streams {pmc.get('streams', 1)}, not of this command"
         in_us = dom.get('in_step_us')
         iso_frac = dom['tflops'] * 1e12 / MFMA_BF16_PEAK
         in_frac = None if in_us is None else dom['flops'] / (in_us * 1e-6) / MFMA_BF16_PEAK
@@ -980,7 +1059,7 @@ def main():
             release(rb)
             del rb
     result['seconds_total'] = time.time() - t_start
-    print(json.dumps(result))
+    emit(result)
 
 
 if __name__ == '__main__':

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 6
+#define PFN_ABI_VERSION 7
 
 enum {
   PFN_OK = 0,
@@ -205,9 +205,11 @@ int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
  * z [B,S] f32 base normals: generated when gen_z != 0 (and written back), else input.
  * lengthscale [B,nf], outputscale [B], noise [B].  kernel: 0 = RBF, 1 / 2 / 3 = Matern nu = 2.5 / 1.5 / 0.5 (gpytorch MaternKernel's three closed forms).
  * K_ws: workspace of pfn_gp_workspace_bytes(B, S) bytes: the [B,S,S] f32 matrix, factored in place, followed by the scratch of the trailing update
- * (the three bf16 planes of the current outer block's solved panel: + 19 % at S = 2000).  info [B]: 0 or (index+1) of the first non-positive pivot. */
+ * (the three bf16 planes of the current outer block's solved panel: + 19 % at S = 2000).  K_ws_bytes (ABI 7): the size the caller allocated --
+ * below B*S*S*4 the call returns PFN_ERR_ARGUMENT; between that and pfn_gp_workspace_bytes(B, S) the trailing update runs without the plane scratch
+ * (same arithmetic, slower), so a caller sized for an older ABI cannot be written past.  info [B]: 0 or (index+1) of the first non-positive pivot. */
 int64_t pfn_gp_workspace_bytes(int B, int S);
-int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws,
+int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws, int64_t K_ws_bytes,
                         const float* lengthscale, const float* outputscale, const float* noise,
                         int B, int S, int nf, int kernel, int gen_x, int gen_z,
                         uint64_t seed, uint64_t offset, int32_t* info, void* stream);
@@ -217,9 +219,9 @@ int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws,
  * the full covariance gives all of them (gp_prior.hip): for every dataset b and position t, the posterior at x[b,t]
  * given (x[b,:t], y[b,:t]) under the GP with the given hyper-parameters:
  *   mean[b,t], var[b,t] (predictive, observation noise included), nll[b,t] = -log N(y[b,t]; mean, var).
- * Position 0 is the prior.  x [B,S,nf], y [B,S]; K_ws: pfn_gp_workspace_bytes(B, S) bytes; resid_ws / w_ws [B,S] scratch; nll / mean / var may be
+ * Position 0 is the prior.  x [B,S,nf], y [B,S]; K_ws / K_ws_bytes as in pfn_gp_prior_sample; resid_ws / w_ws [B,S] scratch; nll / mean / var may be
  * null.  S % 4 == 0.  info as in pfn_gp_prior_sample. */
-int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_ws, float* w_ws,
+int pfn_gp_posterior(const float* x, const float* y, float* K_ws, int64_t K_ws_bytes, float* resid_ws, float* w_ws,
                      const float* lengthscale, const float* outputscale, const float* noise,
                      int B, int S, int nf, int kernel, float* nll, float* mean, float* var,
                      int32_t* info, void* stream);

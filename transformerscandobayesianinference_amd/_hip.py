@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpfn_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 PREC_BF16 = 0
 PREC_F32 = 1
@@ -68,8 +68,8 @@ SIGNATURES = {
     'pfn_bar_mean': (_I, [_P, _L, _P, _L, _I, _I, _P, _P]),
     'pfn_clip_adam_step': (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _I, _P, _P]),
     'pfn_gp_workspace_bytes': (_L, [_I, _I]),
-    'pfn_gp_prior_sample': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P, _P]),
-    'pfn_gp_posterior': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'pfn_gp_prior_sample': (_I, [_P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P, _P]),
+    'pfn_gp_posterior': (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'pfn_mlp_prior_forward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P]),
     'pfn_op_gemm_nt': (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _P]),
     'pfn_op_gemm_tn': (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),

@@ -759,7 +759,13 @@ int64_t pfn_gp_workspace_bytes(int B, int S) {
   if (B < 1 || S < 1) return -1;
   return gp_workspace_bytes(B, S);
 }
-int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws, const float* lengthscale, const float* outputscale,
+static int gp_check_workspace(GpArgs& a, int64_t K_ws_bytes) {      // ABI 7: the planes only when the caller's allocation holds them
+  a.planes = nullptr; a.plane_rows = 0;
+  if (K_ws_bytes < (int64_t)a.B * a.S * a.S * 4) return fail(PFN_ERR_ARGUMENT, "K_ws_bytes %lld < B*S*S*4 = %lld", (long long)K_ws_bytes, (long long)a.B * a.S * a.S * 4);
+  if (g_gp_planes && K_ws_bytes >= gp_workspace_bytes(a.B, a.S)) gp_attach_planes(a);
+  return PFN_OK;
+}
+int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws, int64_t K_ws_bytes, const float* lengthscale, const float* outputscale,
                         const float* noise, int B, int S, int nf, int kernel, int gen_x, int gen_z, uint64_t seed, uint64_t offset,
                         int32_t* info, void* stream) {
   if (!x || !z || !y || !K_ws || !lengthscale || !outputscale || !noise || !info || B < 1 || S < 1 || nf < 1) return fail(PFN_ERR_ARGUMENT, "bad gp_prior_sample arguments");
@@ -768,13 +774,12 @@ int pfn_gp_prior_sample(float* x, float* z, float* y, float* K_ws, const float* 
   a.x = x; a.z = z; a.y = y; a.K = K_ws; a.lengthscale = lengthscale; a.outputscale = outputscale; a.noise = noise;
   a.B = B; a.S = S; a.nf = nf; a.kernel = kernel; a.seed = seed; a.offset = offset; a.gen_x = gen_x; a.gen_z = gen_z; a.info = info;
   a.w = nullptr;
-  a.planes = nullptr; a.plane_rows = 0;
-  if (g_gp_planes) gp_attach_planes(a);
+  if (int rc = gp_check_workspace(a, K_ws_bytes)) return rc;
   PFN_TRY(launch_gp_sample(a, (hipStream_t)stream));
   return PFN_OK;
 }
 
-int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_ws, float* w_ws, const float* lengthscale,
+int pfn_gp_posterior(const float* x, const float* y, float* K_ws, int64_t K_ws_bytes, float* resid_ws, float* w_ws, const float* lengthscale,
                      const float* outputscale, const float* noise, int B, int S, int nf, int kernel, float* nll, float* mean,
                      float* var, int32_t* info, void* stream) {
   if (!x || !y || !K_ws || !resid_ws || !w_ws || !lengthscale || !outputscale || !noise || !info || B < 1 || S < 1 || nf < 1)
@@ -784,8 +789,7 @@ int pfn_gp_posterior(const float* x, const float* y, float* K_ws, float* resid_w
   a.x = const_cast<float*>(x); a.z = nullptr; a.y = resid_ws; a.K = K_ws; a.lengthscale = lengthscale; a.outputscale = outputscale;
   a.noise = noise; a.B = B; a.S = S; a.nf = nf; a.kernel = kernel; a.seed = 0; a.offset = 0; a.gen_x = 0; a.gen_z = 0; a.info = info;
   a.w = w_ws;
-  a.planes = nullptr; a.plane_rows = 0;
-  if (g_gp_planes) gp_attach_planes(a);
+  if (int rc = gp_check_workspace(a, K_ws_bytes)) return rc;
   PFN_TRY(launch_gp_posterior(a, y, nll, mean, var, (hipStream_t)stream));
   return PFN_OK;
 }

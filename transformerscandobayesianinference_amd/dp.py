@@ -136,14 +136,16 @@ class OverlappedGradientReducer:
     def finish(self):
         """All-reduce (sum) the whole buffer; returns after the collectives are ordered before further work of the current stream."""
         was_armed, self._armed = self._armed, False
-        if self._callback_error is not None:
-            err, self._callback_error = self._callback_error, None
-            raise RuntimeError('the first-group host callback of pfn_stack_backward_split failed') from err
+        # an exception raised inside the ctypes host callback is re-raised AFTER the collectives (ADVICE r4): a rank that raised before its all_reduce
+        # would leave the other ranks waiting in theirs -- the job would hang instead of failing; with the error the step simply does not overlap
+        err, self._callback_error = self._callback_error, None
         if not is_distributed():
             self.events = []
+            if err is not None:
+                raise RuntimeError('the first-group host callback of pfn_stack_backward_split failed') from err
             return self.grad
         works = []
-        overlapped = self.split is not None and self.comm is not None and len(self.events) == self.expected and self.expected > 0
+        overlapped = err is None and self.split is not None and self.comm is not None and len(self.events) == self.expected and self.expected > 0
         if was_armed and self.split is not None and self.comm is not None and not overlapped:
             # same collectives, nothing hidden: say so instead of degrading silently (bench.py reports the count; every rank takes the same branch
             # because `expected` and the number of backward passes are rank-uniform)
@@ -169,6 +171,8 @@ class OverlappedGradientReducer:
             self.grad.record_stream(self.comm)
         self.events = []
         self.overlapped_last_step = overlapped
+        if err is not None:
+            raise RuntimeError('the first-group host callback of pfn_stack_backward_split failed') from err
         return self.grad
 
     def detach(self):

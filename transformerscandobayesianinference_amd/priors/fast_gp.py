@@ -95,7 +95,7 @@ def gp_sample(batch_size, seq_len, num_features, device, lengthscale, outputscal
     offset = _call_counter[0]
 
     def run(xs, zs, lss, oscs, noise_vec, y_out, info_out, gx, gz, K_ws):
-        _hip.check(lib.pfn_gp_prior_sample(xs.data_ptr(), zs.data_ptr(), y_out.data_ptr(), K_ws.data_ptr(), lss.data_ptr(), oscs.data_ptr(),
+        _hip.check(lib.pfn_gp_prior_sample(xs.data_ptr(), zs.data_ptr(), y_out.data_ptr(), K_ws.data_ptr(), K_ws.numel() * K_ws.element_size(), lss.data_ptr(), oscs.data_ptr(),
                                            noise_vec.data_ptr(), xs.shape[0], Tp, F, kernel, int(gx), int(gz), seed & (2 ** 64 - 1),
                                            offset, info_out.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_prior_sample')
 
@@ -179,7 +179,7 @@ def gp_posterior(x, y, lengthscale, outputscale, noise, kernel=KERNEL_RBF, check
     def run(noise_vec):
         mean, var, nll = torch.empty_like(yp), torch.empty_like(yp), torch.empty_like(yp)
         info = torch.zeros(B, dtype=torch.int32, device=dev)
-        _hip.check(lib.pfn_gp_posterior(xp.data_ptr(), yp.data_ptr(), K.data_ptr(), resid.data_ptr(), w.data_ptr(), ls.data_ptr(),
+        _hip.check(lib.pfn_gp_posterior(xp.data_ptr(), yp.data_ptr(), K.data_ptr(), K.numel() * K.element_size(), resid.data_ptr(), w.data_ptr(), ls.data_ptr(),
                                         osc.data_ptr(), noise_vec.data_ptr(), B, Tp, F, kernel, nll.data_ptr(), mean.data_ptr(),
                                         var.data_ptr(), info.data_ptr(), _hip.stream_ptr(dev)), 'pfn_gp_posterior')
         return mean, var, nll, info
@@ -234,4 +234,10 @@ DataLoader.prefetch = True        # draws run ahead of the training steps on a s
 DataLoader.prefetch_group = 10    # ... ten steps' worth of datasets per sampler call (MI355X, bptt 2000: 64 us per dataset at 4 x 32, 54 us at 10 x 32;
                                   # 16 MB of factorisation workspace per dataset: 5 GB of the 288)
 DataLoader.prefetch_memory_share = 0.125    # ... but never more than an eighth of the free device memory per group (two groups are alive at a time)
-DataLoader.prefetch_bytes_per_dataset = staticmethod(lambda kw: int(1.2 * 4 * ((kw.get('seq_len', 0) + 3) // 4 * 4) ** 2))   # K_ws[Tp, Tp] f32 + the plane scratch (pfn_gp_workspace_bytes)
+def workspace_bytes_per_dataset(kw):
+    """K_ws per dataset as the library sizes it (the [Tp, Tp] f32 matrix + the plane scratch: +19 % at bptt 2000, +29 % at 1000, +37 % at 512 -- ADVICE r4: not a constant factor)."""
+    Tp = (kw.get('seq_len', 0) + 3) // 4 * 4
+    return int(_hip.lib().pfn_gp_workspace_bytes(1, Tp)) if Tp > 0 else 0
+
+
+DataLoader.prefetch_bytes_per_dataset = staticmethod(workspace_bytes_per_dataset)

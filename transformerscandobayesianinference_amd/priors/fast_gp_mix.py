@@ -102,7 +102,7 @@ class DataLoader(get_batch_to_dataloader(get_batch)):
     prefetch = True
     prefetch_group = 10
     prefetch_memory_share = 0.125          # as priors.fast_gp: a group's factorisation workspace stays inside this share of free memory
-    prefetch_bytes_per_dataset = staticmethod(lambda kw: int(1.2 * 4 * ((kw.get("seq_len", 0) + 3) // 4 * 4) ** 2))
+    prefetch_bytes_per_dataset = staticmethod(fast_gp.workspace_bytes_per_dataset)     # from the library (pfn_gp_workspace_bytes), not a constant factor
 
     @torch.no_grad()
     def validate(self, model, step_size=1, start_pos=0):

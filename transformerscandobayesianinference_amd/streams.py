@@ -85,6 +85,7 @@ class MicroBatchStreams:
             out = losses.detach()
         for t in (x, y, targets):
             t.record_stream(s)
+        out.record_stream(main)       # allocated on `s`, read by the caller on `main` after join(): the allocator must not hand the block back to `s` early
         return out
 
     def join(self):
