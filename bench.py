@@ -692,6 +692,8 @@ def run_config(config, device, rank, world, precision, batch=None, streams=None,
             seps.append(sep)
             (x, y), target = next(batches)
             if alt is not None:
+                if reducer is not None and k == aggregate_k - 1:
+                    reducer.arm(1, wait_for=alt.fence_others(k))      # as train(): the last batch of the step is armed, the collective waits for the others
                 losses = alt.forward_backward_on(k, model, (x, y), target, sep, lambda out, tg, sep=sep: loss_fn(out, tg[sep:]))
                 continue
             if reducer is not None and k == aggregate_k - 1:

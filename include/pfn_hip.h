@@ -69,7 +69,12 @@ enum { PFN_SCHED_TOP_LAYER_ALL_ROWS = 1, /* run the TOP encoder layer on every r
                                           * projection runs on the test rows only -- the reference returns output[single_eval_pos:] (transformer.py:91),
                                           * so that layer's train rows feed nothing (not with live dropout, not when sep < S / 4) */
        PFN_SCHED_FUSE_LN_WIDE = 2,       /* emsize 1024: LayerNorm-fused GEMMs on 64-row x 1024-column tiles (correct, measured slower: default off) */
-       PFN_SCHED_SEPARATE_LNBWD = 4      /* LayerNorm backward as its own kernels instead of inside the data-gradient GEMMs that feed it */ };
+       PFN_SCHED_SEPARATE_LNBWD = 4,     /* LayerNorm backward as its own kernels instead of inside the data-gradient GEMMs that feed it */
+       PFN_SCHED_DETERMINISTIC = 8       /* bit-reproducible gradients (the reference's CPU loop is deterministic, train.py:58-110): every gradient element has
+                                          * exactly ONE writer per launch and launches are stream-ordered -- weight-gradient GEMMs without token splits, LayerNorm
+                                          * gamma / beta / bias gradients through per-workgroup partials summed in a fixed order (implies SEPARATE_LNBWD), the
+                                          * embedding gradient from one workgroup per column block.  The caller runs ONE backward at a time into a gradient buffer
+                                          * (no concurrent micro-batch streams).  Slower (weight gradients under-fill the chip); default off. */ };
 /* schedule bits a binding should put into new descriptors: 0 unless a test / profiling run changed the defaults through pfn_set_tuning
  * (PFN_TUNE_FUSE_LNBWD, PFN_TUNE_FUSE_LN_WIDE, PFN_TUNE_TOP_LAYER_TEST_ROWS) */
 int pfn_default_schedule(void);

@@ -326,7 +326,7 @@ class _OracleModel(nn.Module):
     forward signature, arithmetic by the oracle (tests only; the product model has no CPU path)."""
 
     def __init__(self, encoder, n_out, ninp, nhead, nhid, nlayers, dropout=0.0, y_encoder=None, pos_encoder=None, decoder=None,
-                 input_normalization=False, precision='bf16'):
+                 input_normalization=False, precision='bf16', deterministic=False):
         super().__init__()
         from transformerscandobayesianinference_amd.transformer import _EncoderParams
         self.encoder, self.y_encoder, self.nhead = encoder, y_encoder, nhead

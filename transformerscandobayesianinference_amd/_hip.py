@@ -17,7 +17,7 @@ ABI_VERSION = 7
 
 PREC_BF16 = 0
 PREC_F32 = 1
-SCHED_TOP_LAYER_ALL_ROWS, SCHED_FUSE_LN_WIDE, SCHED_SEPARATE_LNBWD = 1, 2, 4     # pfn_model_desc.schedule bits (include/pfn_hip.h)
+SCHED_TOP_LAYER_ALL_ROWS, SCHED_FUSE_LN_WIDE, SCHED_SEPARATE_LNBWD, SCHED_DETERMINISTIC = 1, 2, 4, 8     # pfn_model_desc.schedule bits (include/pfn_hip.h)
 
 # GEMM epilogue flags (csrc/pfn_kernels.h)
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_OUT_F32, EPI_OUT_T, EPI_OUT2_T, EPI_ACCUM, EPI_RESID_T = 1, 2, 4, 8, 16, 32, 64, 128, 256

@@ -1165,6 +1165,217 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 }
 
 // =============================================================================================
+// backward, exact-f32 mode at head dim 256: plain vector-ALU kernels.
+//
+// The MFMA backward above keeps a key block's V rows (or, in the 4-wave configurations, the K and V fragments of 256 f32 columns) beside two tile
+// buffers; in f32 at head dim 256 neither fits (V image alone 256 KiB).  `precision='f32'` is the parity mode -- the reference trains in fp32
+// everywhere (train.py:93, transformer.py:17-18) and this mode exists so that a layout or algorithm mistake shows at 1e-6 instead of hiding under
+// bf16 rounding -- so at this head dim the backward runs as two plain tiled kernels on f32 FMAs (no matrix instructions, no dS^T scratch: the
+// query pass recomputes S and dP).  Same contract as launch_bwd_k: lse / delta from attn_delta_kernel, queries below q_begin skipped (their dQ rows
+// zero-filled by the launcher), dK / dV rows of the test keys (>= sep) come from the self-key term of the query pass.
+//   key pass   : a workgroup owns 32 keys and streams the queries in tiles of 32:  S, dP -> P, dS (LDS) -> dV += P^T dO, dK += dS^T Q
+//   query pass : a workgroup owns 32 queries and streams the keys  in tiles of 32:  S, dP -> dS (LDS)   -> dQ += dS K;  + the self key of a test row
+// Thread t of 256: phase 1 computes the (query t / 8, keys 4 (t % 8) .. + 3) entries of the 32 x 32 tile; phase 2 owns output row t / 8, columns
+// 4 (t % 8) + 32 m .. + 3 (m < D / 32).  Not a throughput path: ~3.5 kFLOP per (query, key) pair at the vector rate.
+// =============================================================================================
+template <int D> struct BwdPlainCfg {
+  static constexpr int TB = 32;                       // tile: 32 queries x 32 keys
+  static constexpr int RS = D + 4;                    // LDS row stride in floats (16-byte aligned rows, rows 4 banks apart)
+  static constexpr int TILE = TB * RS;                // floats of one [32][D] tile
+  static constexpr int PS = TB + 1;                   // P / dS tile row stride
+  static constexpr int LDS = (4 * TILE + 2 * TB * PS + 2 * TB) * 4;    // Q, dO, K, V tiles; P, dS; lse, delta
+};
+
+template <int D> PFN_DEV void plain_load_tile(float* dst, const float* src, long ld, int row0, int row_lo, int row_hi) {
+  // rows [row0, row0 + 32) of a [*, ld] matrix (D columns from src) -> dst[32][RS]; rows outside [row_lo, row_hi) read as zero
+  using P = BwdPlainCfg<D>;
+  for (int c = threadIdx.x; c < P::TB * (D / 4); c += 256) {
+    const int r = c / (D / 4), c4 = c % (D / 4), row = row0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row >= row_lo && row < row_hi) v = *reinterpret_cast<const f32x4*>(src + (long)row * ld + c4 * 4);
+    *reinterpret_cast<f32x4*>(dst + r * P::RS + c4 * 4) = v;
+  }
+}
+
+// phase 1 of both passes: s[j] = q_row . k_rows[kj0 + j], dp[j] = do_row . v_rows[kj0 + j]
+template <int D> PFN_DEV void plain_dots(const float* qrow, const float* orow, const float* Ks, const float* Vs, int kj0, float (&s)[4], float (&dp)[4]) {
+  using P = BwdPlainCfg<D>;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s[j] = 0.f; dp[j] = 0.f; }
+  for (int d = 0; d < D; d += 4) {
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qrow + d), o4 = *reinterpret_cast<const f32x4*>(orow + d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(Ks + (kj0 + j) * P::RS + d), v4 = *reinterpret_cast<const f32x4*>(Vs + (kj0 + j) * P::RS + d);
+      s[j] += q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+      dp[j] += o4[0] * v4[0] + o4[1] * v4[1] + o4[2] * v4[2] + o4[3] * v4[3];
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_plain_kv_kernel(AttnArgs a) {
+  using P = BwdPlainCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Qs = reinterpret_cast<float*>(smem_raw);
+  float* Os = Qs + P::TILE; float* Ks = Os + P::TILE; float* Vs = Ks + P::TILE;
+  float* Ps = Vs + P::TILE; float* Ds = Ps + P::TB * P::PS; float* Ls = Ds + P::TB * P::PS; float* Dl = Ls + P::TB;
+  const int nkb = (a.sep + P::TB - 1) / P::TB;
+  const int kb = blockIdx.x % nkb, hd = (blockIdx.x / nkb) % a.H, b = blockIdx.x / (nkb * a.H);
+  const long rs = 3L * a.E;
+  const float* base = reinterpret_cast<const float*>(a.qkv) + (long)b * a.S * rs;
+  const float* Qp = base + hd * D; const float* Kp = base + a.E + hd * D; const float* Vp = base + 2 * a.E + hd * D;
+  const float* dOp = reinterpret_cast<const float*>(a.dctx) + (long)b * a.S * a.E + hd * D;
+  float* dbase = reinterpret_cast<float*>(a.dqkv) + (long)b * a.S * rs;
+  const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
+  const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
+  const int key0 = kb * P::TB, t = threadIdx.x, r1 = t >> 3, c1 = (t & 7) * 4;
+  const float scale = rsqrtf((float)D), scale_log2 = scale * LOG2E;
+  // dropout on the probabilities (as in attn_bwd_kv_kernel): dV takes P' = P keep / (1 - p), dP = (dO V^T) keep / (1 - p), dS = P (dP - delta) with the unmasked P
+  const bool drop = a.p_drop > 0.f;
+  const unsigned dseed = dropout_pair_seed(a.drop_seed, b * a.H + hd), dthr = dropout_threshold(a.p_drop);
+  const float dscale = drop ? 1.f / (1.f - a.p_drop) : 1.f;
+  plain_load_tile<D>(Ks, Kp, rs, key0, 0, a.sep);
+  plain_load_tile<D>(Vs, Vp, rs, key0, 0, a.sep);
+  f32x4 dk[D / 32], dv[D / 32];
+#pragma unroll
+  for (int m = 0; m < D / 32; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int q0 = a.q_begin / P::TB * P::TB; q0 < a.S; q0 += P::TB) {
+    __syncthreads();                                   // the previous tile's phase 2 has read Qs / Os / Ps / Ds (first tile: K / V tiles written)
+    plain_load_tile<D>(Qs, Qp, rs, q0, a.q_begin, a.S);
+    plain_load_tile<D>(Os, dOp, a.E, q0, a.q_begin, a.S);
+    if (t < P::TB) { const int q = min(q0 + t, a.S - 1); Ls[t] = lse_g[q] * LOG2E; Dl[t] = delta_g[q]; }
+    __syncthreads();
+    {
+      float s[4], dp[4];
+      plain_dots<D>(Qs + r1 * P::RS, Os + r1 * P::RS, Ks, Vs, c1, s, dp);
+      const int q = q0 + r1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = q >= a.q_begin && q < a.S && key0 + c1 + j < a.sep;
+        const float p = live ? fast_exp2(s[j] * scale_log2 - Ls[r1]) : 0.f;
+        const float mf = !drop ? 1.f : dropout_keep(dseed, (unsigned)q, (unsigned)(key0 + c1 + j), dthr) ? dscale : 0.f;
+        Ps[r1 * P::PS + c1 + j] = p * mf;
+        Ds[r1 * P::PS + c1 + j] = p * (mf * dp[j] - Dl[r1]);
+      }
+    }
+    __syncthreads();
+    for (int qi = 0; qi < P::TB; ++qi) {               // thread: key r1, columns c1 + 32 m
+      const float p = Ps[qi * P::PS + r1], ds = Ds[qi * P::PS + r1];
+#pragma unroll
+      for (int m = 0; m < D / 32; ++m) {
+        const f32x4 o4 = *reinterpret_cast<const f32x4*>(Os + qi * P::RS + c1 + 32 * m), q4 = *reinterpret_cast<const f32x4*>(Qs + qi * P::RS + c1 + 32 * m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dv[m][e] += p * o4[e]; dk[m][e] += ds * q4[e]; }
+      }
+    }
+  }
+  const int key = key0 + r1;
+  if (key < a.sep) {
+#pragma unroll
+    for (int m = 0; m < D / 32; ++m) {
+      f32x4 k4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) k4[e] = dk[m][e] * scale;
+      *reinterpret_cast<f32x4*>(dbase + (long)key * rs + a.E + hd * D + c1 + 32 * m) = k4;
+      *reinterpret_cast<f32x4*>(dbase + (long)key * rs + 2 * a.E + hd * D + c1 + 32 * m) = dv[m];
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_plain_dq_kernel(AttnArgs a) {
+  using P = BwdPlainCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Qs = reinterpret_cast<float*>(smem_raw);
+  float* Os = Qs + P::TILE; float* Ks = Os + P::TILE; float* Vs = Ks + P::TILE;
+  float* Ps = Vs + P::TILE; float* Ds = Ps + P::TB * P::PS; float* Ls = Ds + P::TB * P::PS; float* Dl = Ls + P::TB;
+  const int qb0 = a.q_begin / P::TB, nqb = (a.S + P::TB - 1) / P::TB - qb0;
+  const int qb = qb0 + blockIdx.x % nqb, hd = (blockIdx.x / nqb) % a.H, b = blockIdx.x / (nqb * a.H);
+  const long rs = 3L * a.E;
+  const float* base = reinterpret_cast<const float*>(a.qkv) + (long)b * a.S * rs;
+  const float* Qp = base + hd * D; const float* Kp = base + a.E + hd * D; const float* Vp = base + 2 * a.E + hd * D;
+  const float* dOp = reinterpret_cast<const float*>(a.dctx) + (long)b * a.S * a.E + hd * D;
+  float* dbase = reinterpret_cast<float*>(a.dqkv) + (long)b * a.S * rs;
+  const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
+  const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
+  const int q0 = qb * P::TB, t = threadIdx.x, r1 = t >> 3, c1 = (t & 7) * 4;
+  const float scale = rsqrtf((float)D), scale_log2 = scale * LOG2E;
+  const bool drop = a.p_drop > 0.f;
+  const unsigned dseed = dropout_pair_seed(a.drop_seed, b * a.H + hd), dthr = dropout_threshold(a.p_drop);
+  const float dscale = drop ? 1.f / (1.f - a.p_drop) : 1.f;
+  plain_load_tile<D>(Qs, Qp, rs, q0, a.q_begin, a.S);
+  plain_load_tile<D>(Os, dOp, a.E, q0, a.q_begin, a.S);
+  if (t < P::TB) { const int q = min(q0 + t, a.S - 1); Ls[t] = lse_g[q] * LOG2E; Dl[t] = delta_g[q]; }
+  f32x4 dq[D / 32];
+#pragma unroll
+  for (int m = 0; m < D / 32; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int q = q0 + r1;
+  const bool qlive = q >= a.q_begin && q < a.S;
+  for (int key0 = 0; key0 < a.sep; key0 += P::TB) {
+    __syncthreads();
+    plain_load_tile<D>(Ks, Kp, rs, key0, 0, a.sep);
+    plain_load_tile<D>(Vs, Vp, rs, key0, 0, a.sep);
+    __syncthreads();
+    {
+      float s[4], dp[4];
+      plain_dots<D>(Qs + r1 * P::RS, Os + r1 * P::RS, Ks, Vs, c1, s, dp);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = qlive && key0 + c1 + j < a.sep;
+        const float p = live ? fast_exp2(s[j] * scale_log2 - Ls[r1]) : 0.f;
+        const float mf = !drop ? 1.f : dropout_keep(dseed, (unsigned)q, (unsigned)(key0 + c1 + j), dthr) ? dscale : 0.f;
+        Ds[r1 * P::PS + c1 + j] = p * (mf * dp[j] - Dl[r1]);
+      }
+    }
+    __syncthreads();
+    for (int kj = 0; kj < P::TB; ++kj) {               // thread: query r1, columns c1 + 32 m
+      const float ds = Ds[r1 * P::PS + kj];
+#pragma unroll
+      for (int m = 0; m < D / 32; ++m) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(Ks + kj * P::RS + c1 + 32 * m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dq[m][e] += ds * k4[e];
+      }
+    }
+  }
+  // ---- the self key of a test row (i >= sep), as in attn_bwd_dq_kernel: p_i = exp(q_i.k_i scale - lse_i), ds_i = p_i (dO_i.v_i - delta_i),
+  //      dQ_i += ds_i k_i,  dK_i = scale ds_i q_i,  dV_i = p_i dO_i.  The 8 threads of a row hold partial dots over their columns.
+  __syncthreads();                                     // (sep == 0: the Q / dO tiles and Ls / Dl written above)
+  const bool test = qlive && q >= a.sep;
+  const int qc = min(max(q, 0), a.S - 1);
+  float tq = 0.f, dpv = 0.f;
+  f32x4 kself[D / 32], vself[D / 32];
+#pragma unroll
+  for (int m = 0; m < D / 32; ++m) {
+    kself[m] = *reinterpret_cast<const f32x4*>(Kp + (long)qc * rs + c1 + 32 * m);
+    vself[m] = *reinterpret_cast<const f32x4*>(Vp + (long)qc * rs + c1 + 32 * m);
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(Qs + r1 * P::RS + c1 + 32 * m), o4 = *reinterpret_cast<const f32x4*>(Os + r1 * P::RS + c1 + 32 * m);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { tq += q4[e] * kself[m][e]; dpv += o4[e] * vself[m][e]; }
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) { tq += __shfl_xor(tq, off, 64); dpv += __shfl_xor(dpv, off, 64); }
+  const float p_self = test ? fast_exp2(tq * scale_log2 - Ls[r1]) : 0.f;
+  const float mself = !drop ? 1.f : dropout_keep(dseed, (unsigned)max(q, 0), (unsigned)max(q, 0), dthr) ? dscale : 0.f;      // keep(i, i) / (1 - p) of the self key
+  const float ds_self = p_self * (mself * dpv - Dl[r1]);
+  if (qlive) {
+#pragma unroll
+    for (int m = 0; m < D / 32; ++m) {
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(Qs + r1 * P::RS + c1 + 32 * m), o4 = *reinterpret_cast<const f32x4*>(Os + r1 * P::RS + c1 + 32 * m);
+      f32x4 xq, xk, xv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xq[e] = (dq[m][e] + ds_self * kself[m][e]) * scale; xk[e] = ds_self * scale * q4[e]; xv[e] = p_self * mself * o4[e]; }
+      *reinterpret_cast<f32x4*>(dbase + (long)q * rs + hd * D + c1 + 32 * m) = xq;
+      if (test) {
+        *reinterpret_cast<f32x4*>(dbase + (long)q * rs + a.E + hd * D + c1 + 32 * m) = xk;
+        *reinterpret_cast<f32x4*>(dbase + (long)q * rs + 2 * a.E + hd * D + c1 + 32 * m) = xv;
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 template <typename T, int D, bool DROP> static int launch_fwd_k(const AttnArgs& a, hipStream_t s) {
@@ -1225,6 +1436,34 @@ template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& 
 template <typename T, int D> static int launch_bwd_t(const AttnArgs& a, hipStream_t s) {
   return a.p_drop > 0.f ? launch_bwd_k<T, D, true>(a, s) : launch_bwd_k<T, D, false>(a, s);
 }
+// exact-f32 mode at head dim 256: the plain kernels (attn_bwd_plain_*)
+template <int D> static int launch_bwd_plain_f32(const AttnArgs& a, hipStream_t s) {
+  using P = BwdPlainCfg<D>;
+  static_assert(P::LDS <= 160 * 1024, "plain attention backward: tiles exceed the CU's LDS");
+  const int parts = a.parts ? a.parts : ~0;
+  if (parts & ATTN_BWD_DELTA) {
+    const long pairs = (long)a.B * a.S * a.H;
+    int grid = (int)std::min<long>((pairs + 15) / 16, 4096);
+    hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(grid), dim3(256), 0, s, a, D);
+  }
+  static LdsAllowance allow_kv, allow_dq;
+  if ((parts & ATTN_BWD_KV) && a.sep > 0) {
+    allow_kv.ensure(attn_bwd_plain_kv_kernel<D>, P::LDS);
+    hipLaunchKernelGGL(attn_bwd_plain_kv_kernel<D>, dim3(((a.sep + P::TB - 1) / P::TB) * a.H * a.B), dim3(256), P::LDS, s, a);
+  }
+  if (parts & ATTN_BWD_DQ) {
+    if (a.q_begin > 0) {
+      const int rc = launch_zero_row_prefix(a.dqkv, a.S, a.B, a.q_begin, 3L * a.E * 4L, (long)a.E * 4L, s);
+      if (rc != PFN_OK) return rc;
+    }
+    const int nqb = (a.S + P::TB - 1) / P::TB - a.q_begin / P::TB;
+    if (nqb > 0) {
+      allow_dq.ensure(attn_bwd_plain_dq_kernel<D>, P::LDS);
+      hipLaunchKernelGGL(attn_bwd_plain_dq_kernel<D>, dim3(nqb * a.H * a.B), dim3(256), P::LDS, s, a);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
 
 static int check_attn(const AttnArgs& a, int precision) {
   if (a.B <= 0 || a.S <= 0 || a.H <= 0 || a.E % a.H) return PFN_ERR_ARGUMENT;
@@ -1234,8 +1473,8 @@ static int check_attn(const AttnArgs& a, int precision) {
   return PFN_OK;
 }
 
-// F32_256: what the exact-f32 mode does at head dim 256 -- the forward has a kernel (V / O columns in two slices), the backward has none
-// (its tiles do not fit the LDS in f32): training at that head dim runs in the product precision, inference in either
+// F32_256: what the exact-f32 mode does at head dim 256 -- the forward runs the MFMA kernel with the V / O columns in two slices, the backward the plain
+// vector-ALU kernels (attn_bwd_plain_*: the MFMA backward's tiles do not fit the LDS in f32 at that head dim)
 #define PFN_ATTN_DISPATCH(FN, F32_256)                                                    \
   const int D = a.E / a.H;                                                                 \
   if (precision == PFN_PREC_BF16) {                                                        \
@@ -1284,7 +1523,7 @@ int launch_attn_bwd(const AttnArgs& a_in, int precision, hipStream_t s) {
   AttnArgs a = a_in;
   attn_bwd_ds_dims(a.S, a.sep, &a.ds_rows, &a.ds_ld);
   a.q_begin = a.q_begin / 256 * 256;
-  PFN_ATTN_DISPATCH(launch_bwd_t, return PFN_ERR_UNSUPPORTED)
+  PFN_ATTN_DISPATCH(launch_bwd_t, return (launch_bwd_plain_f32<256>(a, s)))
 }
 
 }  // namespace pfn

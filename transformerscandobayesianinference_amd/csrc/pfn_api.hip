@@ -74,7 +74,7 @@ int check_desc(const pfn_model_desc* d) {
   const bool ok = dh == 32 || dh == 64 || dh == 128 || dh == 256;
   if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128/256)", dh);
   if (d->emsize > 2048) return fail(PFN_ERR_UNSUPPORTED, "emsize > 2048 unsupported by the LayerNorm kernels");
-  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
+  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
   if (!(d->dropout >= 0.f && d->dropout < 1.f)) return fail(PFN_ERR_ARGUMENT, "dropout %g outside [0, 1)", (double)d->dropout);
   return PFN_OK;
 }
@@ -141,6 +141,7 @@ struct Ws {
   // the top layer on the test rows only (top_layer_on_test_rows below): compact [S - sep, B] row order
   char *top_ctx_t, *top_dy1_t, *top_dctx_t;   // attention output / LN1-input gradient / d(attention output) of the test rows
   float *top_ry, *top_rmean, *top_rrstd;      // the layer input (the residual of its first LayerNorm) of the test rows
+  float* ln_part;                             // PFN_SCHED_DETERMINISTIC: per-workgroup column sums of the LayerNorm backward (launch_layernorm_bwd `partials`)
   int64_t bytes;
 };
 
@@ -175,6 +176,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   const int64_t Mtop = (d.nlayers > 0 && d.dropout == 0.f && !(d.schedule & PFN_SCHED_TOP_LAYER_ALL_ROWS)) ? (int64_t)B * (S - (S + 3) / 4) : 0;
   w.top_ctx_t = take(Mtop * E * es); w.top_dy1_t = take(Mtop * E * es); w.top_dctx_t = take(Mtop * E * es);
   w.top_ry = (float*)take(Mtop * E * 4); w.top_rmean = (float*)take(Mtop * 4); w.top_rrstd = (float*)take(Mtop * 4);
+  w.ln_part = (d.schedule & PFN_SCHED_DETERMINISTIC) ? (float*)take((int64_t)LNB_MAX_BLOCKS * 3 * E * 4) : nullptr;
   w.bytes = cur;
   return w;
 }
@@ -481,10 +483,12 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
                              const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
                              int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed) {
   PFN_TRY(check_desc(d));
-  if (d->precision == PFN_PREC_F32 && d->emsize / d->nhead == 256)
-    return fail(PFN_ERR_UNSUPPORTED, "the exact-f32 mode has no attention backward at head dim 256 (forward / inference only): train in PFN_PREC_BF16");
   const float pdrop = use_dropout ? d->dropout : 0.f;
   const bool top_mode = top_layer_on_test_rows(*d, S, sep, pdrop);       // (the forward took the same decision: same descriptor, shape, dropout)
+  // PFN_SCHED_DETERMINISTIC: one writer per gradient element and launch -- no token splits in the weight-gradient GEMMs, the LayerNorm backward as its own
+  // kernel with ordered partial sums, the embedding gradient from one workgroup per column block
+  const bool det = (d->schedule & PFN_SCHED_DETERMINISTIC) != 0;
+  auto tn_det = [&](GemmTN g) { if (det) g.max_splits = 1; return g; };
   auto dseed = [&](int layer, int site) { return dropout_site_seed(dropout_seed, layer, site); };
   if (!params || !shadow || !workspace || !grads) return fail(PFN_ERR_ARGUMENT, "null pointer");
   if (!dsrc_sbe && (!x || !y)) return fail(PFN_ERR_ARGUMENT, "need x and y (or dsrc_sbe)");
@@ -517,7 +521,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     TnProblem dp0; memset(&dp0, 0, sizeof(dp0));
     dp0.A = w.dd_t; dp0.lda = F; dp0.B = xt_t; dp0.ldb = E; dp0.C = grads + L.dec0_w; dp0.ldc = E; dp0.P = F; dp0.Q = E; dp0.colsum = grads + L.dec0_b;
     const bool dec_grouped = prec == PFN_PREC_BF16 && gemm_tn_group_supported(dp2) && gemm_tn_group_supported(dp0);
-    if (!dec_grouped) PFN_TRY(launch_gemm_tn(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b), prec, s));
+    if (!dec_grouped) PFN_TRY(launch_gemm_tn(tn_det(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b)), prec, s));
     {
       // (contraction over the zero-padded width when that is whole 64-deep stages: the LDS-DMA kernel then takes it)
       GemmNT g = nt(w.dlog_t, npad, WT(L.dec2_wt), npad, Mt, F, npad % 64 == 0 ? npad : O, EPI_GELU_BWD | EPI_OUT_T);
@@ -526,10 +530,10 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     }
     if (dec_grouped) {
       GemmTNGroup g; memset(&g, 0, sizeof(g));
-      g.n = 2; g.M = Mt; g.p[0] = dp2; g.p[1] = dp0;
+      g.n = 2; g.M = Mt; g.p[0] = dp2; g.p[1] = dp0; g.splits = det ? 1 : 0;
       PFN_TRY(launch_gemm_tn_group(g, s));
     } else {
-      PFN_TRY(launch_gemm_tn(tn(w.dd_t, F, xt_t, E, grads + L.dec0_w, E, Mt, F, E, grads + L.dec0_b), prec, s));
+      PFN_TRY(launch_gemm_tn(tn_det(tn(w.dd_t, F, xt_t, E, grads + L.dec0_w, E, Mt, F, E, grads + L.dec0_b)), prec, s));
     }
     {
       GemmNT g = nt(w.dd_t, F, WT(L.dec0_wt), F, Mt, E, F, EPI_OUT_F32);
@@ -560,7 +564,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   // split-K TN kernel does the rest (the register kernel it replaces streamed d(src) at 0.7 TB/s).  Custom encoders
   // (dsrc_sbe), the exact-f32 mode and wide encoders keep the f32 path.
   const bool emb_gemm = !dsrc_sbe && prec == PFN_PREC_BF16 && d->nlayers > 0 && d->num_features + 2 <= EMB_AUG && E % 8 == 0;
-  bool fuse_lnb = !(d->schedule & PFN_SCHED_SEPARATE_LNBWD) && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
+  bool fuse_lnb = !det && !(d->schedule & PFN_SCHED_SEPARATE_LNBWD) && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
   if (fuse_lnb) {
     const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
     fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1, M)) &&
@@ -595,11 +599,12 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
         memset(&g, 0, sizeof(g));
         g.n = (int)probs_top.size();
         g.M = Mt;
+        g.splits = det ? 1 : 0;
         for (int i = 0; i < g.n; ++i) g.p[i] = probs_top[i];
         PFN_TRY(launch_gemm_tn_group(g, s));
       } else {
         for (const TnProblem& t : probs_top)
-          PFN_TRY(launch_gemm_tn(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, Mt, t.P, t.Q, t.colsum), prec, s));
+          PFN_TRY(launch_gemm_tn(tn_det(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, Mt, t.P, t.Q, t.colsum)), prec, s));
       }
     }
     bool grouped = prec == PFN_PREC_BF16;
@@ -611,12 +616,13 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
         memset(&g, 0, sizeof(g));
         g.n = (int)std::min<size_t>(TN_GROUP_MAX, probs.size() - i0);
         g.M = M;
+        g.splits = det ? 1 : 0;
         for (int i = 0; i < g.n; ++i) g.p[i] = probs[i0 + i];
         PFN_TRY(launch_gemm_tn_group(g, s));
       }
     } else {  // exact-f32 parity mode and shapes outside the 256-tile kernel: one split-K launch per gradient
       for (const TnProblem& t : probs)
-        PFN_TRY(launch_gemm_tn(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, M, t.P, t.Q, t.colsum), prec, s));
+        PFN_TRY(launch_gemm_tn(tn_det(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, M, t.P, t.Q, t.colsum)), prec, s));
     }
     return PFN_OK;
   };
@@ -634,7 +640,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     // the residual path keeps the unmasked one, and the two bias gradients become column sums of the masked operands (weight-gradient launch)
     if (!fuse_lnb || l == d->nlayers - 1)
       PFN_TRY(launch_layernorm_bwd(top ? (const void*)dxt : (const void*)w.gA_t, top ? 0 : 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t,
-                                   grads + p.g2, grads + p.be2, pdrop > 0.f ? nullptr : grads + p.b2, Ml, E, prec, s));
+                                   grads + p.g2, grads + p.be2, pdrop > 0.f ? nullptr : grads + p.b2, Ml, E, prec, s, w.ln_part));
     const char* dy2_op = a.dy2_t;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy2_t, a.dy2m_t, nullptr, nullptr, M, E, dseed(l, 3), pdrop, prec, s)); dy2_op = a.dy2m_t; }
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
@@ -653,7 +659,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
         PFN_TRY(launch_gemm_nt(g, prec, s));
       }
       PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, dy1_t, grads + p.g1, grads + p.be1,
-                                   pdrop > 0.f ? nullptr : grads + p.b_o, Ml, E, prec, s));
+                                   pdrop > 0.f ? nullptr : grads + p.b_o, Ml, E, prec, s, w.ln_part));
     }
     const char* dy1_op = dy1_t;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy1_t, a.dy1m_t, nullptr, nullptr, M, E, dseed(l, 1), pdrop, prec, s)); dy1_op = a.dy1m_t; }
@@ -704,14 +710,14 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   } else if (emb_gemm) {
     if (hipMemsetAsync(w.embacc, 0, sizeof(float) * E * EMB_AUG, s) != hipSuccess) return fail(PFN_ERR_LAUNCH, "memset");
     GemmTN g = tn(w.gA_t, E, w.xaug_t, EMB_AUG, w.embacc, EMB_AUG, M, E, EMB_AUG, grads + L.enc_b);
-    g.max_splits = 128;      // a 512 x 32 result: measured 67 / 62 / 88 us with 64 / 128 / 256 splits (the partial sums are added atomically)
+    g.max_splits = det ? 1 : 128;      // a 512 x 32 result: measured 67 / 62 / 88 us with 64 / 128 / 256 splits (the partial sums are added atomically)
     PFN_TRY(launch_gemm_tn(g, prec, s));
     PFN_TRY(launch_embed_grad_scatter(w.embacc, grads + L.enc_w, grads + L.yenc_w, grads + L.yenc_b, E, d->num_features, s));
   } else {
     EmbedBwdArgs e;
     e.dsrc = w.gA; e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;
     e.dwx = grads + L.enc_w; e.dbx = grads + L.enc_b; e.dwy = grads + L.yenc_w; e.dby = grads + L.yenc_b;
-    e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep;
+    e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep; e.single_block = det ? 1 : 0;
     PFN_TRY(launch_embed_bwd(e, s));
   }
   return PFN_OK;

@@ -210,6 +210,7 @@ struct EmbedBwdArgs {
   const float* dsrc; const float* x; long x_st, x_sb; const float* y; long y_st, y_sb;
   float* dwx; float* dbx; float* dwy; float* dby;
   int S, B, nf, E, sep;
+  int single_block;     // 1: one workgroup per column block walks every token (one writer per gradient element: PFN_SCHED_DETERMINISTIC)
 };
 int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s);
 // the GEMM form: acc[E, EMB_AUG] = d(src)^T . xaug (launch_gemm_tn) -> dwx += acc[:, :nf], dwy += acc[:, nf], dby += acc[:, nf + 1]
@@ -226,7 +227,10 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 // accumulates colsum(dx) (the bias gradient of the linear that produced x's pre-LN sum).
 int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd,
                          float* dx_f32, void* dx_t, float* dgamma, float* dbeta, float* dbias_extra,
-                         long rows, int E, int precision, hipStream_t s);
+                         long rows, int E, int precision, hipStream_t s, float* partials = nullptr);
+// `partials` (PFN_SCHED_DETERMINISTIC): scratch of LNB_MAX_BLOCKS * 3 * E floats -- every workgroup leaves its column sums there and a second tiny launch adds
+// them to dgamma / dbeta / dbias_extra in block order (one writer per element, a fixed summation order) instead of the f32 atomics
+constexpr int LNB_MAX_BLOCKS = 512;
 // out[n] += sum_m a[m,n]
 int launch_colsum(const void* a_t, long lda, long rows, int cols, float* out, int precision, hipStream_t s);
 

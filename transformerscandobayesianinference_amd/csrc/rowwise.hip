@@ -276,7 +276,8 @@ int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s) {
 #ifndef PFN_EMBB_WGS
 #define PFN_EMBB_WGS 512
 #endif
-    const dim3 grid((unsigned)std::max<long>(1, std::min<long>((ntok + EMBB_TOK - 1) / EMBB_TOK, std::max(1, PFN_EMBB_WGS / ey))), ey);
+    // (single_block: one workgroup per column block walks every token -- each gradient element then has one writer: PFN_SCHED_DETERMINISTIC)
+    const dim3 grid(a.single_block ? 1u : (unsigned)std::max<long>(1, std::min<long>((ntok + EMBB_TOK - 1) / EMBB_TOK, std::max(1, PFN_EMBB_WGS / ey))), ey);
     const size_t lds = std::max((size_t)EMBB_TOK * nf8, (size_t)4 * 64 * (nf8 + 1)) * sizeof(float);
     switch (nf8) {
       case 8: hipLaunchKernelGGL(embed_bwd_kernel<8>, grid, dim3(256), lds, s, a); break;
@@ -286,6 +287,7 @@ int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s) {
     }
     return PFN_LAUNCH_OK();
   }
+  if (a.single_block) return PFN_ERR_UNSUPPORTED;      // the wide-encoder kernel splits the tokens over workgroups (atomics): no deterministic form
   const int grid = (int)((ntok + 127) / 128);
   const size_t lds = 128 * (size_t)nf8 * sizeof(float);
   if (lds > 64 * 1024) return PFN_ERR_UNSUPPORTED;
@@ -561,7 +563,7 @@ template <typename T, int EV> PFN_DEV void ln_store(T* p, const float (&v)[EV]) 
 }
 template <typename T, int NV, int EV, bool DY_T>
 __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const void* dy_any, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                                                      float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E) {
+                                                                      float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E, float* partials) {
   extern __shared__ __attribute__((aligned(16))) float part[];  // [LNB_WAVES][E]
   const float* dy = reinterpret_cast<const float*>(dy_any);     // upstream gradient: f32, or operand precision when DY_T
   const T* dy_t = reinterpret_cast<const T*>(dy_any);
@@ -650,26 +652,38 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const voi
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < LNB_WAVES; ++w) t += part[w * E + c];
-      unsafeAtomicAdd(out + c, t);
+      // deterministic schedule (PFN_SCHED_DETERMINISTIC): the block's partial goes to scratch, ln_partials_reduce_kernel adds the blocks in index order
+      if (partials) partials[((long)blockIdx.x * 3 + q) * E + c] = t;
+      else unsafeAtomicAdd(out + c, t);
     }
   }
 }
+// out_q[c] += sum over blocks (in index order) of partials[block][q][c]: one writer per element, a fixed summation order
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* partials, int nblocks, int E, float* dgamma, float* dbeta, float* dbias) {
+  const int c = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
+  float* out = q == 0 ? dgamma : q == 1 ? dbeta : dbias;
+  if (c >= E || out == nullptr) return;
+  float t = 0.f;
+  for (int b = 0; b < nblocks; ++b) t += partials[((long)b * 3 + q) * E + c];
+  out[c] += t;
+}
 int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, void* dxt,
-                         float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s) {
+                         float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s, float* partials) {
   if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
   if (rows == 0) return PFN_OK;
-  const int grid = grid_for(rows, LNB_WAVES * 8, 512);
+  const int grid = grid_for(rows, LNB_WAVES * 8, LNB_MAX_BLOCKS);
   const size_t lds = LNB_WAVES * E * sizeof(float);
 #define LN_BWD_K(TT, NV, EV, DT) do { \
     static LdsAllowance allowance; \
     allowance.ensure(layernorm_bwd_kernel<TT, NV, EV, DT>, lds); \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, EV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E); } while (0)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, EV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E, partials); } while (0)
 #define LN_BWD(TT, NV, EV) do { if (dy_is_t) LN_BWD_K(TT, NV, EV, true); else LN_BWD_K(TT, NV, EV, false); } while (0)
   // rows of >= 512 elements in 8-element lane chunks (16-byte operand-precision accesses), narrower rows in 4-element ones
 #define LN_BWD_NV(TT) do { \
     if (E % 8 == 0 && E >= 512) { if (E <= 512) LN_BWD(TT, 1, 8); else if (E <= 1024) LN_BWD(TT, 2, 8); else LN_BWD(TT, 4, 8); } \
     else if (E <= 256) LN_BWD(TT, 1, 4); else if (E <= 512) LN_BWD(TT, 2, 4); else if (E <= 1024) LN_BWD(TT, 4, 4); else LN_BWD(TT, 8, 4); } while (0)
   if (precision == PFN_PREC_BF16) LN_BWD_NV(bf16); else LN_BWD_NV(float);
+  if (partials) hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((E + 255) / 256, 3), dim3(256), 0, s, partials, grid, E, dgamma, dbeta, dbias);
   return PFN_LAUNCH_OK();
 }
 

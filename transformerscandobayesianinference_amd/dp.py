@@ -100,6 +100,7 @@ class OverlappedGradientReducer:
     def __init__(self, model=None, flat_grad=None, split=None, first_group_layers=None):
         self.model = model
         self.events, self._armed, self.expected = [], False, 0
+        self.extra_events = []
         self.overlapped_last_step = False
         self.fallbacks = 0            # armed steps whose early collective could NOT be overlapped (the hook fired fewer times than armed for)
         self._callback_error = None   # an exception raised inside the ctypes host callback (ctypes swallows it): re-raised by finish()
@@ -129,9 +130,13 @@ class OverlappedGradientReducer:
             self._callback_error = e
 
     # ---- called by the training loop ----
-    def arm(self, passes=1):
-        """The next `passes` backward passes complete this optimizer step's gradients (not armed: accumulation micro-steps)."""
+    def arm(self, passes=1, wait_for=()):
+        """The next `passes` backward passes complete this optimizer step's gradients (not armed: accumulation micro-steps).
+        `wait_for`: events the early collective must ALSO wait for -- batches of the same optimizer step still running on other streams (train()'s
+        alternating-stream schedule: only the last batch of a step is armed; the batches before it were enqueued earlier on their streams and
+        their weight gradients land in the same buffer)."""
         self.events, self._armed, self.expected = [], True, passes
+        self.extra_events = list(wait_for)
 
     def finish(self):
         """All-reduce (sum) the whole buffer; returns after the collectives are ordered before further work of the current stream."""
@@ -156,7 +161,7 @@ class OverlappedGradientReducer:
                               f'{len(self.events)} time(s); the gradient all-reduce of this step is not overlapped')
         if overlapped:
             with torch.cuda.stream(self.comm):
-                for ev in self.events:
+                for ev in self.events + self.extra_events:
                     self.comm.wait_event(ev)
                 works.append(dist.all_reduce(self.grad[self.split:], op=dist.ReduceOp.SUM, async_op=True))
             works.append(dist.all_reduce(self.grad[:self.split], op=dist.ReduceOp.SUM, async_op=True))
@@ -169,7 +174,7 @@ class OverlappedGradientReducer:
             wk.wait()
         if overlapped:
             self.grad.record_stream(self.comm)
-        self.events = []
+        self.events, self.extra_events = [], []
         self.overlapped_last_step = overlapped
         if err is not None:
             raise RuntimeError('the first-group host callback of pfn_stack_backward_split failed') from err

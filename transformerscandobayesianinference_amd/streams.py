@@ -25,7 +25,8 @@ class MicroBatchStreams:
         # accumulation into the shared flat buffer (non-atomic read-modify-write) would run on two streams at once
         # ... and so would a custom `decoder=` module: it runs in PyTorch on the stack's output, and AccumulateGrad's in-place
         # `+=` on its parameters (views of the flat buffer) is not atomic across the two streams
-        fused = getattr(model, '_fused_embedding', lambda: False)() and not getattr(model, '_custom_decoder', False)
+        # ... nor a deterministic model (PFN_SCHED_DETERMINISTIC): its gradient kernels write each element from one place, in stream order
+        fused = getattr(model, '_fused_embedding', lambda: False)() and not getattr(model, '_custom_decoder', False) and not getattr(model, 'deterministic', False)
         return self.n if (self.streams and fused and batch % self.n == 0 and batch >= 2 * self.n) else 1
 
     def forward_backward(self, model, data, targets, single_eval_pos, loss_fn):
@@ -67,7 +68,7 @@ class MicroBatchStreams:
     # batches of one optimizer step are independent given the weights, so they run WHOLE, round-robin on the streams: up to `n` batches in flight,
     # their gradients accumulated atomically into the shared flat buffer, joined before the optimizer step.
     def can_alternate(self, model):
-        fused = getattr(model, '_fused_embedding', lambda: False)() and not getattr(model, '_custom_decoder', False)
+        fused = getattr(model, '_fused_embedding', lambda: False)() and not getattr(model, '_custom_decoder', False) and not getattr(model, 'deterministic', False)
         return bool(self.streams) and fused
 
     def forward_backward_on(self, slot, model, data, targets, single_eval_pos, loss_fn):
@@ -87,6 +88,17 @@ class MicroBatchStreams:
             t.record_stream(s)
         out.record_stream(main)       # allocated on `s`, read by the caller on `main` after join(): the allocator must not hand the block back to `s` early
         return out
+
+    def fence_others(self, slot):
+        """Events behind everything enqueued so far on the streams that will NOT run batch `slot` (earlier batches on the stream that will are ordered
+        before it by the stream itself)."""
+        evs = []
+        for i, s in enumerate(self.streams):
+            if i != slot % self.n:
+                ev = torch.cuda.Event()
+                ev.record(s)
+                evs.append(ev)
+        return evs
 
     def join(self):
         main = torch.cuda.current_stream()

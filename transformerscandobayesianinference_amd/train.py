@@ -69,7 +69,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
           y_encoder_generator=None, pos_encoder_generator=None, decoder=None, extra_prior_kwargs_dict={},
           scheduler=get_cosine_schedule_with_warmup, load_weights_from_this_state_dict=None, validation_period=10,
           single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16', micro_streams=2, epoch_callback=None,
-          aggregate_streams=None):
+          aggregate_streams=None, deterministic=False):
     device = gpu_device if torch.cuda.is_available() else 'cpu:0'
     print(f'Using {device} device')
     if not str(device).startswith('cuda') and getattr(TransformerModel, 'requires_gpu', False):
@@ -96,7 +96,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     model = TransformerModel(encoder, n_out, emsize, nhead, nhid, nlayers, dropout,
                              y_encoder=y_encoder_generator(1, emsize), input_normalization=input_normalization,
                              pos_encoder=(pos_encoder_generator or positional_encodings.NoPositionalEncoding)(emsize, bptt * 2),
-                             decoder=decoder, precision=precision)
+                             decoder=decoder, precision=precision, deterministic=deterministic)
     model.criterion = criterion
     if load_weights_from_this_state_dict is not None:
         model.load_state_dict(load_weights_from_this_state_dict)
@@ -139,6 +139,11 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
             last_micro_step = batch % aggregate_k_gradients == aggregate_k_gradients - 1
             if isinstance(data, tuple) and single_eval_pos is not None and alt is not None and alt.can_alternate(model):
                 targets = targets.to(device)
+                if reducer is not None and last_micro_step:
+                    # data-parallel + alternating streams: the LAST batch of the optimizer step is armed, so the upper layers' half of the
+                    # all-reduce starts behind its early weight-gradient launch; the collective also waits for the batches of this step that are still
+                    # running on the other streams (their weight gradients land in the same buffer)
+                    reducer.arm(1, wait_for=alt.fence_others(batch))
                 losses = alt.forward_backward_on(batch, model, data, targets, single_eval_pos,
                                                  lambda out, tg, sep=single_eval_pos: compute_losses(criterion, out, tg[sep:], n_out))
                 pending.append((single_eval_pos, losses))
