@@ -720,7 +720,8 @@ def run_config(config, device, rank, world, precision, batch=None, streams=None,
     loader_cls = prior_module(w).DataLoader
     nb = steps * aggregate_k
     group = math.gcd(nb, int(prefetch_group or getattr(loader_cls, 'prefetch_group', 1))) if getattr(loader_cls, 'prefetch', False) else 1
-    num_batches = ((warmup + steps + profile_steps) * aggregate_k + group + group - 1) // group * group
+    solo_steps = 3 if profile_steps > 0 else 0      # further steps that time ONE kernel class only (the usually dominant one: less perturbation)
+    num_batches = ((warmup + steps + profile_steps + solo_steps) * aggregate_k + group + group - 1) // group * group
     with quiet():   # DataLoader.__init__ prints its kwargs (reference behaviour)
         dl = loader_cls(num_steps=num_batches, batch_size=batch, seq_len=S, device=device, **prior_kwargs(w))
     dl.prefetch_group = group
@@ -762,8 +763,15 @@ def run_config(config, device, rank, world, precision, batch=None, streams=None,
         # the same steps once more with an event pair around every launch of the step's kernel classes, ON their launch streams: how long each
         # kernel runs INSIDE the step, where two micro-batch streams and the prior sampler share the chip
         lib = _hip.lib()
-        _hip.check(lib.pfn_profile_enable(1), 'pfn_profile_enable')
+        # ... first for the key-block pass of the attention backward ALONE (the dominant kernel at every shape seen): an event pair is a marker in the
+        # hardware queue, and with every class bracketed the step itself stretches (round 4: the all-class figure was 11 % above rocprofv3's)
+        _hip.check(lib.pfn_profile_enable(2 + PROF_SLOTS['attn_bwd_kv']), 'pfn_profile_enable')
         read_profile()
+        for _ in range(solo_steps):
+            step(batches)
+        torch.cuda.synchronize()
+        out['in_step_solo'] = read_profile()
+        _hip.check(lib.pfn_profile_enable(1), 'pfn_profile_enable')
         for _ in range(profile_steps):
             step(batches)
         torch.cuda.synchronize()
@@ -970,6 +978,7 @@ def main():
         mean_sep = int(round(sum(seps) / len(seps)))
         ks = kernel_breakdown(batch // groups, mean_sep, w, fused_ln_wide=bool(tuning.get(5)), top_rows=top_rows_of(batch // groups, mean_sep))
         in_step = r.get('in_step', {})
+        in_solo = r.get('in_step_solo', {})
         for k in ks:
             k['launches_per_step'] *= groups * args.aggregate_k
             k['step_seconds'] *= groups * args.aggregate_k
@@ -977,6 +986,10 @@ def main():
             if cls and cls in in_step:
                 k['in_step_us'] = in_step[cls]['avg_us']
                 k['in_step_launches_timed'] = in_step[cls]['launches']
+            if cls and cls in in_solo:      # timed with no other class bracketed: the figure `roofline` quotes
+                k['in_step_all_classes_us'] = k.get('in_step_us')
+                k['in_step_us'] = in_solo[cls]['avg_us']
+                k['in_step_launches_timed'] = in_solo[cls]['launches']
         dom = max(ks, key=lambda k: k['step_seconds'])   # the kernel the step spends most time in
         traffic, traffic_src = None, None
         pmc = json.load(open(PMC_TRAFFIC)) if os.path.exists(PMC_TRAFFIC) else {}

@@ -26,7 +26,9 @@ std::atomic<int> g_prof_on{0};
 }  // namespace
 bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed) != 0; }
 void* prof_begin(int slot, hipStream_t s) {
-  if (!prof_enabled() || slot < 0 || slot >= PFN_PROF_SLOTS) return nullptr;
+  const int on = g_prof_on.load(std::memory_order_relaxed);
+  if (!on || slot < 0 || slot >= PFN_PROF_SLOTS) return nullptr;
+  if (on >= 2 && (slot & ~1) != on - 2) return nullptr;      // pfn_profile_enable(2 + class): that kernel class alone (fewer events in the queues: less perturbation)
   ProfPair* p = new ProfPair;
   if (hipEventCreate(&p->a) != hipSuccess || hipEventCreate(&p->b) != hipSuccess) { delete p; return nullptr; }
   (void)hipEventRecord(p->a, s);
@@ -213,7 +215,7 @@ static bool top_layer_on_test_rows(const pfn_model_desc& d, int S, int sep, floa
 // emsize 1024: the 64-row fused kernels exist and are correct, but lose to GEMM + LayerNorm kernels (PFN_SCHED_FUSE_LN_WIDE)
 int pfn_abi_version(void) { return PFN_ABI_VERSION; }
 int pfn_default_schedule(void) { return g_default_schedule; }
-int pfn_profile_enable(int on) { g_prof_on.store(on ? 1 : 0); return PFN_OK; }
+int pfn_profile_enable(int on) { g_prof_on.store(on < 0 ? 0 : on); return PFN_OK; }
 int pfn_profile_read(int slot, double* total_ms, int64_t* launches) {
   if (slot < 0 || slot >= PFN_PROF_SLOTS) return fail(PFN_ERR_ARGUMENT, "bad profile slot %d", slot);
   std::vector<ProfPair> pairs;
