@@ -1317,12 +1317,12 @@ def test_trained_head_dim_256_inference_parity():
                 nll = model.criterion(lg.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean().item()
                 mean = model.criterion.mean(lg)
             tight = not train_mode
-            # (measured over two full-suite runs, profiles/r04_parity_measured.json: inference 0.7-7e-7 / 6-8e-7 / 0.9-1.1e-6; the bf16 training forward on these
-            # weights -- 2500 optimizer steps, the loss 2.7 nats below its start -- 3.6-7.5e-4 / 0.9-1.1e-3 / 1.35-1.4e-3.  The weights differ from run to run
-            # (the weight gradients are atomic split-K sums: the training trajectory is not bit-reproducible), so these bf16 bounds are 3 x the largest value seen)
-            within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3 if tight else 3e-3)
-            within(f'{mode}: means rel l2 (own norm)', relerr(mean, mean_o), 1e-3 if tight else 3e-3)
-            within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 4e-3)
+            # (round 5: the model is trained under the deterministic schedule, so these values repeat to the last digit -- two runs, gpurun call 3 of round 5:
+            # inference 7.18e-7 / 1.10e-6 / 9.37e-7; the bf16 training forward on these weights -- 2500 optimizer steps, the loss 2.8 nats below its start --
+            # 4.20e-4 / 1.13e-3 / 1.28e-3 in both.  bf16 bounds = 2 x measured, as everywhere else; rounds 3-4 had to use 3 x the largest of two differing runs)
+            within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3 if tight else 8.5e-4)
+            within(f'{mode}: means rel l2 (own norm)', relerr(mean, mean_o), 1e-3 if tight else 2.3e-3)
+            within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 2.6e-3)
 
 
 @pytest.mark.parametrize('precision,aggregate_streams', [('f32', 0), ('bf16', 0), ('f32', 2)])
