@@ -848,7 +848,7 @@ def compact_line(result):
     line = _pick(result, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'))
     cfg = result['config']
     line['config'] = _pick(cfg, ('workload', 'baseline_config', 'per_gpu_batch', 'global_batch', 'aggregate_k_gradients', 'aggregate_streams', 'seq_len', 'parallelism',
-                                 'micro_batch_streams', 'eval_pos', 'mean_sep', 'final_loss', 'tuning'))
+                                 'micro_batch_streams', 'eval_pos', 'mean_sep', 'final_loss', 'tuning', 'library_variant'))
     line['step_roofline'] = _pick(result['step_roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'reference_graph_frac'))
     if 'roofline' in result:
         line['roofline'] = _pick(result['roofline'], ('bound', 'kernel', 'rocprof_kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_is', 'avg_launch_us', 'isolated_frac',
@@ -928,6 +928,8 @@ def main():
     w = CONFIGS[args.config]
     tuning = {int(k): int(v) for k, v in (kv.split('=') for kv in args.tune.split(',') if kv)}
     from transformerscandobayesianinference_amd import _hip
+    if os.environ.get('PFN_LIB'):      # experiment builds of the library (tools/build_variants.sh): same-box A/B of a kernel change inside the step; recorded in config
+        _hip.LIB_PATH = os.path.abspath(os.environ['PFN_LIB'])
     for k, v in tuning.items():
         _hip.check(_hip.lib().pfn_set_tuning(k, v), 'pfn_set_tuning')
     t_start = time.time()
@@ -958,6 +960,8 @@ def main():
     }
     if tuning:
         result['config']['tuning'] = tuning
+    if os.environ.get('PFN_LIB'):
+        result['config']['library_variant'] = os.path.basename(os.environ['PFN_LIB'])
     if world > 1:
         result['ranks_seen'] = r['ranks_seen']
         result['per_rank_ms_per_step'] = [e / args.steps * 1e3 for e in r['per_rank_elapsed']]      # spread = load imbalance / stragglers at the all-reduce

@@ -56,6 +56,27 @@ int main(int argc, char** argv) {
   /* error path: head dim 100 (the reference's train() default emsize 200 / nhead 2) is refused with a message, not computed wrongly */
   d.emsize = 200; d.nhead = 2; d.nhid = 200;
   CHECK(param_count(&d) < 0 && strstr(last_error(), "head dim") != 0);
+  /* ABI 7: the GP sampler is told how large the caller's K_ws is -- an allocation below B*S*S*4 bytes is refused before anything touches the device, and
+   * pfn_gp_workspace_bytes is what a caller should allocate (the matrix + the trailing update's plane scratch) */
+  int64_t (*gp_ws)(int, int) = (int64_t (*)(int, int))dlsym(lib, "pfn_gp_workspace_bytes");
+  int (*gp_sample)(float*, float*, float*, float*, int64_t, const float*, const float*, const float*, int, int, int, int, int, int, uint64_t, uint64_t, int32_t*, void*) =
+      (int (*)(float*, float*, float*, float*, int64_t, const float*, const float*, const float*, int, int, int, int, int, int, uint64_t, uint64_t, int32_t*, void*))dlsym(lib, "pfn_gp_prior_sample");
+  CHECK(gp_ws(2, 2000) >= (int64_t)2 * 2000 * 2000 * 4 && gp_ws(2, 2000) < (int64_t)2 * 2000 * 2000 * 6);
+  {
+    float dummy[4]; int32_t info[2];
+    CHECK(gp_sample(dummy, dummy, dummy, dummy, (int64_t)2 * 2000 * 2000 * 4 - 1, dummy, dummy, dummy, 2, 2000, 18, 0, 1, 1, 0, 0, info, 0) == PFN_ERR_ARGUMENT);
+    CHECK(strstr(last_error(), "K_ws_bytes") != 0);
+  }
+  /* the deterministic schedule is a descriptor bit like the others and asks for its scratch in the workspace */
+  d.emsize = 512; d.nhead = 4; d.nhid = 1024;
+  {
+    const int64_t plain = workspace_bytes(&d, 8, 2000);
+    d.schedule = PFN_SCHED_DETERMINISTIC;
+    CHECK(workspace_bytes(&d, 8, 2000) > plain);
+    d.schedule = 64;
+    CHECK(workspace_bytes(&d, 8, 2000) < 0 && strstr(last_error(), "schedule") != 0);
+    d.schedule = 0;
+  }
   printf("cabi_check ok: ABI %d, %d parameter tensors, %lld parameters\n", abi_version(), n, (long long)total);
   dlclose(lib);
   return 0;

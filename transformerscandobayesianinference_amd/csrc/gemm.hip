@@ -170,6 +170,58 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 
 // The epilogue of the big NT kernels, straight from the accumulators (a wave's 128 x 64 sub-tile of the tile at (m0, n0); ep_base:
 // BigEpi<NWM>::BYTES of LDS free for staging).
+// ---------------------------------------------------------------------------------------------
+// Contraction of one 64- (or 32-) deep LDS stage by a wave that owns a (4 x 2) grid of 32 x 32 blocks, software-pipelined (round 5).
+// Written as "6 fragment reads, 8 MFMAs" per 16-deep step, hipcc emitted exactly that: reads, s_waitcnt lgkmcnt(0), MFMAs -- every
+// wave waited out an LDS round trip per step and only the second wave of the SIMD covered it (1.4-2.7 us per stage against 0.93 us of
+// MFMA time).  Here the fragments of step s + 1 are requested BEFORE the MFMAs of step s (two register sets, PFN_PIN_LDS_MFMA keeps the
+// machine scheduler from sinking the reads back to their consumers; the waits become counted lgkmcnt), and the first step of the NEXT
+// stage is requested right behind the stage barrier, ahead of the last step's MFMAs.
+// MEASURED (profiles/r05_gemm_fragment_pipelining.txt, same-box A/B): 0-5 % slower alone and -1.7 % in the step -- the second wave of each SIMD already covered the
+// LDS round trips; the stage time is set by the operand stream into LDS.  So the plain loop stays the default; -DPFN_GEMM_FRAG_PIPE=1 builds this form.
+// ---------------------------------------------------------------------------------------------
+#ifndef PFN_GEMM_FRAG_PIPE
+#define PFN_GEMM_FRAG_PIPE 0
+#endif
+struct NtFrags { Frag<bf16> a[4], b[2]; };
+template <int RB> PFN_DEV void nt_load_frags(NtFrags& f, const lds_char* ta, const lds_char* tb, int arow, int brow, int ks) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) f.b[j] = load_frag_row<bf16, RB>(tb, brow + j * 32, ks);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f.a[i] = load_frag_row<bf16, RB>(ta, arow + i * 32, ks);
+}
+PFN_DEV void nt_mma_frags(f32x16 (&acc)[4][2], const NtFrags& f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = mma32(f.b[j], f.a[i], acc[i][j]);
+}
+// One stage: fragments of step 0 are already in f0 (requested by the previous stage, or by the caller for the first).  `tan` / `tbn`: the NEXT stage's
+// tiles (garbage on the last stage: read, never used).  The barrier (with the DMA's vmcnt(0)) sits between the last two steps' MFMAs.
+template <int RB, int BK> PFN_DEV void nt_contract_stage(f32x16 (&acc)[4][2], NtFrags& f0, NtFrags& f1, const lds_char* ta, const lds_char* tb,
+                                                         const lds_char* tan, const lds_char* tbn, int arow, int brow) {
+  static_assert(BK == 64 || BK == 32, "stage depth");
+  nt_load_frags<RB>(f1, ta, tb, arow, brow, 16);
+  PFN_PIN_LDS_MFMA();
+  nt_mma_frags(acc, f0);
+  PFN_PIN_LDS_MFMA();
+  if constexpr (BK == 64) {
+    nt_load_frags<RB>(f0, ta, tb, arow, brow, 32);
+    PFN_PIN_LDS_MFMA();
+    nt_mma_frags(acc, f1);
+    PFN_PIN_LDS_MFMA();
+    nt_load_frags<RB>(f1, ta, tb, arow, brow, 48);
+    PFN_PIN_LDS_MFMA();
+    nt_mma_frags(acc, f0);
+    PFN_PIN_LDS_MFMA();
+  }
+  __syncthreads();      // every wave has read this stage (its reads are retired: lgkmcnt(0)); the next stage's DMA has landed (vmcnt(0))
+  nt_load_frags<RB>(f0, tan, tbn, arow, brow, 0);
+  PFN_PIN_LDS_MFMA();
+  nt_mma_frags(acc, f1);
+  PFN_PIN_LDS_MFMA();
+}
+
 template <int NWM> struct BigEpi {
   static constexpr int EP_T = 32 * 144, EP_F = 32 * 272, EP_WAVE = (2 * EP_T > EP_F ? 2 * EP_T : EP_F), BYTES = NWM * 4 * EP_WAVE;
 };
@@ -429,6 +481,17 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
   const int nk = g.K / BK;
   stage(0, 0);
   __syncthreads();  // (carries the vmcnt(0) of the DMA)
+  if constexpr (PFN_GEMM_FRAG_PIPE && NWM == 2) {      // (the 128 x 256 / three-per-CU variant is held to 168 registers: no room for the second fragment set)
+  NtFrags f0, f1;
+  nt_load_frags<C::RB>(f0, smem, smem + C::TILE_A, wm * 128 + li, wn * 64 + li, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * C::STAGE;
+    const lds_char* tan = smem + (cur ^ 1) * C::STAGE;
+    nt_contract_stage<C::RB, BK>(acc, f0, f1, ta, ta + C::TILE_A, tan, tan + C::TILE_A, wm * 128 + li, wn * 64 + li);
+  }
+  } else {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
@@ -447,6 +510,7 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
         for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
     }
     __syncthreads();
+  }
   }
 
   static_assert(BigEpi<NWM>::BYTES <= 2 * C::STAGE, "epilogue staging must fit the (dead) stage buffers");
@@ -625,6 +689,17 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   const int nk = g.K / BK;
   stage(0, 0);
   __syncthreads();
+#if PFN_GEMM_FRAG_PIPE
+  NtFrags f0, f1;
+  nt_load_frags<RB>(f0, smem, smem + TILE_A, li, wave * 64 + li, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * STAGE;
+    const lds_char* tan = smem + (cur ^ 1) * STAGE;
+    nt_contract_stage<RB, BK>(acc, f0, f1, ta, ta + TILE_A, tan, tan + TILE_A, li, wave * 64 + li);
+  }
+#else
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
@@ -644,6 +719,7 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
     }
     __syncthreads();
   }
+#endif
 
   // ---- epilogue: v = acc + bias + residual (kept in the accumulator registers), row statistics, outputs ----
   // The compiler never moves a global load above a global store and waits for each group of loads where it is used, so an
@@ -660,20 +736,20 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
     cvec[n] = c0; cvec[BN + n] = c1; cvec[2 * BN + n] = c2; cvec[3 * BN + n] = c3; cvec[4 * BN + n] = c4;
   }
   const float* rsrc = RESID_LN ? g.ry : g.resid;
-  float rm[4], rr[4];
-  long mrow[4];
+  // (32-bit row indices, the 64-bit element offsets formed where they are used; the residual rows' LayerNorm statistics travel with the rows, one block
+  // ahead, instead of all four blocks' up front: this epilogue sits at the 256-register limit and a handful of long-lived values is a spill)
+  float rm[2], rr[2];
+  int mrow[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    mrow[i] = min((long)m0 + i * 32 + li, (long)g.M - 1);
-    rm[i] = 0.f; rr[i] = 1.f;
-    if constexpr (RESID_LN) { rm[i] = g.rmean[mrow[i]]; rr[i] = g.rrstd[mrow[i]]; }
-  }
+  for (int i = 0; i < 4; ++i) mrow[i] = min(m0 + i * 32 + li, g.M - 1);
   f32x4 rv[2][8];
   auto fetch_rows = [&](int i, f32x4 (&dst)[8]) {
+    rm[i & 1] = 0.f; rr[i & 1] = 1.f;
+    if constexpr (RESID_LN) { rm[i & 1] = g.rmean[mrow[i]]; rr[i & 1] = g.rrstd[mrow[i]]; }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) dst[j * 4 + gq] = *reinterpret_cast<const f32x4*>(rsrc + mrow[i] * BN + wave * 64 + j * 32 + 8 * gq + 4 * h);
+      for (int gq = 0; gq < 4; ++gq) dst[j * 4 + gq] = *reinterpret_cast<const f32x4*>(rsrc + (long)mrow[i] * BN + wave * 64 + j * 32 + 8 * gq + 4 * h);
   };
   fetch_rows(0, rv[0]);
   __syncthreads();                                          // cvec visible
@@ -692,7 +768,7 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
         if constexpr (RESID_LN) {
           const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + n), be = *reinterpret_cast<const f32x4*>(cvec + BN + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = (r[e] - rm[i]) * rr[i] * ga[e] + be[e];
+          for (int e = 0; e < 4; ++e) r[e] = (r[e] - rm[i & 1]) * rr[i & 1] * ga[e] + be[e];
         }
         const f32x4 bi = *reinterpret_cast<const f32x4*>(cvec + 2 * BN + n);
 #pragma unroll
@@ -740,8 +816,7 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   LdsPtr sf = smem + LnEpi<NWN>::STRIPS + wave * LnEpi<NWN>::WAVE, st = sf + 32 * 272;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long m_row = (long)m0 + i * 32 + li;
-    const bool mvalid = m_row < g.M;
+    const bool mvalid = m0 + i * 32 + li < g.M;
     const long m = mrow[i];
     if (mvalid && wave == 0 && h == 0) { g.mean[m] = mean[i]; g.rstd[m] = rstd[i]; }
 #pragma unroll
@@ -1084,6 +1159,17 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   const int nk = g.K / BK;
   stage(0, 0);
   __syncthreads();
+#if PFN_GEMM_FRAG_PIPE
+  NtFrags f0, f1;
+  nt_load_frags<RB>(f0, smem, smem + TILE_A, li, wave * 64 + li, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const lds_char* ta = smem + cur * STAGE;
+    const lds_char* tan = smem + (cur ^ 1) * STAGE;
+    nt_contract_stage<RB, BK>(acc, f0, f1, ta, ta + TILE_A, tan, tan + TILE_A, li, wave * 64 + li);
+  }
+#else
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
@@ -1103,6 +1189,7 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
     }
     __syncthreads();
   }
+#endif
 
   // ---- epilogue ----
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -1732,6 +1819,78 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
   };
   static_assert(TNB_NS <= 6, "wait_stage cases");
   // the main loop exists twice (with / without the bias-gradient MFMA) so neither carries a branch
+#if PFN_GEMM_FRAG_PIPE
+  // Software-pipelined (round 5, as nt_contract_stage): the transposed fragments of step s + 1 are requested before the MFMAs of step s, and the first
+  // step of stage t + 1 right behind that stage's barrier, ahead of the last MFMAs of stage t.  The plain loop waited out an LDS round trip per step.
+  static_assert(TNB_KT == 64 || TNB_KT == 32, "two fragment sets alternate over an even number of 16-token steps");
+  auto main_loop = [&](auto with_colsum) {
+    constexpr bool CS = decltype(with_colsum)::value;
+    struct TnFrags { Frag<bf16> a[4], b[2], c; };
+    TnFrags f0, f1;
+    auto ld = [&](TnFrags& f, const lds_char* ta, const lds_char* tb, int ks) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) f.b[j] = load_frag_tr<bf16, 512, 1>(tb, ks, wq * 64 + j * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.a[i] = load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + i * 32);
+      // bias gradient: Q wave wq sums the columns of P sub-tile wq (one more fragment read, one more MFMA)
+      if constexpr (CS) f.c = load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + wq * 32);
+    };
+    auto mm = [&](const TnFrags& f) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(f.a[i], f.b[j], acc[i][j]);
+      if constexpr (CS) cs = mma32(f.c, ones, cs);
+    };
+    // stage t has landed for every wave (and every read of the slot it is about to overwrite has retired: wait_vm_barrier waits lgkmcnt(0));
+    // request stage t + TNB_NS - 1 into that slot; clear the rows past the end of a ragged last stage
+    auto enter_stage = [&](int t, int slot, int slot_next) {
+      wait_stage(min(nt - t - 1, TNB_NS - 2));
+      if (t + TNB_NS - 1 < nt) stage(slot_next, (t + TNB_NS - 1) * TNB_KT);
+      const int valid = rows_total - t * TNB_KT;
+      if (valid < TNB_KT) {
+        // (the DMA clamped its source rows.  A only: a zero A row contributes nothing whatever B holds there, and B's clamped rows are finite data)
+        LdsPtr ta = smem + slot * 2 * TNB_TILE;
+        for (int idx = threadIdx.x; idx < (TNB_KT - valid) * 32; idx += 512) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          lds_write16(ta + (valid + idx / 32) * 512 + (idx % 32) * 16, z);
+        }
+        __syncthreads();
+      }
+    };
+    int slot = 0, slot_next = TNB_NS - 1;
+    enter_stage(0, slot, slot_next);
+    ld(f0, smem, smem + TNB_TILE, 0);
+    for (int t = 0; t < nt; ++t) {
+      const lds_char* ta = smem + slot * 2 * TNB_TILE;
+      const lds_char* tb = ta + TNB_TILE;
+      ld(f1, ta, tb, 16);
+      PFN_PIN_LDS_MFMA();
+      mm(f0);
+      PFN_PIN_LDS_MFMA();
+      if constexpr (TNB_KT == 64) {
+        ld(f0, ta, tb, 32);
+        PFN_PIN_LDS_MFMA();
+        mm(f1);
+        PFN_PIN_LDS_MFMA();
+        ld(f1, ta, tb, 48);
+        PFN_PIN_LDS_MFMA();
+        mm(f0);
+        PFN_PIN_LDS_MFMA();
+      }
+      slot_next = slot;
+      slot = slot + 1 == TNB_NS ? 0 : slot + 1;
+      if (t + 1 < nt) {
+        enter_stage(t + 1, slot, slot_next);
+        const lds_char* tan = smem + slot * 2 * TNB_TILE;
+        ld(f0, tan, tan + TNB_TILE, 0);
+      }
+      PFN_PIN_LDS_MFMA();
+      mm(f1);
+      PFN_PIN_LDS_MFMA();
+    }
+  };
+#else
   auto main_loop = [&](auto with_colsum) {
     constexpr bool CS = decltype(with_colsum)::value;
     int slot = 0, slot_next = TNB_NS - 1;
@@ -1768,6 +1927,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
       slot = slot + 1 == TNB_NS ? 0 : slot + 1;
     }
   };
+#endif
   if (do_colsum) main_loop(std::true_type{});
   else main_loop(std::false_type{});
 
