@@ -38,6 +38,8 @@ tot = {}
 for name, N, K, flags, cnt in cases:
     K = a.k or K
     A, B = r(M, K), r(N, K)
+    if os.environ.get('PFN_A_RESIDENT') == '1':      # experiment: every row of A is the same 2-3 KB (row stride 0): the A operand stream hits in cache instead of coming from HBM
+        A = A[:1].expand(M, K)
     kw = {}
     if flags & H.EPI_BIAS: kw['bias'] = f(N)
     if flags & H.EPI_RESID: kw['resid'] = f(M, N)

@@ -13,6 +13,8 @@ M, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 16) * 2000, 512
 dev = torch.device('cuda'); bf = torch.bfloat16
 for K in (512, 1024):
     A, B = (torch.randn(M, K, device=dev) * .5).to(bf), (torch.randn(N, K, device=dev) * .1).to(bf)
+    if os.environ.get('PFN_A_RESIDENT') == '1':      # experiment: every row of A is the same 2-3 KB (row stride 0): the A operand stream hits in cache instead of coming from HBM
+        A = A[:1].expand(M, K)
     bias, gamma, beta = torch.randn(N, device=dev), torch.randn(N, device=dev) + 1, torch.randn(N, device=dev)
     resid = torch.randn(M, N, device=dev)
     bufs = (torch.empty(M + 2, N, device=dev), torch.empty(M, N, dtype=bf, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev))

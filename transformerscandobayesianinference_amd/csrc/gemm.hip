@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 // MFMA time).  Here the fragments of step s + 1 are requested BEFORE the MFMAs of step s (two register sets, PFN_PIN_LDS_MFMA keeps the
 // machine scheduler from sinking the reads back to their consumers; the waits become counted lgkmcnt), and the first step of the NEXT
 // stage is requested right behind the stage barrier, ahead of the last step's MFMAs.
-// MEASURED (profiles/r05_gemm_fragment_pipelining.txt, same-box A/B): 0-5 % slower alone and -1.7 % in the step -- the second wave of each SIMD already covered the
+// MEASURED (profiles/r05_gemm_experiments.txt, same-box A/B): 0-5 % slower alone and -1.7 % in the step -- the second wave of each SIMD already covered the
 // LDS round trips; the stage time is set by the operand stream into LDS.  So the plain loop stays the default; -DPFN_GEMM_FRAG_PIPE=1 builds this form.
 // ---------------------------------------------------------------------------------------------
 #ifndef PFN_GEMM_FRAG_PIPE
