@@ -85,7 +85,8 @@ const char* pfn_last_error_string(void);
  * while no call is in flight).  Keys 2, 5 and 6 do not act on calls directly: they change what pfn_default_schedule() hands to NEW
  * descriptors (pfn_model_desc::schedule), so a forward / backward pair can never disagree about them.
  * PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
- * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one.
+ * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one, 4 the 256x256 tile fed by a ring of four 32-deep stages
+ * (gemm_nt_ring_kernel: round-5 experiment).
  * PFN_TUNE_FUSE_LNBWD: 1 (default) the stack backward runs LayerNorm backward inside the data-gradient GEMMs that feed it
  * (pfn_op_gemm_lnbwd), 0 as separate kernels.  PFN_TUNE_GEMM_PERSIST: > 0 runs the 256x256 NT GEMM as that many persistent
  * workgroups walking tiles (gemm_nt_persist_kernel; measured, off by default). */

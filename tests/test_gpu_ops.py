@@ -94,7 +94,7 @@ def test_gemm_nt_epilogues(prec):
     assert relerr(out, base + 1.0) < 2e-6
 
 
-@pytest.fixture(params=[2, 3], ids=['256x256', '128x256'])
+@pytest.fixture(params=[2, 3, 4], ids=['256x256', '128x256', '256x256-ring'])
 def big_gemm(request):
     """Force one of the LDS-DMA NT kernels (pfn_set_tuning) for the duration of a test."""
     _hip.check(_hip.lib().pfn_set_tuning(0, request.param), 'pfn_set_tuning')

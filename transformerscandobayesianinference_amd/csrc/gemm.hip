@@ -518,6 +518,95 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_nt_ring_kernel (round 5 experiment, PFN_TUNE_GEMM_NT_KERNEL = 4): the 256 x 256 tile with its operand stream as a RING of four 32-deep stages
+// (4 x 32 KiB = the same 128 KiB as two 64-deep stages), three of them in flight under the one being multiplied.  The big kernel has ONE stage in flight and ends
+// every stage with vmcnt(0) + barrier: a stage can then never take less than the round trip of its own 64 KiB (issue -> last piece landed), whatever the matrix
+// pipe could do with it.  Here stage t + 3 is requested when stage t is entered and the wait for stage t is vmcnt(pieces of the two younger stages): the stream
+// is bound by its RATE, not by a round trip per stage.  All operand traffic is LDS-DMA from assembly, every barrier a raw s_barrier behind its own s_waitcnt
+// (wait_vm_barrier), as in gemm_tn_big_kernel.  Price: a barrier and a fragment restart every 32 of K instead of every 64.
+// ---------------------------------------------------------------------------------------------
+constexpr int RING_NS = 4;
+template <int FLAGS>
+__global__ __launch_bounds__(512, 1) void gemm_nt_ring_kernel(GemmNT g) {
+  using C = BigCfg<2, 32>;
+  static_assert(RING_NS * C::STAGE >= BigEpi<2>::BYTES, "epilogue staging must fit the (dead) ring");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  const int tiles_n = (g.N + C::BN - 1) / C::BN;
+  const int tiles_m = (g.M + C::BM - 1) / C::BM;
+  const int tid_lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tid_lin / tiles_n, tn = tid_lin % tiles_n;
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31;
+
+  const bf16* pa[C::PA];
+  const bf16* pb[C::PB];
+#pragma unroll
+  for (int i = 0; i < C::PA; ++i) {
+    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
+    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + swz16<C::RB>(row, lane % C::CPR) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < C::PB; ++i) {
+    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
+    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)min(n0 + row, g.N - 1) * g.ldb + swz16<C::RB>(row, lane % C::CPR) * 8;
+  }
+  auto stage = [&](int slot, int k0) {
+    LdsPtr ta = smem + slot * C::STAGE + wave * 1024;
+    LdsPtr tb = smem + slot * C::STAGE + C::TILE_A + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < C::PA; ++i) dma16_global(pa[i] + k0, ta + i * C::NW * 1024);
+#pragma unroll
+    for (int i = 0; i < C::PB; ++i) dma16_global(pb[i] + k0, tb + i * C::NW * 1024);
+  };
+  constexpr int PIECES = C::PA + C::PB;      // DMA instructions of a wave per stage
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / 32;
+#pragma unroll
+  for (int st = 0; st < RING_NS - 1; ++st)
+    if (st < nk) stage(st, st * 32);
+  int slot = 0, slot_next = RING_NS - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed for every wave (loads retire in order: everything but the pieces of the younger stages), and every wave's reads of the slot that is
+    // about to be overwritten -- stage kt - 1's -- have retired (lgkmcnt(0) in front of the barrier)
+    switch (min(nk - kt - 1, RING_NS - 2)) {
+      case 0: wait_vm_barrier<0>(); break;
+      case 1: wait_vm_barrier<PIECES>(); break;
+      default: wait_vm_barrier<2 * PIECES>(); break;
+    }
+    if (kt + RING_NS - 1 < nk) stage(slot_next, (kt + RING_NS - 1) * 32);
+    const lds_char* ta = smem + slot * C::STAGE;
+    const lds_char* tb = ta + C::TILE_A;
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 16) {
+      Frag<bf16> fa[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, C::RB>(tb, wn * 64 + j * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, C::RB>(ta, wm * 128 + i * 32 + li, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
+    }
+    slot_next = slot;
+    slot = slot + 1 == RING_NS ? 0 : slot + 1;
+  }
+  wait_vm_barrier<0>();      // every wave is done reading the ring before the epilogue's strips go there
+  nt_big_epilogue<FLAGS, 2>(g, acc, m0, n0, wave, lane, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
 // gemm_nt_persist_kernel: the 256 x 256 kernel as ONE workgroup per CU walking tiles (t = blockIdx.x, + gridDim.x, ...).
 // A tile of a K = 512 GEMM spends 7-8 of its ~20 us in latencies that sit in series: the first stage's DMA, the epilogue's loads, the
 // stores' acknowledgements before the workgroup may retire, the next workgroup's launch (tools/bench_gemm_epi.py --k 64).  Here
@@ -1965,13 +2054,13 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int g_tn_debug_wrap = 0;
 void set_gemm_tn_debug_wrap(int rows) { g_tn_debug_wrap = rows; }
 // 0: automatic, 1: only the generic 128x128 kernel, 2: the 256x256 LDS-DMA kernel whenever legal,
-// 3: the 128x256 LDS-DMA kernel whenever legal (tests / profiling)
+// 3: the 128x256 LDS-DMA kernel whenever legal, 4: the 256x256 tile fed by a ring of four 32-deep stages (tests / profiling)
 static int g_big_mode = 0;
 void set_gemm_nt_big_mode(int mode) { g_big_mode = mode; }
 // returns 0 (generic kernel), 1 (256x256) or 2 (128x256)
 static int gemm_nt_pick(const GemmNT& g) {
   if (g_big_mode == 1 || !g.vec_ok || g.K % 64 || g.N % 4) return 0;
-  if (g_big_mode == 2) return 1;
+  if (g_big_mode == 2 || g_big_mode == 4) return 1;      // (4: the 256 x 256 tile fed by a four-stage ring, gemm_nt_ring_kernel)
   if (g_big_mode == 3) return 2;
   const int ntail = g.N % BIG_BN;
   if (ntail && ntail < BIG_BN - BIG_BN / 8) return 0;   // no mostly-empty tile columns (1000 bars: the last of four is 232 wide)
@@ -1995,6 +2084,15 @@ template <int FLAGS> static bool launch_persist_t(const GemmNT& g, hipStream_t s
   hipLaunchKernelGGL((gemm_nt_persist_kernel<FLAGS>), dim3(std::min(tiles, g_nt_persist)), dim3(512), P::LDS, stream, g);
   return true;
 }
+template <int FLAGS> static bool launch_ring_t(const GemmNT& g, hipStream_t stream) {
+  using C = BigCfg<2, 32>;
+  if (g_big_mode != 4 || g.K % 32) return false;
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_ring_kernel<FLAGS>, RING_NS * C::STAGE);
+  const int tiles = ((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<FLAGS>), dim3(tiles), dim3(512), RING_NS * C::STAGE, stream, g);
+  return true;
+}
 template <int FLAGS, int NWM, int BK> static void launch_big_t(const GemmNT& g, hipStream_t stream) {
   using C = BigCfg<NWM, BK>;
   static LdsAllowance allowance;
@@ -2005,7 +2103,7 @@ template <int FLAGS, int NWM, int BK> static void launch_big_t(const GemmNT& g, 
 // the epilogue flag combinations the encoder stack uses; anything else takes the generic kernel
 static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
   switch (g.flags) {
-#define PFN_BIG_CASE(F) case (F): if (small_tile) launch_big_t<(F), 1, 32>(g, stream); else if (!launch_persist_t<(F)>(g, stream)) launch_big_t<(F), 2, 64>(g, stream); return true;
+#define PFN_BIG_CASE(F) case (F): if (small_tile) launch_big_t<(F), 1, 32>(g, stream); else if (!launch_ring_t<(F)>(g, stream) && !launch_persist_t<(F)>(g, stream)) launch_big_t<(F), 2, 64>(g, stream); return true;
     PFN_BIG_CASE(EPI_BIAS | EPI_OUT_T)                            // q/k/v projection
     PFN_BIG_CASE(EPI_BIAS | EPI_RESID | EPI_OUT_F32)              // out_proj, linear2 (+ residual)
     PFN_BIG_CASE(EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T)    // linear1 + GELU
