@@ -46,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK = 2.5e15     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default command (tools/profile_bench.sh)
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default command (tools/profile_bench.sh)
 TRAINED = os.path.join(ROOT, 'profiles', 'r03_trained_config2.json')
 
 # BASELINE.json configs (index = position in the list; 3 is configs[1] on 8 GPUs)
