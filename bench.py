@@ -641,7 +641,7 @@ def read_profile():
 
 
 def run_config(config, device, rank, world, precision, batch=None, streams=None, steps=20, warmup=5, aggregate_k=1, fixed_sep=None, prefetch_group=None,
-               profile_steps=0, aggregate_streams=0):
+               profile_steps=0, aggregate_streams=0, aggregate_stacked=False):
     """One benchmark run of a BASELINE.json configuration: builds criterion, model, optimizer and the prior's loader, runs `warmup` untimed and
     `steps` timed OPTIMIZER steps (each = `aggregate_k` batches of `batch` datasets per rank: forward + loss + backward per batch, gradients
     summed, then [all-reduce +] clip + Adam -- reference train.py:66-97) between barrier + synchronize on both sides, max over ranks.
@@ -686,7 +686,22 @@ def run_config(config, device, rank, world, precision, batch=None, streams=None,
                              f'GPU(s) are visible -- a multi-GPU number over a host-side backend would not be a measurement of this design')
         reducer = dp.OverlappedGradientReducer(model)
 
+    stacked = aggregate_stacked and aggregate_k > 1 and micro.can_stack(model)
+
     def step(batches):
+        if stacked:      # the batches of the optimizer step as one launch set per micro-batch stream, every dataset with its own eval position (streams.py)
+            stack = []
+            for k in range(aggregate_k):
+                sep = fixed_sep if fixed_sep is not None else sampler()
+                seps.append(sep)
+                (x, y), target = next(batches)
+                stack.append(((x, y), target, sep))
+            outs = micro.forward_backward_batches(model, stack, lambda out, tg, sep: loss_fn(out, tg[sep:]),
+                                                  before=(lambda n: reducer.arm(n)) if reducer is not None else None)
+            if reducer is not None:
+                reducer.finish()
+            opt.step(zero_grad=True)
+            return outs[-1].mean()
         for k in range(aggregate_k):       # reference train.py:92-97: micro-batch gradients are summed, one optimizer step per aggregate_k batches
             sep = fixed_sep if fixed_sep is not None else sampler()
             seps.append(sep)
@@ -847,7 +862,7 @@ def compact_line(result):
     CPU baseline, parity details) lives in `bench_detail.json` next to this script, whose path the line names."""
     line = _pick(result, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'))
     cfg = result['config']
-    line['config'] = _pick(cfg, ('workload', 'baseline_config', 'per_gpu_batch', 'global_batch', 'aggregate_k_gradients', 'aggregate_streams', 'seq_len', 'parallelism',
+    line['config'] = _pick(cfg, ('workload', 'baseline_config', 'per_gpu_batch', 'global_batch', 'aggregate_k_gradients', 'aggregate_streams', 'aggregate_stacked', 'seq_len', 'parallelism',
                                  'micro_batch_streams', 'eval_pos', 'mean_sep', 'final_loss', 'tuning', 'library_variant'))
     line['step_roofline'] = _pick(result['step_roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'reference_graph_frac'))
     if 'roofline' in result:
@@ -866,7 +881,7 @@ def compact_line(result):
     for name, e in result.get('other_configs', {}).items():
         line.setdefault('other_configs', {})[name] = dict(value=e['value'], ms_per_step=e['ms_per_step'], per_gpu_batch=e['per_gpu_batch'], frac=e['step_roofline']['frac'])
     if 'batch_sweep' in result:
-        line['batch_sweep'] = [dict(b=e['per_gpu_batch'], k=e['aggregate_k_gradients'], schedule=e['schedule'], value=e['value']) for e in result['batch_sweep']]
+        line['batch_sweep'] = [dict(b=e['per_gpu_batch'], k=e['aggregate_k_gradients'], schedule=e['schedule'].split(' (')[0], value=e['value']) for e in result['batch_sweep']]
     for k in ('ranks_seen', 'per_rank_ms_per_step', 'allreduce_ms', 'allreduce_bytes', 'collective_backend', 'devices_visible', 'ranks_share_device'):
         if k in result:
             line[k] = result[k]
@@ -907,6 +922,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='datasets per GPU per batch (default: per configuration)')
     ap.add_argument('--aggregate-k', type=int, default=1, help='batches per optimizer step (train()\'s aggregate_k_gradients)')
     ap.add_argument('--aggregate-streams', type=int, default=0, help='> 1: the aggregate_k batches of a step run whole, round-robin on that many streams (small batches)')
+    ap.add_argument('--aggregate-stacked', action='store_true', help='the aggregate_k batches of a step stacked into one launch set per micro-batch stream, every dataset with its own eval position (what train() picks for small batches since round 5)')
     ap.add_argument('--streams', type=int, default=None, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -934,7 +950,7 @@ def main():
         _hip.check(_hip.lib().pfn_set_tuning(k, v), 'pfn_set_tuning')
     t_start = time.time()
     r = run_config(args.config, device, rank, world, args.precision, batch=args.batch, streams=args.streams, steps=args.steps, warmup=args.warmup,
-                   aggregate_k=args.aggregate_k, fixed_sep=args.fixed_sep, prefetch_group=args.prefetch_group, aggregate_streams=args.aggregate_streams,
+                   aggregate_k=args.aggregate_k, fixed_sep=args.fixed_sep, prefetch_group=args.prefetch_group, aggregate_streams=args.aggregate_streams, aggregate_stacked=args.aggregate_stacked,
                    profile_steps=0 if (world > 1 or args.no_kernel_breakdown) else 5)
     if rank != 0:
         return
@@ -948,7 +964,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
         'config': {'workload': w['workload'], 'baseline_config': args.config,
-                   'per_gpu_batch': batch, 'global_batch': batch * world, 'aggregate_k_gradients': args.aggregate_k, 'aggregate_streams': args.aggregate_streams, 'seq_len': S, 'parallelism': f'dp{world}',
+                   'per_gpu_batch': batch, 'global_batch': batch * world, 'aggregate_k_gradients': args.aggregate_k, 'aggregate_streams': args.aggregate_streams, 'aggregate_stacked': bool(args.aggregate_stacked), 'seq_len': S, 'parallelism': f'dp{world}',
                    'micro_batch_streams': streams,
                    'eval_pos': f"{w['eval_pos']} sampler({S})" if args.fixed_sep is None else args.fixed_sep, 'mean_sep': sum(seps) / len(seps),
                    'sampler_group_steps': r['group'], 'final_loss': r['final_loss']},
@@ -1067,12 +1083,12 @@ def main():
         result['batch_sweep'] = []
         # (schedule: `alternating` = the batches of one optimizer step whole, round-robin on that many streams -- what train() picks for small batches;
         # `column groups` = every batch split over the two micro-batch streams, what the large batches use)
-        for b, k, st, alt_streams in ((4, 25, 3, 8), (4, 25, 3, 0), (8, 1, 10, 0), (16, 1, 10, 0), (32, 1, 10, 0)):
+        for b, k, st, alt_streams in ((4, 25, 3, -1), (4, 25, 3, 8), (4, 25, 3, 0), (8, 1, 10, 0), (16, 1, 10, 0), (32, 1, 10, 0)):      # (-1: the stacked schedule)
             t0 = time.time()
-            rb = run_config(2, device, 0, 1, args.precision, batch=b, aggregate_k=k, steps=st, warmup=2, aggregate_streams=alt_streams)
+            rb = run_config(2, device, 0, 1, args.precision, batch=b, aggregate_k=k, steps=st, warmup=2, aggregate_streams=max(alt_streams, 0), aggregate_stacked=alt_streams < 0)
             tb = throughput_fields(rb, 1)
             result['batch_sweep'].append(dict(per_gpu_batch=b, aggregate_k_gradients=k, datasets_per_optimizer_step=b * k,
-                                              schedule=f'alternating x {alt_streams}' if alt_streams else f"column groups x {rb['micro_groups']}",
+                                              schedule='stacked (one launch set per stream, per-dataset eval positions)' if alt_streams < 0 else f'alternating x {alt_streams}' if alt_streams else f"column groups x {rb['micro_groups']}",
                                               value=tb['value'], unit='datasets/s', ms_per_optimizer_step=tb['ms_per_step'], steps=st,
                                               step_roofline_frac=tb['frac'], seconds=time.time() - t0))
             release(rb)

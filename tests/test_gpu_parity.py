@@ -1325,8 +1325,8 @@ def test_trained_head_dim_256_inference_parity():
             within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 2.6e-3)
 
 
-@pytest.mark.parametrize('precision,aggregate_streams', [('f32', 0), ('bf16', 0), ('f32', 2)])
-def test_training_loop_vs_reference_train_golden(precision, aggregate_streams):
+@pytest.mark.parametrize('precision,aggregate_streams,aggregate_stacked', [('f32', 0, False), ('bf16', 0, False), ('f32', 2, False), ('f32', 0, True), ('bf16', 0, True)])
+def test_training_loop_vs_reference_train_golden(precision, aggregate_streams, aggregate_stacked):
     """The training loop pinned to the reference's OWN `train.train` (train.py:58-110,134; utils.py:10-22):
     tests/golden/train_loop_small.pt = recorded batches + recorded eval positions + what the reference's loop made of them (4 epochs x 8
     batches, aggregate_k_gradients 2, per-epoch cosine schedule whose first epoch runs at lr 0; oracle/make_golden.py::train_loop_case).
@@ -1336,9 +1336,10 @@ def test_training_loop_vs_reference_train_golden(precision, aggregate_streams):
     from transformerscandobayesianinference_amd import train as train_mod, utils
     rec = torch.load(os.path.join(GOLD, 'train_loop_small.pt'))
     losses, lrs, total, final = replay.replay(train_mod.train, rec, bar_distribution.FullSupportBarDistribution, encoders, utils.get_cosine_schedule_with_warmup,
-                                              gpu_device=DEV, precision=precision, micro_streams=1, aggregate_streams=aggregate_streams)
-    # (aggregate_streams = 2: the two batches of every optimizer step run whole on alternating HIP streams -- streams.py forward_backward_on, train()'s
-    # choice for small batches -- and must reproduce the reference's sequential accumulation just the same)
+                                              gpu_device=DEV, precision=precision, micro_streams=1, aggregate_streams=aggregate_streams, aggregate_stacked=aggregate_stacked)
+    # (aggregate_streams = 2: the two batches of every optimizer step run whole on alternating HIP streams -- streams.py forward_backward_on; aggregate_stacked:
+    # the two batches stacked into ONE launch set, every dataset with its own eval position -- forward_backward_batches, train()'s choice for small batches
+    # since round 5.  Both must reproduce the reference's sequential accumulation just the same)
     cfg = rec['config']
     assert lrs == pytest.approx(rec['batch_lr'], rel=1e-12, abs=0) and lrs[0] == 0.0
     tight = precision == 'f32'
@@ -1478,14 +1479,19 @@ run = lambda r, **kw: replay.replay(train_mod.train, r, bar_distribution.FullSup
 _, _, total_dp, final_dp = run(mine, aggregate_streams=2)
 steps = cfg['epochs'] * cfg['steps_per_epoch'] // cfg['aggregate_k_gradients']
 assert seen['armed'] == steps and seen['overlapped'] == steps and seen['fallbacks'] == 0, seen
+# ... and with the two batches of a step STACKED into one launch set (per-dataset eval positions; the reducer is armed for the launch sets of the step)
+seen.update(armed=0, overlapped=0)
+_, _, total_st, final_st = run(mine, aggregate_stacked=True)
+assert seen['armed'] == steps and seen['overlapped'] == steps and seen['fallbacks'] == 0, seen
 # ... against this process alone on the whole batches (no process group: world 1)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 _, _, total_1, final_1 = run(whole, aggregate_streams=2)
 err = replay.update_error(final_dp, dict(rec, final_state_dict=final_1))
-assert err < 1e-3, err                                            # the whole parameter update over 16 optimizer steps (f32 kernels; summation order + Adam's normalisation of near-zero gradients)
-assert abs(total_dp - total_1) < 1e-5 * abs(total_1), (total_dp, total_1)     # the returned loss is the mean over ranks
-print('rank', rank, 'ok', err)
+err_st = replay.update_error(final_st, dict(rec, final_state_dict=final_1))
+assert err < 1e-3 and err_st < 1e-3, (err, err_st)                # the whole parameter update over 16 optimizer steps (f32 kernels; summation order + Adam's normalisation of near-zero gradients)
+assert abs(total_dp - total_1) < 1e-5 * abs(total_1) and abs(total_st - total_1) < 1e-5 * abs(total_1), (total_dp, total_st, total_1)     # the returned loss is the mean over ranks
+print('rank', rank, 'ok', err, err_st)
 """
 
 
@@ -1587,3 +1593,49 @@ def test_deterministic_schedule_gradients_at_a_benchmark_like_shape(precision):
     assert torch.equal(g1, g2)
     g0 = grad(build(False))
     within(f'{precision} deterministic vs default schedule: gradient rel l2', relerr(g1, g0), 1e-5 if precision == 'f32' else 5e-3)
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_forward_batches_equals_separate_forwards(precision):
+    """Round 5: `model.forward_batches` runs several micro-batches -- each with its OWN single_eval_pos, as the reference's accumulation loop
+    draws them (train.py:66-69, 92-97) -- as ONE launch set (pfn_stack_forward_ragged: per-dataset eval positions in the embedding, the three attention kernels
+    and the test-row gather / scatter).  It must return exactly the logits of the separate `model((x, y), single_eval_pos=sep)` calls, and the backward of the
+    summed per-batch mean losses must leave the gradient the sequential accumulation leaves."""
+    cfg = dict(T=300, F=5, E=128, H=2, nhid=256, L=3, nbars=40)
+    torch.manual_seed(21)
+    borders = torch.sort(torch.randn(cfg['nbars'] + 1) * 1.5)[0]
+    model = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], 0.0,
+                             y_encoder=encoders.Linear(1, cfg['E']), precision=precision, eval_precision=precision)
+    model.criterion = bar_distribution.FullSupportBarDistribution(borders)
+    with torch.no_grad():
+        for layer in model.transformer_encoder.layers:
+            layer.linear2.weight.normal_(0, 0.05); layer.self_attn.out_proj.weight.normal_(0, 0.05)
+    model = model.to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    widths, seps = [4, 1, 3, 4, 2], [257, 0, 300, 131, 299]          # incl. no train rows at all, no test rows at all, one test row
+    batches = [(torch.rand(cfg['T'], w, cfg['F'], generator=g).to(DEV), torch.randn(cfg['T'], w, generator=g).to(DEV)) for w in widths]
+    loss_of = lambda out, y, sep: model.criterion(out.reshape(-1, cfg['nbars']), y[sep:].reshape(-1)).mean() if sep < cfg['T'] else out.sum() * 0
+    # sequential accumulation, as the reference does it
+    _, grad = model.flat_parameters()
+    grad.zero_()
+    want = []
+    for (x, y), sep in zip(batches, seps):
+        out = model((x, y), single_eval_pos=sep)
+        want.append(out.detach().clone())
+        if sep < cfg['T']:
+            loss_of(out, y, sep).backward()
+    g_seq = grad.clone()
+    # one launch set
+    grad.zero_()
+    outs = model.forward_batches(batches, seps)
+    for got, ref, w, sep in zip(outs, want, widths, seps):
+        assert got.shape == ref.shape == (cfg['T'] - sep, w, cfg['nbars'])
+        assert torch.equal(got, ref), (sep, relerr(got, ref) if ref.numel() else 0)
+    sum(loss_of(o, y, sep) for o, (_, y), sep in zip(outs, batches, seps) if sep < cfg['T']).backward()
+    within(f'{precision} stacked vs sequential accumulation: gradient rel l2', relerr(grad, g_seq), 1e-5 if precision == 'f32' else 5e-3)
+    # and the inference pass (eval mode, no_grad) takes the same route
+    model.eval()
+    with torch.no_grad():
+        outs_e = model.forward_batches(batches, seps)
+        for got, (x, y), sep in zip(outs_e, batches, seps):
+            assert torch.equal(got, model((x, y), single_eval_pos=sep))

@@ -224,7 +224,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   const int qi = wg.blk * C::QBLK + wave * 32 + li;
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
-  const int sep = a.sep;
+  const int sep = a.sep_of ? a.sep_of[b] : a.sep;      // (wave-uniform: b comes from the block index)
   const float scale_log2 = rsqrtf((float)D) * LOG2E;
   // DROP: dropout on the probabilities (pfn_device.h dropout_keep with i = query, j = key).  The normaliser (row sum, lse) is that of
   // the UNMASKED softmax -- torch drops entries of the normalised P -- so only the values fed to the P.V product are masked, and the
@@ -547,7 +547,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   auto Oc = [&](int buf) { return smem + K::VIMG + buf * K::BUF + (K::ONE ? K::RIMG : 2 * K::RIMG + K::CIMG); };
   auto St = [&](int buf) { return smem + K::VIMG + buf * K::BUF + K::IMG; };   // [lse x QB][delta x QB]
 
-  const AttnBlock wg = attn_block_ragged_last((a.sep + C::QBLK - 1) / C::QBLK, a.sep / C::QBLK, a.H);
+  // (ragged batch: the grid has ceil(max position / 256) blocks per (dataset, head); a dataset's blocks past ITS position leave at once)
+  const AttnBlock wg = a.sep_of ? attn_block((a.sep + C::QBLK - 1) / C::QBLK, a.H) : attn_block_ragged_last((a.sep + C::QBLK - 1) / C::QBLK, a.sep / C::QBLK, a.H);
   const int b = wg.b, hd = wg.hd;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
   const long rs = 3L * a.E;
@@ -557,7 +558,8 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   const T* Vp = base + 2 * a.E + hd * D;
   const T* dOp = reinterpret_cast<const T*>(a.dctx) + (long)b * a.S * a.E + hd * D;
   T* dbase = reinterpret_cast<T*>(a.dqkv) + (long)b * a.S * rs;
-  const int sep = a.sep;
+  const int sep = a.sep_of ? a.sep_of[b] : a.sep;
+  if (wg.blk * C::QBLK >= sep) return;      // (only in a ragged batch; uniform over the workgroup, ahead of every barrier)
   const int lip = K::ONE ? kv_row_perm(li) : li;      // the LDS row of the Q / dO tiles this lane reads along (query li of the tile)
   const bool lag = K::NBUF == 3 && (a.pingpong & 2) && wave >= 4;      // ping-pong (BwdKvCfg::NBUF): this wave takes its barrier in the middle of the tile
   const int key0 = wg.blk * C::QBLK;
@@ -972,7 +974,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   const int qi = q0 + wave * 32 + li;
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
-  const int sep = a.sep;
+  const int sep = a.sep_of ? a.sep_of[b] : a.sep;
   const float scale = rsqrtf((float)D);
   const float scale_log2 = scale * LOG2E;
   f32x16 dq[C::NDB];
@@ -1230,13 +1232,15 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_kv_kernel(AttnArgs a) {
   const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
   const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
   const int key0 = kb * P::TB, t = threadIdx.x, r1 = t >> 3, c1 = (t & 7) * 4;
+  const int sep = a.sep_of ? a.sep_of[b] : a.sep;
+  if (key0 >= sep) return;      // (ragged batch: the grid covers the largest position)
   const float scale = rsqrtf((float)D), scale_log2 = scale * LOG2E;
   // dropout on the probabilities (as in attn_bwd_kv_kernel): dV takes P' = P keep / (1 - p), dP = (dO V^T) keep / (1 - p), dS = P (dP - delta) with the unmasked P
   const bool drop = a.p_drop > 0.f;
   const unsigned dseed = dropout_pair_seed(a.drop_seed, b * a.H + hd), dthr = dropout_threshold(a.p_drop);
   const float dscale = drop ? 1.f / (1.f - a.p_drop) : 1.f;
-  plain_load_tile<D>(Ks, Kp, rs, key0, 0, a.sep);
-  plain_load_tile<D>(Vs, Vp, rs, key0, 0, a.sep);
+  plain_load_tile<D>(Ks, Kp, rs, key0, 0, sep);
+  plain_load_tile<D>(Vs, Vp, rs, key0, 0, sep);
   f32x4 dk[D / 32], dv[D / 32];
 #pragma unroll
   for (int m = 0; m < D / 32; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1252,7 +1256,7 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_kv_kernel(AttnArgs a) {
       const int q = q0 + r1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool live = q >= a.q_begin && q < a.S && key0 + c1 + j < a.sep;
+        const bool live = q >= a.q_begin && q < a.S && key0 + c1 + j < sep;
         const float p = live ? fast_exp2(s[j] * scale_log2 - Ls[r1]) : 0.f;
         const float mf = !drop ? 1.f : dropout_keep(dseed, (unsigned)q, (unsigned)(key0 + c1 + j), dthr) ? dscale : 0.f;
         Ps[r1 * P::PS + c1 + j] = p * mf;
@@ -1271,7 +1275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_kv_kernel(AttnArgs a) {
     }
   }
   const int key = key0 + r1;
-  if (key < a.sep) {
+  if (key < sep) {
 #pragma unroll
     for (int m = 0; m < D / 32; ++m) {
       f32x4 k4;
@@ -1300,6 +1304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_dq_kernel(AttnArgs a) {
   const float* lse_g = a.lse + ((long)b * a.H + hd) * a.S;
   const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
   const int q0 = qb * P::TB, t = threadIdx.x, r1 = t >> 3, c1 = (t & 7) * 4;
+  const int sep = a.sep_of ? a.sep_of[b] : a.sep;
   const float scale = rsqrtf((float)D), scale_log2 = scale * LOG2E;
   const bool drop = a.p_drop > 0.f;
   const unsigned dseed = dropout_pair_seed(a.drop_seed, b * a.H + hd), dthr = dropout_threshold(a.p_drop);
@@ -1312,17 +1317,17 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_dq_kernel(AttnArgs a) {
   for (int m = 0; m < D / 32; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int q = q0 + r1;
   const bool qlive = q >= a.q_begin && q < a.S;
-  for (int key0 = 0; key0 < a.sep; key0 += P::TB) {
+  for (int key0 = 0; key0 < sep; key0 += P::TB) {
     __syncthreads();
-    plain_load_tile<D>(Ks, Kp, rs, key0, 0, a.sep);
-    plain_load_tile<D>(Vs, Vp, rs, key0, 0, a.sep);
+    plain_load_tile<D>(Ks, Kp, rs, key0, 0, sep);
+    plain_load_tile<D>(Vs, Vp, rs, key0, 0, sep);
     __syncthreads();
     {
       float s[4], dp[4];
       plain_dots<D>(Qs + r1 * P::RS, Os + r1 * P::RS, Ks, Vs, c1, s, dp);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool live = qlive && key0 + c1 + j < a.sep;
+        const bool live = qlive && key0 + c1 + j < sep;
         const float p = live ? fast_exp2(s[j] * scale_log2 - Ls[r1]) : 0.f;
         const float mf = !drop ? 1.f : dropout_keep(dseed, (unsigned)q, (unsigned)(key0 + c1 + j), dthr) ? dscale : 0.f;
         Ds[r1 * P::PS + c1 + j] = p * (mf * dp[j] - Dl[r1]);
@@ -1342,7 +1347,7 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_dq_kernel(AttnArgs a) {
   // ---- the self key of a test row (i >= sep), as in attn_bwd_dq_kernel: p_i = exp(q_i.k_i scale - lse_i), ds_i = p_i (dO_i.v_i - delta_i),
   //      dQ_i += ds_i k_i,  dK_i = scale ds_i q_i,  dV_i = p_i dO_i.  The 8 threads of a row hold partial dots over their columns.
   __syncthreads();                                     // (sep == 0: the Q / dO tiles and Ls / Dl written above)
-  const bool test = qlive && q >= a.sep;
+  const bool test = qlive && q >= sep;
   const int qc = min(max(q, 0), a.S - 1);
   float tq = 0.f, dpv = 0.f;
   f32x4 kself[D / 32], vself[D / 32];

@@ -147,6 +147,10 @@ struct Ws {
   int64_t bytes;
 };
 
+// A ragged batch (round 5; pfn_stack_forward_ragged / pfn_stack_backward_ragged): the micro-batches of one optimizer step as ONE launch set, each dataset with its
+// own eval position.  sep_of [B] int32 and row_off [B + 1] int64 live on the device; row_off[b] = first compact test row of dataset b, row_off[B] = test_rows.
+struct Ragged { const int32_t* sep_of; const int64_t* row_off; int64_t test_rows; };
+
 Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   Ws w;
   const int64_t M = (int64_t)B * S, E = d.emsize, F = d.nhid, es = esize(d.precision);
@@ -307,7 +311,7 @@ int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shado
 static int stack_forward_impl(const pfn_model_desc* d, const float* params, const void* shadow,
                               const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
                               const float* src_sbe, int B, int S, int sep, void* workspace, int64_t workspace_bytes,
-                              float* logits, void* stream, bool use_dropout, uint64_t dropout_seed);
+                              float* logits, void* stream, bool use_dropout, uint64_t dropout_seed, const Ragged* rg = nullptr);
 int pfn_stack_forward(const pfn_model_desc* d, const float* params, const void* shadow,
                       const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
                       const float* src_sbe, int B, int S, int sep, void* workspace, int64_t workspace_bytes,
@@ -323,7 +327,7 @@ int pfn_stack_forward_dropout(const pfn_model_desc* d, const float* params, cons
 static int stack_forward_impl(const pfn_model_desc* d, const float* params, const void* shadow,
                               const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
                               const float* src_sbe, int B, int S, int sep, void* workspace, int64_t workspace_bytes,
-                              float* logits, void* stream, bool use_dropout, uint64_t dropout_seed) {
+                              float* logits, void* stream, bool use_dropout, uint64_t dropout_seed, const Ragged* rg) {
   PFN_TRY(check_desc(d));
   const float pdrop = use_dropout ? d->dropout : 0.f;     // > 0: TransformerEncoderLayer's four dropout sites are live (training)
   auto dseed = [&](int layer, int site) { return dropout_site_seed(dropout_seed, layer, site); };
@@ -337,7 +341,11 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   Layout L = make_layout(*d);
   Ws w = carve(*d, B, S, (char*)workspace);
   if (workspace_bytes < w.bytes) return fail(PFN_ERR_ARGUMENT, "workspace too small: %lld < %lld", (long long)workspace_bytes, (long long)w.bytes);
-  const int M = B * S, Mt = (S - sep) * B;
+  // ragged batch (pfn_stack_forward_ragged): every dataset has its own eval position (rg->sep_of, device), `sep` is their maximum, the decoder's compact
+  // rows are dataset-major (rg->row_off) and there are rg->test_rows of them; the top layer then runs on every row
+  const int* sep_of = rg ? rg->sep_of : nullptr;
+  if (rg && (src_sbe || rg->test_rows < 0 || rg->test_rows > (int64_t)B * S || !rg->sep_of || !rg->row_off)) return fail(PFN_ERR_ARGUMENT, "bad ragged-batch arguments");
+  const int M = B * S, Mt = rg ? (int)rg->test_rows : (S - sep) * B;
   const char* sh = (const char*)shadow;
   auto W = [&](int64_t off) { return (const void*)(sh + off * es); };
 
@@ -347,7 +355,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
     EmbedArgs e;
     e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;
     e.wx = params + L.enc_w; e.bx = params + L.enc_b; e.wy = params + L.yenc_w; e.by = params + L.yenc_b;
-    e.out_f32 = w.x0; e.out_t = w.x0_t; e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep;
+    e.out_f32 = w.x0; e.out_t = w.x0_t; e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep; e.sep_of = sep_of;
     e.xaug_t = d->num_features + 2 <= EMB_AUG ? w.xaug_t : nullptr;
     PFN_TRY(launch_embed_fwd(e, prec, s));
   }
@@ -366,7 +374,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   auto set_resid = [](GemmLN& g, const Resid& r) {
     g.resid = r.plain; g.ry = r.y; g.rmean = r.mean; g.rrstd = r.rstd; g.rgamma = r.gamma; g.rbeta = r.beta;
   };
-  const bool top_mode = top_layer_on_test_rows(*d, S, sep, pdrop);
+  const bool top_mode = !rg && top_layer_on_test_rows(*d, S, sep, pdrop);
   for (int l = 0; l < d->nlayers; ++l) {
     const LayerP& p = L.layer[l];
     LayerWs& a = w.layer[l];
@@ -380,7 +388,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
     }
     {
       AttnArgs at; memset(&at, 0, sizeof(at));
-      at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
+      at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep; at.sep_of = sep_of;
       at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
       at.q_begin = top ? sep : 0;
       PFN_TRY(launch_attn_fwd(at, prec, s));
@@ -453,9 +461,11 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   // output went straight to the caller when there is no decoder)
   if (Mt > 0 && O == 0) {
     // no decoder (a custom decoder module runs in PyTorch, reference transformer.py:23): hand out the test rows [Mt, E] in f32
-    if (!top_mode) PFN_TRY(launch_gather_test_rows(xin, logits, S, B, E, sep, PFN_PREC_F32, s));
+    if (rg) PFN_TRY(launch_gather_test_rows_ragged(xin, logits, S, B, E, rg->sep_of, (const long*)rg->row_off, PFN_PREC_F32, s));
+    else if (!top_mode) PFN_TRY(launch_gather_test_rows(xin, logits, S, B, E, sep, PFN_PREC_F32, s));
   } else if (Mt > 0) {
-    if (!top_mode) PFN_TRY(launch_gather_test_rows(xin, w.xt_t, S, B, E, sep, prec, s));
+    if (rg) PFN_TRY(launch_gather_test_rows_ragged(xin, w.xt_t, S, B, E, rg->sep_of, (const long*)rg->row_off, prec, s));
+    else if (!top_mode) PFN_TRY(launch_gather_test_rows(xin, w.xt_t, S, B, E, sep, prec, s));
     const char* xt_t = top_mode ? w.layer[d->nlayers - 1].x2_t : w.xt_t;
     {
       GemmNT g = nt(xt_t, E, W(L.dec0_w), E, Mt, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
@@ -479,14 +489,50 @@ int pfn_stack_backward(const pfn_model_desc* d, const float* params, const void*
                                   stream, 0, nullptr, nullptr, 0, 0);
 }
 
+static int stack_backward_impl(const pfn_model_desc* d, const float* params, const void* shadow,
+                               const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                               int B, int S, int sep, void* workspace, int64_t workspace_bytes,
+                               const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
+                               int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed, const Ragged* rg);
 int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const void* shadow,
                              const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
                              int B, int S, int sep, void* workspace, int64_t workspace_bytes,
                              const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
                              int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed) {
+  return stack_backward_impl(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, B, S, sep, workspace, workspace_bytes, dlogits, grads, dsrc_sbe, stream,
+                             first_group_layers, on_first_group, user, use_dropout, dropout_seed, nullptr);
+}
+// ---- the micro-batches of one optimizer step as ONE launch set (round 5): reference train.py:66-97 runs the k batches of an optimizer step one after the other, each
+// with its own single_eval_pos; a batch of 4 datasets fills a fraction of the chip, so the datasets of several batches are stacked along B here and every kernel that
+// looks at the eval position reads its dataset's own (sep_of [B], device).  Compact test rows (decoder input, logits, dlogits): dataset-major, row_off[b] + (t - sep_of[b]).
+// sep_max = max(sep_of) (grid of the attention backward's key-block pass, scratch dims); test_rows = row_off[B] = sum(S - sep_of[b]).  Fused embedding only; the top
+// encoder layer runs on every row (its compact-row schedule assumes one position).
+int pfn_stack_forward_ragged(const pfn_model_desc* d, const float* params, const void* shadow,
+                             const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                             int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_max, int64_t test_rows,
+                             void* workspace, int64_t workspace_bytes, float* logits, void* stream, int use_dropout, uint64_t dropout_seed) {
+  Ragged rg = {sep_of, row_off, test_rows};
+  return stack_forward_impl(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, nullptr, B, S, sep_max, workspace, workspace_bytes, logits, stream, use_dropout != 0, dropout_seed, &rg);
+}
+int pfn_stack_backward_ragged(const pfn_model_desc* d, const float* params, const void* shadow,
+                              const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                              int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_max, int64_t test_rows,
+                              void* workspace, int64_t workspace_bytes, const float* dlogits, float* grads, void* stream,
+                              int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed) {
+  Ragged rg = {sep_of, row_off, test_rows};
+  return stack_backward_impl(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, B, S, sep_max, workspace, workspace_bytes, dlogits, grads, nullptr, stream,
+                             first_group_layers, on_first_group, user, use_dropout, dropout_seed, &rg);
+}
+static int stack_backward_impl(const pfn_model_desc* d, const float* params, const void* shadow,
+                               const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
+                               int B, int S, int sep, void* workspace, int64_t workspace_bytes,
+                               const float* dlogits, float* grads, float* dsrc_sbe, void* stream,
+                               int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed, const Ragged* rg) {
   PFN_TRY(check_desc(d));
   const float pdrop = use_dropout ? d->dropout : 0.f;
-  const bool top_mode = top_layer_on_test_rows(*d, S, sep, pdrop);       // (the forward took the same decision: same descriptor, shape, dropout)
+  const bool top_mode = !rg && top_layer_on_test_rows(*d, S, sep, pdrop);       // (the forward took the same decision: same descriptor, shape, dropout)
+  const int* sep_of = rg ? rg->sep_of : nullptr;
+  if (rg && (dsrc_sbe || rg->test_rows < 0 || rg->test_rows > (int64_t)B * S || !rg->sep_of || !rg->row_off)) return fail(PFN_ERR_ARGUMENT, "bad ragged-batch arguments");
   // PFN_SCHED_DETERMINISTIC: one writer per gradient element and launch -- no token splits in the weight-gradient GEMMs, the LayerNorm backward as its own
   // kernel with ordered partial sums, the embedding gradient from one workgroup per column block
   const bool det = (d->schedule & PFN_SCHED_DETERMINISTIC) != 0;
@@ -501,7 +547,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
   Layout L = make_layout(*d);
   Ws w = carve(*d, B, S, (char*)workspace);
   if (workspace_bytes < w.bytes) return fail(PFN_ERR_ARGUMENT, "workspace too small");
-  const int M = B * S, Mt = (S - sep) * B, npad = L.n_out_pad;
+  const int M = B * S, Mt = rg ? (int)rg->test_rows : (S - sep) * B, npad = L.n_out_pad;
   const char* sh = (const char*)shadow;
   auto W = [&](int64_t off) { return (const void*)(sh + off * es); };
   auto WT = [&](int64_t off) { return (const void*)(sh + (L.total + off) * es); };
@@ -544,7 +590,8 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     }
   }
   // (top_mode: the top layer's backward runs on the compact test rows and takes dxt as it is)
-  if (!top_mode) PFN_TRY(launch_scatter_test_rows(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
+  if (rg) PFN_TRY(launch_scatter_test_rows_ragged(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, rg->sep_of, (const long*)rg->row_off, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
+  else if (!top_mode) PFN_TRY(launch_scatter_test_rows(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
 
   // ---- encoder layers, last to first; gA holds d(loss)/d(layer output) ----
   // Only the data-gradient chain runs here.  Each layer leaves the output-gradient operands of its four
@@ -679,7 +726,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     }
     {
       AttnArgs at; memset(&at, 0, sizeof(at));
-      at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep;
+      at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep; at.sep_of = sep_of;
       at.dctx = w.dctx_t; at.dqkv = a.dqkv_t; at.delta = w.delta; at.ds = w.ds;
       at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
       at.q_begin = top ? sep : 0;
@@ -719,7 +766,7 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
     EmbedBwdArgs e;
     e.dsrc = w.gA; e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;
     e.dwx = grads + L.enc_w; e.dbx = grads + L.enc_b; e.dwy = grads + L.yenc_w; e.dby = grads + L.yenc_b;
-    e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep; e.single_block = det ? 1 : 0;
+    e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep; e.sep_of = sep_of; e.single_block = det ? 1 : 0;
     PFN_TRY(launch_embed_bwd(e, s));
   }
   return PFN_OK;

@@ -167,6 +167,9 @@ int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream);
 struct AttnArgs {
   const void* qkv; void* ctx; float* lse;
   int B, S, E, H, sep;
+  // ragged batch (round 5): per-dataset eval positions [B] on the device; then `sep` is their maximum (grid of the key-block pass, dS^T scratch dims) and
+  // every workgroup reads its own dataset's position.  nullptr = every dataset at `sep`.
+  const int* sep_of;
   // backward
   const void* dctx; void* dqkv; float* delta;  // delta: [B,H,S] f32 scratch
   void* ds;   // dS^T scratch [B, H, ds_rows, ds_ld] T: written by the key-block pass, read by the query-block pass (attn_bwd_ds_bytes)
@@ -202,6 +205,7 @@ struct EmbedArgs {
   float* out_f32; void* out_t;
   void* xaug_t;   // optional [B*S, EMB_AUG] T: the token's features, masked y, train flag, zero padding -- the B operand of the backward's GEMM
   int S, B, nf, E, sep;
+  const int* sep_of;   // ragged batch: per-dataset eval positions [B] on the device (then `sep` is unused); nullptr = every dataset at `sep`
 };
 constexpr int EMB_AUG = 32;   // columns of xaug_t (num_features + 2 <= EMB_AUG for the GEMM form of the backward)
 int launch_embed_fwd(const EmbedArgs& a, int precision, hipStream_t s);
@@ -210,6 +214,7 @@ struct EmbedBwdArgs {
   const float* dsrc; const float* x; long x_st, x_sb; const float* y; long y_st, y_sb;
   float* dwx; float* dbx; float* dwy; float* dby;
   int S, B, nf, E, sep;
+  const int* sep_of;    // ragged batch: per-dataset eval positions [B] (nullptr = every dataset at `sep`)
   int single_block;     // 1: one workgroup per column block walks every token (one writer per gradient element: PFN_SCHED_DETERMINISTIC)
 };
 int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s);
@@ -241,6 +246,10 @@ int launch_dropout_add(float* y, const float* resid, long rows, int cols, unsign
 // dst[r, c] = keep * src[r, c] / (1 - p) in operand precision; src == dst allowed; a second pair shares the mask (h and gelu'(hpre))
 int launch_dropout_scale(const void* src, void* dst, const void* src2, void* dst2, long rows, int cols, unsigned site_seed, float p, int precision, hipStream_t s);
 int launch_gather_test_rows(const float* src_bse, void* dst_t, int S, int B, int E, int sep, int precision, hipStream_t s);
+// ragged batch (per-dataset eval positions sep_of[B], compact rows dataset-major: row_off[b] + (s - sep_of[b]), row_off[B] = total):
+// dst[row_off[b] + s - sep_of[b], :] = (T) src[b, s, :] for s >= sep_of[b]   /   dst[b, s, :] = s >= sep_of[b] ? (T) src[row_off[b] + s - sep_of[b], :] : 0
+int launch_gather_test_rows_ragged(const float* src_bse, void* dst_t, int S, int B, int E, const int* sep_of, const long* row_off, int precision, hipStream_t s);
+int launch_scatter_test_rows_ragged(const float* src, void* dst_bse_t, int S, int B, int E, const int* sep_of, const long* row_off, int precision, hipStream_t s);
 // dst[b, s, :] = (s >= sep) ? src[(s-sep)*B + b, :] : 0
 int launch_scatter_test_rows(const float* src, void* dst_bse_t, int S, int B, int E, int sep, int precision, hipStream_t s);
 // the same row moves for any operand, as bytes (the top encoder layer runs on the test rows only, pfn_api.hip): compact order [S - sep, B]

@@ -102,9 +102,10 @@ template <typename T> __global__ __launch_bounds__(256) void embed_fwd_kernel(Em
     float v = 0.f;
     if (tok < ntok) {
       const long b = tok / a.S, sidx = tok % a.S;
+      const int sep = a.sep_of ? a.sep_of[b] : a.sep;
       if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
-      else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
-      else v = (sidx < a.sep) ? 1.f : 0.f;
+      else if (f == a.nf) v = (sidx < sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
+      else v = (sidx < sep) ? 1.f : 0.f;
     }
     xs[i] = v;
   }
@@ -173,9 +174,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
       float v = 0.f;
       if (tok < tend) {
         const long b = tok / a.S, sidx = tok % a.S;
+        const int sep = a.sep_of ? a.sep_of[b] : a.sep;
         if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
-        else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
-        else if (f == a.nf + 1) v = (sidx < a.sep) ? 1.f : 0.f;
+        else if (f == a.nf) v = (sidx < sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
+        else if (f == a.nf + 1) v = (sidx < sep) ? 1.f : 0.f;
       }
       xs[i] = v;
     }
@@ -226,9 +228,10 @@ __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(EmbedBwdArgs a) {
     float v = 0.f;
     if (tok < ntok) {
       const long b = tok / a.S, sidx = tok % a.S;
+      const int sep = a.sep_of ? a.sep_of[b] : a.sep;
       if (f < a.nf) v = a.x[sidx * a.x_st + b * a.x_sb + f];
-      else if (f == a.nf) v = (sidx < a.sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
-      else if (f == a.nf + 1) v = (sidx < a.sep) ? 1.f : 0.f;
+      else if (f == a.nf) v = (sidx < sep) ? a.y[sidx * a.y_st + b * a.y_sb] : 0.f;
+      else if (f == a.nf + 1) v = (sidx < sep) ? 1.f : 0.f;
     }
     xs[i] = v;
   }
@@ -409,6 +412,45 @@ int launch_scatter_test_rows(const float* src, void* dst, int S, int B, int E, i
   const long n4 = (long)S * B * E / 4;
   if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(scatter_test_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep);
   else hipLaunchKernelGGL(scatter_test_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep);
+  return PFN_LAUNCH_OK();
+}
+
+// ragged batch (round 5: the micro-batches of one optimizer step in ONE launch set, each dataset with its own eval position): the decoder's compact rows are
+// dataset-major, row_off[b] + (s - sep_of[b]).  Both kernels walk the [B, S] token order.
+template <typename T> __global__ __launch_bounds__(256) void gather_test_ragged_kernel(const float* src, T* dst, int S, int B, int E, const int* sep_of, const long* row_off) {
+  const int e4 = E / 4;
+  const long n4 = (long)S * B * e4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long tok = i / e4; const int c = (int)(i % e4) * 4;
+    const long b = tok / S, sidx = tok % S;
+    const int sep = sep_of[b];
+    if (sidx >= sep) st4<T>(dst + (row_off[b] + sidx - sep) * E + c, *reinterpret_cast<const f32x4*>(src + tok * E + c));
+  }
+}
+template <typename T> __global__ __launch_bounds__(256) void scatter_test_ragged_kernel(const float* src, T* dst, int S, int B, int E, const int* sep_of, const long* row_off) {
+  const int e4 = E / 4;
+  const long n4 = (long)S * B * e4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long tok = i / e4; const int c = (int)(i % e4) * 4;
+    const long b = tok / S, sidx = tok % S;
+    const int sep = sep_of[b];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (sidx >= sep) v = *reinterpret_cast<const f32x4*>(src + (row_off[b] + sidx - sep) * E + c);
+    st4<T>(dst + tok * E + c, v);
+  }
+}
+int launch_gather_test_rows_ragged(const float* src, void* dst, int S, int B, int E, const int* sep_of, const long* row_off, int precision, hipStream_t s) {
+  if (E % 4) return PFN_ERR_ALIGNMENT;
+  const long n4 = (long)S * B * E / 4;
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gather_test_ragged_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep_of, row_off);
+  else hipLaunchKernelGGL(gather_test_ragged_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep_of, row_off);
+  return PFN_LAUNCH_OK();
+}
+int launch_scatter_test_rows_ragged(const float* src, void* dst, int S, int B, int E, const int* sep_of, const long* row_off, int precision, hipStream_t s) {
+  if (E % 4) return PFN_ERR_ALIGNMENT;
+  const long n4 = (long)S * B * E / 4;
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(scatter_test_ragged_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep_of, row_off);
+  else hipLaunchKernelGGL(scatter_test_ragged_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep_of, row_off);
   return PFN_LAUNCH_OK();
 }
 

@@ -89,6 +89,56 @@ class MicroBatchStreams:
         out.record_stream(main)       # allocated on `s`, read by the caller on `main` after join(): the allocator must not hand the block back to `s` early
         return out
 
+    # ---- the batches of one optimizer step as ONE launch set per stream (ragged batch, round 5) ------------------------------------------------------
+    # Alternating streams keep up to n small batches in flight, but every launch is still a small batch's (8000 tokens at batch_size 4: 128 attention
+    # workgroups, <= 192 GEMM tiles on 256 CUs) and a step of 25 batches is ~7500 launches.  Here the datasets of several batches are stacked along B
+    # and run as one launch set in which every dataset carries its own eval position (TransformerModel.forward_batches, pfn_stack_forward_ragged):
+    # the launches are as large as a big batch's.  The batches of a step are split into `groups` contiguous chunks, one per stream.
+    MAX_GROUP_DATASETS = 64      # datasets per launch set (the activation workspace grows with it: ~0.34 GB per dataset at the north-star shape)
+
+    def can_stack(self, model):
+        return getattr(model, 'can_forward_batches', lambda: False)()
+
+    def forward_backward_batches(self, model, batches, loss_fn, before=None):
+        """batches = [(data=(x, y), targets, single_eval_pos), ...]: the micro-batches of ONE optimizer step.  Runs backward of sum_k mean(loss_k) -- the
+        reference's accumulated gradient (train.py:92-97) -- and returns the detached per-(position, dataset) losses of every batch, in order.
+        loss_fn(output_k, targets_k, sep_k) -> losses [T - sep_k, b_k].  before(n_groups): called once ahead of the first launch set with the number of backward
+        passes that follow (data-parallel runs arm their reducer for that many)."""
+        total = sum(b[0][0].shape[1] for b in batches)
+        n_groups = max(1, -(-total // self.MAX_GROUP_DATASETS))
+        if self.streams and not getattr(model, 'deterministic', False):
+            n_groups = max(n_groups, min(self.n, len(batches)))
+        n_groups = min(n_groups, len(batches))
+        bounds = [round(i * len(batches) / n_groups) for i in range(n_groups + 1)]
+        groups = [batches[bounds[i]:bounds[i + 1]] for i in range(n_groups)]
+        main = torch.cuda.current_stream()
+        model.flat_parameters()
+        dev = batches[0][0][0].device
+        model._refresh_shadow(_hip.stream_ptr(dev))
+        use_streams = bool(self.streams) and n_groups > 1 and not getattr(model, 'deterministic', False)
+        outs = []
+        if before is not None:
+            before(n_groups)
+        for gi, group in enumerate(groups):
+            s = self.streams[gi % self.n] if use_streams else main
+            if use_streams:
+                s.wait_stream(main)
+            with torch.cuda.stream(s):
+                logits = model.forward_batches([d for d, _, _ in group], [sep for _, _, sep in group])
+                losses = [loss_fn(out, tg, sep) for out, (_, tg, sep) in zip(logits, group)]
+                sum(l.mean() for l in losses).backward()
+                outs += [l.detach() for l in losses]
+            if use_streams:
+                for d, tg, _ in group:
+                    for t in (d[0], d[1], tg):
+                        t.record_stream(s)
+        if use_streams:
+            for s in self.streams:
+                main.wait_stream(s)
+            for o in outs:
+                o.record_stream(main)
+        return outs
+
     def fence_others(self, slot):
         """Events behind everything enqueued so far on the streams that will NOT run batch `slot` (earlier batches on the stream that will are ordered
         before it by the stream itself)."""

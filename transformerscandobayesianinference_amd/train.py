@@ -69,7 +69,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
           y_encoder_generator=None, pos_encoder_generator=None, decoder=None, extra_prior_kwargs_dict={},
           scheduler=get_cosine_schedule_with_warmup, load_weights_from_this_state_dict=None, validation_period=10,
           single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16', micro_streams=2, epoch_callback=None,
-          aggregate_streams=None, deterministic=False):
+          aggregate_streams=None, deterministic=False, aggregate_stacked=None):
     device = gpu_device if torch.cuda.is_available() else 'cpu:0'
     print(f'Using {device} device')
     if not str(device).startswith('cuda') and getattr(TransformerModel, 'requires_gpu', False):
@@ -114,11 +114,19 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     micro = MicroBatchStreams(micro_streams if str(device).startswith('cuda') else 1)   # concurrent half-batches (streams.py)
     # gradient accumulation over SMALL batches (the notebooks' batch_size 4 x aggregate_k_gradients 25): the batches of one optimizer step run whole, round-robin on
     # `aggregate_streams` HIP streams, instead of each being split into column groups (streams.py; measured in bench.py's batch_sweep).  None = automatic.
+    explicit_streams = aggregate_streams is not None and aggregate_streams > 1
     if aggregate_streams is None:
         # (one MI355X, configs[1]: batch 4 x 25 batches 956 datasets/s as column groups, 1680 / 1688 / 1927 on 2 / 4 / 8 alternating streams; batch 8 x 4:
         # 1637 -> 2066; batch 16 x 4: 2175 -> 2346 -- gpurun call 3 of round 4, profiles/r04_small_batch_streams.txt)
         aggregate_streams = min(8, aggregate_k_gradients) if (aggregate_k_gradients >= 2 and dp.local_batch_size(batch_size) * bptt <= 16 * 2048) else 0
     alt = MicroBatchStreams(aggregate_streams) if (aggregate_streams and aggregate_streams > 1 and aggregate_k_gradients > 1 and str(device).startswith('cuda')) else None
+    # ... or, better (round 5): the batches of one optimizer step STACKED into one launch set per micro-batch stream, every dataset with its own eval position
+    # (streams.py forward_backward_batches, TransformerModel.forward_batches).  aggregate_stacked: None = automatic (small batches under aggregate_k_gradients, a
+    # model whose embedding and decoder run inside the HIP stack, and no explicit aggregate_streams request), True / False = forced.
+    small_batches = aggregate_k_gradients >= 2 and dp.local_batch_size(batch_size) * bptt <= 16 * 2048
+    if aggregate_stacked is None:
+        aggregate_stacked = small_batches and not explicit_streams
+    stacked = bool(aggregate_stacked) and aggregate_k_gradients >= 2 and str(device).startswith('cuda') and micro.can_stack(model)
     # data-parallel runs: the flat gradient buffer is all-reduced as two collectives, the upper layers' half under the backward
     reducer = dp.OverlappedGradientReducer(model) if world > 1 and hasattr(model, 'flat_parameters') else None
 
@@ -131,13 +139,23 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
         time_to_get_batch = forward_time = step_time = 0.
         assert len(dl) % aggregate_k_gradients == 0, 'Please set the number of steps per epoch s.t. `aggregate_k_gradients` divides it.'
         pending = []      # (eval position, losses) of batches still running on the alternating streams
+        stack = []        # (data, targets, eval position) of the batches of the current optimizer step (stacked schedule)
         for batch, (data, targets) in enumerate(dl):
             time_to_get_batch = time.time() - before_get_batch
             before_forward = time.time()
             single_eval_pos = single_eval_pos_gen() if callable(single_eval_pos_gen) else single_eval_pos_gen
             data = tuple(e.to(device) for e in data) if isinstance(data, tuple) else data.to(device)
             last_micro_step = batch % aggregate_k_gradients == aggregate_k_gradients - 1
-            if isinstance(data, tuple) and single_eval_pos is not None and alt is not None and alt.can_alternate(model):
+            if isinstance(data, tuple) and single_eval_pos is not None and stacked:
+                stack.append((data, targets.to(device), single_eval_pos))
+                loss = None
+                if last_micro_step:
+                    outs = micro.forward_backward_batches(model, stack, lambda out, tg, sep: compute_losses(criterion, out, tg[sep:], n_out),
+                                                          before=(lambda n: reducer.arm(n)) if reducer is not None else None)
+                    pending = [(sep_k, l) for (_, _, sep_k), l in zip(stack, outs)]
+                    stack = []
+                forward_time = time.time() - before_forward
+            elif isinstance(data, tuple) and single_eval_pos is not None and alt is not None and alt.can_alternate(model):
                 targets = targets.to(device)
                 if reducer is not None and last_micro_step:
                     # data-parallel + alternating streams: the LAST batch of the optimizer step is armed, so the upper layers' half of the

@@ -57,7 +57,7 @@ class _StackFunction(torch.autograd.Function):
     """logits = stack(x, y | src); one node for embedding + L layers + decoder."""
 
     @staticmethod
-    def forward(ctx, flat_params, model, x, y, src, sep, inference):
+    def forward(ctx, flat_params, model, x, y, src, sep, inference, ragged=None):
         lib = _hip.lib()
         dev = flat_params.device
         stream = _hip.stream_ptr(dev)
@@ -81,6 +81,20 @@ class _StackFunction(torch.autograd.Function):
         ws_bytes = lib.pfn_workspace_bytes(ctypes.byref(desc), B, S)
         _hip.check(ws_bytes, 'pfn_workspace_bytes')
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ctx.ragged = ragged
+        if ragged is not None:
+            # a ragged batch (forward_batches): per-dataset eval positions, compact test rows dataset-major -- one launch set for several micro-batches
+            sep_of, row_off, sep_max, test_rows = ragged
+            logits = torch.empty((test_rows, desc.n_out or desc.emsize), dtype=torch.float32, device=dev)
+            ctx.dropout_seed = model._next_dropout_seed() if (model.training and desc.dropout > 0) else None
+            _hip.check(lib.pfn_stack_forward_ragged(ctypes.byref(desc), flat_params.data_ptr(), shadow.data_ptr(), x_ptr, x_st, x_sb, y_ptr, y_st, y_sb, B, S,
+                                                    sep_of.data_ptr(), row_off.data_ptr(), sep_max, test_rows, ws.data_ptr(), ws_bytes, logits.data_ptr(), stream,
+                                                    int(ctx.dropout_seed is not None), ctx.dropout_seed or 0), 'pfn_stack_forward_ragged')
+            ctx.model, ctx.ws, ctx.dims = model, ws, (B, S, sep_max)
+            ctx.operands = (desc, shadow)
+            ctx.inputs = (x, y, None)
+            ctx.src_needs_grad = False
+            return logits
         logits = torch.empty((S - sep, B, desc.n_out or desc.emsize), dtype=torch.float32, device=dev)   # n_out 0: the encoder's test rows
         # dropout (reference train.py:22 default 0.2; TransformerEncoderLayer's four sites): live in training mode only.  Every pass
         # takes its own 64-bit seed; the masks are counter-based functions of it, regenerated by the backward (include/pfn_hip.h)
@@ -121,6 +135,15 @@ class _StackFunction(torch.autograd.Function):
             args = (x.data_ptr(), x.stride(0), x.stride(1), y.data_ptr(), y.stride(0), y.stride(1))
         hook = model._first_group_hook
         split = hook is not None and hook.armed()
+        if ctx.ragged is not None:
+            sep_of, row_off, sep_max, test_rows = ctx.ragged
+            cb = _hip.HOST_CALLBACK(lambda user: hook.first_group_launched()) if split else None
+            _hip.check(lib.pfn_stack_backward_ragged(ctypes.byref(desc), model._flat.data_ptr(), shadow.data_ptr(), *args, B, S,
+                                                     sep_of.data_ptr(), row_off.data_ptr(), sep_max, test_rows, ws.data_ptr(), ws.numel(), dlogits.data_ptr(),
+                                                     model._flat_grad.data_ptr(), stream, hook.first_group_layers if split else 0, cb, None,
+                                                     int(ctx.dropout_seed is not None), ctx.dropout_seed or 0), 'pfn_stack_backward_ragged')
+            ctx.ws = None
+            return None, None, None, None, None, None, None, None
         if split or ctx.dropout_seed is not None:
             # data-parallel runs (dp.OverlappedGradientReducer): the top layers' weight gradients are launched early and the hook
             # records an event right behind them, so their all-reduce can run under the rest of this backward.
@@ -137,7 +160,7 @@ class _StackFunction(torch.autograd.Function):
                                               B, S, sep, ws.data_ptr(), ws.numel(), dlogits.data_ptr(),
                                               model._flat_grad.data_ptr(), _hip.ptr(dsrc), stream), 'pfn_stack_backward')
         ctx.ws = None
-        return None, None, None, None, (dsrc if ctx.src_needs_grad else None), None, None
+        return None, None, None, None, (dsrc if ctx.src_needs_grad else None), None, None, None
 
 
 class TransformerModel(nn.Module):
@@ -390,6 +413,50 @@ class TransformerModel(nn.Module):
             self._flatten(dev)
         self._attach_grads()
         return self._flat, self._flat_grad
+
+    # ---- several micro-batches in one launch set ----
+    def can_forward_batches(self):
+        return self._fused_embedding() and not self._custom_decoder
+
+    def forward_batches(self, batches, single_eval_positions):
+        """`model((x_k, y_k), single_eval_pos=sep_k)` for several batches at once: batches = [(x_k[T, b_k, F], y_k[T, b_k]), ...] with one T, one eval position
+        per batch.  Returns the list of logits [T - sep_k, b_k, n_out] -- the tensors the separate calls would return -- from ONE launch set in which every
+        dataset carries its own eval position (pfn_stack_forward_ragged).  The reference runs the k batches of an optimizer step one after the other
+        (train.py:66-97); a batch of 4 datasets fills a fraction of the chip.  Losses formed per batch and summed give the reference's accumulated gradient."""
+        assert self.can_forward_batches(), 'forward_batches needs the built-in linear encoders and decoder'
+        assert len(batches) == len(single_eval_positions) and len(batches) > 0
+        x = torch.cat([b[0] for b in batches], 1)
+        y = torch.cat([b[1].to(x.device) for b in batches], 1)
+        _hip.require_gpu_tensor(x, 'x')
+        _hip.require_gpu_tensor(next(self.parameters()), 'model parameters')
+        T = x.shape[0]
+        seps, widths = [], []
+        for (xb, _), sep in zip(batches, single_eval_positions):
+            assert xb.shape[0] == T, 'forward_batches: every batch needs the same sequence length'
+            sep = int(sep)
+            sep = max(0, min(T, sep + T if sep < 0 else sep))
+            seps.append(sep)
+            widths.append(xb.shape[1])
+        per_dataset = [s for s, w in zip(seps, widths) for _ in range(w)]
+        offs = [0]
+        for s in per_dataset:
+            offs.append(offs[-1] + T - s)
+        meta = torch.tensor(per_dataset + offs, dtype=torch.int64)          # one host-to-device copy for both arrays
+        sep_of = meta[:len(per_dataset)].to(torch.int32).to(x.device, non_blocking=True)
+        row_off = meta[len(per_dataset):].to(x.device, non_blocking=True)
+        if not self._is_flat():
+            self._flatten(x.device)
+        flat = self._flat
+        inference = self._inference_pass()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            flat = flat.detach().requires_grad_(True)
+        logits = _StackFunction.apply(flat, self, x, y, None, max(seps), inference, (sep_of, row_off, max(seps), offs[-1]))
+        out, d0 = [], 0
+        for sep, w in zip(seps, widths):
+            r0, r1 = offs[d0], offs[d0 + w]
+            out.append(logits[r0:r1].view(w, T - sep, logits.shape[1]).transpose(0, 1))      # dataset-major rows -> the reference's [T - sep, b, n_out]
+            d0 += w
+        return out
 
     # ---- forward ----
     def forward(self, src, src_mask=None, single_eval_pos=None):
