@@ -734,12 +734,15 @@ def run_config(config, device, rank, world, precision, batch=None, streams=None,
     # executed work equal the enqueued work.  The loader is a whole number of groups long and extends one group past the window.
     loader_cls = prior_module(w).DataLoader
     nb = steps * aggregate_k
-    group = math.gcd(nb, int(prefetch_group or getattr(loader_cls, 'prefetch_group', 1))) if getattr(loader_cls, 'prefetch', False) else 1
+    # (group: the loader's own rule -- its step count, or for small batches its dataset count, priors/utils.py -- rounded down to a divisor of the timed batches)
+    target = int(prefetch_group or max(getattr(loader_cls, 'prefetch_group', 1), -(-int(getattr(loader_cls, 'prefetch_group_datasets', 0) or 0) // batch)))
+    group = max(d for d in range(1, nb + 1) if nb % d == 0 and d <= max(1, target)) if getattr(loader_cls, 'prefetch', False) else 1
     solo_steps = 3 if profile_steps > 0 else 0      # further steps that time ONE kernel class only (the usually dominant one: less perturbation)
     num_batches = ((warmup + steps + profile_steps + solo_steps) * aggregate_k + group + group - 1) // group * group
     with quiet():   # DataLoader.__init__ prints its kwargs (reference behaviour)
         dl = loader_cls(num_steps=num_batches, batch_size=batch, seq_len=S, device=device, **prior_kwargs(w))
     dl.prefetch_group = group
+    dl._prefetch_group_fixed = True      # (the group is exactly what the accounting above assumes)
     batches = iter(dl)
     for _ in range(warmup):
         step(batches)

@@ -233,6 +233,7 @@ def evaluate(x, y, y_non_noisy, use_mse=False, hyperparameters={}, get_model_on_
 DataLoader.prefetch = True        # draws run ahead of the training steps on a side stream (priors/utils.py)
 DataLoader.prefetch_group = 10    # ... ten steps' worth of datasets per sampler call (MI355X, bptt 2000: 64 us per dataset at 4 x 32, 54 us at 10 x 32;
                                   # 16 MB of factorisation workspace per dataset: 5 GB of the 288)
+DataLoader.prefetch_group_datasets = 640    # ... and at least this many datasets per call when the batches are small (priors/utils.py)
 DataLoader.prefetch_memory_share = 0.125    # ... but never more than an eighth of the free device memory per group (two groups are alive at a time)
 def workspace_bytes_per_dataset(kw):
     """K_ws per dataset as the library sizes it (the [Tp, Tp] f32 matrix + the plane scratch: +19 % at bptt 2000, +29 % at 1000, +37 % at 512 -- ADVICE r4: not a constant factor)."""

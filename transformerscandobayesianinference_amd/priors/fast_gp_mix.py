@@ -101,6 +101,7 @@ class DataLoader(get_batch_to_dataloader(get_batch)):
     num_outputs = 1
     prefetch = True
     prefetch_group = 10
+    prefetch_group_datasets = 640
     prefetch_memory_share = 0.125          # as priors.fast_gp: a group's factorisation workspace stays inside this share of free memory
     prefetch_bytes_per_dataset = staticmethod(fast_gp.workspace_bytes_per_dataset)     # from the library (pfn_gp_workspace_bytes), not a constant factor
 

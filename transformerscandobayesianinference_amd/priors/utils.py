@@ -45,6 +45,12 @@ def get_batch_to_dataloader(get_batch_method_):
             draw = lambda: self.gbm(**self.get_batch_kwargs, fuse_x_y=self.fuse_x_y)
             if getattr(self, 'prefetch', False) and torch.cuda.is_available():
                 group = max(1, int(getattr(self, 'prefetch_group', 1)))
+                # ... counted in DATASETS for small batches (round 5): the blocked Cholesky is a chain of ~100 dependent launches whatever the batch, so a group
+                # of 10 steps x 4 datasets pays it for 40 datasets where 10 x 64 pay it for 640 (the notebooks train at batch_size 4)
+                want = getattr(self, 'prefetch_group_datasets', None)
+                if want and 'batch_size' in self.get_batch_kwargs and not getattr(self, '_prefetch_group_fixed', False):
+                    group = max(group, -(-int(want) // max(1, self.get_batch_kwargs['batch_size'])))
+                group = min(group, self.num_steps)
                 budget = getattr(self, 'prefetch_bytes_per_dataset', None)
                 if budget is not None and 'batch_size' in self.get_batch_kwargs:
                     # sampler workspace of one group (and the pending group holds as much again): keep it inside a fixed share

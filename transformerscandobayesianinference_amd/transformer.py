@@ -451,12 +451,9 @@ class TransformerModel(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             flat = flat.detach().requires_grad_(True)
         logits = _StackFunction.apply(flat, self, x, y, None, max(seps), inference, (sep_of, row_off, max(seps), offs[-1]))
-        out, d0 = [], 0
-        for sep, w in zip(seps, widths):
-            r0, r1 = offs[d0], offs[d0 + w]
-            out.append(logits[r0:r1].view(w, T - sep, logits.shape[1]).transpose(0, 1))      # dataset-major rows -> the reference's [T - sep, b, n_out]
-            d0 += w
-        return out
+        # (torch.split: its backward is ONE concatenation of the per-batch gradients; slicing would zero-fill and add a full-size tensor per batch)
+        parts = torch.split(logits, [w * (T - sep) for sep, w in zip(seps, widths)])
+        return [p.view(w, T - sep, logits.shape[1]).transpose(0, 1) for p, sep, w in zip(parts, seps, widths)]      # dataset-major rows -> the reference's [T - sep, b, n_out]
 
     # ---- forward ----
     def forward(self, src, src_mask=None, single_eval_pos=None):
