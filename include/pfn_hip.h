@@ -186,22 +186,23 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
 /* ---- RAGGED BATCH (ABI 7): the micro-batches of one optimizer step as ONE launch set.  The reference runs the k batches of an optimizer step one after the
  * other, each with its own single_eval_pos (train.py:66-97; the notebooks train at batch_size 4 x aggregate_k_gradients 25); a batch of 4 datasets fills a
  * fraction of the chip.  Here the datasets of several batches are stacked along B and every dataset carries its own eval position:
- *   sep_of  [B]     int32, device: eval position of dataset b (0 <= sep_of[b] <= S);  sep_max = max over b (host value)
+ *   sep_of  [B]     int32, device: eval position of dataset b (0 <= sep_of[b] <= S);  sep_min / sep_max = min / max over b (host values)
  *   row_off [B + 1] int64, device: first compact test row of dataset b; row_off[B] = test_rows = sum_b (S - sep_of[b])
  * Compact test rows (logits / dlogits [test_rows, n_out]) are DATASET-MAJOR: row_off[b] + (t - sep_of[b]) -- not the (t - sep) * B + b of the uniform entry
- * points (a micro-batch's rows are one contiguous slice [b][t]).  Fused embedding only (x / y given, no src_sbe); the top encoder layer runs on every row.
+ * points (a micro-batch's rows are one contiguous slice [b][t]).  Fused embedding only (x / y given, no src_sbe); the top encoder layer runs on the test rows
+ * only when every dataset leaves room for it (4 sep_min >= S), on every row otherwise.
  * Same workspace (pfn_workspace_bytes(d, B, S)); gradients are accumulated into `grads` as in pfn_stack_backward; first_group_layers / on_first_group as in
  * pfn_stack_backward_split.  The caller forms each micro-batch's loss from its slice, so the summed gradient equals the reference's sequential accumulation. */
 int pfn_stack_forward_ragged(const pfn_model_desc* d, const float* params, const void* shadow,
                              const float* x, int64_t x_st, int64_t x_sb,
                              const float* y, int64_t y_st, int64_t y_sb,
-                             int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_max, int64_t test_rows,
+                             int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_min, int sep_max, int64_t test_rows,
                              void* workspace, int64_t workspace_bytes, float* logits, void* stream,
                              int use_dropout, uint64_t dropout_seed);
 int pfn_stack_backward_ragged(const pfn_model_desc* d, const float* params, const void* shadow,
                               const float* x, int64_t x_st, int64_t x_sb,
                               const float* y, int64_t y_st, int64_t y_sb,
-                              int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_max, int64_t test_rows,
+                              int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_min, int sep_max, int64_t test_rows,
                               void* workspace, int64_t workspace_bytes,
                               const float* dlogits, float* grads, void* stream,
                               int first_group_layers, pfn_host_callback on_first_group, void* user,

@@ -1595,8 +1595,9 @@ def test_deterministic_schedule_gradients_at_a_benchmark_like_shape(precision):
     within(f'{precision} deterministic vs default schedule: gradient rel l2', relerr(g1, g0), 1e-5 if precision == 'f32' else 5e-3)
 
 
+@pytest.mark.parametrize('seps', [[257, 0, 300, 131, 299], [257, 290, 80, 131, 299]], ids=['every-row-top-layer', 'test-row-top-layer'])
 @pytest.mark.parametrize('precision', ['f32', 'bf16'])
-def test_forward_batches_equals_separate_forwards(precision):
+def test_forward_batches_equals_separate_forwards(precision, seps):
     """Round 5: `model.forward_batches` runs several micro-batches -- each with its OWN single_eval_pos, as the reference's accumulation loop
     draws them (train.py:66-69, 92-97) -- as ONE launch set (pfn_stack_forward_ragged: per-dataset eval positions in the embedding, the three attention kernels
     and the test-row gather / scatter).  It must return exactly the logits of the separate `model((x, y), single_eval_pos=sep)` calls, and the backward of the
@@ -1612,7 +1613,8 @@ def test_forward_batches_equals_separate_forwards(precision):
             layer.linear2.weight.normal_(0, 0.05); layer.self_attn.out_proj.weight.normal_(0, 0.05)
     model = model.to(DEV).train()
     g = torch.Generator().manual_seed(4)
-    widths, seps = [4, 1, 3, 4, 2], [257, 0, 300, 131, 299]          # incl. no train rows at all, no test rows at all, one test row
+    widths = [4, 1, 3, 4, 2]          # first id: incl. no train rows at all, no test rows at all, one test row (the top layer then runs on every row);
+                                      # second id: every position >= T / 4, so the top layer runs on the (ragged) test rows only
     batches = [(torch.rand(cfg['T'], w, cfg['F'], generator=g).to(DEV), torch.randn(cfg['T'], w, generator=g).to(DEV)) for w in widths]
     loss_of = lambda out, y, sep: model.criterion(out.reshape(-1, cfg['nbars']), y[sep:].reshape(-1)).mean() if sep < cfg['T'] else out.sum() * 0
     # sequential accumulation, as the reference does it

@@ -63,10 +63,10 @@ SIGNATURES = {
     'pfn_stack_backward': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P]),
     'pfn_stack_forward_dropout': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P, _L, _P, _P, _U64]),
     'pfn_stack_backward_split': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P, _I, _U64]),
-    # (d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, B, S, sep_of, row_off, sep_max, test_rows, ws, ws_bytes, logits, stream, use_dropout, seed)
-    'pfn_stack_forward_ragged': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _P, _P, _I, _L, _P, _L, _P, _P, _I, _U64]),
+    # (d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, B, S, sep_of, row_off, sep_min, sep_max, test_rows, ws, ws_bytes, logits, stream, use_dropout, seed)
+    'pfn_stack_forward_ragged': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _P, _P, _I, _I, _L, _P, _L, _P, _P, _I, _U64]),
     # (..., ws, ws_bytes, dlogits, grads, stream, first_group_layers, callback, user, use_dropout, seed)
-    'pfn_stack_backward_ragged': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _P, _P, _I, _L, _P, _L, _P, _P, _P, _I, _P, _P, _I, _U64]),
+    'pfn_stack_backward_ragged': (_I, [_D, _P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _P, _P, _I, _I, _L, _P, _L, _P, _P, _P, _I, _P, _P, _I, _U64]),
     'pfn_bar_nll_forward': (_I, [_P, _L, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
     'pfn_bar_nll_backward': (_I, [_P, _L, _P, _P, _P, _L, _I, _P, _P]),
     'pfn_bar_mean': (_I, [_P, _L, _P, _L, _I, _I, _P, _P]),

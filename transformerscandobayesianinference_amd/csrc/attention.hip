@@ -225,6 +225,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
   const int sep = a.sep_of ? a.sep_of[b] : a.sep;      // (wave-uniform: b comes from the block index)
+  if (a.q_from_sep && (wg.blk + 1) * C::QBLK <= sep / 256 * 256) return;      // ragged batch, top layer: this dataset's queries start above the block (ahead of every barrier)
   const float scale_log2 = rsqrtf((float)D) * LOG2E;
   // DROP: dropout on the probabilities (pfn_device.h dropout_keep with i = query, j = key).  The normaliser (row sum, lse) is that of
   // the UNMASKED softmax -- torch drops entries of the normalised P -- so only the values fed to the P.V product are masked, and the
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, int D) {
   for (long pr = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pr < pairs; pr += (long)gridDim.x * 16) {
     const long tok = pr / a.H;
     const int hd = (int)(pr % a.H);
-    if ((int)(tok % a.S) < a.q_begin) continue;      // (uniform over the 16-lane group; no wave-wide operation below)
+    if ((int)(tok % a.S) < (a.q_from_sep ? a.sep_of[tok / a.S] / 256 * 256 : a.q_begin)) continue;      // (uniform over the 16-lane group; no wave-wide operation below)
     const T* o = reinterpret_cast<const T*>(a.ctx) + tok * a.E + hd * D;
     const T* d = reinterpret_cast<const T*>(a.dctx) + tok * a.E + hd * D;
     float s = 0.f;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
     if (wave == 0) { if (lane < QB) dma4(rl, St(buf), (lane + q0) * 4); }
     else if (wave == 1) { if (lane < QB) dma4(rdl, St(buf) + QB * 4, (lane + q0) * 4); }
   };
-  const int t0 = a.q_begin / QB;      // first query tile (0 unless the caller skips the queries below q_begin: AttnArgs)
+  const int t0 = (a.q_from_sep ? sep / 256 * 256 : a.q_begin) / QB;      // first query tile (0 unless the caller skips the queries below q_begin: AttnArgs; ragged: the dataset's own)
   dma(0, t0);
   stage_stats(0, t0 * QB);
   dma_wait_all();
@@ -975,6 +976,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   const bool qvalid = qi < a.S;
   const int qc = min(qi, a.S - 1);
   const int sep = a.sep_of ? a.sep_of[b] : a.sep;
+  if (a.q_from_sep && (wg.blk + 1) * C::QBLK <= sep / 256 * 256) return;      // (as the forward: the launcher zero-fills those dQ rows)
   const float scale = rsqrtf((float)D);
   const float scale_log2 = scale * LOG2E;
   f32x16 dq[C::NDB];
@@ -1234,6 +1236,7 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_kv_kernel(AttnArgs a) {
   const int key0 = kb * P::TB, t = threadIdx.x, r1 = t >> 3, c1 = (t & 7) * 4;
   const int sep = a.sep_of ? a.sep_of[b] : a.sep;
   if (key0 >= sep) return;      // (ragged batch: the grid covers the largest position)
+  const int qbeg = a.q_from_sep ? sep / 256 * 256 : a.q_begin;
   const float scale = rsqrtf((float)D), scale_log2 = scale * LOG2E;
   // dropout on the probabilities (as in attn_bwd_kv_kernel): dV takes P' = P keep / (1 - p), dP = (dO V^T) keep / (1 - p), dS = P (dP - delta) with the unmasked P
   const bool drop = a.p_drop > 0.f;
@@ -1244,10 +1247,10 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_kv_kernel(AttnArgs a) {
   f32x4 dk[D / 32], dv[D / 32];
 #pragma unroll
   for (int m = 0; m < D / 32; ++m) { dk[m] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int q0 = a.q_begin / P::TB * P::TB; q0 < a.S; q0 += P::TB) {
+  for (int q0 = qbeg / P::TB * P::TB; q0 < a.S; q0 += P::TB) {
     __syncthreads();                                   // the previous tile's phase 2 has read Qs / Os / Ps / Ds (first tile: K / V tiles written)
-    plain_load_tile<D>(Qs, Qp, rs, q0, a.q_begin, a.S);
-    plain_load_tile<D>(Os, dOp, a.E, q0, a.q_begin, a.S);
+    plain_load_tile<D>(Qs, Qp, rs, q0, qbeg, a.S);
+    plain_load_tile<D>(Os, dOp, a.E, q0, qbeg, a.S);
     if (t < P::TB) { const int q = min(q0 + t, a.S - 1); Ls[t] = lse_g[q] * LOG2E; Dl[t] = delta_g[q]; }
     __syncthreads();
     {
@@ -1256,7 +1259,7 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_kv_kernel(AttnArgs a) {
       const int q = q0 + r1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool live = q >= a.q_begin && q < a.S && key0 + c1 + j < sep;
+        const bool live = q >= qbeg && q < a.S && key0 + c1 + j < sep;
         const float p = live ? fast_exp2(s[j] * scale_log2 - Ls[r1]) : 0.f;
         const float mf = !drop ? 1.f : dropout_keep(dseed, (unsigned)q, (unsigned)(key0 + c1 + j), dthr) ? dscale : 0.f;
         Ps[r1 * P::PS + c1 + j] = p * mf;
@@ -1305,18 +1308,20 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_dq_kernel(AttnArgs a) {
   const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
   const int q0 = qb * P::TB, t = threadIdx.x, r1 = t >> 3, c1 = (t & 7) * 4;
   const int sep = a.sep_of ? a.sep_of[b] : a.sep;
+  const int qbeg = a.q_from_sep ? sep / 256 * 256 : a.q_begin;
+  if ((qb + 1) * P::TB <= qbeg) return;      // (ragged batch: the grid starts at the smallest first block; the launcher zero-fills these dQ rows)
   const float scale = rsqrtf((float)D), scale_log2 = scale * LOG2E;
   const bool drop = a.p_drop > 0.f;
   const unsigned dseed = dropout_pair_seed(a.drop_seed, b * a.H + hd), dthr = dropout_threshold(a.p_drop);
   const float dscale = drop ? 1.f / (1.f - a.p_drop) : 1.f;
-  plain_load_tile<D>(Qs, Qp, rs, q0, a.q_begin, a.S);
-  plain_load_tile<D>(Os, dOp, a.E, q0, a.q_begin, a.S);
+  plain_load_tile<D>(Qs, Qp, rs, q0, qbeg, a.S);
+  plain_load_tile<D>(Os, dOp, a.E, q0, qbeg, a.S);
   if (t < P::TB) { const int q = min(q0 + t, a.S - 1); Ls[t] = lse_g[q] * LOG2E; Dl[t] = delta_g[q]; }
   f32x4 dq[D / 32];
 #pragma unroll
   for (int m = 0; m < D / 32; ++m) dq[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int q = q0 + r1;
-  const bool qlive = q >= a.q_begin && q < a.S;
+  const bool qlive = q >= qbeg && q < a.S;
   for (int key0 = 0; key0 < sep; key0 += P::TB) {
     __syncthreads();
     plain_load_tile<D>(Ks, Kp, rs, key0, 0, sep);
@@ -1427,7 +1432,10 @@ template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& 
     }
   }
   if (parts & ATTN_BWD_DQ) {
-    if (a.q_begin > 0) {      // dQ of the skipped queries: zeros (every row of dqkv is read by the GEMMs behind this launch)
+    if (a.q_from_sep) {       // ragged batch: every dataset's own prefix
+      const int rc = launch_zero_row_prefix_ragged(a.dqkv, a.S, a.B, a.sep_of, 3L * a.E * (long)sizeof(T), (long)a.E * (long)sizeof(T), s);
+      if (rc != PFN_OK) return rc;
+    } else if (a.q_begin > 0) {      // dQ of the skipped queries: zeros (every row of dqkv is read by the GEMMs behind this launch)
       const int rc = launch_zero_row_prefix(a.dqkv, a.S, a.B, a.q_begin, 3L * a.E * (long)sizeof(T), (long)a.E * (long)sizeof(T), s);
       if (rc != PFN_OK) return rc;
     }
@@ -1457,7 +1465,10 @@ template <int D> static int launch_bwd_plain_f32(const AttnArgs& a, hipStream_t 
     hipLaunchKernelGGL(attn_bwd_plain_kv_kernel<D>, dim3(((a.sep + P::TB - 1) / P::TB) * a.H * a.B), dim3(256), P::LDS, s, a);
   }
   if (parts & ATTN_BWD_DQ) {
-    if (a.q_begin > 0) {
+    if (a.q_from_sep) {
+      const int rc = launch_zero_row_prefix_ragged(a.dqkv, a.S, a.B, a.sep_of, 3L * a.E * 4L, (long)a.E * 4L, s);
+      if (rc != PFN_OK) return rc;
+    } else if (a.q_begin > 0) {
       const int rc = launch_zero_row_prefix(a.dqkv, a.S, a.B, a.q_begin, 3L * a.E * 4L, (long)a.E * 4L, s);
       if (rc != PFN_OK) return rc;
     }
@@ -1472,7 +1483,7 @@ template <int D> static int launch_bwd_plain_f32(const AttnArgs& a, hipStream_t 
 
 static int check_attn(const AttnArgs& a, int precision) {
   if (a.B <= 0 || a.S <= 0 || a.H <= 0 || a.E % a.H) return PFN_ERR_ARGUMENT;
-  if (a.sep < 0 || a.sep > a.S || a.q_begin < 0 || a.q_begin > a.S) return PFN_ERR_ARGUMENT;
+  if (a.sep < 0 || a.sep > a.S || a.q_begin < 0 || a.q_begin > a.S || (a.q_from_sep && !a.sep_of)) return PFN_ERR_ARGUMENT;
   const int es = precision == PFN_PREC_BF16 ? 2 : 4;
   if ((a.E * es) % 16) return PFN_ERR_ALIGNMENT;
   return PFN_OK;

@@ -149,7 +149,7 @@ struct Ws {
 
 // A ragged batch (round 5; pfn_stack_forward_ragged / pfn_stack_backward_ragged): the micro-batches of one optimizer step as ONE launch set, each dataset with its
 // own eval position.  sep_of [B] int32 and row_off [B + 1] int64 live on the device; row_off[b] = first compact test row of dataset b, row_off[B] = test_rows.
-struct Ragged { const int32_t* sep_of; const int64_t* row_off; int64_t test_rows; };
+struct Ragged { const int32_t* sep_of; const int64_t* row_off; int64_t test_rows; int sep_min; };
 
 Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   Ws w;
@@ -215,6 +215,10 @@ static int g_default_schedule = 0;
 // (d.dropout, not the live probability: with dropout configured the top_* buffers are not carved -- an inference pass of such a model keeps every row)
 static bool top_layer_on_test_rows(const pfn_model_desc& d, int S, int sep, float pdrop) {
   return !(d.schedule & PFN_SCHED_TOP_LAYER_ALL_ROWS) && d.nlayers > 0 && pdrop == 0.f && d.dropout == 0.f && sep < S && 4L * sep >= S;
+}
+// ... for a ragged batch: every dataset needs 4 sep_b >= S (the compact buffers hold 3/4 of the rows), i.e. the smallest position decides
+static bool top_layer_on_test_rows_ragged(const pfn_model_desc& d, int S, const Ragged& rg, float pdrop) {
+  return !(d.schedule & PFN_SCHED_TOP_LAYER_ALL_ROWS) && d.nlayers > 0 && pdrop == 0.f && d.dropout == 0.f && rg.test_rows > 0 && 4L * rg.sep_min >= S;
 }
 // emsize 1024: the 64-row fused kernels exist and are correct, but lose to GEMM + LayerNorm kernels (PFN_SCHED_FUSE_LN_WIDE)
 int pfn_abi_version(void) { return PFN_ABI_VERSION; }
@@ -374,7 +378,11 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   auto set_resid = [](GemmLN& g, const Resid& r) {
     g.resid = r.plain; g.ry = r.y; g.rmean = r.mean; g.rrstd = r.rstd; g.rgamma = r.gamma; g.rbeta = r.beta;
   };
-  const bool top_mode = !rg && top_layer_on_test_rows(*d, S, sep, pdrop);
+  const bool top_mode = rg ? top_layer_on_test_rows_ragged(*d, S, *rg, pdrop) : top_layer_on_test_rows(*d, S, sep, pdrop);
+  // the top layer's row moves (token order -> the decoder's compact rows): (t - sep) B + b, or dataset-major for a ragged batch
+  auto gather_top = [&](const void* src, void* dst, long row_bytes) {
+    return rg ? launch_gather_rows_ragged(src, dst, S, B, row_bytes, rg->sep_of, (const long*)rg->row_off, s) : launch_gather_rows(src, dst, S, B, row_bytes, sep, s);
+  };
   for (int l = 0; l < d->nlayers; ++l) {
     const LayerP& p = L.layer[l];
     LayerWs& a = w.layer[l];
@@ -390,20 +398,21 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       AttnArgs at; memset(&at, 0, sizeof(at));
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep; at.sep_of = sep_of;
       at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
-      at.q_begin = top ? sep : 0;
+      at.q_begin = top ? (rg ? rg->sep_min : sep) : 0;
+      at.q_from_sep = (top && rg) ? 1 : 0;
       PFN_TRY(launch_attn_fwd(at, prec, s));
     }
     const char* ctx_in = a.ctx;
     if (top) {      // the test rows of the attention output and of the layer input, gathered
-      PFN_TRY(launch_gather_rows(a.ctx, w.top_ctx_t, S, B, (long)E * es, sep, s));
+      PFN_TRY(gather_top(a.ctx, w.top_ctx_t, (long)E * es));
       ctx_in = w.top_ctx_t;
       if (fuse_ln && !res.plain) {
-        PFN_TRY(launch_gather_rows(res.y, w.top_ry, S, B, (long)E * 4, sep, s));
-        PFN_TRY(launch_gather_rows(res.mean, w.top_rmean, S, B, 4, sep, s));
-        PFN_TRY(launch_gather_rows(res.rstd, w.top_rrstd, S, B, 4, sep, s));
+        PFN_TRY(gather_top(res.y, w.top_ry, (long)E * 4));
+        PFN_TRY(gather_top(res.mean, w.top_rmean, 4));
+        PFN_TRY(gather_top(res.rstd, w.top_rrstd, 4));
         res = Resid{nullptr, w.top_ry, w.top_rmean, w.top_rrstd, res.gamma, res.beta};
       } else {
-        PFN_TRY(launch_gather_rows(fuse_ln ? res.plain : xin, w.top_ry, S, B, (long)E * 4, sep, s));
+        PFN_TRY(gather_top(fuse_ln ? res.plain : xin, w.top_ry, (long)E * 4));
         res = Resid{w.top_ry, nullptr, nullptr, nullptr, nullptr, nullptr};
         xin = w.top_ry;
       }
@@ -461,11 +470,13 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   // output went straight to the caller when there is no decoder)
   if (Mt > 0 && O == 0) {
     // no decoder (a custom decoder module runs in PyTorch, reference transformer.py:23): hand out the test rows [Mt, E] in f32
-    if (rg) PFN_TRY(launch_gather_test_rows_ragged(xin, logits, S, B, E, rg->sep_of, (const long*)rg->row_off, PFN_PREC_F32, s));
-    else if (!top_mode) PFN_TRY(launch_gather_test_rows(xin, logits, S, B, E, sep, PFN_PREC_F32, s));
+    if (top_mode) {}
+    else if (rg) PFN_TRY(launch_gather_test_rows_ragged(xin, logits, S, B, E, rg->sep_of, (const long*)rg->row_off, PFN_PREC_F32, s));
+    else PFN_TRY(launch_gather_test_rows(xin, logits, S, B, E, sep, PFN_PREC_F32, s));
   } else if (Mt > 0) {
-    if (rg) PFN_TRY(launch_gather_test_rows_ragged(xin, w.xt_t, S, B, E, rg->sep_of, (const long*)rg->row_off, prec, s));
-    else if (!top_mode) PFN_TRY(launch_gather_test_rows(xin, w.xt_t, S, B, E, sep, prec, s));
+    if (top_mode) {}
+    else if (rg) PFN_TRY(launch_gather_test_rows_ragged(xin, w.xt_t, S, B, E, rg->sep_of, (const long*)rg->row_off, prec, s));
+    else PFN_TRY(launch_gather_test_rows(xin, w.xt_t, S, B, E, sep, prec, s));
     const char* xt_t = top_mode ? w.layer[d->nlayers - 1].x2_t : w.xt_t;
     {
       GemmNT g = nt(xt_t, E, W(L.dec0_w), E, Mt, F, E, EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T);
@@ -505,21 +516,23 @@ int pfn_stack_backward_split(const pfn_model_desc* d, const float* params, const
 // ---- the micro-batches of one optimizer step as ONE launch set (round 5): reference train.py:66-97 runs the k batches of an optimizer step one after the other, each
 // with its own single_eval_pos; a batch of 4 datasets fills a fraction of the chip, so the datasets of several batches are stacked along B here and every kernel that
 // looks at the eval position reads its dataset's own (sep_of [B], device).  Compact test rows (decoder input, logits, dlogits): dataset-major, row_off[b] + (t - sep_of[b]).
-// sep_max = max(sep_of) (grid of the attention backward's key-block pass, scratch dims); test_rows = row_off[B] = sum(S - sep_of[b]).  Fused embedding only; the top
-// encoder layer runs on every row (its compact-row schedule assumes one position).
+// sep_min / sep_max = min / max(sep_of) (grids, scratch dims, whether the top layer can run on the test rows only: 4 sep_min >= S); test_rows = row_off[B] =
+// sum(S - sep_of[b]).  Fused embedding only.
 int pfn_stack_forward_ragged(const pfn_model_desc* d, const float* params, const void* shadow,
                              const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
-                             int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_max, int64_t test_rows,
+                             int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_min, int sep_max, int64_t test_rows,
                              void* workspace, int64_t workspace_bytes, float* logits, void* stream, int use_dropout, uint64_t dropout_seed) {
-  Ragged rg = {sep_of, row_off, test_rows};
+  if (sep_min < 0 || sep_min > sep_max) return fail(PFN_ERR_ARGUMENT, "bad sep_min=%d sep_max=%d", sep_min, sep_max);
+  Ragged rg = {sep_of, row_off, test_rows, sep_min};
   return stack_forward_impl(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, nullptr, B, S, sep_max, workspace, workspace_bytes, logits, stream, use_dropout != 0, dropout_seed, &rg);
 }
 int pfn_stack_backward_ragged(const pfn_model_desc* d, const float* params, const void* shadow,
                               const float* x, int64_t x_st, int64_t x_sb, const float* y, int64_t y_st, int64_t y_sb,
-                              int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_max, int64_t test_rows,
+                              int B, int S, const int32_t* sep_of, const int64_t* row_off, int sep_min, int sep_max, int64_t test_rows,
                               void* workspace, int64_t workspace_bytes, const float* dlogits, float* grads, void* stream,
                               int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed) {
-  Ragged rg = {sep_of, row_off, test_rows};
+  if (sep_min < 0 || sep_min > sep_max) return fail(PFN_ERR_ARGUMENT, "bad sep_min=%d sep_max=%d", sep_min, sep_max);
+  Ragged rg = {sep_of, row_off, test_rows, sep_min};
   return stack_backward_impl(d, params, shadow, x, x_st, x_sb, y, y_st, y_sb, B, S, sep_max, workspace, workspace_bytes, dlogits, grads, nullptr, stream,
                              first_group_layers, on_first_group, user, use_dropout, dropout_seed, &rg);
 }
@@ -530,7 +543,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
                                int first_group_layers, pfn_host_callback on_first_group, void* user, int use_dropout, uint64_t dropout_seed, const Ragged* rg) {
   PFN_TRY(check_desc(d));
   const float pdrop = use_dropout ? d->dropout : 0.f;
-  const bool top_mode = !rg && top_layer_on_test_rows(*d, S, sep, pdrop);       // (the forward took the same decision: same descriptor, shape, dropout)
+  const bool top_mode = rg ? top_layer_on_test_rows_ragged(*d, S, *rg, pdrop) : top_layer_on_test_rows(*d, S, sep, pdrop);       // (the forward took the same decision: same descriptor, shape, dropout)
   const int* sep_of = rg ? rg->sep_of : nullptr;
   if (rg && (dsrc_sbe || rg->test_rows < 0 || rg->test_rows > (int64_t)B * S || !rg->sep_of || !rg->row_off)) return fail(PFN_ERR_ARGUMENT, "bad ragged-batch arguments");
   // PFN_SCHED_DETERMINISTIC: one writer per gradient element and launch -- no token splits in the weight-gradient GEMMs, the LayerNorm backward as its own
@@ -590,8 +603,9 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     }
   }
   // (top_mode: the top layer's backward runs on the compact test rows and takes dxt as it is)
-  if (rg) PFN_TRY(launch_scatter_test_rows_ragged(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, rg->sep_of, (const long*)rg->row_off, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
-  else if (!top_mode) PFN_TRY(launch_scatter_test_rows(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
+  if (top_mode) {}
+  else if (rg) PFN_TRY(launch_scatter_test_rows_ragged(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, rg->sep_of, (const long*)rg->row_off, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
+  else PFN_TRY(launch_scatter_test_rows(dxt, d->nlayers > 0 ? (void*)w.gA_t : (void*)w.gA, S, B, E, sep, d->nlayers > 0 ? prec : PFN_PREC_F32, s));
 
   // ---- encoder layers, last to first; gA holds d(loss)/d(layer output) ----
   // Only the data-gradient chain runs here.  Each layer leaves the output-gradient operands of its four
@@ -721,15 +735,21 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     if (top) {
       // back to the token order for the attention backward and for the dx product of the K / V projection: d(attention output) is needed from the first
       // query block the attention kernels touch (AttnArgs::q_begin: zeros up to sep), the LayerNorm-input gradient as the residual term of every row
-      PFN_TRY(launch_scatter_rows(w.top_dctx_t, w.dctx_t, S, B, (long)E * es, sep, sep / 256 * 256, s));
-      PFN_TRY(launch_scatter_rows(w.top_dy1_t, a.dy1_t, S, B, (long)E * es, sep, 0, s));
+      if (rg) {
+        PFN_TRY(launch_scatter_rows_ragged(w.top_dctx_t, w.dctx_t, S, B, (long)E * es, rg->sep_of, (const long*)rg->row_off, 1, s));
+        PFN_TRY(launch_scatter_rows_ragged(w.top_dy1_t, a.dy1_t, S, B, (long)E * es, rg->sep_of, (const long*)rg->row_off, 0, s));
+      } else {
+        PFN_TRY(launch_scatter_rows(w.top_dctx_t, w.dctx_t, S, B, (long)E * es, sep, sep / 256 * 256, s));
+        PFN_TRY(launch_scatter_rows(w.top_dy1_t, a.dy1_t, S, B, (long)E * es, sep, 0, s));
+      }
     }
     {
       AttnArgs at; memset(&at, 0, sizeof(at));
       at.qkv = a.qkv; at.ctx = a.ctx; at.lse = a.lse; at.B = B; at.S = S; at.E = E; at.H = H; at.sep = sep; at.sep_of = sep_of;
       at.dctx = w.dctx_t; at.dqkv = a.dqkv_t; at.delta = w.delta; at.ds = w.ds;
       at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
-      at.q_begin = top ? sep : 0;
+      at.q_begin = top ? (rg ? rg->sep_min : sep) : 0;
+      at.q_from_sep = (top && rg) ? 1 : 0;
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     if (fuse_lnb && l > 0) {  // dy2 of the layer below = its LN2 backward of (dqkv . Win + dy1)

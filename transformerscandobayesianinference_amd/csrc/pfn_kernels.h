@@ -170,6 +170,7 @@ struct AttnArgs {
   // ragged batch (round 5): per-dataset eval positions [B] on the device; then `sep` is their maximum (grid of the key-block pass, dS^T scratch dims) and
   // every workgroup reads its own dataset's position.  nullptr = every dataset at `sep`.
   const int* sep_of;
+  int q_from_sep;      // ragged batch with the top layer on the test rows: dataset b skips the queries below sep_of[b] / 256 * 256 (q_begin then = the smallest of them: the grids)
   // backward
   const void* dctx; void* dqkv; float* delta;  // delta: [B,H,S] f32 scratch
   void* ds;   // dS^T scratch [B, H, ds_rows, ds_ld] T: written by the key-block pass, read by the query-block pass (attn_bwd_ds_bytes)
@@ -248,6 +249,11 @@ int launch_dropout_scale(const void* src, void* dst, const void* src2, void* dst
 int launch_gather_test_rows(const float* src_bse, void* dst_t, int S, int B, int E, int sep, int precision, hipStream_t s);
 // ragged batch (per-dataset eval positions sep_of[B], compact rows dataset-major: row_off[b] + (s - sep_of[b]), row_off[B] = total):
 // dst[row_off[b] + s - sep_of[b], :] = (T) src[b, s, :] for s >= sep_of[b]   /   dst[b, s, :] = s >= sep_of[b] ? (T) src[row_off[b] + s - sep_of[b], :] : 0
+// the top layer's row moves for a ragged batch (compact rows dataset-major): dst[row_off[b] + s - sep_of[b]] = src[b, s] (s >= sep_of[b]);
+// dst[b, s] = s >= sep_of[b] ? src[row_off[b] + s - sep_of[b]] : 0 for s >= zero_from(b) = zero_from_block ? sep_of[b] / 256 * 256 : 0; base[b, s, 0 : width] = 0 for s < sep_of[b] / 256 * 256
+int launch_gather_rows_ragged(const void* src_bs, void* dst, int S, int B, long row_bytes, const int* sep_of, const long* row_off, hipStream_t s);
+int launch_scatter_rows_ragged(const void* src, void* dst_bs, int S, int B, long row_bytes, const int* sep_of, const long* row_off, int zero_from_block, hipStream_t s);
+int launch_zero_row_prefix_ragged(void* base, int S, int B, const int* sep_of, long row_bytes, long width_bytes, hipStream_t s);
 int launch_gather_test_rows_ragged(const float* src_bse, void* dst_t, int S, int B, int E, const int* sep_of, const long* row_off, int precision, hipStream_t s);
 int launch_scatter_test_rows_ragged(const float* src, void* dst_bse_t, int S, int B, int E, const int* sep_of, const long* row_off, int precision, hipStream_t s);
 // dst[b, s, :] = (s >= sep) ? src[(s-sep)*B + b, :] : 0

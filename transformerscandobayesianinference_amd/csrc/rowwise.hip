@@ -500,6 +500,64 @@ int launch_scatter_rows(const void* src_tb, void* dst_bs, int S, int B, long row
   }
   return PFN_LAUNCH_OK();
 }
+// ---- the same three row moves for a ragged batch (per-dataset eval positions, compact rows dataset-major: row_off[b] + s - sep_of[b]); all walk the [B, S] order ----
+template <typename U> __global__ __launch_bounds__(256) void gather_rows_ragged_kernel(const U* src, U* dst, int S, int B, int row_units, const int* sep_of, const long* row_off) {
+  const long n = (long)S * B * row_units;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long tok = i / row_units; const int c = (int)(i % row_units);
+    const long b = tok / S, sidx = tok % S;
+    const int sep = sep_of[b];
+    if (sidx >= sep) dst[(row_off[b] + sidx - sep) * row_units + c] = src[i];
+  }
+}
+template <typename U> __global__ __launch_bounds__(256) void scatter_rows_ragged_kernel(const U* src, U* dst, int S, int B, int row_units, const int* sep_of, const long* row_off, int zero_from_block) {
+  const long n = (long)S * B * row_units;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long tok = i / row_units; const int c = (int)(i % row_units);
+    const long b = tok / S, sidx = tok % S;
+    const int sep = sep_of[b];
+    if (sidx < (zero_from_block ? sep / 256 * 256 : 0)) continue;      // rows below the dataset's first live query block are not touched
+    U v = {};
+    if (sidx >= sep) v = src[(row_off[b] + sidx - sep) * row_units + c];
+    dst[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void zero_row_prefix_ragged_kernel(u32x4* base, int S, int B, const int* sep_of, int row_units, int width_units) {
+  const long n = (long)S * B * width_units;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long tok = i / width_units; const int c = (int)(i % width_units);
+    const long b = tok / S, sidx = tok % S;
+    if (sidx < sep_of[b] / 256 * 256) base[tok * row_units + c] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+int launch_gather_rows_ragged(const void* src_bs, void* dst, int S, int B, long row_bytes, const int* sep_of, const long* row_off, hipStream_t s) {
+  if (row_bytes % 4) return PFN_ERR_ALIGNMENT;
+  if (row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(src_bs) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0) {
+    const int ru = (int)(row_bytes / 16);
+    hipLaunchKernelGGL(gather_rows_ragged_kernel<u32x4>, dim3(grid_for((long)S * B * ru, 256)), dim3(256), 0, s, (const u32x4*)src_bs, (u32x4*)dst, S, B, ru, sep_of, row_off);
+  } else {
+    const int ru = (int)(row_bytes / 4);
+    hipLaunchKernelGGL(gather_rows_ragged_kernel<unsigned>, dim3(grid_for((long)S * B * ru, 256)), dim3(256), 0, s, (const unsigned*)src_bs, (unsigned*)dst, S, B, ru, sep_of, row_off);
+  }
+  return PFN_LAUNCH_OK();
+}
+int launch_scatter_rows_ragged(const void* src, void* dst_bs, int S, int B, long row_bytes, const int* sep_of, const long* row_off, int zero_from_block, hipStream_t s) {
+  if (row_bytes % 4) return PFN_ERR_ALIGNMENT;
+  if (row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst_bs)) % 16 == 0) {
+    const int ru = (int)(row_bytes / 16);
+    hipLaunchKernelGGL(scatter_rows_ragged_kernel<u32x4>, dim3(grid_for((long)S * B * ru, 256)), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst_bs, S, B, ru, sep_of, row_off, zero_from_block);
+  } else {
+    const int ru = (int)(row_bytes / 4);
+    hipLaunchKernelGGL(scatter_rows_ragged_kernel<unsigned>, dim3(grid_for((long)S * B * ru, 256)), dim3(256), 0, s, (const unsigned*)src, (unsigned*)dst_bs, S, B, ru, sep_of, row_off, zero_from_block);
+  }
+  return PFN_LAUNCH_OK();
+}
+int launch_zero_row_prefix_ragged(void* base, int S, int B, const int* sep_of, long row_bytes, long width_bytes, hipStream_t s) {
+  if (row_bytes % 16 || width_bytes % 16 || reinterpret_cast<uintptr_t>(base) % 16) return PFN_ERR_ALIGNMENT;
+  hipLaunchKernelGGL(zero_row_prefix_ragged_kernel, dim3(grid_for((long)S * B * (width_bytes / 16), 256)), dim3(256), 0, s, (u32x4*)base, S, B, sep_of,
+                     (int)(row_bytes / 16), (int)(width_bytes / 16));
+  return PFN_LAUNCH_OK();
+}
 // base[b, s, 0 : width] = 0 for s < nrows (rows of row_bytes bytes; width_bytes, row_bytes multiples of 16)
 __global__ __launch_bounds__(256) void zero_row_prefix_kernel(u32x4* base, int S, int B, int nrows, int row_units, int width_units) {
   const long per_b = (long)nrows * width_units, n = per_b * B;

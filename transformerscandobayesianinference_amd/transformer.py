@@ -84,11 +84,11 @@ class _StackFunction(torch.autograd.Function):
         ctx.ragged = ragged
         if ragged is not None:
             # a ragged batch (forward_batches): per-dataset eval positions, compact test rows dataset-major -- one launch set for several micro-batches
-            sep_of, row_off, sep_max, test_rows = ragged
+            sep_of, row_off, sep_min, sep_max, test_rows = ragged
             logits = torch.empty((test_rows, desc.n_out or desc.emsize), dtype=torch.float32, device=dev)
             ctx.dropout_seed = model._next_dropout_seed() if (model.training and desc.dropout > 0) else None
             _hip.check(lib.pfn_stack_forward_ragged(ctypes.byref(desc), flat_params.data_ptr(), shadow.data_ptr(), x_ptr, x_st, x_sb, y_ptr, y_st, y_sb, B, S,
-                                                    sep_of.data_ptr(), row_off.data_ptr(), sep_max, test_rows, ws.data_ptr(), ws_bytes, logits.data_ptr(), stream,
+                                                    sep_of.data_ptr(), row_off.data_ptr(), sep_min, sep_max, test_rows, ws.data_ptr(), ws_bytes, logits.data_ptr(), stream,
                                                     int(ctx.dropout_seed is not None), ctx.dropout_seed or 0), 'pfn_stack_forward_ragged')
             ctx.model, ctx.ws, ctx.dims = model, ws, (B, S, sep_max)
             ctx.operands = (desc, shadow)
@@ -136,10 +136,10 @@ class _StackFunction(torch.autograd.Function):
         hook = model._first_group_hook
         split = hook is not None and hook.armed()
         if ctx.ragged is not None:
-            sep_of, row_off, sep_max, test_rows = ctx.ragged
+            sep_of, row_off, sep_min, sep_max, test_rows = ctx.ragged
             cb = _hip.HOST_CALLBACK(lambda user: hook.first_group_launched()) if split else None
             _hip.check(lib.pfn_stack_backward_ragged(ctypes.byref(desc), model._flat.data_ptr(), shadow.data_ptr(), *args, B, S,
-                                                     sep_of.data_ptr(), row_off.data_ptr(), sep_max, test_rows, ws.data_ptr(), ws.numel(), dlogits.data_ptr(),
+                                                     sep_of.data_ptr(), row_off.data_ptr(), sep_min, sep_max, test_rows, ws.data_ptr(), ws.numel(), dlogits.data_ptr(),
                                                      model._flat_grad.data_ptr(), stream, hook.first_group_layers if split else 0, cb, None,
                                                      int(ctx.dropout_seed is not None), ctx.dropout_seed or 0), 'pfn_stack_backward_ragged')
             ctx.ws = None
@@ -450,7 +450,7 @@ class TransformerModel(nn.Module):
         inference = self._inference_pass()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             flat = flat.detach().requires_grad_(True)
-        logits = _StackFunction.apply(flat, self, x, y, None, max(seps), inference, (sep_of, row_off, max(seps), offs[-1]))
+        logits = _StackFunction.apply(flat, self, x, y, None, max(seps), inference, (sep_of, row_off, min(seps), max(seps), offs[-1]))
         # (torch.split: its backward is ONE concatenation of the per-batch gradients; slicing would zero-fill and add a full-size tensor per batch)
         parts = torch.split(logits, [w * (T - sep) for sep, w in zip(seps, widths)])
         return [p.view(w, T - sep, logits.shape[1]).transpose(0, 1) for p, sep, w in zip(parts, seps, widths)]      # dataset-major rows -> the reference's [T - sep, b, n_out]
