@@ -120,13 +120,16 @@ template <typename T> __global__ __launch_bounds__(256) void embed_fwd_kernel(Em
   }
   for (int e = threadIdx.x; e < a.E; e += 256) {
     const float be = a.bx[e], wye = a.wy[e], bye = a.by[e];
+    // explicit fused multiply-adds: left to the compiler, the 16 unrolled tokens were contracted differently (packed multiply + add for some pairs, fma for
+    // others), so a token's value depended on its position modulo 16 in the last bit -- and with it a dataset's logits on its index in the batch (found in
+    // round 5 by the ragged-batch test: bit-equal to the separate forwards only when the row offset was a multiple of 16)
     float acc[EMB_TOK];
 #pragma unroll
-    for (int tk = 0; tk < EMB_TOK; ++tk) acc[tk] = be + xs[tk * nfp + a.nf] * wye + xs[tk * nfp + a.nf + 1] * bye;
+    for (int tk = 0; tk < EMB_TOK; ++tk) acc[tk] = __builtin_fmaf(xs[tk * nfp + a.nf + 1], bye, __builtin_fmaf(xs[tk * nfp + a.nf], wye, be));
     for (int f = 0; f < a.nf; ++f) {
       const float w = a.wx[(long)e * a.nf + f];
 #pragma unroll
-      for (int tk = 0; tk < EMB_TOK; ++tk) acc[tk] += w * xs[tk * nfp + f];
+      for (int tk = 0; tk < EMB_TOK; ++tk) acc[tk] = __builtin_fmaf(w, xs[tk * nfp + f], acc[tk]);
     }
 #pragma unroll
     for (int tk = 0; tk < EMB_TOK; ++tk) {
