@@ -20,6 +20,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return str(sk.getsockname()[1])
+
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, 'include', 'pfn_hip.h')).read()
     declared = set(re.findall(r'\b(pfn_[a-z0-9_]+)\s*\(', header))
@@ -467,9 +474,10 @@ print('rank', rank, 'ok')
 def test_data_parallel_helpers_over_gloo(tmp_path):
     script = tmp_path / 'dp_check.py'
     script.write_text(_DP_SCRIPT)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    _PORT = _free_port()      # (a fixed port collided once in a full-suite run: a listener of an earlier test was still closing)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_PORT)
     res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                          '--master-port', '29533', str(script), ROOT], capture_output=True, text=True, env=env, timeout=240)
+                          '--master-port', _PORT, str(script), ROOT], capture_output=True, text=True, env=env, timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count('ok') == 2
 
