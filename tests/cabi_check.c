@@ -77,6 +77,17 @@ int main(int argc, char** argv) {
     CHECK(workspace_bytes(&d, 8, 2000) < 0 && strstr(last_error(), "schedule") != 0);
     d.schedule = 0;
   }
+  /* ragged batches (ABI 7): the arguments are checked before anything is launched -- missing per-dataset arrays or an impossible row count are refused */
+  {
+    int (*fwd_ragged)(const pfn_model_desc*, const float*, const void*, const float*, int64_t, int64_t, const float*, int64_t, int64_t, int, int,
+                      const int32_t*, const int64_t*, int, int, int64_t, void*, int64_t, float*, void*, int, uint64_t) =
+        (int (*)(const pfn_model_desc*, const float*, const void*, const float*, int64_t, int64_t, const float*, int64_t, int64_t, int, int,
+                 const int32_t*, const int64_t*, int, int, int64_t, void*, int64_t, float*, void*, int, uint64_t))dlsym(lib, "pfn_stack_forward_ragged");
+    float dummy[4]; int32_t seps[2] = {3, 5}; int64_t offs[3] = {0, 5, 8};
+    CHECK(fwd_ragged(&d, dummy, dummy, dummy, 36, 18, dummy, 2, 1, 2, 8, 0, offs, 3, 5, 8, dummy, 1 << 20, dummy, 0, 0, 0) == PFN_ERR_ARGUMENT);      /* no sep_of */
+    CHECK(fwd_ragged(&d, dummy, dummy, dummy, 36, 18, dummy, 2, 1, 2, 8, seps, offs, 3, 5, 17, dummy, 1 << 20, dummy, 0, 0, 0) == PFN_ERR_ARGUMENT);   /* more test rows than rows */
+    CHECK(fwd_ragged(&d, dummy, dummy, dummy, 36, 18, dummy, 2, 1, 2, 8, seps, offs, 6, 5, 8, dummy, 1 << 20, dummy, 0, 0, 0) == PFN_ERR_ARGUMENT);    /* sep_min > sep_max */
+  }
   printf("cabi_check ok: ABI %d, %d parameter tensors, %lld parameters\n", abi_version(), n, (long long)total);
   dlclose(lib);
   return 0;
