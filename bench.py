@@ -141,7 +141,8 @@ def build_model(device, precision, w=WORKLOAD, criterion=None):
     torch.manual_seed(0)
     criterion = criterion if criterion is not None else make_criterion(w, device)
     model = TransformerModel(encoders.Linear(w['num_features'], w['emsize']), w['num_bars'], w['emsize'], w['nhead'], w['nhid'],
-                             w['nlayers'], 0.0, y_encoder=encoders.Linear(1, w['emsize']), precision=precision)
+                             w['nlayers'], 0.0, y_encoder=encoders.Linear(1, w['emsize']), precision=precision,
+                             deterministic=os.environ.get('PFN_BENCH_DETERMINISTIC') == '1')      # (experiment hook: the bit-reproducible schedule's cost)
     model.criterion = criterion
     with torch.no_grad():  # random-init weights of the named architecture; un-zero the residual branches so all kernels see real data
         for layer in model.transformer_encoder.layers:
@@ -866,7 +867,7 @@ def compact_line(result):
     line = _pick(result, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'))
     cfg = result['config']
     line['config'] = _pick(cfg, ('workload', 'baseline_config', 'per_gpu_batch', 'global_batch', 'aggregate_k_gradients', 'aggregate_streams', 'aggregate_stacked', 'seq_len', 'parallelism',
-                                 'micro_batch_streams', 'eval_pos', 'mean_sep', 'final_loss', 'tuning', 'library_variant'))
+                                 'micro_batch_streams', 'eval_pos', 'mean_sep', 'final_loss', 'tuning', 'library_variant', 'deterministic_schedule'))
     line['step_roofline'] = _pick(result['step_roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'reference_graph_frac'))
     if 'roofline' in result:
         line['roofline'] = _pick(result['roofline'], ('bound', 'kernel', 'rocprof_kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_is', 'avg_launch_us', 'isolated_frac',
@@ -981,6 +982,8 @@ def main():
         result['config']['tuning'] = tuning
     if os.environ.get('PFN_LIB'):
         result['config']['library_variant'] = os.path.basename(os.environ['PFN_LIB'])
+    if os.environ.get('PFN_BENCH_DETERMINISTIC') == '1':
+        result['config']['deterministic_schedule'] = True
     if world > 1:
         result['ranks_seen'] = r['ranks_seen']
         result['per_rank_ms_per_step'] = [e / args.steps * 1e3 for e in r['per_rank_elapsed']]      # spread = load imbalance / stragglers at the all-reduce
