@@ -38,6 +38,13 @@ def main():
         us = timeit(lambda: torch.matmul(A, W.t(), out=C))
         out['gemms'].append(dict(gemm=name, M=M, N=N, K=K, us=us, tflops=2.0 * M * N * K / us / 1e6,
                                  hbm_floor_us=(M * K + N * K + M * N) * 2 / 6.3e12 * 1e6))
+    # what the same library sustains on large cubes (uniform random operands): the practical bf16 matrix-core ceiling of THIS box under its power limit
+    for n in (4096, 8192):
+        A = (torch.rand(n, n, device=dev, generator=g) * 2 - 1).bfloat16()
+        W = (torch.rand(n, n, device=dev, generator=g) * 2 - 1).bfloat16()
+        C = torch.empty(n, n, device=dev, dtype=torch.bfloat16)
+        us = timeit(lambda: torch.matmul(A, W.t(), out=C), iters=30 if n == 4096 else 10)
+        out['gemms'].append(dict(gemm=f'cube {n}^3 (NT, bf16 out)', M=n, N=n, K=n, us=us, tflops=2.0 * n ** 3 / us / 1e6))
     # weight-gradient form: C[P, Q] = A[M, P]^T B[M, Q]
     for name, P, Q in [('dW_qkv', 1536, 512), ('dW_lin1', 1024, 512), ('dW_lin2', 512, 1024), ('dW_out', 512, 512)]:
         A = (torch.rand(M, P, device=dev, generator=g) * 2 - 1).bfloat16()
