@@ -178,6 +178,12 @@ constexpr int PRIO = PFN_ATTN_PRIO;
 #define PFN_KV_PD_DP 2
 #endif
 constexpr int KVABL = PFN_KV_ABLATE;
+// ... and -DPFN_DQ_ABLATE=1 in the query-block pass: the stored dS^T is not fetched (round 5: with PFN_KV_ABLATE=1 the whole dS^T round trip is gone -- results are
+// garbage, the step time is the UPPER bound of what any form of the backward without that round trip could gain before paying for its own extra work)
+#ifndef PFN_DQ_ABLATE
+#define PFN_DQ_ABLATE 0
+#endif
+constexpr int DQABL = PFN_DQ_ABLATE;
 typedef __attribute__((address_space(3))) void lvoid_t;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -1026,9 +1032,12 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
     }
   };
   static_assert(Q::NPW <= 10, "piece count per wave exceeds the vmcnt cases above");
+  if constexpr (DQABL & 1) {      // ablation build: nothing is fetched into the ring -- zero it, so that the (wrong) dQ stays finite and the step keeps running on ordinary numbers
+    for (int o = lane * 16; o < Q::NDS * Q::DSW; o += 64 * 16) lds_write16(dsw + o, u32x4{0u, 0u, 0u, 0u});
+  }
   if (ntiles > 0) { dma_k(0, 0); dma_ds(0, 0); }
-  if (ntiles > 1 && !(ABL & 1)) dma_ds(1, 1);
-  wait_all_but(ntiles > 1 && !(ABL & 1) ? my_ds_pieces : 0);
+  if (ntiles > 1 && !(ABL & 1) && !(DQABL & 1)) dma_ds(1, 1);
+  wait_all_but(ntiles > 1 && !(ABL & 1) && !(DQABL & 1) ? my_ds_pieces : 0);
   __syncthreads();
   int sd = 0, sk = 0;                  // ring slots of tile t
   for (int t = 0; t < ntiles; ++t) {
@@ -1036,7 +1045,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
     const lds_char* kc = Kc(sk);
     constexpr int NKS = C::KVB / 16;     // contraction steps per tile
     const int sd2 = sd == 0 ? 2 : sd - 1;                      // (t + 2) % 3
-    const bool more_ds = !(ABL & 1) && t + 2 < ntiles;
+    const bool more_ds = !(ABL & 1) && !(DQABL & 1) && t + 2 < ntiles;
     if (t + 1 < ntiles) dma_k(sk ^ 1, t + 1);                  // slots last read in tile t-1: every wave is past that tile's barrier
     if (more_ds) dma_ds(sd2, t + 2);
     Frag<T> dsf[NKS];
