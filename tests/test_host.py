@@ -607,3 +607,14 @@ def test_checkpoint_tuple_roundtrip_on_cpu(tmp_path):
     assert tabular.load_checkpoint(b, path) is None
     mean, half = evaluation.compute_mean_and_conf_interval([1., 2., 3., 4.])
     assert mean == 2.5 and abs(half - 2.0541) < 1e-3
+
+
+def test_ragged_batch_layout():
+    """Host side of forward_batches / pfn_stack_forward_ragged: per-dataset eval positions and the dataset-major compact test-row offsets."""
+    from transformerscandobayesianinference_amd.transformer import ragged_layout
+    seps, per_dataset, offs = ragged_layout(10, [2, 1, 3], [7, -2, 0])
+    assert seps == [7, 8, 0]                                   # -2 counts from the end, as single_eval_pos does through slicing in the reference
+    assert per_dataset == [7, 7, 8, 0, 0, 0]
+    assert offs == [0, 3, 6, 8, 18, 28, 38] and offs[-1] == sum(10 - s for s in per_dataset)
+    seps, per_dataset, offs = ragged_layout(10, [1, 1], [10, 25])      # no test rows at all (clamped)
+    assert seps == [10, 10] and offs == [0, 0, 0]

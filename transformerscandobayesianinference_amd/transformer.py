@@ -163,6 +163,21 @@ class _StackFunction(torch.autograd.Function):
         return None, None, None, None, (dsrc if ctx.src_needs_grad else None), None, None, None
 
 
+def ragged_layout(T, widths, single_eval_positions):
+    """Host side of a ragged batch (pfn_stack_forward_ragged): batch k has widths[k] datasets at eval position single_eval_positions[k] (negative positions count
+    from the end, as slicing does in the reference).  Returns (clamped positions per batch, eval position per dataset [B], first compact test row per dataset
+    [B + 1]): dataset b's test rows are row_off[b] + (t - sep_of[b]) for t >= sep_of[b], batches and datasets in order."""
+    seps = []
+    for sep in single_eval_positions:
+        sep = int(sep)
+        seps.append(max(0, min(T, sep + T if sep < 0 else sep)))
+    per_dataset = [s for s, w in zip(seps, widths) for _ in range(w)]
+    offs = [0]
+    for s in per_dataset:
+        offs.append(offs[-1] + T - s)
+    return seps, per_dataset, offs
+
+
 class TransformerModel(nn.Module):
     requires_gpu = True   # train() checks this before building anything (the host-plumbing tests substitute a CPU stand-in)
 
@@ -430,17 +445,10 @@ class TransformerModel(nn.Module):
         _hip.require_gpu_tensor(x, 'x')
         _hip.require_gpu_tensor(next(self.parameters()), 'model parameters')
         T = x.shape[0]
-        seps, widths = [], []
-        for (xb, _), sep in zip(batches, single_eval_positions):
+        for xb, _ in batches:
             assert xb.shape[0] == T, 'forward_batches: every batch needs the same sequence length'
-            sep = int(sep)
-            sep = max(0, min(T, sep + T if sep < 0 else sep))
-            seps.append(sep)
-            widths.append(xb.shape[1])
-        per_dataset = [s for s, w in zip(seps, widths) for _ in range(w)]
-        offs = [0]
-        for s in per_dataset:
-            offs.append(offs[-1] + T - s)
+        widths = [xb.shape[1] for xb, _ in batches]
+        seps, per_dataset, offs = ragged_layout(T, widths, single_eval_positions)
         meta = torch.tensor(per_dataset + offs, dtype=torch.int64)          # one host-to-device copy for both arrays
         sep_of = meta[:len(per_dataset)].to(torch.int32).to(x.device, non_blocking=True)
         row_off = meta[len(per_dataset):].to(x.device, non_blocking=True)
