@@ -298,18 +298,27 @@ int pfn_prepare_params(const pfn_model_desc* d, const float* params, void* shado
   char* sh = (char*)shadow;
   PFN_TRY(launch_cast_params(params, sh, L.total, prec, s));
   char* tr = sh + L.total * es;
+  TransposeGroup g;      // all transposed copies in one launch per TRANSPOSE_GROUP_MAX matrices
+  auto add = [&](long src_off, long dst_off, int rows, int cols, int ld_dst) -> int {
+    if (g.n == TRANSPOSE_GROUP_MAX) {
+      PFN_TRY(launch_transpose_cast_group(params, tr, g, prec, s));
+      g = TransposeGroup();
+    }
+    transpose_group_add(g, src_off, dst_off, rows, cols, ld_dst);
+    return PFN_OK;
+  };
   for (int l = 0; l < d->nlayers; ++l) {
     const LayerP &p = L.layer[l], &t = L.layer_t[l];
-    PFN_TRY(launch_transpose_cast(params + p.w_in, tr + t.w_in * es, 3 * E, E, 3 * E, prec, s));  // [3E,E] -> [E,3E]
-    PFN_TRY(launch_transpose_cast(params + p.w_o, tr + t.w_o * es, E, E, E, prec, s));
-    PFN_TRY(launch_transpose_cast(params + p.w1, tr + t.w1 * es, F, E, F, prec, s));               // [F,E] -> [E,F]
-    PFN_TRY(launch_transpose_cast(params + p.w2, tr + t.w2 * es, E, F, E, prec, s));               // [E,F] -> [F,E]
+    PFN_TRY(add(p.w_in, t.w_in, 3 * E, E, 3 * E));  // [3E,E] -> [E,3E]
+    PFN_TRY(add(p.w_o, t.w_o, E, E, E));
+    PFN_TRY(add(p.w1, t.w1, F, E, F));               // [F,E] -> [E,F]
+    PFN_TRY(add(p.w2, t.w2, E, F, E));               // [E,F] -> [F,E]
   }
   if (d->n_out > 0) {
-    PFN_TRY(launch_transpose_cast(params + L.dec0_w, tr + L.dec0_wt * es, F, E, F, prec, s));
-    PFN_TRY(launch_transpose_cast(params + L.dec2_w, tr + L.dec2_wt * es, d->n_out, F, L.n_out_pad, prec, s));  // [O,F] -> [F,Opad]
+    PFN_TRY(add(L.dec0_w, L.dec0_wt, F, E, F));
+    PFN_TRY(add(L.dec2_w, L.dec2_wt, d->n_out, F, L.n_out_pad));  // [O,F] -> [F,Opad]
   }
-  return PFN_OK;
+  return launch_transpose_cast_group(params, tr, g, prec, s);
 }
 
 static int stack_forward_impl(const pfn_model_desc* d, const float* params, const void* shadow,

@@ -193,6 +193,14 @@ int launch_attn_bwd(const AttnArgs& a, int precision, hipStream_t stream);
 
 // ---- row-wise / element-wise kernels (rowwise.hip) --------------------------------------------
 int launch_cast_params(const float* src, void* dst_t, long n, int precision, hipStream_t s);
+constexpr int TRANSPOSE_GROUP_MAX = 64;
+struct TransposeGroup {     // by value in the kernel arguments: offsets in elements from one source / one destination base
+  int n = 0, blocks = 0;
+  long src_off[TRANSPOSE_GROUP_MAX], dst_off[TRANSPOSE_GROUP_MAX];
+  int rows[TRANSPOSE_GROUP_MAX], cols[TRANSPOSE_GROUP_MAX], ld_dst[TRANSPOSE_GROUP_MAX], first_block[TRANSPOSE_GROUP_MAX];
+};
+void transpose_group_add(TransposeGroup& g, long src_off, long dst_off, int rows, int cols, int ld_dst);
+int launch_transpose_cast_group(const float* src, void* dst, const TransposeGroup& g, int precision, hipStream_t s);
 int launch_transpose_cast(const float* src, void* dst_t, int rows, int cols, long ld_dst, int precision, hipStream_t s);
 // dst[r, 0:C] = (T) src[r, 0:C], dst[r, C:ld_dst] = 0
 int launch_cast_rows(const float* src, long ld_src, void* dst_t, long ld_dst, long R, int C, int precision, hipStream_t s);

@@ -80,6 +80,40 @@ template <typename T> __global__ __launch_bounds__(256) void transpose_cast_kern
     if (c < cols && r < ld_dst) dst[(long)c * ld_dst + r] = (T)tile[tx][j];  // r >= rows writes the zero padding
   }
 }
+// every transposed operand copy of a model in ONE launch (pfn_prepare_params runs after each optimizer step: 26 launches of a few microseconds each before)
+template <typename T> __global__ __launch_bounds__(256) void transpose_cast_group_kernel(const float* src, T* dst, TransposeGroup g) {
+  __shared__ float tile[32][33];
+  int e = 0;
+  while (e + 1 < g.n && (int)blockIdx.x >= g.first_block[e + 1]) ++e;
+  const int rows = g.rows[e], cols = g.cols[e];
+  const long ld_dst = g.ld_dst[e];
+  const int bx = (cols + 31) / 32, blk = blockIdx.x - g.first_block[e];
+  const int c0 = (blk % bx) * 32, r0 = (blk / bx) * 32;
+  const float* sp = src + g.src_off[e];
+  T* dp = dst + g.dst_off[e];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < rows && c < cols) ? sp[(long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < cols && r < ld_dst) dp[(long)c * ld_dst + r] = (T)tile[tx][j];  // r >= rows writes the zero padding
+  }
+}
+void transpose_group_add(TransposeGroup& g, long src_off, long dst_off, int rows, int cols, int ld_dst) {
+  const int e = g.n++;
+  g.src_off[e] = src_off; g.dst_off[e] = dst_off; g.rows[e] = rows; g.cols[e] = cols; g.ld_dst[e] = ld_dst;
+  g.first_block[e] = g.blocks;
+  g.blocks += ((cols + 31) / 32) * ((ld_dst + 31) / 32);
+}
+int launch_transpose_cast_group(const float* src, void* dst, const TransposeGroup& g, int precision, hipStream_t s) {
+  if (g.n == 0) return PFN_OK;
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(transpose_cast_group_kernel<bf16>, dim3(g.blocks), dim3(256), 0, s, src, (bf16*)dst, g);
+  else hipLaunchKernelGGL(transpose_cast_group_kernel<float>, dim3(g.blocks), dim3(256), 0, s, src, (float*)dst, g);
+  return PFN_LAUNCH_OK();
+}
 int launch_transpose_cast(const float* src, void* dst, int rows, int cols, long ld_dst, int precision, hipStream_t s) {
   dim3 grid((cols + 31) / 32, (unsigned)((ld_dst + 31) / 32));
   if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16>, grid, dim3(256), 0, s, src, (bf16*)dst, rows, cols, ld_dst);
