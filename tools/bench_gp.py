@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import bench
 from transformerscandobayesianinference_amd.priors import fast_gp
 from transformerscandobayesianinference_amd import _hip
+if os.environ.get('PFN_LIB'):
+    _hip.LIB_PATH = os.path.abspath(os.environ['PFN_LIB'])
 for kv in os.environ.get('PFN_TUNE', '').split(','):      # e.g. PFN_TUNE=8=0: pfn_set_tuning keys (include/pfn_hip.h)
     if kv:
         _hip.check(_hip.lib().pfn_set_tuning(*[int(v) for v in kv.split('=')]), 'pfn_set_tuning')
@@ -17,4 +19,4 @@ for _ in range(2): f()
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(a.iters): f()
 torch.cuda.synchronize(); t = (time.time() - t0) / a.iters
-print(f'[PFN_TUNE={os.environ.get("PFN_TUNE", "")}] gp draw B={a.batch}: {t * 1e3:.3f} ms = {t / a.batch * 1e6:.1f} us per dataset ({a.batch / t:.0f} datasets/s)')
+print(f'[{os.path.basename(_hip.LIB_PATH)} PFN_TUNE={os.environ.get("PFN_TUNE", "")}] gp draw B={a.batch}: {t * 1e3:.3f} ms = {t / a.batch * 1e6:.1f} us per dataset ({a.batch / t:.0f} datasets/s)')

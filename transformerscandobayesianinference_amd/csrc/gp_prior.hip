@@ -444,28 +444,58 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r
 }
 
 // ---------------------------------------------------------------------------------------------
-// The rank-256 trailing update from PRE-SPLIT panels (round 4).  gp_syrk_kernel above re-reads its two f32 panels for every tile and
-// splits every value into its three bf16 terms again as the chunk goes to LDS -- for the trailing update of an outer block that is ~10x
-// redundant vector work (one split per tile that touches the row) staged through 64 registers per lane.  Here gp_trsm_wide_kernel, which
-// produces the solved panel anyway, ALSO leaves its three bf16 planes in a scratch behind K_ws (GpArgs::planes), laid out for the consumer:
-//     slab (plane p, k-chunk kc of PL_KC columns)  =  [rows below the outer block][PL_KC] bf16, contiguous (32 bytes per row),
-//     the two 16-byte halves of a row swapped when (row >> 3) & 1 -- the bank swizzle of load_frag_row<bf16, 32>.
-// A 128-row operand chunk of one plane is then 4 contiguous KiB: the update's tiles fetch them by LDS-DMA (dma16, no staging registers, no
-// vector work), two stages of 6 slabs x 4 KiB each, and multiply exactly as before (six bf16 MFMAs per block product).  L2 traffic per tile
-// goes up 1.5x (6 instead of 4 bytes per panel value); the split and the register staging are gone.
+// The rank-256 trailing update from PRE-SPLIT panels (round 4; fp16 planes round 5).  gp_syrk_kernel above re-reads its two f32 panels for every
+// tile and splits every value again as the chunk goes to LDS -- for the trailing update of an outer block that is ~10x redundant vector work (one
+// split per tile that touches the row) staged through 64 registers per lane.  Here gp_trsm_wide_kernel, which produces the solved panel anyway, ALSO
+// leaves it split in a scratch behind K_ws (GpArgs::planes), laid out for the consumer:
+//     slab (plane p, k-chunk kc of PL_KC columns)  =  [rows below the outer block][PL_KC] 2-byte values, contiguous (32 bytes per row),
+//     the two 16-byte halves of a row swapped when (row >> 3) & 1 -- the bank swizzle of load_frag_row<.., 32>.
+// A 128-row operand chunk of one plane is then 4 contiguous KiB: the update's tiles fetch them by LDS-DMA (dma16, no staging registers, no vector work).
+//
+// Round 5: TWO fp16 planes on a per-dataset power-of-two scale instead of three bf16 planes.  x s = hi + lo with hi = fp16(x s), lo = fp16(x s - hi):
+// 11 + 11 mantissa bits, |x s - hi - lo| <= 2^-22 |x s|, and a block product is the THREE fp16 MFMAs  lo.hi + hi.lo + hi.hi  (the dropped lo.lo term is
+// below 2^-22 of the product; products are exact in the f32 accumulator) -- half the matrix-pipe cycles of the six bf16 products and 4 instead of 6 bytes
+// per panel value through L2 / the infinity cache, which is what the kernel was bound by.  fp16's narrow exponent is what the scale is for: every entry of
+// a Cholesky factor obeys |L_ij| <= sqrt(K_ii) = sqrt(outputscale + noise), so s = 2^(14 - ceil(log2 sqrt(K_ii))) puts the largest entry below 2^14 (no
+// overflow: fp16 reaches 65504; the products' sum stays far inside f32) and an entry keeps a NORMAL lo term down to 2^-16 of the largest; below that lo
+// goes subnormal (absolute error 2^-25, i.e. 2^-39 of the largest entry -- and 2^-28 of it if the hardware flushed subnormals).  The scale is a power of
+// two, so applying it and taking s^-2 out of the accumulator are exact.  Accuracy was priced BEFORE the kernel was written (tools/sim_gp_split.py, CPU
+// emulation of the blocked factorisation): error of y against the f64 factorisation 7.0e-4 / 5.3e-7 (nf 5 / nf 18) where exact f32 gives 6.6e-4 / 5.3e-7
+// and the six bf16 products 7.0e-4 / 4.9e-7; two bf16 terms / three products FAIL outright (non-positive pivots) on the nf-5 matrices.
 // ---------------------------------------------------------------------------------------------
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 constexpr int PL_KC = 16;                           // panel columns per slab / per LDS stage
 constexpr int PL_NKC = 256 / PL_KC;                 // slabs per plane of a 256-wide panel
 constexpr int PL_ROWB = PL_KC * 2;                  // bytes per slab row
+constexpr int PL_NPL = 2;                           // planes: hi, lo
 PFN_DEV long plane_slab_bytes(long rows_alloc) { return rows_alloc * PL_ROWB; }
 // byte offset of (plane, chunk, row) inside one dataset's plane scratch of `rows_alloc` rows
 PFN_DEV long plane_offset(long rows_alloc, int plane, int kc, long row) { return ((long)(plane * PL_NKC + kc) * rows_alloc + row) * PL_ROWB; }
+// exponent e of a dataset's plane scale s = 2^e (see above)
+PFN_DEV int plane_scale_exp(const GpArgs& a, int b) {
+  const float kii = a.outputscale[b] + a.noise[b];
+  const int e = 14 - (int)ceilf(0.5f * __log2f(fmaxf(kii, 1e-30f)));
+  return max(-60, min(60, e));
+}
 
 constexpr int SYP_SLAB = 128 * PL_ROWB;             // one plane of one 128-row operand chunk in LDS: 4 KiB
-constexpr int SYP_STAGE = 2 * 3 * SYP_SLAB;         // A and B, three planes each: 24 KiB
-constexpr int SYP_LDS = 2 * SYP_STAGE;              // two stages: 48 KiB, three workgroups per CU
+constexpr int SYP_STAGE = 2 * PL_NPL * SYP_SLAB;    // A and B, two planes each: 16 KiB
+#ifndef PFN_SYP_NST
+#define PFN_SYP_NST 3
+#endif
+#ifndef PFN_SYP_WGS
+#define PFN_SYP_WGS 3
+#endif
+constexpr int SYP_NST = PFN_SYP_NST;                // stages in the ring: two in flight under the one being multiplied
+constexpr int SYP_LDS = SYP_NST * SYP_STAGE;        // 48 KiB, three workgroups per CU
+constexpr int SYP_PPW = 2 * PL_NPL * 4 / 4;         // 1-KiB DMA pieces per wave and stage
 
-__global__ __launch_bounds__(256, 3) void gp_syrk_planes_kernel(GpArgs a, int r0, int r1) {
+PFN_DEV f32x16 mma32_f16(const Frag<bf16>& a, const Frag<bf16>& b, f32x16 c) {      // the fragments carry fp16 bit patterns
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v), __builtin_bit_cast(f16x8, b.v), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, PFN_SYP_WGS) void gp_syrk_planes_kernel(GpArgs a, int r0, int r1) {
   // C[i][j] -= sum_k X[i][k] X[j][k] for rows / columns >= r0 (lower triangle, 128 x 128 tiles), X = the 256-wide solved panel of the outer
   // block that ends at r0, read from its planes (row index in the planes: global row - r0)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -478,8 +508,8 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_planes_kernel(GpArgs a, int r0
   const int i0 = r0 + (t / gridDim.x) * 128, j0 = r0 + (t % gridDim.x) * 128;
   if (j0 > i0 + 127) return;          // tile entirely above the diagonal
   float* Kb = a.K + (long)b * S * S;
-  const char* pl = reinterpret_cast<const char*>(a.planes) + (long)b * 3 * PL_NKC * plane_slab_bytes(a.plane_rows);
-  const DmaRsrc rp = make_dma_rsrc(pl, 3L * PL_NKC * plane_slab_bytes(a.plane_rows));
+  const char* pl = reinterpret_cast<const char*>(a.planes) + (long)b * PL_NPL * PL_NKC * plane_slab_bytes(a.plane_rows);
+  const DmaRsrc rp = make_dma_rsrc(pl, (long)PL_NPL * PL_NKC * plane_slab_bytes(a.plane_rows));
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, wm = wave >> 1, wn = wave & 1;
   f32x16 acc[2][2];
 #pragma unroll
@@ -488,48 +518,54 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_planes_kernel(GpArgs a, int r0
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // a stage = 24 one-KiB pieces: piece q = (operand o = q / 12, plane p = (q / 4) % 3, quarter qq = q % 4) -> LDS (o * 3 + p) * SYP_SLAB + qq * 1024; wave w
+  // a stage = 16 one-KiB pieces: piece q = (operand o = q / 8, plane p = (q / 4) % 2, quarter qq = q % 4) -> LDS (o * 2 + p) * SYP_SLAB + qq * 1024; wave w
   // moves pieces w, w + 4, ...  Source: 32 consecutive slab rows = one contiguous KiB (the swizzle is already in the slab).
   auto stage = [&](int buf, int kc) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < SYP_PPW; ++i) {
       const int q = wave + 4 * i;
-      const int o = q / 12, p = (q / 4) % 3, qq = q % 4;
+      const int o = q / (4 * PL_NPL), p = (q / 4) % PL_NPL, qq = q % 4;
       const long row = (long)((o ? j0 : i0) - r0) + qq * 32;
       const long off = plane_offset(a.plane_rows, p, kc, row) + lane * 16;
-      dma16(rp, smem + buf * SYP_STAGE + (o * 3 + p) * SYP_SLAB + qq * 1024, (int)off);
+      dma16(rp, smem + buf * SYP_STAGE + (o * PL_NPL + p) * SYP_SLAB + qq * 1024, (int)off);
     }
   };
   stage(0, 0);
+  if (SYP_NST > 2) stage(1, 1);
+  int cur = 0;
   for (int kc = 0; kc < PL_NKC; ++kc) {
-    const int cur = kc & 1;
-    dma_wait_all();
-    __syncthreads();                   // stage kc has landed for everyone; the other buffer's readers (stage kc - 1) are done
-    if (kc + 1 < PL_NKC) stage(cur ^ 1, kc + 1);
+    // stage kc has landed for everyone (a wave's pieces retire in order: all but the SYP_PPW of stage kc + 1), and everyone is done reading stage kc - 1
+    if (SYP_NST > 2 && kc + 1 < PL_NKC) wait_vm_barrier<SYP_PPW>(); else wait_vm_barrier<0>();
+    if (kc + SYP_NST - 1 < PL_NKC) stage(cur == 0 ? SYP_NST - 1 : cur - 1, kc + SYP_NST - 1);      // into the buffer stage kc - 1 was read from
     const lds_char* tA = smem + cur * SYP_STAGE;
-    const lds_char* tB = tA + 3 * SYP_SLAB;
-    Frag<bf16> fa[2][3], fb[2][3];     // [block][hi, mid, lo]
+    const lds_char* tB = tA + PL_NPL * SYP_SLAB;
+    Frag<bf16> fa[2][2], fb[2][2];     // [block][hi, lo]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[i][p] = load_frag_row<bf16, PL_ROWB>(tA + p * SYP_SLAB, wm * 64 + i * 32 + (lane & 31), 0);
+      for (int p = 0; p < 2; ++p) fa[i][p] = load_frag_row<bf16, PL_ROWB>(tA + p * SYP_SLAB, wm * 64 + i * 32 + (lane & 31), 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fb[j][p] = load_frag_row<bf16, PL_ROWB>(tB + p * SYP_SLAB, wn * 64 + j * 32 + (lane & 31), 0);
+      for (int p = 0; p < 2; ++p) fb[j][p] = load_frag_row<bf16, PL_ROWB>(tB + p * SYP_SLAB, wn * 64 + j * 32 + (lane & 31), 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {   // swapped operands: a lane owns one ROW of the tile; smallest terms first (as gp_syrk_kernel)
         f32x16 c = acc[i][j];
-        c = mma32(fb[j][2], fa[i][0], c);
-        c = mma32(fb[j][0], fa[i][2], c);
-        c = mma32(fb[j][1], fa[i][1], c);
-        c = mma32(fb[j][1], fa[i][0], c);
-        c = mma32(fb[j][0], fa[i][1], c);
-        acc[i][j] = mma32(fb[j][0], fa[i][0], c);
+        c = mma32_f16(fb[j][1], fa[i][0], c);
+        c = mma32_f16(fb[j][0], fa[i][1], c);
+        acc[i][j] = mma32_f16(fb[j][0], fa[i][0], c);
       }
+    cur = cur == SYP_NST - 1 ? 0 : cur + 1;
   }
+  const float inv_s2 = __builtin_ldexpf(1.f, -2 * plane_scale_exp(a, b));      // exact: the scale is a power of two
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv_s2;
   syrk_rmw(Kb, S, acc, i0 + wm * 64, j0 + wn * 64, __builtin_amdgcn_readfirstlane((j0 + 127 < i0 && i0 + 127 < r1) ? 1 : 0) != 0, r1, r1, lane);
 }
 
@@ -549,67 +585,100 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_planes_kernel(GpArgs a, int r0
 // ---------------------------------------------------------------------------------------------
 constexpr int OBW = 4 * NB;               // outer block width
 constexpr int TW_STRIDE = OBW * 4 + 16;   // padded LDS row (pfn_device.h PadStride)
-__global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
+// Round 5: the factor's blocks are NOT staged in LDS any more.  With row block j of L_d beside the workgroup's rows the kernel held 133 KiB of LDS -- one
+// workgroup (four waves) per CU, so nothing ran under its panel load (64 KiB from HBM), its store + plane writes (128 KiB) or its barriers: 4.05 ms per 320
+// datasets for 1.0 ms of MFMA chain and ~1.3 ms of HBM traffic.  The L operand of both products is now read straight from global memory into the B fragments
+// (a lane's 8 contraction values are 32 contiguous bytes of a row of L_d; the 256-KiB factor of a dataset stays in the L2 of the XCD all its workgroups run
+// on -- the dataset -> XCD deal below), one 64-column block ahead of the MFMAs that consume it.  LDS = the rows alone, 67.6 KiB: two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr V = lds_cast(smem_raw);                     // [64][TW_STRIDE]  the workgroup's rows
-  LdsPtr Lr = V + 64 * TW_STRIDE;                    // [64][TW_STRIDE]  row block j of L_d, columns 0 .. 64(j+1)
-  float* zs = reinterpret_cast<float*>(smem_raw + 2 * 64 * TW_STRIDE);  // [256]
-  const int b = blockIdx.y, S = a.S;
-  const int row0 = kout + OBW + blockIdx.x * 64;
+  float* zs = reinterpret_cast<float*>(smem_raw + 64 * TW_STRIDE);  // [256]
+  const int S = a.S;
+  int b = blockIdx.y, rb = blockIdx.x;
+  if (a.B % 8 == 0) {      // hardware places workgroup n on XCD n % 8: all row blocks of a dataset on one XCD, whose L2 then holds that dataset's factor
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, j = lin >> 3;
+    b = xcd + 8 * (j / (int)gridDim.x); rb = j % (int)gridDim.x;
+  }
+  const int row0 = kout + OBW + rb * 64;
   const int rows_valid = min(64, S - row0);
   float* Kb = a.K + (long)b * S * S;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31;
-  // row block jb of L_d reaches LDS through registers; the request for block jb + 1 is issued as soon as block jb has been committed, so its round trip
-  // (L2 / HBM, one workgroup per CU: nothing else hides it) runs under block jb's MFMA phases instead of in front of block jb + 1's -- and block 0 travels
-  // together with the workgroup's own rows
-  TileStage<float, 64, OBW * 4, 256> sl;
+  const float* Ld = Kb + (long)kout * S + kout;      // the factored 256 x 256 diagonal block [L \ L^-T of its 64 x 64 diagonal blocks]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const int rt = wave >> 1, ct = wave & 1, c = ct * 32 + li;
   {
     TileStage<float, 64, OBW * 4, 256> sv;
     sv.issue(Kb + (long)row0 * S + kout, S, rows_valid, OBW);
-    sl.issue(Kb + (long)kout * S + kout, S, NB, NB);
     const float zv = (a.w ? a.w : a.z)[(long)b * S + kout + threadIdx.x];
     sv.template commit_p<TW_STRIDE>(V);
     zs[threadIdx.x] = zv;
   }
+  // B fragment of the block products: rows of L_d are the tile's columns, a lane's slots k0 + 8h .. + 7 of row r are 32 contiguous bytes
+  auto l_frag = [&](int r, int k0) {
+    const float* p = Ld + (long)r * S + k0 + 8 * h;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+    Frag<float> f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f.v[e] = lo[e]; f.v[4 + e] = hi[e]; }
+    return f;
+  };
   for (int jb = 0; jb < 4; ++jb) {
-    __syncthreads();   // V current (initial load / previous block's solution), Lr free
-    sl.template commit_p<TW_STRIDE>(Lr);
-    if (jb + 1 < 4) sl.issue(Kb + (long)(kout + (jb + 1) * NB) * S + kout, S, NB, (jb + 2) * NB);
-    __syncthreads();
+    // X_j = V_j L_jj^-T needs the inverse block: L^-1[c][k] (k < c) sits at (row k, column c) of the diagonal block, the diagonal holds L[c][c], everything with
+    // k > c is masked to zero.  Requested first, so that the round trip runs under the products below.
+    const float* dcol = Ld + (long)(jb * NB) * S + jb * NB + c;
+    const int kmax = ct == 0 ? 32 : NB;      // columns c < 32 only see k < 32
+    Frag<float> finv[4];
+    const float ldiag = dcol[(long)c * S];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = q * 16 + 8 * h + e;
+        finv[q].v[e] = (q * 16 < kmax) ? dcol[(long)k * S] : 0.f;
+      }
+    __syncthreads();   // V current (initial load / previous block's solution)
     if (jb > 0) {
-      const int rt = wave >> 1, ct = wave & 1;
+      // V_j -= sum_{i<j} X_i L_ji^T
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      for (int k = 0; k < jb * NB; k += 16)
-        acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, k), load_frag_row_p<float, TW_STRIDE>(Lr, ct * 32 + li, k), acc);
-      __syncthreads();  // every wave has read the X_i it needs before V_j changes (disjoint columns, but keep the phases apart)
+      const int lrow = jb * NB + c;
+      Frag<float> fcur[4], fnext[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fcur[q] = l_frag(lrow, q * 16);
+      for (int ib = 0; ib < jb; ++ib) {
+        if (ib + 1 < jb) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fnext[q] = l_frag(lrow, (ib + 1) * NB + q * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, ib * NB + q * 16), fcur[q], acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fcur[q] = fnext[q];
+      }
+      // (columns jb * 64 .. are read by nobody in this phase: no barrier in front of the update)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        LdsPtr p = V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + (jb * NB + ct * 32 + li) * 4;
+        LdsPtr p = V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + (jb * NB + c) * 4;
         lds_write_f32(p, lds_read_f32(p) - acc[r]);
       }
       __syncthreads();
     }
     {
-      // X_j = V_j L_jj^-T on the MFMA.  The staged diagonal block holds [L \ L^-T]: L^-1[c][k] (k < c) sits at
-      // (row k, column c), the diagonal holds L[c][c], everything with k > c is masked to zero.
-      const int rt = wave >> 1, ct = wave & 1, h = lane >> 5;
-      const int c = ct * 32 + li;
-      const float rdiag = 1.f / lds_read_f32(Lr + c * TW_STRIDE + (jb * NB + c) * 4);
+      const float rdiag = 1.f / ldiag;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const int kmax = ct == 0 ? 32 : NB;      // columns c < 32 only see k < 32
-      for (int k0 = 0; k0 < kmax; k0 += 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q * 16 >= kmax) break;
         Frag<float> fb;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int k = k0 + 8 * h + e;
-          const float st = lds_read_f32(Lr + k * TW_STRIDE + (jb * NB + c) * 4);
-          fb.v[e] = k < c ? st : (k == c ? rdiag : 0.f);
+          const int k = q * 16 + 8 * h + e;
+          fb.v[e] = k < c ? finv[q].v[e] : (k == c ? rdiag : 0.f);
         }
-        acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, jb * NB + k0), fb, acc);
+        acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, jb * NB + q * 16), fb, acc);
       }
       __syncthreads();   // all of V_j has been read
 #pragma unroll
@@ -635,30 +704,28 @@ __global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
     if (r < rows_valid) *reinterpret_cast<u32x4*>(Kb + (long)(row0 + r) * S + kout + c * 4) = lds_read16(V + r * TW_STRIDE + c * 16);
   }
   if (a.planes) {
-    // the solved rows once more, as the three bf16 planes the trailing update multiplies (gp_syrk_planes_kernel: layout and why).  A task = 8 consecutive
-    // columns of a row (two 16-byte reads of V) -> one 16-byte half row in each plane; a = hi + mid + lo to 2^-27 |a|, each residual exact in f32.
-    char* pl = reinterpret_cast<char*>(a.planes) + (long)b * 3 * PL_NKC * plane_slab_bytes(a.plane_rows);
+    // the solved rows once more, as the two scaled fp16 planes the trailing update multiplies (gp_syrk_planes_kernel: layout, scale and why).  A task = 8
+    // consecutive columns of a row (two 16-byte reads of V) -> one 16-byte half row in each plane
+    char* pl = reinterpret_cast<char*>(a.planes) + (long)b * PL_NPL * PL_NKC * plane_slab_bytes(a.plane_rows);
     const long prow0 = (long)row0 - (kout + OBW);                      // row index inside the planes: rows below the outer block
+    const float sc = __builtin_ldexpf(1.f, plane_scale_exp(a, b));
     for (int id = threadIdx.x; id < 64 * (OBW / 8); id += 256) {
       const int r = id / (OBW / 8), c8 = id % (OBW / 8);                 // columns 8 c8 .. 8 c8 + 7
       if (r >= rows_valid) continue;
       const f32x4 v0 = __builtin_bit_cast(f32x4, lds_read16(V + r * TW_STRIDE + c8 * 32));
       const f32x4 v1 = __builtin_bit_cast(f32x4, lds_read16(V + r * TW_STRIDE + c8 * 32 + 16));
-      bf16x8 hi, mid, lo;
+      f16x8 hi, lo;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float v = e < 4 ? v0[e] : v1[e - 4];
-        hi[e] = (bf16)v;
-        const float r1 = v - (float)hi[e];
-        mid[e] = (bf16)r1;
-        lo[e] = (bf16)(r1 - (float)mid[e]);
+        const float v = (e < 4 ? v0[e] : v1[e - 4]) * sc;
+        hi[e] = (f16)v;
+        lo[e] = (f16)(v - (float)hi[e]);
       }
       const int kc = c8 / 2;
       const long prow = prow0 + r;
-      const int half = (c8 & 1) ^ (int)((prow >> 3) & 1);                // the consumer's bank swizzle (load_frag_row<bf16, 32>), applied at the source
-      *reinterpret_cast<bf16x8*>(pl + plane_offset(a.plane_rows, 0, kc, prow) + half * 16) = hi;
-      *reinterpret_cast<bf16x8*>(pl + plane_offset(a.plane_rows, 1, kc, prow) + half * 16) = mid;
-      *reinterpret_cast<bf16x8*>(pl + plane_offset(a.plane_rows, 2, kc, prow) + half * 16) = lo;
+      const int half = (c8 & 1) ^ (int)((prow >> 3) & 1);                // the consumer's bank swizzle (load_frag_row<.., 32>), applied at the source
+      *reinterpret_cast<f16x8*>(pl + plane_offset(a.plane_rows, 0, kc, prow) + half * 16) = hi;
+      *reinterpret_cast<f16x8*>(pl + plane_offset(a.plane_rows, 1, kc, prow) + half * 16) = lo;
     }
   }
 }
@@ -666,7 +733,7 @@ __global__ __launch_bounds__(256) void gp_trsm_wide_kernel(GpArgs a, int kout) {
 // K_ws of the C ABI: K [B, S, S] f32, then (256-byte aligned) the plane scratch of gp_syrk_planes_kernel
 static long gp_plane_rows(int S) { return S > OBW ? ((long)(S - OBW + 127) / 128) * 128 : 0; }      // whole 128-row tiles of the trailing update
 static int64_t gp_k_bytes(int B, int S) { return ((int64_t)B * S * S * 4 + 255) / 256 * 256; }
-int64_t gp_workspace_bytes(int B, int S) { return gp_k_bytes(B, S) + (int64_t)B * 3 * PL_NKC * gp_plane_rows(S) * PL_ROWB; }
+int64_t gp_workspace_bytes(int B, int S) { return gp_k_bytes(B, S) + (int64_t)B * PL_NPL * PL_NKC * gp_plane_rows(S) * PL_ROWB; }
 void gp_attach_planes(GpArgs& a) {      // a.K = the caller's K_ws of gp_workspace_bytes(B, S) bytes
   a.plane_rows = gp_plane_rows(a.S);
   a.planes = a.plane_rows > 0 ? reinterpret_cast<char*>(a.K) + gp_k_bytes(a.B, a.S) : nullptr;
@@ -695,7 +762,7 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
     const int ti = (r1 - r0 + 127) / 128, tj = (c1 - c0 + 127) / 128;
     if (ti > 0 && tj > 0) hipLaunchKernelGGL(gp_syrk_kernel, dim3(tj, ti, B), dim3(256), SYRK_LDS, s, a, r0, r1, c0, c1, kp0, K);
   };
-  const size_t tw_lds = 2 * 64 * TW_STRIDE + OBW * sizeof(float);
+  const size_t tw_lds = 64 * TW_STRIDE + OBW * sizeof(float);
   static LdsAllowance tw_allowance;   // (constant size; per device; the call costs tens of microseconds of host time)
   tw_allowance.ensure(gp_trsm_wide_kernel, tw_lds);
   for (int kout = 0; kout < S; kout += OBW) {

@@ -318,8 +318,8 @@ struct GpArgs {
   // running residual (y_data on entry), w the solution, and every panel subtracts L[rows, panel] w[panel] from the
   // residual below it where the sampler adds L[rows, panel] z[panel] to the draw
   float* w;                  // [B,S]; null = sampler mode
-  // scratch behind K (gp_workspace_bytes): the three bf16 planes of the current outer block's solved panel, written by gp_trsm_wide_kernel and read by
-  // gp_syrk_planes_kernel -- [B][3 planes][16 k-chunks][plane_rows][16] bf16.  null = the trailing update splits the f32 panel itself (gp_syrk_kernel)
+  // scratch behind K (gp_workspace_bytes): the two scaled fp16 planes (hi, lo) of the current outer block's solved panel, written by gp_trsm_wide_kernel and
+  // read by gp_syrk_planes_kernel -- [B][2 planes][16 k-chunks][plane_rows][16] fp16.  null = the trailing update splits the f32 panel itself (gp_syrk_kernel)
   void* planes;
   long plane_rows;           // rows allocated per slab (>= S - 256, a multiple of 128)
 };
