@@ -97,7 +97,7 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_ATTN_PINGPONG = 4, /* bit 0: attention forward, bit 1: backward key-block pass -- the two waves of a SIMD run half a tile apart (default: see attention.hip) */
        PFN_TUNE_FUSE_LN_WIDE = 5,  /* 1: emsize 1024 runs the LayerNorm-fused GEMMs on 64-row x 1024-column tiles (gemm_nt_ln_wide / lnbwd_wide); 0 (default): the
                                     * 256 x 256 GEMM + LayerNorm kernels -- measured faster at that width */
-       PFN_TUNE_GP_PLANES = 8,     /* 1 (default): the GP sampler's rank-256 trailing update reads pre-split bf16 planes by LDS-DMA; 0: it splits the f32 panel per tile (rounds 2-3) */
+       PFN_TUNE_GP_PLANES = 8,     /* 1 (default): the GP sampler's rank-256 trailing update reads pre-split fp16 planes (hi, lo on a power-of-two scale) by LDS-DMA; 0: it splits the f32 panel into three bf16 terms per tile (rounds 2-3) */
        PFN_TUNE_GEMM_LN_ROWS = 7,  /* 1: the LayerNorm-fused GEMMs at emsize 512 run on 64-row tiles, two workgroups per CU (gemm.hip g_ln_rows64); 0 (default): 128-row tiles */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
                                     * returns output[single_eval_pos:] (transformer.py:91), so that layer's train rows feed nothing; 0: every layer on every row */ };
@@ -235,8 +235,9 @@ int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
  * x [B,S,nf] f32: filled with U[0,1) from the counter-based generator when gen_x != 0, else input.
  * z [B,S] f32 base normals: generated when gen_z != 0 (and written back), else input.
  * lengthscale [B,nf], outputscale [B], noise [B].  kernel: 0 = RBF, 1 / 2 / 3 = Matern nu = 2.5 / 1.5 / 0.5 (gpytorch MaternKernel's three closed forms).
- * K_ws: workspace of pfn_gp_workspace_bytes(B, S) bytes: the [B,S,S] f32 matrix, factored in place, followed by the scratch of the trailing update
- * (the three bf16 planes of the current outer block's solved panel: + 19 % at S = 2000).  K_ws_bytes (ABI 7): the size the caller allocated --
+ * K_ws: workspace of pfn_gp_workspace_bytes(B, S) bytes: the [B,S,S] f32 matrix, factored in place (SCRATCH: with the plane scratch attached only the
+ * 256 x 256 diagonal blocks of the factor are left in it -- the panels below them are consumed from the planes and never stored), followed by the scratch of
+ * the trailing update (the two scaled fp16 planes of the current outer block's solved panel: + 11 % at S = 2000).  K_ws_bytes (ABI 7): the size the caller allocated --
  * below B*S*S*4 the call returns PFN_ERR_ARGUMENT; between that and pfn_gp_workspace_bytes(B, S) the trailing update runs without the plane scratch
  * (same arithmetic, slower), so a caller sized for an older ABI cannot be written past.  info [B]: 0 or (index+1) of the first non-positive pivot. */
 int64_t pfn_gp_workspace_bytes(int B, int S);

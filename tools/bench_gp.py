@@ -12,9 +12,13 @@ for kv in os.environ.get('PFN_TUNE', '').split(','):      # e.g. PFN_TUNE=8=0: p
     if kv:
         _hip.check(_hip.lib().pfn_set_tuning(*[int(v) for v in kv.split('=')]), 'pfn_set_tuning')
 ap = argparse.ArgumentParser(); ap.add_argument('--batch', type=int, default=64); ap.add_argument('--iters', type=int, default=5)
+ap.add_argument('--no-check', action='store_true', help='leave the failure flags alone (timing of ablation builds whose factorisations fail by construction)')
 a = ap.parse_args()
 w = bench.WORKLOAD
 f = lambda: fast_gp.get_batch(a.batch, w['bptt'], w['num_features'], device='cuda', hyperparameters=w['hyperparameters'])
+if a.no_check:
+    hp = w['hyperparameters']; noise, osc, ls = hp['noise'], hp['outputscale'], hp['lengthscale']
+    f = lambda: fast_gp.gp_sample(a.batch, w['bptt'], w['num_features'], 'cuda', ls, osc, noise, check=False)
 for _ in range(2): f()
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(a.iters): f()

@@ -469,7 +469,9 @@ constexpr int PL_KC = 16;                           // panel columns per slab / 
 constexpr int PL_NKC = 256 / PL_KC;                 // slabs per plane of a 256-wide panel
 constexpr int PL_ROWB = PL_KC * 2;                  // bytes per slab row
 constexpr int PL_NPL = 2;                           // planes: hi, lo
+constexpr int PL_NSET = 2;                          // plane sets per dataset: the solved panels of an even and an odd outer block (delayed update, launch_gp_sample)
 PFN_DEV long plane_slab_bytes(long rows_alloc) { return rows_alloc * PL_ROWB; }
+PFN_DEV long plane_set_bytes(long rows_alloc) { return (long)PL_NPL * PL_NKC * plane_slab_bytes(rows_alloc); }
 // byte offset of (plane, chunk, row) inside one dataset's plane scratch of `rows_alloc` rows
 PFN_DEV long plane_offset(long rows_alloc, int plane, int kc, long row) { return ((long)(plane * PL_NKC + kc) * rows_alloc + row) * PL_ROWB; }
 // exponent e of a dataset's plane scale s = 2^e (see above)
@@ -487,6 +489,9 @@ constexpr int SYP_STAGE = 2 * PL_NPL * SYP_SLAB;    // A and B, two planes each:
 #ifndef PFN_SYP_WGS
 #define PFN_SYP_WGS 3
 #endif
+#ifndef PFN_SYP_ABLATE      // timing experiments only (results are wrong): 1 = no C read-modify-write, 2 = no MFMAs, 4 = no plane DMA
+#define PFN_SYP_ABLATE 0
+#endif
 constexpr int SYP_NST = PFN_SYP_NST;                // stages in the ring: two in flight under the one being multiplied
 constexpr int SYP_LDS = SYP_NST * SYP_STAGE;        // 48 KiB, three workgroups per CU
 constexpr int SYP_PPW = 2 * PL_NPL * 4 / 4;         // 1-KiB DMA pieces per wave and stage
@@ -495,9 +500,11 @@ PFN_DEV f32x16 mma32_f16(const Frag<bf16>& a, const Frag<bf16>& b, f32x16 c) {  
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v), __builtin_bit_cast(f16x8, b.v), c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, PFN_SYP_WGS) void gp_syrk_planes_kernel(GpArgs a, int r0, int r1) {
-  // C[i][j] -= sum_k X[i][k] X[j][k] for rows / columns >= r0 (lower triangle, 128 x 128 tiles), X = the 256-wide solved panel of the outer
-  // block that ends at r0, read from its planes (row index in the planes: global row - r0)
+// One launch applies `nsets` solved panels (rank 256 each) to its region, so the region's C tiles are read and written once for all of them:
+// set s in {set0, set1} holds the panel whose plane row 0 is global row r0 - off_s.
+__global__ __launch_bounds__(256, PFN_SYP_WGS) void gp_syrk_planes_kernel(GpArgs a, int r0, int r1, int nsets, int set0, int off0, int set1, int off1) {
+  // C[i][j] -= sum_s sum_k X_s[i][k] X_s[j][k] for rows >= r0 and the grid's tile columns from r0 on (lower triangle, 128 x 128 tiles), X_s = a 256-wide solved
+  // panel read from its planes
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
   const int S = a.S, T = gridDim.x * gridDim.y;
@@ -508,8 +515,9 @@ __global__ __launch_bounds__(256, PFN_SYP_WGS) void gp_syrk_planes_kernel(GpArgs
   const int i0 = r0 + (t / gridDim.x) * 128, j0 = r0 + (t % gridDim.x) * 128;
   if (j0 > i0 + 127) return;          // tile entirely above the diagonal
   float* Kb = a.K + (long)b * S * S;
-  const char* pl = reinterpret_cast<const char*>(a.planes) + (long)b * PL_NPL * PL_NKC * plane_slab_bytes(a.plane_rows);
-  const DmaRsrc rp = make_dma_rsrc(pl, (long)PL_NPL * PL_NKC * plane_slab_bytes(a.plane_rows));
+  const char* pl = reinterpret_cast<const char*>(a.planes) + (long)b * PL_NSET * plane_set_bytes(a.plane_rows);
+  const DmaRsrc rp = make_dma_rsrc(pl, (long)PL_NSET * plane_set_bytes(a.plane_rows));
+  const int nk = nsets * PL_NKC;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, wm = wave >> 1, wn = wave & 1;
   f32x16 acc[2][2];
 #pragma unroll
@@ -520,23 +528,26 @@ __global__ __launch_bounds__(256, PFN_SYP_WGS) void gp_syrk_planes_kernel(GpArgs
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // a stage = 16 one-KiB pieces: piece q = (operand o = q / 8, plane p = (q / 4) % 2, quarter qq = q % 4) -> LDS (o * 2 + p) * SYP_SLAB + qq * 1024; wave w
   // moves pieces w, w + 4, ...  Source: 32 consecutive slab rows = one contiguous KiB (the swizzle is already in the slab).
-  auto stage = [&](int buf, int kc) {
+  auto stage = [&](int buf, int ks) {
+    const int second = ks >= PL_NKC, kc = ks & (PL_NKC - 1);
+    const long sbase = (long)(second ? set1 : set0) * plane_set_bytes(a.plane_rows);
+    const int roff = second ? off1 : off0;
 #pragma unroll
     for (int i = 0; i < SYP_PPW; ++i) {
       const int q = wave + 4 * i;
       const int o = q / (4 * PL_NPL), p = (q / 4) % PL_NPL, qq = q % 4;
-      const long row = (long)((o ? j0 : i0) - r0) + qq * 32;
-      const long off = plane_offset(a.plane_rows, p, kc, row) + lane * 16;
-      dma16(rp, smem + buf * SYP_STAGE + (o * PL_NPL + p) * SYP_SLAB + qq * 1024, (int)off);
+      const long row = (long)((o ? j0 : i0) - r0) + roff + qq * 32;
+      const long off = sbase + plane_offset(a.plane_rows, p, kc, row) + lane * 16;
+      if (!(PFN_SYP_ABLATE & 4)) dma16(rp, smem + buf * SYP_STAGE + (o * PL_NPL + p) * SYP_SLAB + qq * 1024, (int)off);
     }
   };
   stage(0, 0);
   if (SYP_NST > 2) stage(1, 1);
   int cur = 0;
-  for (int kc = 0; kc < PL_NKC; ++kc) {
+  for (int kc = 0; kc < nk; ++kc) {
     // stage kc has landed for everyone (a wave's pieces retire in order: all but the SYP_PPW of stage kc + 1), and everyone is done reading stage kc - 1
-    if (SYP_NST > 2 && kc + 1 < PL_NKC) wait_vm_barrier<SYP_PPW>(); else wait_vm_barrier<0>();
-    if (kc + SYP_NST - 1 < PL_NKC) stage(cur == 0 ? SYP_NST - 1 : cur - 1, kc + SYP_NST - 1);      // into the buffer stage kc - 1 was read from
+    if (SYP_NST > 2 && kc + 1 < nk) wait_vm_barrier<SYP_PPW>(); else wait_vm_barrier<0>();
+    if (kc + SYP_NST - 1 < nk) stage(cur == 0 ? SYP_NST - 1 : cur - 1, kc + SYP_NST - 1);      // into the buffer stage kc - 1 was read from
     const lds_char* tA = smem + cur * SYP_STAGE;
     const lds_char* tB = tA + PL_NPL * SYP_SLAB;
     Frag<bf16> fa[2][2], fb[2][2];     // [block][hi, lo]
@@ -553,6 +564,7 @@ __global__ __launch_bounds__(256, PFN_SYP_WGS) void gp_syrk_planes_kernel(GpArgs
 #pragma unroll
       for (int j = 0; j < 2; ++j) {   // swapped operands: a lane owns one ROW of the tile; smallest terms first (as gp_syrk_kernel)
         f32x16 c = acc[i][j];
+        if (PFN_SYP_ABLATE & 2) { c[0] += (float)fb[j][1].v[0] + (float)fa[i][0].v[0] + (float)fb[j][0].v[0] + (float)fa[i][1].v[0]; acc[i][j] = c; continue; }
         c = mma32_f16(fb[j][1], fa[i][0], c);
         c = mma32_f16(fb[j][0], fa[i][1], c);
         acc[i][j] = mma32_f16(fb[j][0], fa[i][0], c);
@@ -566,6 +578,17 @@ __global__ __launch_bounds__(256, PFN_SYP_WGS) void gp_syrk_planes_kernel(GpArgs
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv_s2;
+  if (PFN_SYP_ABLATE & 1) {      // keep the accumulators alive without the 128 KiB of traffic
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 123.456f) Kb[0] = sum;
+    return;
+  }
   syrk_rmw(Kb, S, acc, i0 + wm * 64, j0 + wn * 64, __builtin_amdgcn_readfirstlane((j0 + 127 < i0 && i0 + 127 < r1) ? 1 : 0) != 0, r1, r1, lane);
 }
 
@@ -590,7 +613,7 @@ constexpr int TW_STRIDE = OBW * 4 + 16;   // padded LDS row (pfn_device.h PadStr
 // datasets for 1.0 ms of MFMA chain and ~1.3 ms of HBM traffic.  The L operand of both products is now read straight from global memory into the B fragments
 // (a lane's 8 contraction values are 32 contiguous bytes of a row of L_d; the 256-KiB factor of a dataset stays in the L2 of the XCD all its workgroups run
 // on -- the dataset -> XCD deal below), one 64-column block ahead of the MFMAs that consume it.  LDS = the rows alone, 67.6 KiB: two workgroups per CU.
-__global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout) {
+__global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout, int plane_set) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr V = lds_cast(smem_raw);                     // [64][TW_STRIDE]  the workgroup's rows
   float* zs = reinterpret_cast<float*>(smem_raw + 64 * TW_STRIDE);  // [256]
@@ -699,14 +722,19 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
     d += __shfl_xor(d, 2, 64);
     if (q == 0 && r < rows_valid) a.y[(long)b * S + row0 + r] += a.w ? -d : d;
   }
-  for (int id = threadIdx.x; id < 64 * (OBW / 4); id += 256) {
-    const int r = id / (OBW / 4), c = id % (OBW / 4);
-    if (r < rows_valid) *reinterpret_cast<u32x4*>(Kb + (long)(row0 + r) * S + kout + c * 4) = lds_read16(V + r * TW_STRIDE + c * 16);
+  // the solved rows go back to the matrix only for a reader: the per-tile-split update (gp_syrk_kernel).  With planes nobody reads these columns again -- their
+  // part of y = L z (or of the forward solve) was taken above, the later outer blocks touch rows AND columns >= their own first row, the posterior reads the
+  // diagonal -- and the store was a third of this kernel's HBM traffic (64 of 192 KiB per workgroup)
+  if (!a.planes) {
+    for (int id = threadIdx.x; id < 64 * (OBW / 4); id += 256) {
+      const int r = id / (OBW / 4), c = id % (OBW / 4);
+      if (r < rows_valid) *reinterpret_cast<u32x4*>(Kb + (long)(row0 + r) * S + kout + c * 4) = lds_read16(V + r * TW_STRIDE + c * 16);
+    }
   }
   if (a.planes) {
     // the solved rows once more, as the two scaled fp16 planes the trailing update multiplies (gp_syrk_planes_kernel: layout, scale and why).  A task = 8
     // consecutive columns of a row (two 16-byte reads of V) -> one 16-byte half row in each plane
-    char* pl = reinterpret_cast<char*>(a.planes) + (long)b * PL_NPL * PL_NKC * plane_slab_bytes(a.plane_rows);
+    char* pl = reinterpret_cast<char*>(a.planes) + ((long)b * PL_NSET + plane_set) * plane_set_bytes(a.plane_rows);
     const long prow0 = (long)row0 - (kout + OBW);                      // row index inside the planes: rows below the outer block
     const float sc = __builtin_ldexpf(1.f, plane_scale_exp(a, b));
     for (int id = threadIdx.x; id < 64 * (OBW / 8); id += 256) {
@@ -733,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
 // K_ws of the C ABI: K [B, S, S] f32, then (256-byte aligned) the plane scratch of gp_syrk_planes_kernel
 static long gp_plane_rows(int S) { return S > OBW ? ((long)(S - OBW + 127) / 128) * 128 : 0; }      // whole 128-row tiles of the trailing update
 static int64_t gp_k_bytes(int B, int S) { return ((int64_t)B * S * S * 4 + 255) / 256 * 256; }
-int64_t gp_workspace_bytes(int B, int S) { return gp_k_bytes(B, S) + (int64_t)B * PL_NPL * PL_NKC * gp_plane_rows(S) * PL_ROWB; }
+int64_t gp_workspace_bytes(int B, int S) { return gp_k_bytes(B, S) + (int64_t)B * PL_NSET * PL_NPL * PL_NKC * gp_plane_rows(S) * PL_ROWB; }
 void gp_attach_planes(GpArgs& a) {      // a.K = the caller's K_ws of gp_workspace_bytes(B, S) bytes
   a.plane_rows = gp_plane_rows(a.S);
   a.planes = a.plane_rows > 0 ? reinterpret_cast<char*>(a.K) + gp_k_bytes(a.B, a.S) : nullptr;
@@ -775,10 +803,17 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
       syrk(next, kend, next, kend, k0, NB);
     }
     if (kend < S) {
-      hipLaunchKernelGGL(gp_trsm_wide_kernel, dim3((S - kend + 63) / 64, B), dim3(256), tw_lds, s, a, kout);
-      if (a.planes) {      // the trailing update from the pre-split planes gp_trsm_wide_kernel just wrote (every full 256-wide outer block)
+      const int odd = (kout / OBW) & 1;
+      hipLaunchKernelGGL(gp_trsm_wide_kernel, dim3((S - kend + 63) / 64, B), dim3(256), tw_lds, s, a, kout, odd);
+      if (a.planes) {
+        // DELAYED trailing update from the pre-split planes (round 5): the read-modify-write of the trailing matrix is what the update is bound by (HBM: alone it
+        // takes 19.2 of the kernel's 28.3 ms per 7 x 320 datasets, profiles/r05_gp_sampler.txt), so the matrix is touched once per PAIR of outer blocks.  After an
+        // even block only the next block's 256 columns are brought up to date (a strip, rank 256, plane set 0); after the odd block the rest takes both panels in
+        // one pass (rank 512: set 0 = the even block's panel, whose plane row 0 is global row kend - 256; set 1 = this block's).  C traffic per dataset at
+        // S = 2000: 21.5 MB instead of 34.
         const int tn = (S - kend + 127) / 128;
-        hipLaunchKernelGGL(gp_syrk_planes_kernel, dim3(tn, tn, B), dim3(256), SYP_LDS, s, a, kend, S);
+        if (!odd) hipLaunchKernelGGL(gp_syrk_planes_kernel, dim3(std::min(tn, OBW / 128), tn, B), dim3(256), SYP_LDS, s, a, kend, S, 1, 0, 0, 0, 0);
+        else hipLaunchKernelGGL(gp_syrk_planes_kernel, dim3(tn, tn, B), dim3(256), SYP_LDS, s, a, kend, S, 2, 0, OBW, 1, 0);
       } else {
         syrk(kend, S, kend, S, kout, OBW);
       }

@@ -837,8 +837,9 @@ int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
   return PFN_OK;
 }
 
-// PFN_TUNE_GP_PLANES (test / profiling knob): 1 (default) = the rank-256 trailing update of the blocked Cholesky multiplies the pre-split bf16 planes the wide
-// triangular solve leaves behind K (gp_syrk_planes_kernel); 0 = it re-reads and re-splits the f32 panel per tile (gp_syrk_kernel, rounds 2-3).  Same arithmetic.
+// PFN_TUNE_GP_PLANES (test / profiling knob): 1 (default) = the rank-256 trailing update of the blocked Cholesky multiplies the pre-split fp16 planes the wide
+// triangular solve leaves behind K (gp_syrk_planes_kernel: two terms on a power-of-two scale, three products); 0 = it re-reads the f32 panel per tile and splits it
+// into three bf16 terms, six products (gp_syrk_kernel, rounds 2-3).  Both are f32-accurate (tools/sim_gp_split.py, tools/exp_gp_accuracy.py).
 int64_t pfn_gp_workspace_bytes(int B, int S) {
   if (B < 1 || S < 1) return -1;
   return gp_workspace_bytes(B, S);

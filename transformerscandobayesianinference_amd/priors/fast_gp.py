@@ -236,7 +236,7 @@ DataLoader.prefetch_group = 10    # ... ten steps' worth of datasets per sampler
 DataLoader.prefetch_group_datasets = 640    # ... and at least this many datasets per call when the batches are small (priors/utils.py)
 DataLoader.prefetch_memory_share = 0.125    # ... but never more than an eighth of the free device memory per group (two groups are alive at a time)
 def workspace_bytes_per_dataset(kw):
-    """K_ws per dataset as the library sizes it (the [Tp, Tp] f32 matrix + the plane scratch: +19 % at bptt 2000, +29 % at 1000, +37 % at 512 -- ADVICE r4: not a constant factor)."""
+    """K_ws per dataset as the library sizes it (the [Tp, Tp] f32 matrix + the plane scratch: +11 % at bptt 2000, +20 % at 1000, +25 % at 512 -- ADVICE r4: not a constant factor)."""
     Tp = (kw.get('seq_len', 0) + 3) // 4 * 4
     return int(_hip.lib().pfn_gp_workspace_bytes(1, Tp)) if Tp > 0 else 0
 
