@@ -15,5 +15,7 @@ for lib in "" $ROOT/transformerscandobayesianinference_amd/_variants/*.so; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gpprof -o gp -- python $ROOT/tools/bench_gp.py --batch 320 > /tmp/gpprof.log 2>&1
   f=$(find /tmp/gpprof -name "*kernel_stats.csv" | head -1)
   echo "--- kernel stats, $(basename ${lib:-product}) (bench_gp --batch 320, 7 draws): name, calls, total ns, average ns, %" >> $O
-  [ -n "$f" ] && head -9 "$f" | tail -8 | cut -d, -f1-5 | cut -c1-150 >> $O || tail -3 /tmp/gpprof.log >> $O
+  [ -n "$f" ] && python -c "
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:7]: print(f\"{r['Name'][:44]:46s} calls {r['Calls']:>4s}  total {float(r['TotalDurationNs']) / 1e6:8.3f} ms  avg {float(r['AverageNs']) / 1e3:8.1f} us  {float(r['Percentage']):5.1f} %\")" "$f" >> $O || tail -3 /tmp/gpprof.log >> $O
 done

@@ -38,7 +38,29 @@ def update(X, mode):
     raise ValueError(mode)
 
 
-def chol_blocked(K, z, mode):
+def prod(A, B, mode, scale):
+    """A B^T the way a split product computes it (A, B f32; products exact, f32 accumulation)."""
+    if mode == 'f32':
+        return A @ B.t()
+    ah, al = split(A * scale, torch.float16, 2)
+    bh, bl = split(B * scale, torch.float16, 2)
+    return (al @ bh.t() + ah @ bl.t() + ah @ bh.t()) / (scale * scale)
+
+
+def solve_wide(Ld, A, mode, scale):
+    """X = A Ld^-T as gp_trsm_wide_kernel does it: 64-wide blocks, V_j -= sum_{i<j} X_i L_ji^T (`mode` products), X_j = V_j L_jj^-T with the explicit f32 inverse."""
+    n = Ld.shape[0]
+    X = A.clone()
+    for j0 in range(0, n, 64):
+        j1 = min(n, j0 + 64)
+        if j0 > 0:
+            X[:, j0:j1] -= prod(X[:, :j0], Ld[j0:j1, :j0], mode, scale)
+        inv = torch.linalg.solve_triangular(Ld[j0:j1, j0:j1], torch.eye(j1 - j0), upper=False)
+        X[:, j0:j1] = X[:, j0:j1] @ inv.t()
+    return X
+
+
+def chol_blocked(K, z, mode, solve_mode=None):
     K = K.clone()
     n = K.shape[0]
     bad = 0
@@ -50,7 +72,11 @@ def chol_blocked(K, z, mode):
             return None, 1
         K[k0:k1, k0:k1] = Ld
         if k1 < n:
-            X = torch.linalg.solve_triangular(Ld, K[k1:, k0:k1].t(), upper=False).t().contiguous()
+            if solve_mode is None:
+                X = torch.linalg.solve_triangular(Ld, K[k1:, k0:k1].t(), upper=False).t().contiguous()
+            else:
+                scale = 2.0 ** (14 - torch.ceil(0.5 * torch.log2(K.diagonal().max())).item())       # sqrt(K_ii) bounds every entry of the factor (the diagonal only shrinks)
+                X = solve_wide(Ld, K[k1:, k0:k1].contiguous(), solve_mode, scale)
             K[k1:, k0:k1] = X
             K[k1:, k1:] -= update(X, mode)
     L = torch.tril(K)
@@ -76,8 +102,11 @@ for (T, F, noise, os_, ls, kernel) in [(2000, 5, 1e-4, 1.0, 0.6, 'rbf'), (2000, 
         K64 = gram(x, ls, os_, noise, kernel)
         want = torch.linalg.cholesky(K64) @ z
         K32 = K64.float()
-        for mode in ('f32', 'bf16x6', 'fp16x3', 'fp16x4', 'bf16x3'):
-            y, bad = chol_blocked(K32, z.float(), mode)
+        for mode in ('f32', 'bf16x6', 'fp16x3', 'fp16x4', 'bf16x3', 'fp16x3+solve-f32', 'fp16x3+solve-fp16x3'):
+            if '+' in mode:
+                y, bad = chol_blocked(K32, z.float(), 'fp16x3', 'f32' if mode.endswith('solve-f32') else 'fp16x3')
+            else:
+                y, bad = chol_blocked(K32, z.float(), mode)
             e = float('nan') if y is None else ((y.double() - want).norm() / want.norm()).item()
             res.setdefault(mode, []).append(e)
     print(f'T={T} F={F} {kernel} noise={noise} outputscale={os_}: rel. L2 error of y vs f64   ' +

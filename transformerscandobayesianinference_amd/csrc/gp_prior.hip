@@ -592,6 +592,12 @@ __global__ __launch_bounds__(256, PFN_SYP_WGS) void gp_syrk_planes_kernel(GpArgs
   syrk_rmw(Kb, S, acc, i0 + wm * 64, j0 + wn * 64, __builtin_amdgcn_readfirstlane((j0 + 127 < i0 && i0 + 127 < r1) ? 1 : 0) != 0, r1, r1, lane);
 }
 
+// What bounds it now (round 5, profiles/r05_gp_sampler.txt): ablation builds (PFN_SYP_ABLATE) of the rank-256 form gave, per 7 x 320 datasets, 28.3 ms whole,
+// 19.2 ms with the C read-modify-write alone (4 TB/s: the HBM's mixed read / write rate), 11.1 ms with the products alone and 14.3 without the read-modify-write
+// -- the two phases ADD instead of overlapping, although three workgroups share a CU.  Requesting the C tile two stages before the subtraction (registers, peeled
+// tail; built and measured: 25.79 vs 25.86 ms) changes nothing, so it is not the C round trip of the workgroup itself: a CU's vector memory path returns in
+// order, and while ANY of its workgroups has C loads out at HBM latency the other workgroups' plane pieces (L2 hits) queue behind them -- the ring's two
+// stages in flight then cover a fraction of that latency.  Hence the delayed update (a third less C traffic, launch_gp_sample) rather than more overlap.
 // (A 256 x 256-tile form of this kernel -- 8 waves, three 48-KiB stages in a ring, one workgroup per CU -- was built and measured in round 4: the update of the first
 // outer block 2013 us per 320 datasets against 1632 here.  The C read-modify-write of a tile costs the HBM as long as its products cost the matrix pipe (512 KiB against
 // 20 us per 256 x 256 tile), and with one workgroup per CU the two no longer overlap; three co-resident 128 x 128 workgroups do overlap them.  profiles/r04_gp_sampler_experiments.txt)
@@ -613,6 +619,13 @@ constexpr int TW_STRIDE = OBW * 4 + 16;   // padded LDS row (pfn_device.h PadStr
 // datasets for 1.0 ms of MFMA chain and ~1.3 ms of HBM traffic.  The L operand of both products is now read straight from global memory into the B fragments
 // (a lane's 8 contraction values are 32 contiguous bytes of a row of L_d; the 256-KiB factor of a dataset stays in the L2 of the XCD all its workgroups run
 // on -- the dataset -> XCD deal below), one 64-column block ahead of the MFMAs that consume it.  LDS = the rows alone, 67.6 KiB: two workgroups per CU.
+#ifndef PFN_TW_ABLATE       // timing experiments only (results are wrong): 1 = no stores of the solved rows / planes, 2 = no MFMAs, 4 = no loads of the factor, 8 = no load of the rows
+#define PFN_TW_ABLATE 0
+#endif
+PFN_DEV f32x16 tw_mma(const Frag<float>& x, const Frag<float>& y, f32x16 c) {
+  if (PFN_TW_ABLATE & 2) { c[0] += x.v[0] + y.v[0] + x.v[7] + y.v[7]; return c; }
+  return mma32(x, y, c);
+}
 __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout, int plane_set) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr V = lds_cast(smem_raw);                     // [64][TW_STRIDE]  the workgroup's rows
@@ -631,51 +644,67 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
   const int rt = wave >> 1, ct = wave & 1, c = ct * 32 + li;
   {
     TileStage<float, 64, OBW * 4, 256> sv;
-    sv.issue(Kb + (long)row0 * S + kout, S, rows_valid, OBW);
+    if (!(PFN_TW_ABLATE & 8)) sv.issue(Kb + (long)row0 * S + kout, S, rows_valid, OBW);
     const float zv = (a.w ? a.w : a.z)[(long)b * S + kout + threadIdx.x];
-    sv.template commit_p<TW_STRIDE>(V);
+    if (!(PFN_TW_ABLATE & 8)) sv.template commit_p<TW_STRIDE>(V);
     zs[threadIdx.x] = zv;
   }
   // B fragment of the block products: rows of L_d are the tile's columns, a lane's slots k0 + 8h .. + 7 of row r are 32 contiguous bytes
   auto l_frag = [&](int r, int k0) {
     const float* p = Ld + (long)r * S + k0 + 8 * h;
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
     Frag<float> f;
+    if (PFN_TW_ABLATE & 4) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f.v[e] = 0.001f * (r + k0 + e);
+      return f;
+    }
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f.v[e] = lo[e]; f.v[4 + e] = hi[e]; }
     return f;
   };
-  for (int jb = 0; jb < 4; ++jb) {
-    // X_j = V_j L_jj^-T needs the inverse block: L^-1[c][k] (k < c) sits at (row k, column c) of the diagonal block, the diagonal holds L[c][c], everything with
-    // k > c is masked to zero.  Requested first, so that the round trip runs under the products below.
+  // X_j = V_j L_jj^-T needs the inverse block: L^-1[c][k] (k < c) sits at (row k, column c) of the diagonal block, the diagonal holds L[c][c], everything with
+  // k > c is masked to zero.
+  const int kmax = ct == 0 ? 32 : NB;      // columns c < 32 only see k < 32
+  auto inv_frags = [&](int jb, Frag<float> (&finv)[4], float& ldiag) {
     const float* dcol = Ld + (long)(jb * NB) * S + jb * NB + c;
-    const int kmax = ct == 0 ? 32 : NB;      // columns c < 32 only see k < 32
-    Frag<float> finv[4];
-    const float ldiag = dcol[(long)c * S];
+    ldiag = (PFN_TW_ABLATE & 4) ? 1.f : dcol[(long)c * S];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = q * 16 + 8 * h + e;
-        finv[q].v[e] = (q * 16 < kmax) ? dcol[(long)k * S] : 0.f;
+        finv[q].v[e] = (q * 16 < kmax && !(PFN_TW_ABLATE & 4)) ? dcol[(long)k * S] : 0.f;
       }
-    __syncthreads();   // V current (initial load / previous block's solution)
+  };
+  // The barriers of the block loop order LDS traffic only (the factor is read-only here), so they wait for the LDS counter and leave the vector-memory
+  // counter alone (wait_vm_barrier<63>): __syncthreads() carries a fence that drains every load in flight, i.e. it put the round trip of whatever had been
+  // requested ahead in front of every phase.  What a block needs from the factor is requested one phase ahead: the inverse block and the first 64 columns of row
+  // block j + 1 travel under the X-phase products of block j.  (Measured: 19.8 vs 20.0 ms per 7 x 320 datasets -- the phases of this kernel ADD: ablation builds,
+  // PFN_TW_ABLATE, give 20.1 ms whole, 14.3 without the factor's loads, 16.9 without the rows' load, 16.8 without the stores, 10.6 without the MFMAs, 3.1 with
+  // none of them; neither more distance for the loads nor starting the two workgroups of a CU out of phase (s_sleep stagger, built and measured) changes that.
+  // profiles/r05_gp_sampler.txt)
+  Frag<float> finv[4], fcur[4];
+  float ldiag;
+  inv_frags(0, finv, ldiag);
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) {
+    wait_vm_barrier<63>();   // V current (initial load / previous block's solution)
     if (jb > 0) {
       // V_j -= sum_{i<j} X_i L_ji^T
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const int lrow = jb * NB + c;
-      Frag<float> fcur[4], fnext[4];
+      Frag<float> fnext[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) fcur[q] = l_frag(lrow, q * 16);
       for (int ib = 0; ib < jb; ++ib) {
         if (ib + 1 < jb) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) fnext[q] = l_frag(lrow, (ib + 1) * NB + q * 16);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, ib * NB + q * 16), fcur[q], acc);
+        for (int q = 0; q < 4; ++q) acc = tw_mma(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, ib * NB + q * 16), fcur[q], acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) fcur[q] = fnext[q];
       }
@@ -685,25 +714,32 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
         LdsPtr p = V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + (jb * NB + c) * 4;
         lds_write_f32(p, lds_read_f32(p) - acc[r]);
       }
-      __syncthreads();
+      wait_vm_barrier<63>();
     }
     {
       const float rdiag = 1.f / ldiag;
+      Frag<float> fb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = q * 16 + 8 * h + e;
+          fb[q].v[e] = k < c ? finv[q].v[e] : (k == c ? rdiag : 0.f);
+        }
+      if (jb + 1 < 4) {      // the next block's share of the factor, requested under this block's products
+        inv_frags(jb + 1, finv, ldiag);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fcur[q] = l_frag((jb + 1) * NB + c, q * 16);
+      }
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (q * 16 >= kmax) break;
-        Frag<float> fb;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int k = q * 16 + 8 * h + e;
-          fb.v[e] = k < c ? finv[q].v[e] : (k == c ? rdiag : 0.f);
-        }
-        acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, jb * NB + q * 16), fb, acc);
+        acc = tw_mma(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, jb * NB + q * 16), fb[q], acc);
       }
-      __syncthreads();   // all of V_j has been read
+      wait_vm_barrier<63>();   // all of V_j has been read
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         lds_write_f32(V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + (jb * NB + c) * 4, acc[r]);
@@ -725,13 +761,13 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
   // the solved rows go back to the matrix only for a reader: the per-tile-split update (gp_syrk_kernel).  With planes nobody reads these columns again -- their
   // part of y = L z (or of the forward solve) was taken above, the later outer blocks touch rows AND columns >= their own first row, the posterior reads the
   // diagonal -- and the store was a third of this kernel's HBM traffic (64 of 192 KiB per workgroup)
-  if (!a.planes) {
+  if (!a.planes && !(PFN_TW_ABLATE & 1)) {
     for (int id = threadIdx.x; id < 64 * (OBW / 4); id += 256) {
       const int r = id / (OBW / 4), c = id % (OBW / 4);
       if (r < rows_valid) *reinterpret_cast<u32x4*>(Kb + (long)(row0 + r) * S + kout + c * 4) = lds_read16(V + r * TW_STRIDE + c * 16);
     }
   }
-  if (a.planes) {
+  if (a.planes && !(PFN_TW_ABLATE & 1)) {
     // the solved rows once more, as the two scaled fp16 planes the trailing update multiplies (gp_syrk_planes_kernel: layout, scale and why).  A task = 8
     // consecutive columns of a row (two 16-byte reads of V) -> one 16-byte half row in each plane
     char* pl = reinterpret_cast<char*>(a.planes) + ((long)b * PL_NSET + plane_set) * plane_set_bytes(a.plane_rows);
