@@ -279,6 +279,33 @@ def test_gp_prior_sampler_vs_oracle():
         assert err < 2e-3, (B, T, F, hp, err)   # f32 Cholesky of a cond ~1e6 matrix (6e-4 at nf=5)
 
 
+def test_gp_sampler_block_structure_and_batch_placement():
+    """The sampler's blocked factorisation at the sizes where its structure changes (256-wide outer blocks handled in PAIRS by the delayed trailing update:
+    a strip after the even block, a rank-512 pass after the odd one; partial last blocks; exact multiples) and at batch sizes that take the dataset -> XCD
+    placement of the wide kernels (B % 8 == 0) as well as the plain one -- every draw against the f64 oracle on the same (x, z), prior and posterior mode."""
+    from transformerscandobayesianinference_amd.priors import fast_gp
+    g = torch.Generator().manual_seed(21)
+    for (B, T, F) in [(8, 516, 4), (16, 772, 3), (8, 1024, 5), (5, 1284, 4), (8, 600, 6), (24, 260, 3), (3, 1540, 4)]:
+        x = torch.rand(B, T, F, generator=g)
+        z = torch.randn(B, T, generator=g)
+        osc = 0.5 + torch.rand(B, generator=g)              # per-dataset scales: the fp16 planes' power-of-two scale differs between datasets
+        noise = 1e-2 * (0.5 + torch.rand(B, generator=g))
+        ls = 0.3 + 0.5 * torch.rand(B, F, generator=g)
+        want = pfn_oracle.gp_sample(x, z, ls, osc, noise, 'rbf')
+        _, got, _, info = fast_gp.gp_sample(B, T, F, DEV, ls, osc, noise, fast_gp.KERNEL_RBF, x=x, z=z)
+        assert int(info.abs().sum()) == 0
+        per_dataset = ((got.double().cpu() - want).norm(dim=1) / want.norm(dim=1)).max().item()
+        assert per_dataset < 1e-4, (B, T, F, per_dataset)    # measured 2e-6 .. 2e-5; a misplaced block or dataset gives O(1)
+    for (B, T, F, hps) in [(8, 600, 4, (0.05, 1.0, 0.6)), (16, 516, 3, (0.1, 0.5, 0.4))]:
+        x, y, _ = pfn_oracle.get_batch_fast_gp(B, T, F, hps, g)
+        mean, var, nll, info = fast_gp.gp_posterior(x.transpose(0, 1).contiguous().to(DEV), y.transpose(0, 1).contiguous().to(DEV), hps[2], hps[1], hps[0])
+        assert int(info.abs().sum()) == 0
+        t64 = lambda v: torch.tensor(v, dtype=torch.float64).reshape(1, 1, 1)
+        C = pfn_oracle.gp_gram(x.transpose(0, 1).double(), t64(hps[2]), t64(hps[1]), t64(hps[0]))
+        joint = -torch.distributions.MultivariateNormal(torch.zeros(B, T, dtype=torch.float64), covariance_matrix=C).log_prob(y.transpose(0, 1).double())
+        assert ((nll.double().sum(1).cpu() - joint).abs() / joint.abs()).max().item() < 1e-4, (B, T)      # chain rule, per dataset
+
+
 def test_gp_prior_sampler_statistics():
     """Generated draws: x ~ U[0,1), and the empirical covariance of y matches os*RBF + noise*I."""
     from transformerscandobayesianinference_amd.priors import fast_gp
