@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256) void gp_rng_kernel(GpArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // Gram matrix, lower-triangular 64x64 tiles.  blockIdx.x enumerates (ti >= tj), blockIdx.y = b.
+// (Round 5: BAND tiles -- 16 rows x 256 columns, every row one contiguous KiB per store instruction, x_j staged transposed -- were built to lift the 2.1 TB/s
+// this kernel writes at, and measured 2x SLOWER: 2528 vs 1280 us per 320 datasets.  profiles/r05_gp_sampler.txt)
 // ---------------------------------------------------------------------------------------------
 PFN_DEV void tri_decode(int t, int& ti, int& tj) {  // t = ti*(ti+1)/2 + tj, tj <= ti
   ti = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
