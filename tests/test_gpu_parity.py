@@ -296,6 +296,19 @@ def test_gp_sampler_block_structure_and_batch_placement():
         assert int(info.abs().sum()) == 0
         per_dataset = ((got.double().cpu() - want).norm(dim=1) / want.norm(dim=1)).max().item()
         assert per_dataset < 1e-4, (B, T, F, per_dataset)    # measured 2e-6 .. 2e-5; a misplaced block or dataset gives O(1)
+    # the same without the plane scratch (PFN_TUNE_GP_PLANES = 0; also what a caller whose K_ws holds the matrix alone gets): the wide solve stores its rows and
+    # the update splits them per tile -- the round-2/3 form, one pass per outer block
+    from transformerscandobayesianinference_amd import _hip
+    _hip.check(_hip.lib().pfn_set_tuning(8, 0), 'pfn_set_tuning')
+    try:
+        for (B, T, F) in [(8, 772, 4), (3, 1284, 3)]:
+            x = torch.rand(B, T, F, generator=g)
+            z = torch.randn(B, T, generator=g)
+            want = pfn_oracle.gp_sample(x, z, 0.5, 1.0, 1e-2, 'rbf')
+            _, got, _, info = fast_gp.gp_sample(B, T, F, DEV, 0.5, 1.0, 1e-2, fast_gp.KERNEL_RBF, x=x, z=z)
+            assert int(info.abs().sum()) == 0 and relerr(got, want) < 1e-4, (B, T, F, relerr(got, want))
+    finally:
+        _hip.check(_hip.lib().pfn_set_tuning(8, 1), 'pfn_set_tuning')
     for (B, T, F, hps) in [(8, 600, 4, (0.05, 1.0, 0.6)), (16, 516, 3, (0.1, 0.5, 0.4))]:
         x, y, _ = pfn_oracle.get_batch_fast_gp(B, T, F, hps, g)
         mean, var, nll, info = fast_gp.gp_posterior(x.transpose(0, 1).contiguous().to(DEV), y.transpose(0, 1).contiguous().to(DEV), hps[2], hps[1], hps[0])
