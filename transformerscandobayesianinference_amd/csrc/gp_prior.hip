@@ -27,6 +27,30 @@ namespace pfn {
 
 constexpr int NB = 64;  // panel width
 
+// ---- split-fp16 operands (round 5; what they are and why: gp_syrk_planes_kernel) ----
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+constexpr int PL_KC = 16;                           // panel columns per slab / per LDS stage
+constexpr int PL_NKC = 256 / PL_KC;                 // slabs per plane of a 256-wide panel
+constexpr int PL_ROWB = PL_KC * 2;                  // bytes per slab row
+constexpr int PL_NPL = 2;                           // planes: hi, lo
+constexpr int PL_NSET = 2;                          // plane sets per dataset: the solved panels of an even and an odd outer block (delayed update, launch_gp_sample)
+PFN_DEV long plane_slab_bytes(long rows_alloc) { return rows_alloc * PL_ROWB; }
+PFN_DEV long plane_set_bytes(long rows_alloc) { return (long)PL_NPL * PL_NKC * plane_slab_bytes(rows_alloc); }
+// byte offset of (plane, chunk, row) inside one dataset's plane scratch of `rows_alloc` rows
+PFN_DEV long plane_offset(long rows_alloc, int plane, int kc, long row) { return ((long)(plane * PL_NKC + kc) * rows_alloc + row) * PL_ROWB; }
+// exponent e of a dataset's plane scale s = 2^e (see above)
+PFN_DEV int plane_scale_exp(const GpArgs& a, int b) {
+  const float kii = a.outputscale[b] + a.noise[b];
+  const int e = 14 - (int)ceilf(0.5f * __log2f(fmaxf(kii, 1e-30f)));
+  return max(-60, min(60, e));
+}
+
+PFN_DEV f32x16 mma32_f16(const Frag<bf16>& a, const Frag<bf16>& b, f32x16 c) {      // the fragments carry fp16 bit patterns
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v), __builtin_bit_cast(f16x8, b.v), c, 0, 0, 0);
+}
+
+
 __global__ __launch_bounds__(256) void gp_rng_kernel(GpArgs a) {
   const long nx = (long)a.B * a.S * a.nf, nz = (long)a.B * a.S;
   const long nx4 = (nx + 3) / 4, nz4 = (nz + 3) / 4;
@@ -225,7 +249,8 @@ __global__ __launch_bounds__(64) void gp_potrf_kernel(GpArgs a, int k0) {
 // trsm: rows below the diagonal block.  One thread per row; row . L_kk^-T by forward substitution
 // with L_kk broadcast from LDS.  Also the panel's contribution to y = L z.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0, int r_end) {
+constexpr int OBW_C = 4 * NB;   // outer block width (OBW below)
+__global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0, int r_end, int mirror_planes) {
   __shared__ float L[NB][NB];  // L[j][m], m <= j
   __shared__ float zs[NB];
   const int b = blockIdx.y, S = a.S;
@@ -259,6 +284,26 @@ __global__ __launch_bounds__(256) void gp_trsm_kernel(GpArgs a, int k0, int r_en
 #pragma unroll
   for (int c = 0; c < NB; c += 4) *reinterpret_cast<f32x4*>(p + c) = f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]};
   a.y[(long)b * S + row] += a.w ? -ydot : ydot;
+  if (mirror_planes) {
+    // The solved row is row rj of block (j, i) of the outer block's factor (i = this panel).  gp_trsm_wide_kernel multiplies those blocks on the fp16 matrix
+    // cores, so the row is left once more as its two scaled fp16 terms (hi | lo, 128 + 128 bytes) -- in the MIRRORED block (i, j) of the matrix, which nothing
+    // else uses (the Gram kernel writes the lower triangle only; potrf's inverses live inside the DIAGONAL 64 x 64 blocks): row k0 + rj, columns of block j.
+    const int kout = k0 & ~(OBW_C - 1), rel = row - kout, jblk = rel >> 6, rj = rel & 63;
+    const float sc = __builtin_ldexpf(1.f, plane_scale_exp(a, b));
+    char* dst = reinterpret_cast<char*>(Kb + (long)(k0 + rj) * S + kout + jblk * NB);
+#pragma unroll
+    for (int c = 0; c < NB; c += 8) {
+      f16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = v[c + e] * sc;
+        hi[e] = (f16)x;
+        lo[e] = (f16)(x - (float)hi[e]);
+      }
+      *reinterpret_cast<f16x8*>(dst + c * 2) = hi;
+      *reinterpret_cast<f16x8*>(dst + 128 + c * 2) = lo;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -465,24 +510,6 @@ __global__ __launch_bounds__(256, 3) void gp_syrk_kernel(GpArgs a, int r0, int r
 // emulation of the blocked factorisation): error of y against the f64 factorisation 7.0e-4 / 5.3e-7 (nf 5 / nf 18) where exact f32 gives 6.6e-4 / 5.3e-7
 // and the six bf16 products 7.0e-4 / 4.9e-7; two bf16 terms / three products FAIL outright (non-positive pivots) on the nf-5 matrices.
 // ---------------------------------------------------------------------------------------------
-typedef _Float16 f16;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-constexpr int PL_KC = 16;                           // panel columns per slab / per LDS stage
-constexpr int PL_NKC = 256 / PL_KC;                 // slabs per plane of a 256-wide panel
-constexpr int PL_ROWB = PL_KC * 2;                  // bytes per slab row
-constexpr int PL_NPL = 2;                           // planes: hi, lo
-constexpr int PL_NSET = 2;                          // plane sets per dataset: the solved panels of an even and an odd outer block (delayed update, launch_gp_sample)
-PFN_DEV long plane_slab_bytes(long rows_alloc) { return rows_alloc * PL_ROWB; }
-PFN_DEV long plane_set_bytes(long rows_alloc) { return (long)PL_NPL * PL_NKC * plane_slab_bytes(rows_alloc); }
-// byte offset of (plane, chunk, row) inside one dataset's plane scratch of `rows_alloc` rows
-PFN_DEV long plane_offset(long rows_alloc, int plane, int kc, long row) { return ((long)(plane * PL_NKC + kc) * rows_alloc + row) * PL_ROWB; }
-// exponent e of a dataset's plane scale s = 2^e (see above)
-PFN_DEV int plane_scale_exp(const GpArgs& a, int b) {
-  const float kii = a.outputscale[b] + a.noise[b];
-  const int e = 14 - (int)ceilf(0.5f * __log2f(fmaxf(kii, 1e-30f)));
-  return max(-60, min(60, e));
-}
-
 constexpr int SYP_SLAB = 128 * PL_ROWB;             // one plane of one 128-row operand chunk in LDS: 4 KiB
 constexpr int SYP_STAGE = 2 * PL_NPL * SYP_SLAB;    // A and B, two planes each: 16 KiB
 #ifndef PFN_SYP_NST
@@ -498,9 +525,6 @@ constexpr int SYP_NST = PFN_SYP_NST;                // stages in the ring: two i
 constexpr int SYP_LDS = SYP_NST * SYP_STAGE;        // 48 KiB, three workgroups per CU
 constexpr int SYP_PPW = 2 * PL_NPL * 4 / 4;         // 1-KiB DMA pieces per wave and stage
 
-PFN_DEV f32x16 mma32_f16(const Frag<bf16>& a, const Frag<bf16>& b, f32x16 c) {      // the fragments carry fp16 bit patterns
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v), __builtin_bit_cast(f16x8, b.v), c, 0, 0, 0);
-}
 
 // One launch applies `nsets` solved panels (rank 256 each) to its region, so the region's C tiles are read and written once for all of them:
 // set s in {set0, set1} holds the panel whose plane row 0 is global row r0 - off_s.
@@ -621,17 +645,18 @@ constexpr int TW_STRIDE = OBW * 4 + 16;   // padded LDS row (pfn_device.h PadStr
 // datasets for 1.0 ms of MFMA chain and ~1.3 ms of HBM traffic.  The L operand of both products is now read straight from global memory into the B fragments
 // (a lane's 8 contraction values are 32 contiguous bytes of a row of L_d; the 256-KiB factor of a dataset stays in the L2 of the XCD all its workgroups run
 // on -- the dataset -> XCD deal below), one 64-column block ahead of the MFMAs that consume it.  LDS = the rows alone, 67.6 KiB: two workgroups per CU.
-#ifndef PFN_TW_ABLATE       // timing experiments only (results are wrong): 1 = no stores of the solved rows / planes, 2 = no MFMAs, 4 = no loads of the factor, 8 = no load of the rows
-#define PFN_TW_ABLATE 0
-#endif
-PFN_DEV f32x16 tw_mma(const Frag<float>& x, const Frag<float>& y, f32x16 c) {
-  if (PFN_TW_ABLATE & 2) { c[0] += x.v[0] + y.v[0] + x.v[7] + y.v[7]; return c; }
-  return mma32(x, y, c);
-}
+// Round 5 (later): the block products V_j -= sum_{i<j} X_i L_ji^T -- two thirds of this kernel's MFMA chain, which the ablation builds showed to be its largest
+// single part (8.5 of 20 ms per 7 x 320 datasets) -- run on the fp16 matrix cores like the trailing update: three products of two scaled fp16 terms per
+// operand (accuracy: gp_syrk_planes_kernel; emulated for this use as well, tools/sim_gp_split.py `fp16x3+solve-fp16x3`).  Both operands arrive pre-split:
+//   L_ji : left by gp_trsm_kernel in the mirrored block (i, j) of the matrix (hi | lo, 128 + 128 bytes per row), read straight into the B fragments;
+//   X_i  : when a solved block X_j leaves the accumulators it is written to LDS AS its two terms, over the f32 values of V_j it replaces (same 256 bytes per row);
+//          the plane scratch of the trailing update is then a copy of these LDS bytes, and y += X z is taken from the (exact f32) accumulators.
+// The solve X_j = V_j L_jj^-T stays on the exact-f32 MFMA (the inverse block's entries have no a-priori bound, hence no safe fp16 scale).
 __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout, int plane_set) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  LdsPtr V = lds_cast(smem_raw);                     // [64][TW_STRIDE]  the workgroup's rows
+  LdsPtr V = lds_cast(smem_raw);                     // [64][TW_STRIDE]  the workgroup's rows: block j as f32 until it is solved, then as hi | lo fp16 terms
   float* zs = reinterpret_cast<float*>(smem_raw + 64 * TW_STRIDE);  // [256]
+  float* yacc = zs + OBW;                            // [2][64] partial y per column half
   const int S = a.S;
   int b = blockIdx.y, rb = blockIdx.x;
   if (a.B % 8 == 0) {      // hardware places workgroup n on XCD n % 8: all row blocks of a dataset on one XCD, whose L2 then holds that dataset's factor
@@ -641,28 +666,25 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
   const int row0 = kout + OBW + rb * 64;
   const int rows_valid = min(64, S - row0);
   float* Kb = a.K + (long)b * S * S;
-  const float* Ld = Kb + (long)kout * S + kout;      // the factored 256 x 256 diagonal block [L \ L^-T of its 64 x 64 diagonal blocks]
+  const float* Ld = Kb + (long)kout * S + kout;      // the factored 256 x 256 diagonal block [L \ L^-T of its 64 x 64 diagonal blocks; planes of L_ji in block (i, j)]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
   const int rt = wave >> 1, ct = wave & 1, c = ct * 32 + li;
+  const int sexp = plane_scale_exp(a, b);
+  const float sc = __builtin_ldexpf(1.f, sexp), inv_s2 = __builtin_ldexpf(1.f, -2 * sexp);
   {
     TileStage<float, 64, OBW * 4, 256> sv;
-    if (!(PFN_TW_ABLATE & 8)) sv.issue(Kb + (long)row0 * S + kout, S, rows_valid, OBW);
+    sv.issue(Kb + (long)row0 * S + kout, S, rows_valid, OBW);
     const float zv = (a.w ? a.w : a.z)[(long)b * S + kout + threadIdx.x];
-    if (!(PFN_TW_ABLATE & 8)) sv.template commit_p<TW_STRIDE>(V);
+    sv.template commit_p<TW_STRIDE>(V);
     zs[threadIdx.x] = zv;
   }
-  // B fragment of the block products: rows of L_d are the tile's columns, a lane's slots k0 + 8h .. + 7 of row r are 32 contiguous bytes
-  auto l_frag = [&](int r, int k0) {
-    const float* p = Ld + (long)r * S + k0 + 8 * h;
-    Frag<float> f;
-    if (PFN_TW_ABLATE & 4) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f.v[e] = 0.001f * (r + k0 + e);
-      return f;
-    }
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { f.v[e] = lo[e]; f.v[4 + e] = hi[e]; }
+  // B fragments of the block products: the two fp16 terms of L_ji[row c of block j][k0 + 8h .. + 7], 16 bytes each (mirrored block (i, j): row kout + 64 i + c)
+  struct LFrag { Frag<bf16> hi, lo; };
+  auto l_frag = [&](int jb, int ib, int k0) {
+    const char* p = reinterpret_cast<const char*>(Ld + (long)(ib * NB + c) * S + jb * NB) + (k0 + 8 * h) * 2;
+    LFrag f;
+    f.hi.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+    f.lo.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + 128));
     return f;
   };
   // X_j = V_j L_jj^-T needs the inverse block: L^-1[c][k] (k < c) sits at (row k, column c) of the diagonal block, the diagonal holds L[c][c], everything with
@@ -670,43 +692,50 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
   const int kmax = ct == 0 ? 32 : NB;      // columns c < 32 only see k < 32
   auto inv_frags = [&](int jb, Frag<float> (&finv)[4], float& ldiag) {
     const float* dcol = Ld + (long)(jb * NB) * S + jb * NB + c;
-    ldiag = (PFN_TW_ABLATE & 4) ? 1.f : dcol[(long)c * S];
+    ldiag = dcol[(long)c * S];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = q * 16 + 8 * h + e;
-        finv[q].v[e] = (q * 16 < kmax && !(PFN_TW_ABLATE & 4)) ? dcol[(long)k * S] : 0.f;
+        finv[q].v[e] = (q * 16 < kmax) ? dcol[(long)k * S] : 0.f;
       }
   };
   // The barriers of the block loop order LDS traffic only (the factor is read-only here), so they wait for the LDS counter and leave the vector-memory
-  // counter alone (wait_vm_barrier<63>): __syncthreads() carries a fence that drains every load in flight, i.e. it put the round trip of whatever had been
-  // requested ahead in front of every phase.  What a block needs from the factor is requested one phase ahead: the inverse block and the first 64 columns of row
-  // block j + 1 travel under the X-phase products of block j.  (Measured: 19.8 vs 20.0 ms per 7 x 320 datasets -- the phases of this kernel ADD: ablation builds,
-  // PFN_TW_ABLATE, give 20.1 ms whole, 14.3 without the factor's loads, 16.9 without the rows' load, 16.8 without the stores, 10.6 without the MFMAs, 3.1 with
-  // none of them; neither more distance for the loads nor starting the two workgroups of a CU out of phase (s_sleep stagger, built and measured) changes that.
-  // profiles/r05_gp_sampler.txt)
-  Frag<float> finv[4], fcur[4];
+  // counter alone (wait_vm_barrier<63>): __syncthreads() carries a fence that drains every load in flight.  What a block needs from the factor is requested
+  // one phase ahead: the inverse block and the first 64 columns of row block j + 1 travel under the X-phase products of block j.
+  Frag<float> finv[4];
+  LFrag fcur[4];
   float ldiag;
+  float ysum[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ysum[r] = 0.f;
   inv_frags(0, finv, ldiag);
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) {
     wait_vm_barrier<63>();   // V current (initial load / previous block's solution)
     if (jb > 0) {
-      // V_j -= sum_{i<j} X_i L_ji^T
+      // V_j -= sum_{i<j} X_i L_ji^T   (three fp16 products per 16 contraction values; smallest terms first)
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const int lrow = jb * NB + c;
-      Frag<float> fnext[4];
+      LFrag fnext[4];
 #pragma unroll
       for (int ib = 0; ib < jb; ++ib) {
         if (ib + 1 < jb) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) fnext[q] = l_frag(lrow, (ib + 1) * NB + q * 16);
+          for (int q = 0; q < 4; ++q) fnext[q] = l_frag(jb, ib + 1, q * 16);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = tw_mma(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, ib * NB + q * 16), fcur[q], acc);
+        for (int q = 0; q < 4; ++q) {
+          const lds_char* xp = V + (rt * 32 + li) * TW_STRIDE + ib * (NB * 4) + (q * 16 + 8 * h) * 2;
+          Frag<bf16> xh, xl;
+          xh.v = __builtin_bit_cast(bf16x8, lds_read16(xp));
+          xl.v = __builtin_bit_cast(bf16x8, lds_read16(xp + 128));
+          acc = mma32_f16(xl, fcur[q].hi, acc);
+          acc = mma32_f16(xh, fcur[q].lo, acc);
+          acc = mma32_f16(xh, fcur[q].hi, acc);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) fcur[q] = fnext[q];
       }
@@ -714,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         LdsPtr p = V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + (jb * NB + c) * 4;
-        lds_write_f32(p, lds_read_f32(p) - acc[r]);
+        lds_write_f32(p, lds_read_f32(p) - acc[r] * inv_s2);
       }
       wait_vm_barrier<63>();
     }
@@ -731,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
       if (jb + 1 < 4) {      // the next block's share of the factor, requested under this block's products
         inv_frags(jb + 1, finv, ldiag);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fcur[q] = l_frag((jb + 1) * NB + c, q * 16);
+        for (int q = 0; q < 4; ++q) fcur[q] = l_frag(jb + 1, 0, q * 16);
       }
       f32x16 acc;
 #pragma unroll
@@ -739,59 +768,60 @@ __global__ __launch_bounds__(256, 2) void gp_trsm_wide_kernel(GpArgs a, int kout
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (q * 16 >= kmax) break;
-        acc = tw_mma(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, jb * NB + q * 16), fb[q], acc);
+        acc = mma32(load_frag_row_p<float, TW_STRIDE>(V, rt * 32 + li, jb * NB + q * 16), fb[q], acc);
+      }
+      // this block's part of y = X z (or of the forward solve), from the exact values: the lane's column times z, summed over the 32 lanes of its half
+      const float zc = zs[jb * NB + c];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float t = acc[r] * zc;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        ysum[r] += t;
+      }
+      if (!a.planes) {      // no plane scratch: the update will split the f32 rows itself (gp_syrk_kernel), so they go back to the matrix -- exact, from the accumulators
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = rt * 32 + acc_row(r, lane);
+          if (rr < rows_valid) Kb[(long)(row0 + rr) * S + kout + jb * NB + c] = acc[r];
+        }
       }
       wait_vm_barrier<63>();   // all of V_j has been read
+      typedef __attribute__((address_space(3))) f16 lds_f16;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        lds_write_f32(V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + (jb * NB + c) * 4, acc[r]);
+      for (int r = 0; r < 16; ++r) {      // X_j as its two scaled fp16 terms, over V_j
+        const float x = acc[r] * sc;
+        const f16 xh = (f16)x;
+        LdsPtr p = V + (rt * 32 + acc_row(r, lane)) * TW_STRIDE + jb * (NB * 4) + c * 2;
+        *reinterpret_cast<lds_f16*>(p) = xh;
+        *reinterpret_cast<lds_f16*>(p + 128) = (f16)(x - (float)xh);
+      }
     }
+  }
+  if (li == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yacc[ct * 64 + rt * 32 + acc_row(r, lane)] = ysum[r];
   }
   __syncthreads();
-  {  // y[row] += X[row, :] . z   (4 threads per row, 64 columns each)
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
-    float d = 0.f;
-#pragma unroll
-    for (int c = 0; c < NB; c += 4) {
-      const f32x4 xv = __builtin_bit_cast(f32x4, lds_read16(V + r * TW_STRIDE + (q * NB + c) * 4));
-      d += xv[0] * zs[q * NB + c] + xv[1] * zs[q * NB + c + 1] + xv[2] * zs[q * NB + c + 2] + xv[3] * zs[q * NB + c + 3];
-    }
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    if (q == 0 && r < rows_valid) a.y[(long)b * S + row0 + r] += a.w ? -d : d;
+  if (threadIdx.x < 64 && (int)threadIdx.x < rows_valid) {
+    const float d = yacc[threadIdx.x] + yacc[64 + threadIdx.x];
+    a.y[(long)b * S + row0 + threadIdx.x] += a.w ? -d : d;
   }
-  // the solved rows go back to the matrix only for a reader: the per-tile-split update (gp_syrk_kernel).  With planes nobody reads these columns again -- their
-  // part of y = L z (or of the forward solve) was taken above, the later outer blocks touch rows AND columns >= their own first row, the posterior reads the
-  // diagonal -- and the store was a third of this kernel's HBM traffic (64 of 192 KiB per workgroup)
-  if (!a.planes && !(PFN_TW_ABLATE & 1)) {
-    for (int id = threadIdx.x; id < 64 * (OBW / 4); id += 256) {
-      const int r = id / (OBW / 4), c = id % (OBW / 4);
-      if (r < rows_valid) *reinterpret_cast<u32x4*>(Kb + (long)(row0 + r) * S + kout + c * 4) = lds_read16(V + r * TW_STRIDE + c * 16);
-    }
-  }
-  if (a.planes && !(PFN_TW_ABLATE & 1)) {
-    // the solved rows once more, as the two scaled fp16 planes the trailing update multiplies (gp_syrk_planes_kernel: layout, scale and why).  A task = 8
-    // consecutive columns of a row (two 16-byte reads of V) -> one 16-byte half row in each plane
+  if (a.planes) {
+    // the solved rows for the trailing update (gp_syrk_planes_kernel: layout, scale and why): a copy of the LDS terms.  A task = 8 consecutive columns of a
+    // row -> one 16-byte half row in each plane.  (The rows themselves are NOT stored: with the planes nobody reads these columns of the matrix again.)
     char* pl = reinterpret_cast<char*>(a.planes) + ((long)b * PL_NSET + plane_set) * plane_set_bytes(a.plane_rows);
     const long prow0 = (long)row0 - (kout + OBW);                      // row index inside the planes: rows below the outer block
-    const float sc = __builtin_ldexpf(1.f, plane_scale_exp(a, b));
     for (int id = threadIdx.x; id < 64 * (OBW / 8); id += 256) {
-      const int r = id / (OBW / 8), c8 = id % (OBW / 8);                 // columns 8 c8 .. 8 c8 + 7
+      const int r = id / (OBW / 8), c8 = id % (OBW / 8);                 // columns 8 c8 .. 8 c8 + 7: block c8 / 8, 16-byte group c8 % 8 of its hi / lo halves
       if (r >= rows_valid) continue;
-      const f32x4 v0 = __builtin_bit_cast(f32x4, lds_read16(V + r * TW_STRIDE + c8 * 32));
-      const f32x4 v1 = __builtin_bit_cast(f32x4, lds_read16(V + r * TW_STRIDE + c8 * 32 + 16));
-      f16x8 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = (e < 4 ? v0[e] : v1[e - 4]) * sc;
-        hi[e] = (f16)v;
-        lo[e] = (f16)(v - (float)hi[e]);
-      }
+      const lds_char* src = V + r * TW_STRIDE + (c8 >> 3) * (NB * 4) + (c8 & 7) * 16;
+      const u32x4 hi = lds_read16(src), lo = lds_read16(src + 128);
       const int kc = c8 / 2;
       const long prow = prow0 + r;
       const int half = (c8 & 1) ^ (int)((prow >> 3) & 1);                // the consumer's bank swizzle (load_frag_row<.., 32>), applied at the source
-      *reinterpret_cast<f16x8*>(pl + plane_offset(a.plane_rows, 0, kc, prow) + half * 16) = hi;
-      *reinterpret_cast<f16x8*>(pl + plane_offset(a.plane_rows, 1, kc, prow) + half * 16) = lo;
+      *reinterpret_cast<u32x4*>(pl + plane_offset(a.plane_rows, 0, kc, prow) + half * 16) = hi;
+      *reinterpret_cast<u32x4*>(pl + plane_offset(a.plane_rows, 1, kc, prow) + half * 16) = lo;
     }
   }
 }
@@ -828,7 +858,7 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
     const int ti = (r1 - r0 + 127) / 128, tj = (c1 - c0 + 127) / 128;
     if (ti > 0 && tj > 0) hipLaunchKernelGGL(gp_syrk_kernel, dim3(tj, ti, B), dim3(256), SYRK_LDS, s, a, r0, r1, c0, c1, kp0, K);
   };
-  const size_t tw_lds = 64 * TW_STRIDE + OBW * sizeof(float);
+  const size_t tw_lds = 64 * TW_STRIDE + (OBW + 128) * sizeof(float);
   static LdsAllowance tw_allowance;   // (constant size; per device; the call costs tens of microseconds of host time)
   tw_allowance.ensure(gp_trsm_wide_kernel, tw_lds);
   for (int kout = 0; kout < S; kout += OBW) {
@@ -837,7 +867,7 @@ int launch_gp_sample(const GpArgs& a, hipStream_t s) {
       hipLaunchKernelGGL(gp_potrf_kernel, dim3(B), dim3(64), 0, s, a, k0);
       const int next = k0 + NB;
       if (next >= kend) break;
-      hipLaunchKernelGGL(gp_trsm_kernel, dim3((kend - next + 255) / 256, B), dim3(256), 0, s, a, k0, kend);
+      hipLaunchKernelGGL(gp_trsm_kernel, dim3((kend - next + 255) / 256, B), dim3(256), 0, s, a, k0, kend, kend < S ? 1 : 0);
       syrk(next, kend, next, kend, k0, NB);
     }
     if (kend < S) {
