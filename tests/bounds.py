@@ -14,7 +14,8 @@ def within(label, value, bound):
     rec['max'] = max(rec['max'], value)
     rec['bound'] = bound
     rec['n'] += 1
-    assert value < bound, f'{label}: {value:.3e} is not below the bound {bound:.1e}'
+    if not os.environ.get('PFN_BOUNDS_MEASURE_ONLY'):      # (measuring a re-based bound: record every value of the test, assert nothing)
+        assert value < bound, f'{label}: {value:.3e} is not below the bound {bound:.1e}'
     return value
 
 

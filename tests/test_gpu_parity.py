@@ -1367,10 +1367,13 @@ def test_trained_head_dim_256_inference_parity():
             tight = not train_mode
             # (round 5: the model is trained under the deterministic schedule, so these values repeat to the last digit -- two runs, gpurun call 3 of round 5:
             # inference 7.18e-7 / 1.10e-6 / 9.37e-7; the bf16 training forward on these weights -- 2500 optimizer steps, the loss 2.8 nats below its start --
-            # 4.20e-4 / 1.13e-3 / 1.28e-3 in both.  bf16 bounds = 2 x measured, as everywhere else; rounds 3-4 had to use 3 x the largest of two differing runs)
-            within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3 if tight else 8.5e-4)
+            # 4.20e-4 / 1.13e-3 / 1.28e-3 in both.  Later in round 5 the GP sampler's arithmetic changed (fp16 two-term products: the draws differ in the last
+            # bits), i.e. ANOTHER trajectory and other weights: inference 7.5e-7 / 6.7e-7 / 1.0e-6 -- the asserted tier does not care -- and the bf16 forward
+            # 1.71e-3 / 6.96e-4 / 1.35e-3, again identical in two runs.  The bf16 error of a trained emsize-1024 model depends on WHICH weights training
+            # arrived at (nll x 4, means x 0.6 between the two); bf16 bounds = 2 x the larger of the two trajectories' values)
+            within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3 if tight else 3.4e-3)
             within(f'{mode}: means rel l2 (own norm)', relerr(mean, mean_o), 1e-3 if tight else 2.3e-3)
-            within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 2.6e-3)
+            within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 2.7e-3)
 
 
 @pytest.mark.parametrize('precision,aggregate_streams,aggregate_stacked', [('f32', 0, False), ('bf16', 0, False), ('f32', 2, False), ('f32', 0, True), ('bf16', 0, True)])
