@@ -98,6 +98,8 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_FUSE_LN_WIDE = 5,  /* 1: emsize 1024 runs the LayerNorm-fused GEMMs on 64-row x 1024-column tiles (gemm_nt_ln_wide / lnbwd_wide); 0 (default): the
                                     * 256 x 256 GEMM + LayerNorm kernels -- measured faster at that width */
        PFN_TUNE_GP_PLANES = 8,     /* 1 (default): the GP sampler's rank-256 trailing update reads pre-split fp16 planes (hi, lo on a power-of-two scale) by LDS-DMA; 0: it splits the f32 panel into three bf16 terms per tile (rounds 2-3) */
+       PFN_TUNE_FUSE_DELTA = 9,    /* 1 (default): on the full-sequence layers of the bf16 stack the attention backward's delta = rowsum(dO . O) is taken in the epilogue of the GEMM that
+                                    * produces dO (f32 atomics into a zeroed scratch: two addends per element at head dim 128); 0: a pass of its own over dO and O (attn_delta_kernel) */
        PFN_TUNE_GEMM_LN_ROWS = 7,  /* 1: the LayerNorm-fused GEMMs at emsize 512 run on 64-row tiles, two workgroups per CU (gemm.hip g_ln_rows64); 0 (default): 128-row tiles */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
                                     * returns output[single_eval_pos:] (transformer.py:91), so that layer's train rows feed nothing; 0: every layer on every row */ };

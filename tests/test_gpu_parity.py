@@ -1648,6 +1648,43 @@ def test_deterministic_schedule_gradients_at_a_benchmark_like_shape(precision):
     within(f'{precision} deterministic vs default schedule: gradient rel l2', relerr(g1, g0), 1e-5 if precision == 'f32' else 5e-3)
 
 
+@pytest.mark.parametrize('E,H', [(256, 4), (512, 4), (1024, 4)], ids=['head-dim-64', 'head-dim-128', 'head-dim-256'])
+def test_delta_from_the_dctx_gemm_equals_the_delta_kernel(E, H):
+    """Round 5: on the full-sequence layers of the bf16 stack the attention backward's delta = rowsum(dO . O) is taken in the epilogue of the GEMM that produces
+    dO (EPI_ROWDOT: f32 atomics of one / two / four 64-column waves per head at head dim 64 / 128 / 256) instead of by attn_delta_kernel (PFN_TUNE_FUSE_DELTA).
+    The two forms must give the same gradient: the 256 x 256 LDS-DMA kernel is forced (tuning key 0 = 2) so that the fused form runs at a test-sized shape, the
+    delta kernel form of the same launch set is the yardstick (itself held to the oracle by the stack-backward parity tests)."""
+    cfg = dict(T=520, B=3, F=7, nhid=512, L=3, nbars=50)
+    sep = 380
+    torch.manual_seed(9)
+    borders = torch.sort(torch.randn(cfg['nbars'] + 1) * 1.5)[0]
+    m = TransformerModel(encoders.Linear(cfg['F'], E), cfg['nbars'], E, H, cfg['nhid'], cfg['L'], 0.0, y_encoder=encoders.Linear(1, E), precision='bf16')
+    m.criterion = bar_distribution.FullSupportBarDistribution(borders)
+    with torch.no_grad():
+        for layer in m.transformer_encoder.layers:
+            layer.linear2.weight.normal_(0, 0.05); layer.self_attn.out_proj.weight.normal_(0, 0.05)
+    m = m.to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.rand(cfg['T'], cfg['B'], cfg['F'], generator=g).to(DEV), torch.randn(cfg['T'], cfg['B'], generator=g).to(DEV)
+    def grad():
+        m.flat_parameters()[1].zero_()
+        out = m((x, y), single_eval_pos=sep)
+        m.criterion(out.reshape(-1, cfg['nbars']), y[sep:].reshape(-1)).mean().backward()
+        return m.flat_parameters()[1].clone()
+    lib = _hip.lib()
+    _hip.check(lib.pfn_set_tuning(0, 2), 'pfn_set_tuning')
+    try:
+        _hip.check(lib.pfn_set_tuning(9, 0), 'pfn_set_tuning')
+        kernel_a, kernel_b = grad(), grad()
+        _hip.check(lib.pfn_set_tuning(9, 1), 'pfn_set_tuning')
+        fused = grad()
+    finally:
+        lib.pfn_set_tuning(9, 1); lib.pfn_set_tuning(0, 0)
+    assert fused.abs().max().item() > 0 and torch.isfinite(fused).all()
+    noise = relerr(kernel_a, kernel_b)             # two runs of ONE form differ by the order of the weight gradients' f32 atomics
+    within(f'fused delta vs delta kernel, head dim {E // H}: gradient rel l2', relerr(fused, kernel_a), max(10 * noise, 1e-4))
+
+
 @pytest.mark.parametrize('seps', [[257, 0, 300, 131, 299], [257, 290, 80, 131, 299]], ids=['every-row-top-layer', 'test-row-top-layer'])
 @pytest.mark.parametrize('precision', ['f32', 'bf16'])
 def test_forward_batches_equals_separate_forwards(precision, seps):

@@ -239,8 +239,9 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
   const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
   bf16* out_t = reinterpret_cast<bf16*>(g.out_t);
   bf16* out2_t = reinterpret_cast<bf16*>(g.out2_t);
-  constexpr bool HAS_AUX = (flags & (EPI_GELU_BWD | EPI_RESID_T)) != 0;
+  constexpr bool HAS_AUX = (flags & (EPI_GELU_BWD | EPI_RESID_T | EPI_ROWDOT)) != 0;
   constexpr bool HAS_RES = (flags & EPI_RESID) != 0;
+  float rowdot = 0.f;     // EPI_ROWDOT: the lane's share of sum_n out[m, n] * aux[m, n] over the two column blocks of its row
   // blocks (32 rows x 32 columns each; 8 per wave) per pass: 4 = half the tile, 2 when an f32 residual is read (twice the
   // registers per block); the 4-wave shape (three workgroups per CU on 168 registers, latency hidden by occupancy) keeps 1
   constexpr bool EARLY = NWM == 2;     // the 4-wave shape loads each 16-byte group where it is used, as before
@@ -314,6 +315,10 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) post[4 * gq + e] = v[e];
+        if (flags & EPI_ROWDOT) {      // with the values as they are stored (operand precision), like the kernel this replaces read them back
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rowdot += (float)(bf16)v[e] * (float)aux_v[HAS_AUX ? bb : 0][gq][e];
+        }
         if (flags & EPI_OUT_F32) {
           if (lines) lds_write16(ep + li * 272 + (j * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
           else if (mvalid && nb + 8 * gq + 4 * h < g.N) *reinterpret_cast<f32x4*>(g.out_f32 + m * g.ld_out_f32 + n) = v;
@@ -332,6 +337,16 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
             for (int e = 0; e < 4; ++e) t[e] = (bf16)pre[4 * gq + e];
             *reinterpret_cast<lds_bf16x4*>(ep + EP_T + li * 144 + (j * 4 + gq) * 16 + h * 8) = t;
           }
+        }
+      }
+      if ((flags & EPI_ROWDOT) && j == 1) {      // both column blocks of row block i are in: the other half-wave holds the other 32 of the 64 columns
+        const float sum = rowdot + __shfl_xor(rowdot, 32, 64);
+        rowdot = 0.f;
+        if (h == 0 && mvalid) {
+          const int nw = n0 + wn * 64;
+          const long bq = m_row / g.rd_S, idx = (bq * g.rd_H + nw / g.rd_D) * g.rd_S + (m_row - bq * g.rd_S);
+          unsafeAtomicAdd(g.rowdot + idx, sum);
+          if (nw % g.rd_D == 0) g.rowdot[g.rd_lse2_off + idx] = g.rd_lse[idx] * 1.4426950408889634f;
         }
       }
       if (lines) {
@@ -2112,6 +2127,7 @@ static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
     PFN_BIG_CASE(EPI_RESID_T | EPI_OUT_F32)                       // dx = dgrad + residual gradient (kept in operand precision)
     PFN_BIG_CASE(EPI_RESID_T | EPI_OUT_T)                         // ... between layers the sum stays in operand precision too
     PFN_BIG_CASE(EPI_OUT_T)                                       // d(ctx)
+    PFN_BIG_CASE(EPI_OUT_T | EPI_ROWDOT)                          // d(ctx) + the attention backward's delta
     PFN_BIG_CASE(EPI_OUT_F32)
     PFN_BIG_CASE(EPI_BIAS | EPI_OUT_F32)
 #undef PFN_BIG_CASE
@@ -2119,29 +2135,42 @@ static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
   }
 }
 
+static void nt_prepare(GemmNT& g, int precision);
+bool gemm_nt_rowdot_fused(const GemmNT& g_in, int precision) {
+  GemmNT g = g_in;
+  if (precision != PFN_PREC_BF16 || g.M <= 0 || g.flags != (EPI_OUT_T | EPI_ROWDOT) || g.N % 64 || g.rd_D % 64 || g.N % g.rd_D) return false;
+  if ((g.lda * 2) % 16 || (g.ldb * 2) % 16 || !aligned16(g.A) || !aligned16(g.B)) return false;
+  nt_prepare(g, precision);
+  return gemm_nt_pick(g) == 1 && g.wide_t;      // the 256 x 256 tile only (the 4-wave 128 x 256 form has no registers left for the row sums: 56 bytes of scratch)
+}
 int launch_gemm_nt(const GemmNT& g_in, int precision, hipStream_t stream) {
   GemmNT g = g_in;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return PFN_OK;
   const size_t es = precision == PFN_PREC_BF16 ? 2 : 4;
   if ((g.lda * es) % 16 || (g.ldb * es) % 16 || !aligned16(g.A) || !aligned16(g.B)) return PFN_ERR_ALIGNMENT;
+  nt_prepare(g, precision);
+  if (precision == PFN_PREC_BF16) {
+    const int pick = gemm_nt_pick(g);
+    if (pick && launch_big(g, pick == 2, stream)) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+  }
+  if (g.flags & EPI_ROWDOT) return PFN_ERR_UNSUPPORTED;      // (callers ask gemm_nt_rowdot_fused first)
+  const int tiles = ((g.M + GEMM_BM - 1) / GEMM_BM) * ((g.N + GEMM_BN - 1) / GEMM_BN);
+  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, dim3(tiles), dim3(256), 65536, stream, g);
+  else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(tiles), dim3(256), 65536, stream, g);
+  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+static void nt_prepare(GemmNT& g, int precision) {
+  const size_t es = precision == PFN_PREC_BF16 ? 2 : 4;
   // the epilogue moves 4 columns per lane when every stream it touches allows it
   bool vec = true;
   if ((g.flags & EPI_OUT_F32) && (g.ld_out_f32 % 4 || !aligned16(g.out_f32))) vec = false;
   if ((g.flags & EPI_OUT_T) && ((g.ld_out_t * es) % (4 * es) || !aligned16(g.out_t))) vec = false;
   if ((g.flags & EPI_OUT2_T) && ((g.ld_out2 * es) % (4 * es) || !aligned16(g.out2_t))) vec = false;
   if ((g.flags & EPI_RESID) && (g.ld_resid % 4 || !aligned16(g.resid))) vec = false;
-  if ((g.flags & (EPI_GELU_BWD | EPI_RESID_T)) && ((g.ld_aux * es) % (4 * es) || !aligned16(g.aux))) vec = false;
+  if ((g.flags & (EPI_GELU_BWD | EPI_RESID_T | EPI_ROWDOT)) && ((g.ld_aux * es) % (4 * es) || !aligned16(g.aux))) vec = false;
   if ((g.flags & EPI_BIAS) && !aligned16(g.bias)) vec = false;
   g.vec_ok = vec ? 1 : 0;
   g.wide_t = (!(g.flags & EPI_OUT_T) || g.ld_out_t % 8 == 0) && (!(g.flags & EPI_OUT2_T) || g.ld_out2 % 8 == 0) ? 1 : 0;   // 16-byte rows
-  if (precision == PFN_PREC_BF16) {
-    const int pick = gemm_nt_pick(g);
-    if (pick && launch_big(g, pick == 2, stream)) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
-  }
-  const int tiles = ((g.M + GEMM_BM - 1) / GEMM_BM) * ((g.N + GEMM_BN - 1) / GEMM_BN);
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, dim3(tiles), dim3(256), 65536, stream, g);
-  else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(tiles), dim3(256), 65536, stream, g);
-  return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 
 int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream) {

@@ -205,6 +205,7 @@ GemmTN tn(const void* A, long lda, const void* B, long ldb, float* C, long ldc, 
 extern "C" {
 
 static bool g_gp_planes = true;      // PFN_TUNE_GP_PLANES (see pfn_gp_prior_sample)
+static bool g_fuse_delta = true;     // PFN_TUNE_FUSE_DELTA: the attention backward's delta from the d(ctx) GEMM's epilogue (stack_backward_impl)
 // Defaults handed to NEW descriptors by pfn_default_schedule() (test / profiling hook); the entry points read pfn_model_desc::schedule only.
 static int g_default_schedule = 0;
 // The reference returns output[single_eval_pos:] (transformer.py:91): the TOP encoder layer's train rows feed nothing -- no later layer reads
@@ -251,6 +252,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
     case PFN_TUNE_GEMM_LN_ROWS: set_gemm_ln_rows64(value); return PFN_OK;
     case PFN_TUNE_GP_PLANES: g_gp_planes = value != 0; return PFN_OK;
+    case PFN_TUNE_FUSE_DELTA: g_fuse_delta = value != 0; return PFN_OK;
     case PFN_TUNE_FUSE_LN_WIDE: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_LN_WIDE) : (g_default_schedule & ~PFN_SCHED_FUSE_LN_WIDE); return PFN_OK;
     case PFN_TUNE_TOP_LAYER_TEST_ROWS: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_TOP_LAYER_ALL_ROWS) : (g_default_schedule | PFN_SCHED_TOP_LAYER_ALL_ROWS); return PFN_OK;
     default: return fail(PFN_ERR_ARGUMENT, "unknown tuning key %d", key);
@@ -734,11 +736,24 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
                                    pdrop > 0.f ? nullptr : grads + p.b_o, Ml, E, prec, s, w.ln_part));
     }
     const char* dy1_op = dy1_t;
+    bool delta_fused = false;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy1_t, a.dy1m_t, nullptr, nullptr, M, E, dseed(l, 1), pdrop, prec, s)); dy1_op = a.dy1m_t; }
     {  // d(ctx) = dy1 . Wo
       ProfScope ps(PFN_PROF_GEMM_DCTX + (top ? 1 : 0), s);
       GemmNT g = nt(dy1_op, E, WT(t.w_o), E, Ml, E, E, EPI_OUT_T);
       g.out_t = top ? w.top_dctx_t : w.dctx_t; g.ld_out_t = E;
+      // The attention backward's delta = rowsum(dO . O) leaves with d(ctx) from this GEMM's epilogue (EPI_ROWDOT) instead of a pass of its own over dO and O
+      // (attn_delta_kernel: 1.4 % of the step's kernel time) -- on the full-sequence layers of the default schedule; the test-row top layer (compact rows), the
+      // deterministic schedule (head dim 256: four atomic addends per element) and the shapes the LDS-DMA kernels do not take keep the kernel.
+      if (!top && !det && g_fuse_delta) {
+        GemmNT gd = g;
+        gd.flags |= EPI_ROWDOT; gd.aux = a.ctx; gd.ld_aux = E;
+        gd.rowdot = w.delta; gd.rd_lse = a.lse; gd.rd_lse2_off = (long)B * H * S; gd.rd_S = S; gd.rd_H = H; gd.rd_D = E / H;
+        if (gemm_nt_rowdot_fused(gd, prec)) {
+          if (hipMemsetAsync(w.delta, 0, sizeof(float) * B * H * S, s) != hipSuccess) return fail(PFN_ERR_LAUNCH, "hipMemsetAsync(delta)");
+          g = gd; delta_fused = true;
+        }
+      }
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     if (top) {
@@ -759,6 +774,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
       at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
       at.q_begin = top ? (rg ? rg->sep_min : sep) : 0;
       at.q_from_sep = (top && rg) ? 1 : 0;
+      if (delta_fused) at.parts = ATTN_BWD_KV | ATTN_BWD_DQ;      // delta and lse2 are in place (EPI_ROWDOT above)
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     if (fuse_lnb && l > 0) {  // dy2 of the layer below = its LN2 backward of (dqkv . Win + dy1)

@@ -73,6 +73,11 @@ enum : int {
   EPI_OUT2_T = 64,   // second T output: with EPI_GELU the GELU DERIVATIVE at the pre-activation, else the value before the activation
   EPI_ACCUM = 128,   // out_f32 += v
   EPI_RESID_T = 256, // + aux[m,n] (T): residual taken from an operand-precision tensor (not with EPI_GELU_BWD)
+  // (LDS-DMA 256 / 128 x 256 kernels only; gemm_nt_rowdot_fused tells the caller beforehand)  rowdot[b, head, i] += sum over the tile's columns of
+  // out_t[m, n] * aux[m, n], m = b * rd_S + i, head = n / rd_D -- the attention backward's delta = rowsum(dO . O) taken while d(ctx) leaves the GEMM that
+  // produces it (aux = the forward's context rows), with f32 atomics (two 64-column waves per head of 128: two addends, order-free; the caller zeroes rowdot);
+  // the wave that owns a head's first columns also writes lse2 = lse * log2(e) behind it (what attn_delta_kernel did)
+  EPI_ROWDOT = 512,
 };
 
 struct GemmNT {
@@ -88,8 +93,11 @@ struct GemmNT {
   void* out2_t; long ld_out2;
   int vec_ok;  // filled by the launcher
   int wide_t;  // filled by the launcher: operand-precision outputs may be stored 16 bytes at a time
+  // EPI_ROWDOT: rowdot [B, H, S] f32 (+ lse2 [B, H, S] behind it at rd_lse2_off), lse [B, H, S]; rows m = b * rd_S + i, heads of rd_D columns
+  float* rowdot; const float* rd_lse; long rd_lse2_off; int rd_S, rd_H, rd_D;
 };
 int launch_gemm_nt(const GemmNT& g, int precision, hipStream_t stream);
+bool gemm_nt_rowdot_fused(const GemmNT& g, int precision);   // true: launch_gemm_nt(g) will run a kernel that implements EPI_ROWDOT (else the caller keeps attn_delta_kernel)
 // kernel selection knob (tests / profiling): 0 automatic, 1 only the 128x128 kernel, 2 the 256x256 kernel whenever legal
 void set_gemm_nt_big_mode(int mode);
 void set_gemm_nt_persist(int wgs);
