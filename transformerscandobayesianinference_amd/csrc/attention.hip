@@ -1175,6 +1175,9 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
       store_row_block<T>(dQo + db * 32, v, h, qvalid);
     }
   }
+  // delta of the wave's 32 queries has had its last reader (the key-block pass before this launch, the self-key term above): cleared for the next layer's
+  // GEMM epilogue, which ADDS into it (EPI_ROWDOT; AttnArgs::zero_delta)
+  if (a.zero_delta && h == 0 && qvalid) a.delta[((long)b * a.H + hd) * a.S + qi] = 0.f;
 }
 
 // =============================================================================================

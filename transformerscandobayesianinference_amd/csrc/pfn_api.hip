@@ -701,6 +701,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     return PFN_OK;
   };
   const int split_at = (on_first_group && first_group_layers > 0 && first_group_layers < d->nlayers) ? d->nlayers - first_group_layers : -1;
+  bool delta_zeroed = false;      // the delta scratch holds zeros for the next EPI_ROWDOT epilogue (d(ctx) below)
   for (int l = d->nlayers - 1; l >= 0; --l) {
     const LayerP &p = L.layer[l], &t = L.layer_t[l];
     LayerWs& a = w.layer[l];
@@ -750,7 +751,10 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
         gd.flags |= EPI_ROWDOT; gd.aux = a.ctx; gd.ld_aux = E;
         gd.rowdot = w.delta; gd.rd_lse = a.lse; gd.rd_lse2_off = (long)B * H * S; gd.rd_S = S; gd.rd_H = H; gd.rd_D = E / H;
         if (gemm_nt_rowdot_fused(gd, prec)) {
-          if (hipMemsetAsync(w.delta, 0, sizeof(float) * B * H * S, s) != hipSuccess) return fail(PFN_ERR_LAUNCH, "hipMemsetAsync(delta)");
+          // the scratch is zero: once per backward pass by a memset, afterwards by every layer's query-block pass (AttnArgs::zero_delta), which runs after the
+          // last reader of the values it clears
+          if (!delta_zeroed && hipMemsetAsync(w.delta, 0, sizeof(float) * B * H * S, s) != hipSuccess) return fail(PFN_ERR_LAUNCH, "hipMemsetAsync(delta)");
+          delta_zeroed = true;
           g = gd; delta_fused = true;
         }
       }
@@ -775,6 +779,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
       at.q_begin = top ? (rg ? rg->sep_min : sep) : 0;
       at.q_from_sep = (top && rg) ? 1 : 0;
       if (delta_fused) at.parts = ATTN_BWD_KV | ATTN_BWD_DQ;      // delta and lse2 are in place (EPI_ROWDOT above)
+      at.zero_delta = delta_zeroed ? 1 : 0;
       PFN_TRY(launch_attn_bwd(at, prec, s));
     }
     if (fuse_lnb && l > 0) {  // dy2 of the layer below = its LN2 backward of (dqkv . Win + dy1)

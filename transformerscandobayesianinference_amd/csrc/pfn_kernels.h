@@ -184,6 +184,7 @@ struct AttnArgs {
   void* ds;   // dS^T scratch [B, H, ds_rows, ds_ld] T: written by the key-block pass, read by the query-block pass (attn_bwd_ds_bytes)
   int ds_rows, ds_ld;  // filled by the launcher
   int parts;  // backward launches to run, bit mask over ATTN_BWD_*; 0 = all (profiling entry point pfn_op_attention_bwd_parts)
+  int zero_delta;  // the query-block pass (the last reader's successor) leaves delta[b, head, its queries] = 0: the next layer's GEMM epilogue ADDS into it (EPI_ROWDOT)
   int pingpong;  // filled by the launcher (PFN_TUNE_ATTN_PINGPONG): bit 0 forward, bit 1 key-block pass
   // Queries below q_begin are skipped: their context rows / dQ rows are not written and they add nothing to dK and dV (the top encoder
   // layer, whose train rows feed nothing: pfn_api.hip).  The launcher rounds it down to a multiple of 256 (whole query blocks / tiles of every
