@@ -618,3 +618,19 @@ def test_ragged_batch_layout():
     assert offs == [0, 3, 6, 8, 18, 28, 38] and offs[-1] == sum(10 - s for s in per_dataset)
     seps, per_dataset, offs = ragged_layout(10, [1, 1], [10, 25])      # no test rows at all (clamped)
     assert seps == [10, 10] and offs == [0, 0, 0]
+
+
+def test_split_precision_products_keep_f32_accuracy_in_the_blocked_cholesky():
+    """The numerical basis of the GP sampler's fp16 products (gp_prior.hip: gp_syrk_planes_kernel, gp_trsm_wide_kernel), on the CPU: the blocked factorisation is
+    emulated in f32 with the rank-256 update -- and the wide solve's block products -- computed from two fp16 terms per operand on a power-of-two scale (three
+    products).  On the ill-conditioned north-star matrices (5 features, noise 1e-4) the draw y = L z stays as close to the f64 factorisation as with exact f32
+    products; two bf16 terms (the cheaper split one might reach for) are several times worse or fail outright.  (tools/sim_gp_split.py: the tool that priced the
+    kernels before they were written.)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import sim_gp_split as sim
+    torch.manual_seed(1)
+    for T in (768, 1280):
+        e = sim.errors(T, 5, 1e-4, 1.0, 0.6, 'rbf', modes=('f32', 'fp16x3', 'fp16x3+solve-fp16x3', 'bf16x3'))
+        assert e['f32'] < 2e-3, e
+        assert e['fp16x3'] < 1.5 * e['f32'] and e['fp16x3+solve-fp16x3'] < 1.5 * e['f32'], e
+        assert not (e['bf16x3'] < 2 * e['f32']), e            # nan (failed factorisation) or clearly worse

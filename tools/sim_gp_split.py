@@ -6,6 +6,7 @@ import sys
 import torch
 
 torch.manual_seed(0)
+
 OB = 256
 
 
@@ -93,21 +94,32 @@ def gram(x, ls, os_, noise, kernel):
     return os_ * k + noise * torch.eye(x.shape[0], dtype=torch.float64)
 
 
-nd = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-for (T, F, noise, os_, ls, kernel) in [(2000, 5, 1e-4, 1.0, 0.6, 'rbf'), (2000, 18, 1e-4, 1.0, 0.6, 'rbf'), (2000, 10, 1e-3, 1.0, 0.5, 'matern'), (2000, 5, 1e-4, 30.0, 0.6, 'rbf'), (2000, 5, 1e-4, 0.02, 0.6, 'rbf')]:
-    res = {}
-    for d in range(nd):
-        x = torch.rand(T, F, dtype=torch.float64)
-        z = torch.randn(T, dtype=torch.float64)
-        K64 = gram(x, ls, os_, noise, kernel)
-        want = torch.linalg.cholesky(K64) @ z
-        K32 = K64.float()
-        for mode in ('f32', 'bf16x6', 'fp16x3', 'fp16x4', 'bf16x3', 'fp16x3+solve-f32', 'fp16x3+solve-fp16x3'):
-            if '+' in mode:
-                y, bad = chol_blocked(K32, z.float(), 'fp16x3', 'f32' if mode.endswith('solve-f32') else 'fp16x3')
-            else:
-                y, bad = chol_blocked(K32, z.float(), mode)
-            e = float('nan') if y is None else ((y.double() - want).norm() / want.norm()).item()
-            res.setdefault(mode, []).append(e)
-    print(f'T={T} F={F} {kernel} noise={noise} outputscale={os_}: rel. L2 error of y vs f64   ' +
-          '   '.join(f'{m} ' + '/'.join(f'{e:.2e}' for e in v) for m, v in res.items()), flush=True)
+MODES = ('f32', 'bf16x6', 'fp16x3', 'fp16x4', 'bf16x3', 'fp16x3+solve-f32', 'fp16x3+solve-fp16x3')
+
+
+def errors(T, F, noise, os_, ls, kernel, modes=MODES):
+    """One dataset: relative L2 error of y = L z against the f64 factorisation for every mode (nan = the factorisation failed)."""
+    x = torch.rand(T, F, dtype=torch.float64)
+    z = torch.randn(T, dtype=torch.float64)
+    K64 = gram(x, ls, os_, noise, kernel)
+    want = torch.linalg.cholesky(K64) @ z
+    K32 = K64.float()
+    out = {}
+    for mode in modes:
+        if '+' in mode:
+            y, bad = chol_blocked(K32, z.float(), 'fp16x3', 'f32' if mode.endswith('solve-f32') else 'fp16x3')
+        else:
+            y, bad = chol_blocked(K32, z.float(), mode)
+        out[mode] = float('nan') if y is None else ((y.double() - want).norm() / want.norm()).item()
+    return out
+
+
+if __name__ == '__main__':
+    nd = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    for (T, F, noise, os_, ls, kernel) in [(2000, 5, 1e-4, 1.0, 0.6, 'rbf'), (2000, 18, 1e-4, 1.0, 0.6, 'rbf'), (2000, 10, 1e-3, 1.0, 0.5, 'matern'), (2000, 5, 1e-4, 30.0, 0.6, 'rbf'), (2000, 5, 1e-4, 0.02, 0.6, 'rbf')]:
+        res = {}
+        for d in range(nd):
+            for m, e in errors(T, F, noise, os_, ls, kernel).items():
+                res.setdefault(m, []).append(e)
+        print(f'T={T} F={F} {kernel} noise={noise} outputscale={os_}: rel. L2 error of y vs f64   ' +
+              '   '.join(f'{m} ' + '/'.join(f'{e:.2e}' for e in v) for m, v in res.items()), flush=True)
