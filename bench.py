@@ -46,6 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK = 2.5e15     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+IN_STEP_TRACE = os.path.join(ROOT, 'profiles', 'r05_in_step_attention.json')   # rocprofv3 --kernel-trace of the default command: in-step durations of the attention kernels (tools/profile_bench.sh)
 PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default command (tools/profile_bench.sh)
 TRAINED = os.path.join(ROOT, 'profiles', 'r03_trained_config2.json')
 
@@ -871,7 +872,7 @@ def compact_line(result):
     line['step_roofline'] = _pick(result['step_roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'reference_graph_frac'))
     if 'roofline' in result:
         line['roofline'] = _pick(result['roofline'], ('bound', 'kernel', 'rocprof_kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_is', 'avg_launch_us', 'isolated_frac',
-                                                      'isolated_avg_launch_us', 'algorithmic_flops_per_launch', 'executed_frac', 'launches_per_step', 'traffic', 'traffic_source'))
+                                                      'isolated_avg_launch_us', 'rocprof_avg_launch_us', 'rocprof_frac', 'algorithmic_flops_per_launch', 'executed_frac', 'launches_per_step', 'traffic', 'traffic_source'))
         line['roofline']['frac_is'] = 'in-step' if str(line['roofline'].get('frac_is', '')).startswith('IN-STEP') else 'isolated'
     if 'cpu_baseline' in result:
         c = result['cpu_baseline']
@@ -1028,6 +1029,12 @@ def main():
             traffic_src = f"none: the committed PMC passes ({os.path.basename(PMC_TRAFFIC)}) are of config {pmc.get('config', 2)} / batch {pmc.get('batch')} / streams {pmc.get('streams', 1)}, not of this command"
         in_us = dom.get('in_step_us')
         iso_frac = dom['tflops'] * 1e12 / MFMA_BF16_PEAK
+        # the committed kernel trace of this command, for the same kernel's full-layer launches: begin / end of the kernel itself, where the event pair of the live
+        # figure also counts the wait of a launch for free CUs behind the other streams (10 - 19 % this round)
+        trace_us = None
+        if pmc.get('config', 2) == args.config and pmc.get('batch') == batch and pmc.get('streams', 1) == streams and os.path.exists(IN_STEP_TRACE):      # (a trace of THIS command)
+            trace_us = next((v.get('avg_us') for name, v in json.load(open(IN_STEP_TRACE)).get('kernels', {}).items()
+                             if name.startswith(dom['rocprof_name']) and 'top layer' not in name), None)
         in_frac = None if in_us is None else dom['flops'] / (in_us * 1e-6) / MFMA_BF16_PEAK
         # (the in-step launches run at the eval positions of the profiled steps; the isolated ones at the mean position -- FLOPs per launch taken at the mean)
         result['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'rocprof_kernel': dom['rocprof_name'],
@@ -1037,6 +1044,7 @@ def main():
                                          'IN-STEP: average launch duration inside the running step (HIP event pairs on the launch stream, pfn_profile_*; two micro-batch '
                                          'streams + the sampler share the chip)',
                               'in_step_avg_launch_us': in_us, 'in_step_launches_timed': dom.get('in_step_launches_timed'),
+                              'rocprof_avg_launch_us': trace_us, 'rocprof_frac': None if not trace_us else dom['flops'] / (trace_us * 1e-6) / MFMA_BF16_PEAK,
                               'isolated_frac': iso_frac, 'isolated_avg_launch_us': dom['seconds'] * 1e6, 'isolated_achieved': dom['tflops'],
                               'traffic': traffic, 'traffic_source': traffic_src, 'algorithmic_flops_per_launch': dom['flops'],
                               'executed_flops_per_launch': dom['executed_flops'], 'executed_frac': dom['executed_tflops'] * 1e12 / MFMA_BF16_PEAK,
