@@ -205,7 +205,7 @@ def time_sequence(fns, iters=10, warm=3):
     return [sum(ev[it][j].elapsed_time(ev[it][j + 1]) for it in range(iters)) / iters / 1e3 for j in range(len(fns))]
 
 
-def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None):
+def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None, precision='bf16'):
     """Isolated timings of the step's kernels at the workload shape (through the single-op C ABI): one entry per kernel
     symbol, with the number of launches per step, so the dominant one can be picked by in-step time.  top_rows (pfn_top_layer_rows): the rows
     the top layer runs on behind its K / V projection -- when that is the (S - sep) * batch test rows, L - 1 launches of every row-wise kernel
@@ -218,7 +218,9 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
     Mt = M if top_rows is None else int(top_rows)
     top = Mt != M                      # the top layer on the test rows only
     Lf = L - 1 if top else L           # launches of a per-layer kernel on all rows
-    bf = torch.bfloat16
+    PREC = _hip.PRECISIONS[precision]      # the 16-bit operand format of the timed path (bf16 / fp16: the same kernels, instantiated per format)
+    bf = hipops.TDT[PREC]
+    tmangle = hipops.MANGLED_OPERAND[PREC]
     r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(bf)
     f32 = lambda *s: torch.randn(*s, device=dev)
     Hh = _hip
@@ -244,9 +246,9 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
         if flags & Hh.EPI_OUT_F32: kw['out_f32'] = torch.empty(M, n, device=dev)
         if flags & Hh.EPI_OUT_T: kw['out_t'] = torch.empty(M, n, dtype=bf, device=dev)
         if flags & Hh.EPI_OUT2_T: kw['out2_t'] = torch.empty(M, n, dtype=bf, device=dev)
-        t = time_kernel(lambda: hipops.gemm_nt(A, B_, flags, Hh.PREC_BF16, **kw))
+        t = time_kernel(lambda: hipops.gemm_nt(A, B_, flags, PREC, **kw))
         nbytes = sum(v.numel() * v.element_size() for v in [A, B_] + list(kw.values()))
-        add(f'gemm_nt[{name} {M}x{n}x{k}]', f'gemm_nt_big_kernel<{flags}, ', t, 2.0 * M * n * k, count, nbytes=nbytes, prof=prof)
+        add(f'gemm_nt[{name} {M}x{n}x{k}]', f'_ZN3pfn18gemm_nt_big_kernelI{tmangle}Li{flags}E', t, 2.0 * M * n * k, count, nbytes=nbytes, prof=prof)
 
     def gemm_ln(name, k, count, M=M, prof=None):
         """out_proj / linear2 with bias + residual + LayerNorm in the epilogue (the kernel the step runs when emsize allows)."""
@@ -288,14 +290,14 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
             return
         gA, y, gamma = r(M, E), f32(M, E), f32(E)
         mean, rstd = y.mean(1), 1 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
-        t = time_kernel(lambda: hipops.layernorm_bwd(gA, y, gamma, mean, rstd, Hh.PREC_BF16, want_f32=False))
+        t = time_kernel(lambda: hipops.layernorm_bwd(gA, y, gamma, mean, rstd, PREC, want_f32=False))
         add(f'layernorm_bwd[{M}x{E}, operand-precision gradient in and out]', 'layernorm_bwd_kernel', t, 0.0, count)
 
     def layernorm_fwd(count, M=M):
         if count <= 0 or M <= 0:
             return
         x, gamma, beta = f32(M, E), f32(E), f32(E)
-        t = time_kernel(lambda: hipops.layernorm_fwd(x, gamma, beta, 1e-5, Hh.PREC_BF16))
+        t = time_kernel(lambda: hipops.layernorm_fwd(x, gamma, beta, 1e-5, PREC))
         add(f'layernorm_fwd[{M}x{E}: f32 in, f32 + operand-precision out]', 'layernorm_fwd_kernel', t, 0.0, count, nbytes=M * E * (4 + 4 + 2))
 
     def wgrad_group():
@@ -347,16 +349,16 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
     qkv = r(batch, S, 3 * E)
     D = E // H
     unit = 2.0 * E * pairs(S, sep) * batch          # one S x keys x head-dim product over all heads
-    ctx, lse = hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16)
+    ctx, lse = hipops.attention_fwd(qkv, H, sep, PREC)
     dctx = r(batch, S, E)
     if Lf > 0:
-        t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16))
-        add('attn_fwd', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit, Lf, prof='attn_fwd')
+        t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, PREC))
+        add('attn_fwd', hipops.ATTENTION_FWD_ROCPROF.format(D=D, T=tmangle), t, 2 * unit, Lf, prof='attn_fwd')
         # the backward's three launches, each timed inside their sequence (delta, key-block pass, query-block pass back to back)
-        seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=part))
+        seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, PREC, parts=part))
                              for _, _, part, _, _ in hipops.ATTENTION_BWD_PARTS])
         for (name, rocprof, part, alg_units, exec_units), t in zip(hipops.ATTENTION_BWD_PARTS, seq):
-            rocprof = rocprof.format(D=D)
+            rocprof = rocprof.format(D=D, T=tmangle)
             if part == 2:
                 exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
             add(name, rocprof, t, alg_units * unit, Lf, exec_units * unit, prof={1: 'attn_bwd_delta', 2: 'attn_bwd_kv', 4: 'attn_bwd_dq'}[part])
@@ -368,14 +370,14 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
         dctx_t = dctx.clone()
         dctx_t[:, :sep] = 0
         bufs_t = (torch.empty_like(ctx), torch.empty_like(lse))
-        t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, _hip.PREC_BF16, q_begin=sep, out=bufs_t))
-        add('top layer: attn_fwd for the queries >= sep', hipops.ATTENTION_FWD_ROCPROF.format(D=D), t, 2 * unit_t, 1, 2 * unit_x, prof='attn_fwd [top layer: test rows]')
-        seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx_t, H, sep, _hip.PREC_BF16, parts=part, q_begin=sep))
+        t = time_kernel(lambda: hipops.attention_fwd(qkv, H, sep, PREC, q_begin=sep, out=bufs_t))
+        add('top layer: attn_fwd for the queries >= sep', hipops.ATTENTION_FWD_ROCPROF.format(D=D, T=tmangle), t, 2 * unit_t, 1, 2 * unit_x, prof='attn_fwd [top layer: test rows]')
+        seq = time_sequence([(lambda part=part: hipops.attention_bwd(qkv, ctx, lse, dctx_t, H, sep, PREC, parts=part, q_begin=sep))
                              for _, _, part, _, _ in hipops.ATTENTION_BWD_PARTS])
         for (name, rocprof, part, alg_units, exec_units), t in zip(hipops.ATTENTION_BWD_PARTS, seq):
             if part == 2:
                 exec_units = hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, exec_units)
-            add('top layer, queries >= sep: ' + name, rocprof.format(D=D), t, alg_units * unit_t, 1, exec_units * unit_x,
+            add('top layer, queries >= sep: ' + name, rocprof.format(D=D, T=tmangle), t, alg_units * unit_t, 1, exec_units * unit_x,
                 prof={1: 'attn_bwd_delta', 2: 'attn_bwd_kv', 4: 'attn_bwd_dq'}[part] + ' [top layer: test rows]')
         # ... and its row moves: attention output / layer input gathered, d(attention output) / LayerNorm-input gradient scattered back
         c_t, y32 = r(batch, S, E), f32(batch, S, E)
@@ -385,7 +387,7 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None)
                                  hipops.scatter_rows(g_t, batch, S, sep, 0, out=o3)))
         add('top layer: test rows gathered (attention output, layer input) and scattered back (2 gradients)', 'gather_rows_kernel / scatter_rows_kernel', t, 0.0, 1,
             nbytes=(S - sep) * batch * E * (2 * 2 + 4 * 2 + 2 + 2) + M * E * 2)
-    t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, _hip.PREC_BF16, parts=7))
+    t = time_kernel(lambda: hipops.attention_bwd(qkv, ctx, lse, dctx, H, sep, PREC, parts=7))
     out.append(dict(kernel='attn_bwd (whole launch set, for reference)', rocprof_name='attn_bwd_* + attn_delta_kernel', launches_per_step=0,
                     seconds=t, flops=4 * unit, executed_flops=(hipops.ATTENTION_BWD_KV_EXECUTED_UNITS.get(D, 4.0) + 1.0) * unit))
     for k in out:
@@ -929,7 +931,7 @@ def main():
     ap.add_argument('--aggregate-streams', type=int, default=0, help='> 1: the aggregate_k batches of a step run whole, round-robin on that many streams (small batches)')
     ap.add_argument('--aggregate-stacked', action='store_true', help='the aggregate_k batches of a step stacked into one launch set per micro-batch stream, every dataset with its own eval position (what train() picks for small batches since round 5)')
     ap.add_argument('--streams', type=int, default=None, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'f32'], help='operand format of the TIMED (training) path; recorded as `dtype`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-kernel-breakdown', action='store_true')
@@ -967,7 +969,7 @@ def main():
         'metric': w['metric'], 'value': tp['value'], 'unit': 'datasets/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': tp['ms_per_step'],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+        'dtype': {'bf16': 'bf16', 'fp16': 'fp16', 'f32': 'f32'}[args.precision], 'data': 'synthetic',
         'config': {'workload': w['workload'], 'baseline_config': args.config,
                    'per_gpu_batch': batch, 'global_batch': batch * world, 'aggregate_k_gradients': args.aggregate_k, 'aggregate_streams': args.aggregate_streams, 'aggregate_stacked': bool(args.aggregate_stacked), 'seq_len': S, 'parallelism': f'dp{world}',
                    'micro_batch_streams': streams,
@@ -1003,7 +1005,7 @@ def main():
         # kernels are launched per micro-batch (column group of the batch, streams.py): time them at THAT shape
         groups = r['micro_groups']
         mean_sep = int(round(sum(seps) / len(seps)))
-        ks = kernel_breakdown(batch // groups, mean_sep, w, fused_ln_wide=bool(tuning.get(5)), top_rows=top_rows_of(batch // groups, mean_sep))
+        ks = kernel_breakdown(batch // groups, mean_sep, w, fused_ln_wide=bool(tuning.get(5)), top_rows=top_rows_of(batch // groups, mean_sep), precision=args.precision)
         in_step = r.get('in_step', {})
         in_solo = r.get('in_step_solo', {})
         for k in ks:

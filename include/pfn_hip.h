@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 7
+#define PFN_ABI_VERSION 8
 
 enum {
   PFN_OK = 0,
@@ -43,7 +43,11 @@ enum {
 };
 
 enum { PFN_PREC_BF16 = 0, /* bf16 MFMA operands, f32 accumulate / residual / statistics */
-       PFN_PREC_F32 = 1 /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity / debugging mode */ };
+       PFN_PREC_F32 = 1,  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity / debugging mode */
+       PFN_PREC_FP16 = 2  /* ABI 8: fp16 MFMA operands (v_mfma_f32_32x32x16_f16: the same rate and bytes as bf16, 11-bit significand -- the format whose
+                           * TRAINING forward meets the reference's outputs to 1e-3, profiles/r06_operand_format_simulation.json); f32 accumulate / residual /
+                           * statistics as in bf16.  The backward runs under a power-of-two loss scale chosen on the device from max|dlogits| and taken out again where
+                           * the gradients are written (csrc/pfn_device.h LossScale): `grads` holds unscaled f32 gradients, as in the other modes. */ };
 
 /* Architecture of TransformerModel (transformer.py:14-26) with the default Linear encoders
  * (encoders.py:8), NoPositionalEncoding (positional_encodings.py:12-18) and the default
@@ -85,15 +89,12 @@ const char* pfn_last_error_string(void);
  * while no call is in flight).  Keys 2, 5 and 6 do not act on calls directly: they change what pfn_default_schedule() hands to NEW
  * descriptors (pfn_model_desc::schedule), so a forward / backward pair can never disagree about them.
  * PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
- * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one, 4 the 256x256 tile fed by a ring of four 32-deep stages
- * (gemm_nt_ring_kernel: round-5 experiment).
+ * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one.
  * PFN_TUNE_FUSE_LNBWD: 1 (default) the stack backward runs LayerNorm backward inside the data-gradient GEMMs that feed it
- * (pfn_op_gemm_lnbwd), 0 as separate kernels.  PFN_TUNE_GEMM_PERSIST: > 0 runs the 256x256 NT GEMM as that many persistent
- * workgroups walking tiles (gemm_nt_persist_kernel; measured, off by default). */
+ * (pfn_op_gemm_lnbwd), 0 as separate kernels.  (Key 3, the persistent NT GEMM of round 5, is gone from the product library: csrc/experiments/.) */
 enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_GEMM_TN_WRAP = 1, /* profiling only: > 0 makes the grouped TN kernel re-read its first `value` token rows (wrong results, cache-resident operands) */
        PFN_TUNE_FUSE_LNBWD = 2,
-       PFN_TUNE_GEMM_PERSIST = 3, /* workgroups of the persistent 256x256 NT GEMM (one per CU walking tiles); 0 = the one-tile-per-workgroup kernel */
        PFN_TUNE_ATTN_PINGPONG = 4, /* bit 0: attention forward, bit 1: backward key-block pass -- the two waves of a SIMD run half a tile apart (default: see attention.hip) */
        PFN_TUNE_FUSE_LN_WIDE = 5,  /* 1: emsize 1024 runs the LayerNorm-fused GEMMs on 64-row x 1024-column tiles (gemm_nt_ln_wide / lnbwd_wide); 0 (default): the
                                     * 256 x 256 GEMM + LayerNorm kernels -- measured faster at that width */
@@ -277,21 +278,22 @@ int pfn_mlp_prior_forward(const float* weights, const float* biases, const int32
                           uint64_t seed, uint64_t offset, void* stream);
 
 /* ---- single-op entry points (unit tests / profiling of individual kernels) --------------------
- * prec selects operand element type T: bf16 (2 bytes) or f32. */
+ * prec selects operand element type T: PFN_PREC_BF16 / PFN_PREC_FP16 (2 bytes) or PFN_PREC_F32; the LDS-DMA kernels (grouped weight gradients,
+ * LayerNorm-fused GEMMs) take the two 16-bit formats only. */
 int pfn_op_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                    int flags, const float* bias, const void* aux, int64_t ld_aux,
                    const float* resid, int64_t ld_resid, float* out_f32, int64_t ld_out_f32,
                    void* out_t, int64_t ld_out_t, void* out2_t, int64_t ld_out2, int prec, void* stream);
 int pfn_op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                    int M, int P, int Q, int atomic, int prec, void* stream);
-/* grouped weight-gradient GEMMs (bf16 only): for i < n, C[i][P[i],Q[i]] += A[i][M,P[i]]^T . B[i][M,Q[i]] and, when
+/* grouped weight-gradient GEMMs (16-bit operands only): for i < n, C[i][P[i],Q[i]] += A[i][M,P[i]]^T . B[i][M,Q[i]] and, when
  * colsum && colsum[i], colsum[i][P[i]] += column sums of A[i]; one launch of 256x256 tiles.  The pointer / size
  * tables are HOST arrays.  splits: 0 automatic, 1 no split (deterministic, no atomics), > 1 token-axis splits.
  * P[i] and Q[i] must be multiples of 256 (PFN_ERR_UNSUPPORTED otherwise). */
 int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb,
                          float* const* C, const int64_t* ldc, const int32_t* P, const int32_t* Q,
-                         float* const* colsum, int M, int splits, void* stream);
-/* fused linear + bias + residual + LayerNorm (bf16 operands, N in {128, 256, 512}, K % 32 == 0):
+                         float* const* colsum, int M, int splits, int prec, void* stream);
+/* fused linear + bias + residual + LayerNorm (16-bit operands, N in {128, 256, 512}, K % 32 == 0):
  *   v = A[M,K] . B[N,K]^T + bias + r;  y = v (f32);  mean / rstd of v per row;  x_t = bf16((v - mean) rstd gamma + beta)
  * r = resid[M,N] (f32) when resid != NULL, else the previous LayerNorm's output recomputed as
  * (ry - rmean) rrstd rgamma + rbeta.  Replaces `x = norm(x + dropout(sublayer(x)))` of torch's TransformerEncoderLayer
@@ -299,8 +301,8 @@ int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const 
 int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
                    const float* resid, const float* ry, const float* rmean, const float* rrstd,
                    const float* rgamma, const float* rbeta, const float* gamma, const float* beta, float eps,
-                   float* y, float* mean, float* rstd, void* x_t, void* stream);
-/* data-gradient GEMM + residual-branch gradient + the backward of the LayerNorm whose output gradient the sum is (bf16
+                   float* y, float* mean, float* rstd, void* x_t, int prec, void* stream);
+/* data-gradient GEMM + residual-branch gradient + the backward of the LayerNorm whose output gradient the sum is (16-bit
  * operands, N in {128, 256, 512}, K % 32 == 0):
  *   v = A[M,K] . B[N,K]^T + aux[M,N];   xhat = (y - mean) rstd;
  *   dx_t = bf16(rstd (gamma v - mean_n(gamma v) - xhat mean_n(gamma v xhat)));   dgamma += sum_m v xhat;   dbeta += sum_m v
@@ -308,7 +310,7 @@ int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M
  * place of pfn_op_gemm_nt(EPI_RESID_T | EPI_OUT_T) followed by pfn_op_layernorm_bwd.  dgamma / dbeta accumulate atomically. */
 int pfn_op_gemm_lnbwd(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const void* aux,
                       const float* y, const float* mean, const float* rstd, const float* gamma,
-                      void* dx_t, float* dgamma, float* dbeta, void* stream);
+                      void* dx_t, float* dgamma, float* dbeta, int prec, void* stream);
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep,
                          int prec, void* stream);
 /* Attention backward = three launches: delta = rowsum(dO * O); the key-block pass (dK, dV and dS^T into ds_ws); the

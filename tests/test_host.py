@@ -72,7 +72,7 @@ def test_attention_kernels_keep_their_register_and_lds_budgets(tmp_path):
     seen = 0
     for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', text, re.S):
         name, body = m.group(1), m.group(2)
-        if 'DF16b' not in name or 'attn_' not in name:          # the bf16 (operand precision) instantiations
+        if not ('DF16b' in name or 'DF16_' in name) or 'attn_' not in name:          # the 16-bit (operand precision) instantiations: bf16 and fp16
             continue
         vgpr = int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1))
         scratch = int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', body).group(1))
@@ -81,13 +81,13 @@ def test_attention_kernels_keep_their_register_and_lds_budgets(tmp_path):
         if head_dim:                                              # (the delta kernel has no head-dim parameter)
             assert vgpr <= (512 if int(head_dim.group(1)) == 256 else 256), (name, vgpr)
         seen += 1
-    assert seen >= 4 * 2 * 3 + 1          # forward / key-block pass / query-block pass x 4 head dims x {plain, dropout}, + delta
+    assert seen >= 2 * (4 * 2 * 3 + 1)    # forward / key-block pass / query-block pass x 4 head dims x {plain, dropout}, + delta; x {bf16, fp16}
 
 
 def test_step_gemm_kernels_have_no_scratch(tmp_path):
     """The same for the GEMMs the training step launches (bench.py's kernel table names them): the 256 x 256 NT kernel in its default tile mode <flags, 2, 64>, the
     LayerNorm-fused forms at 8 waves (emsize 512) and their wide variants, the grouped weight-gradient kernel -- no scratch, at most 256 VGPRs (two waves per SIMD).
-    (Alternative tile modes and the persistent kernel are tuning options outside the step and are not held to it.)"""
+    (Alternative tile modes are tuning options outside the step and are not held to it.)"""
     import shutil
     import subprocess
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
@@ -96,7 +96,7 @@ def test_step_gemm_kernels_have_no_scratch(tmp_path):
     src = os.path.join(ROOT, 'transformerscandobayesianinference_amd', 'csrc', 'gemm.hip')
     asm = str(tmp_path / 'gemm.s')
     subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', src, '-o', asm], check=True, capture_output=True)
-    step = re.compile(r'gemm_nt_big_kernelILi\d+ELi2ELi64E|gemm_nt_ln_kernelILi8E|gemm_nt_lnbwd_kernelILi8E|gemm_nt_ln_wide_kernel|gemm_nt_lnbwd_wide_kernel|gemm_tn_big_kernel')
+    step = re.compile(r'gemm_nt_big_kernelIDF16[b_]Li\d+ELi2ELi64E|gemm_nt_ln_kernelIDF16[b_]Li8E|gemm_nt_lnbwd_kernelIDF16[b_]Li8E|gemm_nt_ln_wide_kernel|gemm_nt_lnbwd_wide_kernel|gemm_tn_big_kernel')
     seen = 0
     for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', open(asm).read(), re.S):
         name, body = m.group(1), m.group(2)
@@ -105,7 +105,7 @@ def test_step_gemm_kernels_have_no_scratch(tmp_path):
         assert int(re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', body).group(1)) == 0, name
         assert int(re.search(r'\.amdhsa_next_free_vgpr (\d+)', body).group(1)) <= 256, name
         seen += 1
-    assert seen >= 10 + 4 + 2 + 3 + 1
+    assert seen >= 2 * (10 + 4 + 2 + 3 + 1)      # x {bf16, fp16}
 
 
 def test_param_layout_matches_reference_state_dict_order():

@@ -13,10 +13,12 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpfn_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 PREC_BF16 = 0
 PREC_F32 = 1
+PREC_FP16 = 2      # fp16 MFMA operands under a device-side loss scale (include/pfn_hip.h): the timed path that holds the north star's 1e-3
+PRECISIONS = {'bf16': PREC_BF16, 'f32': PREC_F32, 'fp32': PREC_F32, 'fp16': PREC_FP16, 'f16': PREC_FP16}
 SCHED_TOP_LAYER_ALL_ROWS, SCHED_FUSE_LN_WIDE, SCHED_SEPARATE_LNBWD, SCHED_DETERMINISTIC = 1, 2, 4, 8     # pfn_model_desc.schedule bits (include/pfn_hip.h)
 
 # GEMM epilogue flags (csrc/pfn_kernels.h)
@@ -77,9 +79,9 @@ SIGNATURES = {
     'pfn_mlp_prior_forward': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U64, _U64, _P]),
     'pfn_op_gemm_nt': (_I, [_P, _L, _P, _L, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _P]),
     'pfn_op_gemm_tn': (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
-    'pfn_op_gemm_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
-    'pfn_op_gemm_ln': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
-    'pfn_op_gemm_lnbwd': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pfn_op_gemm_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'pfn_op_gemm_ln': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P]),
+    'pfn_op_gemm_lnbwd': (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'pfn_op_attention_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'pfn_op_attention_bwd_ws_bytes': (_L, [_I, _I, _I, _I]),
     'pfn_op_attention_fwd_from': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -44,7 +44,7 @@ template <typename T, int D> struct AttnCfg {
 template <typename T> PFN_DEV Frag<T> load_frag_global(const T* p) {
   Frag<T> f;
   if constexpr (sizeof(T) == 2) {
-    f.v = *reinterpret_cast<const bf16x8*>(p);
+    f.v = *reinterpret_cast<const X8<T>*>(p);
   } else {
     f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
@@ -54,10 +54,10 @@ template <typename T> PFN_DEV Frag<T> load_frag_global(const T* p) {
 }
 template <typename T> PFN_DEV void store_frag_global(T* p, const float (&x)[8]) {
   if constexpr (sizeof(T) == 2) {
-    bf16x8 v;
+    X8<T> v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (bf16)x[e];
-    *reinterpret_cast<bf16x8*>(p) = v;
+    for (int e = 0; e < 8; ++e) v[e] = (T)x[e];
+    *reinterpret_cast<X8<T>*>(p) = v;
   } else {
     f32x4 a, b;
 #pragma unroll
@@ -69,7 +69,9 @@ template <typename T> PFN_DEV void store_frag_global(T* p, const float (&x)[8]) 
 template <typename T> PFN_DEV float frag_get(const Frag<T>& f, int e) { return (float)f.v[e]; }
 // the same value read out of the PACKED registers: element e of a bf16 fragment is the low (e even) or high half of dword e / 2
 template <typename T> PFN_DEV float frag_get_bits(const Frag<T>& f, int e) {
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (std::is_same<T, f16>::value) {
+    return (float)f.v[e];      // v_cvt_f32_f16 (the high half through SDWA): one instruction as well
+  } else if constexpr (sizeof(T) == 2) {
     const unsigned w = __builtin_bit_cast(u32x4, f.v)[e >> 1];
     return __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
   } else return f.v[e];
@@ -83,7 +85,7 @@ template <typename T> PFN_DEV float dot8(const Frag<T>& a, const Frag<T>& b) {
 template <typename T> PFN_DEV f32x4 load4(const T* p) {
   f32x4 r;
   if constexpr (sizeof(T) == 2) {
-    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    X4<T> v = *reinterpret_cast<const X4<T>*>(p);
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = (float)v[e];
   } else r = *reinterpret_cast<const f32x4*>(p);
@@ -91,10 +93,10 @@ template <typename T> PFN_DEV f32x4 load4(const T* p) {
 }
 template <typename T> PFN_DEV void store4(T* p, f32x4 x) {
   if constexpr (sizeof(T) == 2) {
-    bf16x4 v;
+    X4<T> v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (bf16)x[e];
-    *reinterpret_cast<bf16x4*>(p) = v;
+    for (int e = 0; e < 4; ++e) v[e] = (T)x[e];
+    *reinterpret_cast<X4<T>*>(p) = v;
   } else *reinterpret_cast<f32x4*>(p) = x;
 }
 PFN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -490,8 +492,8 @@ template <typename T, int STRIDE> PFN_DEV Frag<T> load_frag_tr_perm(const lds_ch
   const int colb = (col0 + 16 * g + 4 * (i & 3)) * 2;
   const int row = 4 * (i >> 2) + h + k0;
   Frag<T> f;
-  bf16x4 lo = ds_read_tr16_b64(tile + row * STRIDE + colb);
-  bf16x4 hi = ds_read_tr16_b64(tile + (row + 2) * STRIDE + colb);
+  const auto lo = ds_read_tr16_b64<T>(tile + row * STRIDE + colb);
+  const auto hi = ds_read_tr16_b64<T>(tile + (row + 2) * STRIDE + colb);
   f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return f;
 }
@@ -946,7 +948,7 @@ template <typename T> PFN_DEV Frag<T> load_frag_ds_blocked(const lds_char* block
   if constexpr (sizeof(T) == 2) {
     const int i = l & 15, g = (l >> 4) & 1;
     const lds_char* p = blk + g * 1024 + (r0 + (i >> 2)) * 32 + 8 * (i & 3);
-    const bf16x4 lo = ds_read_tr16_b64(p), hi = ds_read_tr16_b64(p + 4 * 32);
+    const auto lo = ds_read_tr16_b64<T>(p), hi = ds_read_tr16_b64<T>(p + 4 * 32);
     f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   } else {
     const int n = l & 31;
@@ -1088,7 +1090,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
     const float* delta_g = a.delta + ((long)b * a.H + hd) * a.S;
     auto unpack = [](const u32x4& raw, float (&x)[EPC]) {
       if constexpr (sizeof(T) == 2) {
-        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+        const X8<T> v = __builtin_bit_cast(X8<T>, raw);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) x[e] = (float)v[e];
       } else {
@@ -1099,9 +1101,9 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
     };
     auto pack = [](const float (&x)[EPC]) {
       if constexpr (sizeof(T) == 2) {
-        bf16x8 v;
+        X8<T> v;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] = (bf16)x[e];
+        for (int e = 0; e < EPC; ++e) v[e] = (T)x[e];
         return __builtin_bit_cast(u32x4, v);
       } else {
         return __builtin_bit_cast(u32x4, f32x4{x[0], x[1], x[2], x[3]});
@@ -1162,7 +1164,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
         f32x4 ts = {0.f, 0.f, 0.f, 0.f};
         if (wave_has_test) {   // (the wave's own LDS writes above are ordered before these reads)
           if constexpr (sizeof(T) == 2) {
-            const bf16x4 t4 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x4*>(tself + li * TS + d0 * 2);
+            const X4<T> t4 = *reinterpret_cast<const __attribute__((address_space(3))) X4<T>*>(tself + li * TS + d0 * 2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) ts[e] = (float)t4[e];
           } else {
@@ -1496,7 +1498,7 @@ template <int D> static int launch_bwd_plain_f32(const AttnArgs& a, hipStream_t 
 static int check_attn(const AttnArgs& a, int precision) {
   if (a.B <= 0 || a.S <= 0 || a.H <= 0 || a.E % a.H) return PFN_ERR_ARGUMENT;
   if (a.sep < 0 || a.sep > a.S || a.q_begin < 0 || a.q_begin > a.S || (a.q_from_sep && !a.sep_of)) return PFN_ERR_ARGUMENT;
-  const int es = precision == PFN_PREC_BF16 ? 2 : 4;
+  const int es = prec_esize(precision);
   if ((a.E * es) % 16) return PFN_ERR_ALIGNMENT;
   return PFN_OK;
 }
@@ -1511,6 +1513,14 @@ static int check_attn(const AttnArgs& a, int precision) {
       case 64: return FN<bf16, 64>(a, s);                                                  \
       case 128: return FN<bf16, 128>(a, s);                                                \
       case 256: return FN<bf16, 256>(a, s);                                                \
+      default: return PFN_ERR_UNSUPPORTED;                                                 \
+    }                                                                                      \
+  } else if (precision == PFN_PREC_FP16) {                                                 \
+    switch (D) {                                                                           \
+      case 32: return FN<f16, 32>(a, s);                                                   \
+      case 64: return FN<f16, 64>(a, s);                                                   \
+      case 128: return FN<f16, 128>(a, s);                                                 \
+      case 256: return FN<f16, 256>(a, s);                                                 \
       default: return PFN_ERR_UNSUPPORTED;                                                 \
     }                                                                                      \
   } else {                                                                                 \
@@ -1542,7 +1552,7 @@ void attn_bwd_ds_dims(int S, int sep, int* rows, int* ld) {
 int64_t attn_bwd_ds_bytes(int B, int S, int H, int precision) {
   int rows, ld;
   attn_bwd_ds_dims(S, S, &rows, &ld);
-  return (int64_t)B * H * rows * ld * (precision == PFN_PREC_BF16 ? 2 : 4);
+  return (int64_t)B * H * rows * ld * prec_esize(precision);
 }
 int launch_attn_bwd(const AttnArgs& a_in, int precision, hipStream_t s) {
   int rc = check_attn(a_in, precision);

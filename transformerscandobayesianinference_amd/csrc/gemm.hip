@@ -120,16 +120,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
     if (full) {
       if (flags & EPI_BIAS) { f32x4 b = *reinterpret_cast<const f32x4*>(bias + ncol); v += b; }
       if (flags & EPI_GELU_BWD) {
-        bf16x4 dummy; (void)dummy;
         float a[4];
-        if constexpr (sizeof(T) == 2) { bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) a[e] = (float)t[e]; }
+        if constexpr (sizeof(T) == 2) { X4<T> t = *reinterpret_cast<const X4<T>*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) a[e] = (float)t[e]; }
         else { f32x4 t = *reinterpret_cast<const f32x4*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) a[e] = t[e]; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= a[e];
       }
       if (flags & EPI_RESID) { f32x4 r = *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + ncol); v += r; }
       if (flags & EPI_RESID_T) {
-        if constexpr (sizeof(T) == 2) { bf16x4 t = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) v[e] += (float)t[e]; }
+        if constexpr (sizeof(T) == 2) { X4<T> t = *reinterpret_cast<const X4<T>*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) v[e] += (float)t[e]; }
         else { f32x4 t = *reinterpret_cast<const f32x4*>(aux + m * g.ld_aux + ncol); v += t; }
       }
       f32x4 second = v;          // EPI_OUT2_T: the value before the activation, or with EPI_GELU the activation's derivative there
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
         for (int e = 0; e < 4; ++e) { float y, dy; gelu_and_grad(v[e], y, dy); v[e] = y; second[e] = dy; }
       }
       if (flags & EPI_OUT2_T) {
-        if constexpr (sizeof(T) == 2) { bf16x4 t; for (int e = 0; e < 4; ++e) t[e] = (bf16)second[e]; *reinterpret_cast<bf16x4*>(out2_t + m * g.ld_out2 + ncol) = t; }
+        if constexpr (sizeof(T) == 2) { X4<T> t; for (int e = 0; e < 4; ++e) t[e] = (T)second[e]; *reinterpret_cast<X4<T>*>(out2_t + m * g.ld_out2 + ncol) = t; }
         else *reinterpret_cast<f32x4*>(out2_t + m * g.ld_out2 + ncol) = second;
       }
       if (flags & EPI_OUT_F32) {
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
         *reinterpret_cast<f32x4*>(o) = v;
       }
       if (flags & EPI_OUT_T) {
-        if constexpr (sizeof(T) == 2) { bf16x4 t; for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e]; *reinterpret_cast<bf16x4*>(out_t + m * g.ld_out_t + ncol) = t; }
+        if constexpr (sizeof(T) == 2) { X4<T> t; for (int e = 0; e < 4; ++e) t[e] = (T)v[e]; *reinterpret_cast<X4<T>*>(out_t + m * g.ld_out_t + ncol) = t; }
         else *reinterpret_cast<f32x4*>(out_t + m * g.ld_out_t + ncol) = v;
       }
     } else {
@@ -170,62 +169,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
 
 // The epilogue of the big NT kernels, straight from the accumulators (a wave's 128 x 64 sub-tile of the tile at (m0, n0); ep_base:
 // BigEpi<NWM>::BYTES of LDS free for staging).
-// ---------------------------------------------------------------------------------------------
-// Contraction of one 64- (or 32-) deep LDS stage by a wave that owns a (4 x 2) grid of 32 x 32 blocks, software-pipelined (round 5).
-// Written as "6 fragment reads, 8 MFMAs" per 16-deep step, hipcc emitted exactly that: reads, s_waitcnt lgkmcnt(0), MFMAs -- every
-// wave waited out an LDS round trip per step and only the second wave of the SIMD covered it (1.4-2.7 us per stage against 0.93 us of
-// MFMA time).  Here the fragments of step s + 1 are requested BEFORE the MFMAs of step s (two register sets, PFN_PIN_LDS_MFMA keeps the
-// machine scheduler from sinking the reads back to their consumers; the waits become counted lgkmcnt), and the first step of the NEXT
-// stage is requested right behind the stage barrier, ahead of the last step's MFMAs.
-// MEASURED (profiles/r05_gemm_experiments.txt, same-box A/B): 0-5 % slower alone and -1.7 % in the step -- the second wave of each SIMD already covered the
-// LDS round trips; the stage time is set by the operand stream into LDS.  So the plain loop stays the default; -DPFN_GEMM_FRAG_PIPE=1 builds this form.
-// ---------------------------------------------------------------------------------------------
-#ifndef PFN_GEMM_FRAG_PIPE
-#define PFN_GEMM_FRAG_PIPE 0
-#endif
-struct NtFrags { Frag<bf16> a[4], b[2]; };
-template <int RB> PFN_DEV void nt_load_frags(NtFrags& f, const lds_char* ta, const lds_char* tb, int arow, int brow, int ks) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) f.b[j] = load_frag_row<bf16, RB>(tb, brow + j * 32, ks);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) f.a[i] = load_frag_row<bf16, RB>(ta, arow + i * 32, ks);
-}
-PFN_DEV void nt_mma_frags(f32x16 (&acc)[4][2], const NtFrags& f) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = mma32(f.b[j], f.a[i], acc[i][j]);
-}
-// One stage: fragments of step 0 are already in f0 (requested by the previous stage, or by the caller for the first).  `tan` / `tbn`: the NEXT stage's
-// tiles (garbage on the last stage: read, never used).  The barrier (with the DMA's vmcnt(0)) sits between the last two steps' MFMAs.
-template <int RB, int BK> PFN_DEV void nt_contract_stage(f32x16 (&acc)[4][2], NtFrags& f0, NtFrags& f1, const lds_char* ta, const lds_char* tb,
-                                                         const lds_char* tan, const lds_char* tbn, int arow, int brow) {
-  static_assert(BK == 64 || BK == 32, "stage depth");
-  nt_load_frags<RB>(f1, ta, tb, arow, brow, 16);
-  PFN_PIN_LDS_MFMA();
-  nt_mma_frags(acc, f0);
-  PFN_PIN_LDS_MFMA();
-  if constexpr (BK == 64) {
-    nt_load_frags<RB>(f0, ta, tb, arow, brow, 32);
-    PFN_PIN_LDS_MFMA();
-    nt_mma_frags(acc, f1);
-    PFN_PIN_LDS_MFMA();
-    nt_load_frags<RB>(f1, ta, tb, arow, brow, 48);
-    PFN_PIN_LDS_MFMA();
-    nt_mma_frags(acc, f0);
-    PFN_PIN_LDS_MFMA();
-  }
-  __syncthreads();      // every wave has read this stage (its reads are retired: lgkmcnt(0)); the next stage's DMA has landed (vmcnt(0))
-  nt_load_frags<RB>(f0, tan, tbn, arow, brow, 0);
-  PFN_PIN_LDS_MFMA();
-  nt_mma_frags(acc, f1);
-  PFN_PIN_LDS_MFMA();
-}
 
 template <int NWM> struct BigEpi {
   static constexpr int EP_T = 32 * 144, EP_F = 32 * 272, EP_WAVE = (2 * EP_T > EP_F ? 2 * EP_T : EP_F), BYTES = NWM * 4 * EP_WAVE;
 };
-template <int FLAGS, int NWM>
+template <typename T, int FLAGS, int NWM>
 PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n0, int wave, int lane, LdsPtr ep_base) {
   const int wm = wave >> 2, wn = wave & 3;
   const int h = lane >> 5, li = lane & 31;
@@ -236,9 +184,9 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
   // a full memory round trip PLUS the drain of the previous block's stores -- 8 serial round trips per tile, a third of a
   // K = 512 GEMM's time.  Now: the bias once, then the loads of NB blocks, then their stores (NB below).
   constexpr int flags = FLAGS;  // compile-time: one straight-line epilogue per flag combination in use
-  const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
-  bf16* out_t = reinterpret_cast<bf16*>(g.out_t);
-  bf16* out2_t = reinterpret_cast<bf16*>(g.out2_t);
+  const T* aux = reinterpret_cast<const T*>(g.aux);
+  T* out_t = reinterpret_cast<T*>(g.out_t);
+  T* out2_t = reinterpret_cast<T*>(g.out2_t);
   constexpr bool HAS_AUX = (flags & (EPI_GELU_BWD | EPI_RESID_T | EPI_ROWDOT)) != 0;
   constexpr bool HAS_RES = (flags & EPI_RESID) != 0;
   float rowdot = 0.f;     // EPI_ROWDOT: the lane's share of sum_n out[m, n] * aux[m, n] over the two column blocks of its row
@@ -263,7 +211,7 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
   const bool lines = n0 + wn * 64 + 64 <= g.N && g.wide_t;   // wave-uniform: the strip is inside N and rows are 16-byte aligned
 #pragma unroll
   for (int pass = 0; pass < 8 / NB; ++pass) {
-    bf16x4 aux_v[HAS_AUX ? NB : 1][4];
+    X4<T> aux_v[HAS_AUX ? NB : 1][4];
     f32x4 res_v[HAS_RES ? NB : 1][4];
 #pragma unroll
     for (int bb = 0; bb < NB; ++bb) {
@@ -273,7 +221,7 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int n = min(n0 + wn * 64 + j * 32 + 8 * gq + 4 * h, g.N - 4);
-          if constexpr (HAS_AUX) aux_v[bb][gq] = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
+          if constexpr (HAS_AUX) aux_v[bb][gq] = *reinterpret_cast<const X4<T>*>(aux + m * g.ld_aux + n);
           if constexpr (HAS_RES) res_v[bb][gq] = *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
         }
       }
@@ -294,7 +242,7 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e];
         if constexpr (!EARLY) {
           if (flags & EPI_BIAS) bias_v[j][gq] = *reinterpret_cast<const f32x4*>(g.bias + n);
-          if constexpr (HAS_AUX) aux_v[bb][gq] = *reinterpret_cast<const bf16x4*>(aux + m * g.ld_aux + n);
+          if constexpr (HAS_AUX) aux_v[bb][gq] = *reinterpret_cast<const X4<T>*>(aux + m * g.ld_aux + n);
           if constexpr (HAS_RES) res_v[bb][gq] = *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
         }
         if (flags & EPI_BIAS) v += bias_v[j][gq];
@@ -317,25 +265,25 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
         for (int e = 0; e < 4; ++e) post[4 * gq + e] = v[e];
         if (flags & EPI_ROWDOT) {      // with the values as they are stored (operand precision), like the kernel this replaces read them back
 #pragma unroll
-          for (int e = 0; e < 4; ++e) rowdot += (float)(bf16)v[e] * (float)aux_v[HAS_AUX ? bb : 0][gq][e];
+          for (int e = 0; e < 4; ++e) rowdot += (float)(T)v[e] * (float)aux_v[HAS_AUX ? bb : 0][gq][e];
         }
         if (flags & EPI_OUT_F32) {
           if (lines) lds_write16(ep + li * 272 + (j * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
           else if (mvalid && nb + 8 * gq + 4 * h < g.N) *reinterpret_cast<f32x4*>(g.out_f32 + m * g.ld_out_f32 + n) = v;
         }
         if (lines && (flags & (EPI_OUT_T | EPI_OUT2_T))) {
-          typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+          typedef __attribute__((address_space(3))) X4<T> lds_tx4;
           if (flags & EPI_OUT_T) {
-            bf16x4 t;
+            X4<T> t;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e];
-            *reinterpret_cast<lds_bf16x4*>(ep + li * 144 + (j * 4 + gq) * 16 + h * 8) = t;
+            for (int e = 0; e < 4; ++e) t[e] = (T)v[e];
+            *reinterpret_cast<lds_tx4*>(ep + li * 144 + (j * 4 + gq) * 16 + h * 8) = t;
           }
           if (flags & EPI_OUT2_T) {
-            bf16x4 t;
+            X4<T> t;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = (bf16)pre[4 * gq + e];
-            *reinterpret_cast<lds_bf16x4*>(ep + EP_T + li * 144 + (j * 4 + gq) * 16 + h * 8) = t;
+            for (int e = 0; e < 4; ++e) t[e] = (T)pre[4 * gq + e];
+            *reinterpret_cast<lds_tx4*>(ep + EP_T + li * 144 + (j * 4 + gq) * 16 + h * 8) = t;
           }
         }
       }
@@ -365,7 +313,7 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
 #pragma unroll
           for (int o = 0; o < 2; ++o) {
             if (!(flags & (o ? EPI_OUT2_T : EPI_OUT_T))) continue;
-            bf16* dst = o ? out2_t : out_t;
+            T* dst = o ? out2_t : out_t;
             const long ld = o ? g.ld_out2 : g.ld_out_t;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -383,24 +331,24 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
       if (flags & (EPI_OUT_T | EPI_OUT2_T)) {
         const bool wide = nb + 32 <= g.N && g.wide_t;
         if (wide) {
-          if (flags & EPI_OUT2_T) store_row_block<bf16>(out2_t + m * g.ld_out2 + nb, pre, h, mvalid);
-          if (flags & EPI_OUT_T) store_row_block<bf16>(out_t + m * g.ld_out_t + nb, post, h, mvalid);
+          if (flags & EPI_OUT2_T) store_row_block<T>(out2_t + m * g.ld_out2 + nb, pre, h, mvalid);
+          if (flags & EPI_OUT_T) store_row_block<T>(out_t + m * g.ld_out_t + nb, post, h, mvalid);
         } else {
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             const int n = nb + 8 * gq + 4 * h;
             if (!mvalid || n >= g.N) continue;
             if (flags & EPI_OUT2_T) {
-              bf16x4 t;
+              X4<T> t;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) t[e] = (bf16)pre[4 * gq + e];
-              *reinterpret_cast<bf16x4*>(out2_t + m * g.ld_out2 + n) = t;
+              for (int e = 0; e < 4; ++e) t[e] = (T)pre[4 * gq + e];
+              *reinterpret_cast<X4<T>*>(out2_t + m * g.ld_out2 + n) = t;
             }
             if (flags & EPI_OUT_T) {
-              bf16x4 t;
+              X4<T> t;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) t[e] = (bf16)post[4 * gq + e];
-              *reinterpret_cast<bf16x4*>(out_t + m * g.ld_out_t + n) = t;
+              for (int e = 0; e < 4; ++e) t[e] = (T)post[4 * gq + e];
+              *reinterpret_cast<X4<T>*>(out_t + m * g.ld_out_t + n) = t;
             }
           }
         }
@@ -444,7 +392,7 @@ constexpr int BIG_BM = 256, BIG_BK = 64;            // the large shape (launcher
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-template <int FLAGS, int NWM, int BK>
+template <typename T, int FLAGS, int NWM, int BK>
 __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS)) void gemm_nt_big_kernel(GemmNT g) {
   using C = BigCfg<NWM, BK>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -462,19 +410,19 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
 
   // DMA sources: wave w moves the 1-KiB pieces w, w + NW, ... of each operand tile; the bank-conflict swizzle
   // of load_frag_row goes on the source chunk (the LDS image of a piece is lane-linear)
-  const bf16* pa[C::PA];
-  const bf16* pb[C::PB];
+  const T* pa[C::PA];
+  const T* pb[C::PB];
 #pragma unroll
   for (int i = 0; i < C::PA; ++i) {
     const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
     const int chunk = swz16<C::RB>(row, lane % C::CPR);
-    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+    pa[i] = reinterpret_cast<const T*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < C::PB; ++i) {
     const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
     const int chunk = swz16<C::RB>(row, lane % C::CPR);
-    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
+    pb[i] = reinterpret_cast<const T*>(g.B) + (long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
   }
   auto stage = [&](int buf, int k0) {
     LdsPtr ta = smem + buf * C::STAGE + wave * 1024;
@@ -496,17 +444,6 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
   const int nk = g.K / BK;
   stage(0, 0);
   __syncthreads();  // (carries the vmcnt(0) of the DMA)
-  if constexpr (PFN_GEMM_FRAG_PIPE && NWM == 2) {      // (the 128 x 256 / three-per-CU variant is held to 168 registers: no room for the second fragment set)
-  NtFrags f0, f1;
-  nt_load_frags<C::RB>(f0, smem, smem + C::TILE_A, wm * 128 + li, wn * 64 + li, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-    const lds_char* ta = smem + cur * C::STAGE;
-    const lds_char* tan = smem + (cur ^ 1) * C::STAGE;
-    nt_contract_stage<C::RB, BK>(acc, f0, f1, ta, ta + C::TILE_A, tan, tan + C::TILE_A, wm * 128 + li, wn * 64 + li);
-  }
-  } else {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
@@ -514,11 +451,11 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
     const lds_char* tb = ta + C::TILE_A;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
-      Frag<bf16> fa[4], fb[2];
+      Frag<T> fa[4], fb[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, C::RB>(tb, wn * 64 + j * 32 + li, ks);
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<T, C::RB>(tb, wn * 64 + j * 32 + li, ks);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, C::RB>(ta, wm * 128 + i * 32 + li, ks);
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<T, C::RB>(ta, wm * 128 + i * 32 + li, ks);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -526,207 +463,9 @@ __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS
     }
     __syncthreads();
   }
-  }
 
   static_assert(BigEpi<NWM>::BYTES <= 2 * C::STAGE, "epilogue staging must fit the (dead) stage buffers");
-  nt_big_epilogue<FLAGS, NWM>(g, acc, m0, n0, wave, lane, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// gemm_nt_ring_kernel (round 5 experiment, PFN_TUNE_GEMM_NT_KERNEL = 4): the 256 x 256 tile with its operand stream as a RING of four 32-deep stages
-// (4 x 32 KiB = the same 128 KiB as two 64-deep stages), three of them in flight under the one being multiplied.  The big kernel has ONE stage in flight and ends
-// every stage with vmcnt(0) + barrier: a stage can then never take less than the round trip of its own 64 KiB (issue -> last piece landed), whatever the matrix
-// pipe could do with it.  Here stage t + 3 is requested when stage t is entered and the wait for stage t is vmcnt(pieces of the two younger stages): the stream
-// is bound by its RATE, not by a round trip per stage.  All operand traffic is LDS-DMA from assembly, every barrier a raw s_barrier behind its own s_waitcnt
-// (wait_vm_barrier), as in gemm_tn_big_kernel.  Price: a barrier and a fragment restart every 32 of K instead of every 64.
-// ---------------------------------------------------------------------------------------------
-constexpr int RING_NS = 4;
-template <int FLAGS>
-__global__ __launch_bounds__(512, 1) void gemm_nt_ring_kernel(GemmNT g) {
-  using C = BigCfg<2, 32>;
-  static_assert(RING_NS * C::STAGE >= BigEpi<2>::BYTES, "epilogue staging must fit the (dead) ring");
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  LdsPtr smem = lds_cast(smem_raw);
-  const int tiles_n = (g.N + C::BN - 1) / C::BN;
-  const int tiles_m = (g.M + C::BM - 1) / C::BM;
-  const int tid_lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = tid_lin / tiles_n, tn = tid_lin % tiles_n;
-  const int m0 = tm * C::BM, n0 = tn * C::BN;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int li = lane & 31;
-
-  const bf16* pa[C::PA];
-  const bf16* pb[C::PB];
-#pragma unroll
-  for (int i = 0; i < C::PA; ++i) {
-    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
-    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + swz16<C::RB>(row, lane % C::CPR) * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < C::PB; ++i) {
-    const int row = (wave + C::NW * i) * C::RPP + lane / C::CPR;
-    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)min(n0 + row, g.N - 1) * g.ldb + swz16<C::RB>(row, lane % C::CPR) * 8;
-  }
-  auto stage = [&](int slot, int k0) {
-    LdsPtr ta = smem + slot * C::STAGE + wave * 1024;
-    LdsPtr tb = smem + slot * C::STAGE + C::TILE_A + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < C::PA; ++i) dma16_global(pa[i] + k0, ta + i * C::NW * 1024);
-#pragma unroll
-    for (int i = 0; i < C::PB; ++i) dma16_global(pb[i] + k0, tb + i * C::NW * 1024);
-  };
-  constexpr int PIECES = C::PA + C::PB;      // DMA instructions of a wave per stage
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = g.K / 32;
-#pragma unroll
-  for (int st = 0; st < RING_NS - 1; ++st)
-    if (st < nk) stage(st, st * 32);
-  int slot = 0, slot_next = RING_NS - 1;
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed for every wave (loads retire in order: everything but the pieces of the younger stages), and every wave's reads of the slot that is
-    // about to be overwritten -- stage kt - 1's -- have retired (lgkmcnt(0) in front of the barrier)
-    switch (min(nk - kt - 1, RING_NS - 2)) {
-      case 0: wait_vm_barrier<0>(); break;
-      case 1: wait_vm_barrier<PIECES>(); break;
-      default: wait_vm_barrier<2 * PIECES>(); break;
-    }
-    if (kt + RING_NS - 1 < nk) stage(slot_next, (kt + RING_NS - 1) * 32);
-    const lds_char* ta = smem + slot * C::STAGE;
-    const lds_char* tb = ta + C::TILE_A;
-#pragma unroll
-    for (int ks = 0; ks < 32; ks += 16) {
-      Frag<bf16> fa[4], fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, C::RB>(tb, wn * 64 + j * 32 + li, ks);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, C::RB>(ta, wm * 128 + i * 32 + li, ks);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
-    }
-    slot_next = slot;
-    slot = slot + 1 == RING_NS ? 0 : slot + 1;
-  }
-  wait_vm_barrier<0>();      // every wave is done reading the ring before the epilogue's strips go there
-  nt_big_epilogue<FLAGS, 2>(g, acc, m0, n0, wave, lane, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// gemm_nt_persist_kernel: the 256 x 256 kernel as ONE workgroup per CU walking tiles (t = blockIdx.x, + gridDim.x, ...).
-// A tile of a K = 512 GEMM spends 7-8 of its ~20 us in latencies that sit in series: the first stage's DMA, the epilogue's loads, the
-// stores' acknowledgements before the workgroup may retire, the next workgroup's launch (tools/bench_gemm_epi.py --k 64).  Here
-//   * the first stage of the NEXT tile is requested during the last contraction stage of this one (into the buffer that stage
-//     does not read: the stage count is even);
-//   * the epilogue's stores are fire-and-forget: the next tile's first barrier waits with vmcnt(stores of this wave) -- loads and
-//     stores retire in order, so everything older than the stores, i.e. that first stage, has landed while the stores drain under
-//     the next tile's MFMAs.
-// All operand traffic is LDS-DMA issued from assembly (pfn_device.h dma16_global) and every barrier is a raw s_barrier with its own
-// s_waitcnt: the compiler's __syncthreads() carries vmcnt(0), which would wait for the stores.  The epilogue stages through the
-// second stage buffer (+ 8 KiB past it), the first one is receiving the next tile.
-// Requirements on top of the big kernel's: K / 64 even, every tile full in N.
-// ---------------------------------------------------------------------------------------------
-template <int FLAGS> struct PersistCfg {
-  using C = BigCfg<2, 64>;
-  static constexpr int EP_OFF = C::STAGE;                                  // epilogue strips start at the second stage buffer
-  static constexpr int LDS = EP_OFF + BigEpi<2>::BYTES > 2 * C::STAGE ? EP_OFF + BigEpi<2>::BYTES : 2 * C::STAGE;
-  // global store instructions of one wave's epilogue on the whole-line path (full tile)
-  static constexpr int NST = ((FLAGS & EPI_OUT_T) ? 16 : 0) + ((FLAGS & EPI_OUT2_T) ? 16 : 0) + ((FLAGS & EPI_OUT_F32) ? 32 : 0);
-  static_assert(NST > 0 && NST < 64, "vmcnt is a 6-bit counter");
-};
-
-template <int FLAGS>
-__global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(GemmNT g) {
-  using C = BigCfg<2, 64>;
-  using P = PersistCfg<FLAGS>;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  LdsPtr smem = lds_cast(smem_raw);
-  const int tiles_n = g.N / C::BN;
-  const int tiles_m = (g.M + C::BM - 1) / C::BM;
-  const int ntiles = tiles_m * tiles_n;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int li = lane & 31;
-  const int nk = g.K / 64;
-
-  // DMA sources of a tile: wave w moves the 1-KiB pieces w, w + 8, ... of each operand tile (swizzle on the source chunk, as in
-  // the big kernel); per lane: row inside the tile and swizzled chunk are tile-independent
-  int prow[C::PA], pchunk[C::PA];
-#pragma unroll
-  for (int i = 0; i < C::PA; ++i) {
-    prow[i] = (wave + C::NW * i) * C::RPP + lane / C::CPR;
-    pchunk[i] = swz16<C::RB>(prow[i], lane % C::CPR) * 8;
-  }
-  auto stage = [&](int buf, int m0, int n0, int k0) {
-    LdsPtr ta = smem + buf * C::STAGE + wave * 1024;
-    LdsPtr tb = ta + C::TILE_A;
-#pragma unroll
-    for (int i = 0; i < C::PA; ++i)
-      dma16_global(reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + prow[i], g.M - 1) * g.lda + pchunk[i] + k0, ta + i * C::NW * 1024);
-#pragma unroll
-    for (int i = 0; i < C::PB; ++i)
-      dma16_global(reinterpret_cast<const bf16*>(g.B) + (long)(n0 + prow[i]) * g.ldb + pchunk[i] + k0, tb + i * C::NW * 1024);
-  };
-  auto coords = [&](int t, int& m0, int& n0) {
-    const int lin = xcd_remap(t, ntiles);
-    m0 = (lin / tiles_n) * C::BM; n0 = (lin % tiles_n) * C::BN;
-  };
-
-  int t = blockIdx.x;
-  if (t >= ntiles) return;
-  int m0, n0;
-  coords(t, m0, n0);
-  stage(0, m0, n0, 0);
-  bool stores_pending = false;        // the previous tile's epilogue went through the whole-line path with every row valid
-  for (; t < ntiles; t += gridDim.x) {
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int tn = t + gridDim.x;
-    int m0n = 0, n0n = 0;
-    if (tn < ntiles) coords(tn, m0n, n0n);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      // stage kt has landed (it is older than anything issued since), every wave is done with the other buffer
-      if (kt == 0 && stores_pending) wait_vm_barrier<P::NST>();
-      else wait_vm_barrier<0>();
-      if (kt + 1 < nk) stage(cur ^ 1, m0, n0, (kt + 1) * 64);
-      else if (tn < ntiles) stage(cur ^ 1, m0n, n0n, 0);
-      const lds_char* ta = smem + cur * C::STAGE;
-      const lds_char* tb = ta + C::TILE_A;
-#pragma unroll
-      for (int ks = 0; ks < 64; ks += 16) {
-        Frag<bf16> fa[4], fb[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, C::RB>(tb, wn * 64 + j * 32 + li, ks);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, C::RB>(ta, wm * 128 + i * 32 + li, ks);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fb[j], fa[i], acc[i][j]);
-      }
-    }
-    // every wave is done reading the last stage (buffer 1) before the epilogue's strips go there; the next tile's first stage
-    // (buffer 0) stays in flight
-    asm volatile("s_barrier" ::: "memory");
-    nt_big_epilogue<FLAGS, 2>(g, acc, m0, n0, wave, lane, smem + P::EP_OFF);
-    stores_pending = m0 + C::BM <= g.M && g.wide_t;
-    m0 = m0n; n0 = n0n;
-  }
+  nt_big_epilogue<T, FLAGS, NWM>(g, acc, m0, n0, wave, lane, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -745,7 +484,7 @@ template <int NWN> struct LnEpi {   // LDS of gemm_nt_ln_kernel's epilogue: row 
   static constexpr int WAVE = 32 * 272 + 32 * 144;
   static constexpr int BYTES = STRIPS + NWN * WAVE;
 };
-template <int NWN, bool RESID_LN, int BK>
+template <typename T, int NWN, bool RESID_LN, int BK>
 __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
   constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
@@ -756,21 +495,21 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int h = lane >> 5, li = lane & 31;
 
-  const bf16* pa[PA];
-  const bf16* pb[PB];
+  const T* pa[PA];
+  const T* pb[PB];
   constexpr int APIECES = BM / RPP;
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int piece = wave + NWN * i;
     const int row = piece * RPP + lane / CPR;
     const int chunk = swz16<RB>(row, lane % CPR);
-    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+    pa[i] = reinterpret_cast<const T*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int row = (wave + NWN * i) * RPP + lane / CPR;
     const int chunk = swz16<RB>(row, lane % CPR);
-    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)row * g.ldb + chunk * 8;
+    pb[i] = reinterpret_cast<const T*>(g.B) + (long)row * g.ldb + chunk * 8;
   }
   auto stage = [&](int buf, int k0) {
     LdsPtr ta = smem + buf * STAGE + wave * 1024;
@@ -793,17 +532,6 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   const int nk = g.K / BK;
   stage(0, 0);
   __syncthreads();
-#if PFN_GEMM_FRAG_PIPE
-  NtFrags f0, f1;
-  nt_load_frags<RB>(f0, smem, smem + TILE_A, li, wave * 64 + li, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-    const lds_char* ta = smem + cur * STAGE;
-    const lds_char* tan = smem + (cur ^ 1) * STAGE;
-    nt_contract_stage<RB, BK>(acc, f0, f1, ta, ta + TILE_A, tan, tan + TILE_A, li, wave * 64 + li);
-  }
-#else
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
@@ -811,11 +539,11 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
     const lds_char* tb = ta + TILE_A;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
-      Frag<bf16> fa[4], fb[2];
+      Frag<T> fa[4], fb[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, RB>(tb, wave * 64 + j * 32 + li, ks);
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<T, RB>(tb, wave * 64 + j * 32 + li, ks);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, RB>(ta, i * 32 + li, ks);
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<T, RB>(ta, i * 32 + li, ks);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -823,7 +551,6 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
     }
     __syncthreads();
   }
-#endif
 
   // ---- epilogue: v = acc + bias + residual (kept in the accumulator registers), row statistics, outputs ----
   // The compiler never moves a global load above a global store and waits for each group of loads where it is used, so an
@@ -915,8 +642,8 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   // Outputs leave through wave-private LDS strips (one 32-row block at a time: f32 rows of 256 B + operand-precision rows of
   // 128 B, padded by 16 B) so that every global store instruction writes whole lines -- 4 rows x 256 B of y, 8 rows x 128 B of
   // x_t -- instead of 32 bytes of 32 different rows (as in nt_big_epilogue).
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  bf16* x_t = reinterpret_cast<bf16*>(g.x_t);
+  typedef __attribute__((address_space(3))) X4<T> lds_tx4;
+  T* x_t = reinterpret_cast<T*>(g.x_t);
   LdsPtr sf = smem + LnEpi<NWN>::STRIPS + wave * LnEpi<NWN>::WAVE, st = sf + 32 * 272;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -931,15 +658,15 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
         const int n = nb + 8 * gq + 4 * h;
         const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + 3 * BN + n), be = *reinterpret_cast<const f32x4*>(cvec + 4 * BN + n);
         f32x4 v, xo;
-        bf16x4 xt;
+        X4<T> xt;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[i][j][4 * gq + e];
           xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
-          xt[e] = (bf16)xo[e];
+          xt[e] = (T)xo[e];
         }
         lds_write16(sf + li * 272 + (j * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
-        *reinterpret_cast<lds_bf16x4*>(st + li * 144 + (j * 4 + gq) * 16 + h * 8) = xt;
+        *reinterpret_cast<lds_tx4*>(st + li * 144 + (j * 4 + gq) * 16 + h * 8) = xt;
         if (g.x_f32 && mvalid) *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;   // (last layer only)
       }
     }
@@ -971,7 +698,7 @@ template <int NWN, int MI, int NJ> struct LnEpiW {   // LDS of gemm_nt_ln_kernel
   static constexpr int WAVE = 32 * 272 + 32 * 144;
   static constexpr int BYTES = STRIPS + NWN * WAVE;
 };
-template <int NWN, bool RESID_LN, int BK, int MI, int NJ>
+template <typename T, int NWN, bool RESID_LN, int BK, int MI, int NJ>
 __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_kernel(GemmLN g) {      // (4-wave tiles: two workgroups per CU, 256 registers per wave)
   constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
   constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
@@ -983,21 +710,21 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int h = lane >> 5, li = lane & 31;
 
-  const bf16* pa[PA];
-  const bf16* pb[PB];
+  const T* pa[PA];
+  const T* pb[PB];
   constexpr int APIECES = BM / RPP;
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int piece = wave + NWN * i;
     const int row = piece * RPP + lane / CPR;
     const int chunk = swz16<RB>(row, lane % CPR);
-    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+    pa[i] = reinterpret_cast<const T*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int row = (wave + NWN * i) * RPP + lane / CPR;
     const int chunk = swz16<RB>(row, lane % CPR);
-    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)row * g.ldb + chunk * 8;
+    pb[i] = reinterpret_cast<const T*>(g.B) + (long)row * g.ldb + chunk * 8;
   }
   auto stage = [&](int buf, int k0) {
     LdsPtr ta = smem + buf * STAGE + wave * 1024;
@@ -1027,11 +754,11 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
     const lds_char* tb = ta + TILE_A;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
-      Frag<bf16> fa[MI], fb[NJ];
+      Frag<T> fa[MI], fb[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = load_frag_row<bf16, RB>(tb, wave * WN + j * 32 + li, ks);
+      for (int j = 0; j < NJ; ++j) fb[j] = load_frag_row<T, RB>(tb, wave * WN + j * 32 + li, ks);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = load_frag_row<bf16, RB>(ta, i * 32 + li, ks);
+      for (int i = 0; i < MI; ++i) fa[i] = load_frag_row<T, RB>(ta, i * 32 + li, ks);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1135,8 +862,8 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
   // Outputs leave through wave-private LDS strips (one unit at a time: f32 rows of 256 B + operand-precision rows of
   // 128 B, padded by 16 B) so that every global store instruction writes whole lines -- 4 rows x 256 B of y, 8 rows x 128 B of
   // x_t -- instead of 32 bytes of 32 different rows (as in nt_big_epilogue).
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  bf16* x_t = reinterpret_cast<bf16*>(g.x_t);
+  typedef __attribute__((address_space(3))) X4<T> lds_tx4;
+  T* x_t = reinterpret_cast<T*>(g.x_t);
   LdsPtr sf = smem + LnEpiW<NWN, MI, NJ>::STRIPS + wave * LnEpiW<NWN, MI, NJ>::WAVE, st = sf + 32 * 272;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -1154,15 +881,15 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
         const int n = nb + 8 * gq + 4 * h;
         const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + 3 * BN + n), be = *reinterpret_cast<const f32x4*>(cvec + 4 * BN + n);
         f32x4 v, xo;
-        bf16x4 xt;
+        X4<T> xt;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[i][j][4 * gq + e];
           xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
-          xt[e] = (bf16)xo[e];
+          xt[e] = (T)xo[e];
         }
         lds_write16(sf + li * 272 + (jj * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
-        *reinterpret_cast<lds_bf16x4*>(st + li * 144 + (jj * 4 + gq) * 16 + h * 8) = xt;
+        *reinterpret_cast<lds_tx4*>(st + li * 144 + (jj * 4 + gq) * 16 + h * 8) = xt;
         if (g.x_f32 && mvalid) *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;   // (last layer only)
       }
     }
@@ -1217,7 +944,7 @@ template <int NWN, int BK> struct LnbCfg {
   static constexpr int LDS = STAGES > EPI ? STAGES : EPI;
 };
 
-template <int NWN, int BK>
+template <typename T, int NWN, int BK>
 __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   using C = LnbCfg<NWN, BK>;
   constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
@@ -1229,18 +956,18 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int h = lane >> 5, li = lane & 31;
 
-  const bf16* pa[PA];
-  const bf16* pb[PB];
+  const T* pa[PA];
+  const T* pb[PB];
   constexpr int APIECES = BM / RPP;
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int row = (wave + NWN * i) * RPP + lane / CPR;
-    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + swz16<RB>(row, lane % CPR) * 8;
+    pa[i] = reinterpret_cast<const T*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + swz16<RB>(row, lane % CPR) * 8;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int row = (wave + NWN * i) * RPP + lane / CPR;
-    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)row * g.ldb + swz16<RB>(row, lane % CPR) * 8;
+    pb[i] = reinterpret_cast<const T*>(g.B) + (long)row * g.ldb + swz16<RB>(row, lane % CPR) * 8;
   }
   auto stage = [&](int buf, int k0) {
     LdsPtr ta = smem + buf * STAGE + wave * 1024;
@@ -1263,17 +990,6 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   const int nk = g.K / BK;
   stage(0, 0);
   __syncthreads();
-#if PFN_GEMM_FRAG_PIPE
-  NtFrags f0, f1;
-  nt_load_frags<RB>(f0, smem, smem + TILE_A, li, wave * 64 + li, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-    const lds_char* ta = smem + cur * STAGE;
-    const lds_char* tan = smem + (cur ^ 1) * STAGE;
-    nt_contract_stage<RB, BK>(acc, f0, f1, ta, ta + TILE_A, tan, tan + TILE_A, li, wave * 64 + li);
-  }
-#else
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
@@ -1281,11 +997,11 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
     const lds_char* tb = ta + TILE_A;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
-      Frag<bf16> fa[4], fb[2];
+      Frag<T> fa[4], fb[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<bf16, RB>(tb, wave * 64 + j * 32 + li, ks);
+      for (int j = 0; j < 2; ++j) fb[j] = load_frag_row<T, RB>(tb, wave * 64 + j * 32 + li, ks);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<bf16, RB>(ta, i * 32 + li, ks);
+      for (int i = 0; i < 4; ++i) fa[i] = load_frag_row<T, RB>(ta, i * 32 + li, ks);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1293,16 +1009,15 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
     }
     __syncthreads();
   }
-#endif
 
   // ---- epilogue ----
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  typedef __attribute__((address_space(3))) X4<T> lds_tx4;
   float* red1 = reinterpret_cast<float*>(smem_raw);
   float* red2 = red1 + 128 * NWN;
   float* gam = red2 + 128 * NWN;
   LdsPtr stash = smem + C::STASH + wave * 4 * C::STRIP;
-  const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
-  bf16* dx_t = reinterpret_cast<bf16*>(g.dx_t);
+  const T* aux = reinterpret_cast<const T*>(g.aux);
+  T* dx_t = reinterpret_cast<T*>(g.dx_t);
   gam[threadIdx.x] = g.gamma[threadIdx.x];                  // blockDim.x == BN
   int mrow[4];
   bool mvalid[4];
@@ -1317,13 +1032,13 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   // y rows and the residual-branch gradient: one half row block (a 32-column block of the lane's row) ahead of its use -- a whole
   // block ahead does not fit the registers.  v = product + that gradient replaces the accumulator; rows past M hold zeros.
   f32x4 yv[2][4];
-  bf16x4 av[2][4];
-  auto fetch_half = [&](int hb, f32x4 (&dy)[4], bf16x4 (&da)[4]) {           // hb = 2 i + j
+  X4<T> av[2][4];
+  auto fetch_half = [&](int hb, f32x4 (&dy)[4], X4<T> (&da)[4]) {           // hb = 2 i + j
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const long off = (long)mrow[hb >> 1] * BN + wave * 64 + (hb & 1) * 32 + 8 * gq + 4 * h;
       dy[gq] = *reinterpret_cast<const f32x4*>(g.y + off);
-      da[gq] = *reinterpret_cast<const bf16x4*>(aux + off);
+      da[gq] = *reinterpret_cast<const X4<T>*>(aux + off);
     }
   };
   fetch_half(0, yv[0], av[0]);
@@ -1340,7 +1055,7 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
     for (int gq = 0; gq < 4; ++gq) {
       const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
       const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n);
-      bf16x4 xh_t;
+      X4<T> xh_t;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float v = mvalid[i] ? acc[i][j][4 * gq + e] + (float)av[hb & 1][gq][e] : 0.f;
@@ -1349,9 +1064,9 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
         const float gv = ga[e] * v;
         s1 += gv;
         s2 += gv * xh;
-        xh_t[e] = (bf16)xh;
+        xh_t[e] = (T)xh;
       }
-      *reinterpret_cast<lds_bf16x4*>(stash + i * C::STRIP + li * 144 + (j * 4 + gq) * 16 + h * 8) = xh_t;
+      *reinterpret_cast<lds_tx4*>(stash + i * C::STRIP + li * 144 + (j * 4 + gq) * 16 + h * 8) = xh_t;
     }
     if (j == 1) {
       s1 += __shfl_xor(s1, 32, 64);
@@ -1398,23 +1113,23 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   for (int i = 0; i < 4; ++i) {
     LdsPtr strip = stash + i * C::STRIP;
     asm volatile("" ::: "memory");
-    bf16x4 xh_t[8];
+    X4<T> xh_t[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xh_t[c] = *reinterpret_cast<const lds_bf16x4*>(strip + li * 144 + c * 16 + h * 8);
+    for (int c = 0; c < 8; ++c) xh_t[c] = *reinterpret_cast<const lds_tx4*>(strip + li * 144 + c * 16 + h * 8);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n);
-        bf16x4 o;
+        X4<T> o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (float)xh_t[j * 4 + gq][e], v = acc[i][j][4 * gq + e];
           cg[j][4 * gq + e] += v * xh;
-          o[e] = (bf16)(rs[i] * (ga[e] * v - m1[i] - xh * m2[i]));
+          o[e] = (T)(rs[i] * (ga[e] * v - m1[i] - xh * m2[i]));
         }
-        *reinterpret_cast<lds_bf16x4*>(strip + li * 144 + (j * 4 + gq) * 16 + h * 8) = o;   // (the lane's own xhat slot)
+        *reinterpret_cast<lds_tx4*>(strip + li * 144 + (j * 4 + gq) * 16 + h * 8) = o;   // (the lane's own xhat slot)
       }
     __builtin_amdgcn_wave_barrier();
     const long mb = (long)m0 + i * 32;
@@ -1442,8 +1157,9 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   __syncthreads();
   {
     const int n = threadIdx.x;                              // blockDim.x == BN
-    unsafeAtomicAdd(g.dbeta + n, csum[n] + csum[BN + n]);
-    unsafeAtomicAdd(g.dgamma + n, csum[2 * BN + n] + csum[3 * BN + n]);
+    const float osc = loss_scale_down(g.scale_amax);      // fp16 backward: the parameter gradients leave unscaled (pfn_device.h)
+    unsafeAtomicAdd(g.dbeta + n, (csum[n] + csum[BN + n]) * osc);
+    unsafeAtomicAdd(g.dgamma + n, (csum[2 * BN + n] + csum[3 * BN + n]) * osc);
   }
 }
 
@@ -1459,7 +1175,7 @@ template <int NWN, int BK, int MI, int NJ> struct LnbCfgW {
   static constexpr int LDS = STAGES > EPI ? STAGES : EPI;
 };
 
-template <int NWN, int BK, int MI, int NJ>
+template <typename T, int NWN, int BK, int MI, int NJ>
 __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wide_kernel(GemmLNB g) {
   using C = LnbCfgW<NWN, BK, MI, NJ>;
   constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
@@ -1472,18 +1188,18 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int h = lane >> 5, li = lane & 31;
 
-  const bf16* pa[PA];
-  const bf16* pb[PB];
+  const T* pa[PA];
+  const T* pb[PB];
   constexpr int APIECES = BM / RPP;
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int row = (wave + NWN * i) * RPP + lane / CPR;
-    pa[i] = reinterpret_cast<const bf16*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + swz16<RB>(row, lane % CPR) * 8;
+    pa[i] = reinterpret_cast<const T*>(g.A) + (long)min(m0 + row, g.M - 1) * g.lda + swz16<RB>(row, lane % CPR) * 8;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int row = (wave + NWN * i) * RPP + lane / CPR;
-    pb[i] = reinterpret_cast<const bf16*>(g.B) + (long)row * g.ldb + swz16<RB>(row, lane % CPR) * 8;
+    pb[i] = reinterpret_cast<const T*>(g.B) + (long)row * g.ldb + swz16<RB>(row, lane % CPR) * 8;
   }
   auto stage = [&](int buf, int k0) {
     LdsPtr ta = smem + buf * STAGE + wave * 1024;
@@ -1513,11 +1229,11 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
     const lds_char* tb = ta + TILE_A;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
-      Frag<bf16> fa[MI], fb[NJ];
+      Frag<T> fa[MI], fb[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = load_frag_row<bf16, RB>(tb, wave * WN + j * 32 + li, ks);
+      for (int j = 0; j < NJ; ++j) fb[j] = load_frag_row<T, RB>(tb, wave * WN + j * 32 + li, ks);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = load_frag_row<bf16, RB>(ta, i * 32 + li, ks);
+      for (int i = 0; i < MI; ++i) fa[i] = load_frag_row<T, RB>(ta, i * 32 + li, ks);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1527,13 +1243,13 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
   }
 
   // ---- epilogue ----
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  typedef __attribute__((address_space(3))) X4<T> lds_tx4;
   float* red1 = reinterpret_cast<float*>(smem_raw);
   float* red2 = red1 + BM * NWN;
   float* gam = red2 + BM * NWN;
   LdsPtr stash = smem + C::STASH + wave * NU * C::STRIP;
-  const bf16* aux = reinterpret_cast<const bf16*>(g.aux);
-  bf16* dx_t = reinterpret_cast<bf16*>(g.dx_t);
+  const T* aux = reinterpret_cast<const T*>(g.aux);
+  T* dx_t = reinterpret_cast<T*>(g.dx_t);
   for (int n = threadIdx.x; n < BN; n += NWN * 64) gam[n] = g.gamma[n];
   int mrow[MI];
   bool mvalid[MI];
@@ -1548,13 +1264,13 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
   // y rows and the residual-branch gradient: one half row block (a 32-column block of the lane's row) ahead of its use -- a whole
   // block ahead does not fit the registers.  v = product + that gradient replaces the accumulator; rows past M hold zeros.
   f32x4 yv[2][4];
-  bf16x4 av[2][4];
-  auto fetch_half = [&](int hb, f32x4 (&dy)[4], bf16x4 (&da)[4]) {           // hb = NJ i + j
+  X4<T> av[2][4];
+  auto fetch_half = [&](int hb, f32x4 (&dy)[4], X4<T> (&da)[4]) {           // hb = NJ i + j
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const long off = (long)mrow[hb / NJ] * BN + wave * WN + (hb % NJ) * 32 + 8 * gq + 4 * h;
       dy[gq] = *reinterpret_cast<const f32x4*>(g.y + off);
-      da[gq] = *reinterpret_cast<const bf16x4*>(aux + off);
+      da[gq] = *reinterpret_cast<const X4<T>*>(aux + off);
     }
   };
   fetch_half(0, yv[0], av[0]);
@@ -1571,7 +1287,7 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
     for (int gq = 0; gq < 4; ++gq) {
       const int n = wave * WN + j * 32 + 8 * gq + 4 * h;
       const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n);
-      bf16x4 xh_t;
+      X4<T> xh_t;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float v = mvalid[i] ? acc[i][j][4 * gq + e] + (float)av[hb & 1][gq][e] : 0.f;
@@ -1580,9 +1296,9 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
         const float gv = ga[e] * v;
         s1 += gv;
         s2 += gv * xh;
-        xh_t[e] = (bf16)xh;
+        xh_t[e] = (T)xh;
       }
-      *reinterpret_cast<lds_bf16x4*>(stash + (i * JH + j / 2) * C::STRIP + li * 144 + ((j & 1) * 4 + gq) * 16 + h * 8) = xh_t;
+      *reinterpret_cast<lds_tx4*>(stash + (i * JH + j / 2) * C::STRIP + li * 144 + ((j & 1) * 4 + gq) * 16 + h * 8) = xh_t;
     }
     if (j == NJ - 1) {
       s1 += __shfl_xor(s1, 32, 64);
@@ -1634,9 +1350,9 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
     const int i = u / JH, jh = u % JH;
     LdsPtr strip = stash + u * C::STRIP;
     asm volatile("" ::: "memory");
-    bf16x4 xh_t[8];
+    X4<T> xh_t[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xh_t[c] = *reinterpret_cast<const lds_bf16x4*>(strip + li * 144 + c * 16 + h * 8);
+    for (int c = 0; c < 8; ++c) xh_t[c] = *reinterpret_cast<const lds_tx4*>(strip + li * 144 + c * 16 + h * 8);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -1644,14 +1360,14 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
         const int j = jh * 2 + jj;
         const int n = wave * WN + j * 32 + 8 * gq + 4 * h;
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n);
-        bf16x4 o;
+        X4<T> o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (float)xh_t[jj * 4 + gq][e], v = acc[i][j][4 * gq + e];
           cg[j][4 * gq + e] += v * xh;
-          o[e] = (bf16)(rs[i] * (ga[e] * v - m1[i] - xh * m2[i]));
+          o[e] = (T)(rs[i] * (ga[e] * v - m1[i] - xh * m2[i]));
         }
-        *reinterpret_cast<lds_bf16x4*>(strip + li * 144 + (jj * 4 + gq) * 16 + h * 8) = o;   // (the lane's own xhat slot)
+        *reinterpret_cast<lds_tx4*>(strip + li * 144 + (jj * 4 + gq) * 16 + h * 8) = o;   // (the lane's own xhat slot)
       }
     __builtin_amdgcn_wave_barrier();
     const long mb = (long)m0 + i * 32;
@@ -1677,9 +1393,10 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
       if (li == 0) *reinterpret_cast<f32x4*>(csum + BN + ccol + j * 32 + 8 * gq) = t;
     }
   __syncthreads();
+  const float osc = loss_scale_down(g.scale_amax);
   for (int n = threadIdx.x; n < BN; n += NWN * 64) {
-    unsafeAtomicAdd(g.dbeta + n, csum[n]);
-    unsafeAtomicAdd(g.dgamma + n, csum[BN + n]);
+    unsafeAtomicAdd(g.dbeta + n, csum[n] * osc);
+    unsafeAtomicAdd(g.dgamma + n, csum[BN + n] * osc);
   }
 }
 
@@ -1732,7 +1449,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
 #pragma unroll
     for (int i = 0; i < sa.PER; ++i) {
       if constexpr (sizeof(T) == 2) {
-        const bf16x8 v = __builtin_bit_cast(bf16x8, sa.regs[i]);
+        const X8<T> v = __builtin_bit_cast(X8<T>, sa.regs[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += (float)v[e];
       } else {
@@ -1777,6 +1494,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
     __syncthreads();
   }
 
+  const float osc = loss_scale_down(g.scale_amax);      // fp16 backward: the gradient leaves unscaled (pfn_device.h)
   if (do_colsum) {
     // threads tid, tid+NCH, ... share a column chunk: reduce over the 256/NCH row groups through LDS
     constexpr int NCH = RB / 16;
@@ -1790,7 +1508,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
         float t = 0.f;
         for (int j = 0; j < 256 / NCH; ++j) t += red[(j * NCH + threadIdx.x) * EPC + e];
         const int col = p0 + threadIdx.x * EPC + e;
-        if (col < g.P) unsafeAtomicAdd(g.colsum + col, t);
+        if (col < g.P) unsafeAtomicAdd(g.colsum + col, t * loss_scale_down(g.scale_amax));
       }
     }
   }
@@ -1804,8 +1522,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN g) {
         const int q = q0 + wq * 64 + j * 32 + (lane & 31);
         if (p < g.P && q < g.Q) {
           float* c = g.C + (long)p * g.ldc + q;
-          if (g.atomic) unsafeAtomicAdd(c, acc[i][j][r]);
-          else *c = acc[i][j][r];
+          if (g.atomic) unsafeAtomicAdd(c, acc[i][j][r] * osc);
+          else *c = acc[i][j][r] * osc;
         }
       }
 }
@@ -1839,6 +1557,7 @@ constexpr int TNB_PW = TNB_KT / 16;              // 1-KiB DMA pieces per wave pe
 constexpr int TNB_LDS = TNB_NS * 2 * TNB_TILE;
 static_assert(TNB_LDS <= 160 * 1024 && TNB_KT % 16 == 0 && TNB_NS >= 2 && (TNB_NS - 2) * 2 * TNB_PW < 64, "weight-gradient ring does not fit");
 
+template <typename T>
 __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
@@ -1861,8 +1580,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
   const int wp = wave >> 2, wq = wave & 3;
 
   // DMA sources: a 1-KiB piece is 2 token rows x 512 B; wave w moves pieces w, w + 8, ... of each operand's stage
-  const bf16* pa[TNB_PW];
-  const bf16* pb[TNB_PW];
+  const T* pa[TNB_PW];
+  const T* pb[TNB_PW];
   int prow[TNB_PW];
 #pragma unroll
   for (int i = 0; i < TNB_PW; ++i) {
@@ -1870,8 +1589,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
     const int unit = ((lane & 31) >> 2) ^ (row & 3);
     const int col = unit * 32 + (lane & 3) * 8;
     prow[i] = row;
-    pa[i] = reinterpret_cast<const bf16*>(pr.A) + mbeg * pr.lda + p0 + col;
-    pb[i] = reinterpret_cast<const bf16*>(pr.B) + mbeg * pr.ldb + q0 + col;
+    pa[i] = reinterpret_cast<const T*>(pr.A) + mbeg * pr.lda + p0 + col;
+    pb[i] = reinterpret_cast<const T*>(pr.B) + mbeg * pr.ldb + q0 + col;
   }
   auto stage = [&](int slot, int r0) {
     LdsPtr ta = smem + slot * 2 * TNB_TILE + wave * 1024;
@@ -1899,9 +1618,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) cs[r] = 0.f;
   const bool do_colsum = pr.colsum != nullptr && q0 == 0;
-  Frag<bf16> ones;
+  Frag<T> ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones.v[e] = (bf16)1.0f;
+  for (int e = 0; e < 8; ++e) ones.v[e] = (T)1.0f;
 
   const int nt = (rows_total + TNB_KT - 1) / TNB_KT;
   // Ring of TNB_NS stages: stage t is multiplied while stages t+1 .. t+TNB_NS-2 are in flight and stage t+TNB_NS-1 is requested
@@ -1923,78 +1642,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
   };
   static_assert(TNB_NS <= 6, "wait_stage cases");
   // the main loop exists twice (with / without the bias-gradient MFMA) so neither carries a branch
-#if PFN_GEMM_FRAG_PIPE
-  // Software-pipelined (round 5, as nt_contract_stage): the transposed fragments of step s + 1 are requested before the MFMAs of step s, and the first
-  // step of stage t + 1 right behind that stage's barrier, ahead of the last MFMAs of stage t.  The plain loop waited out an LDS round trip per step.
-  static_assert(TNB_KT == 64 || TNB_KT == 32, "two fragment sets alternate over an even number of 16-token steps");
-  auto main_loop = [&](auto with_colsum) {
-    constexpr bool CS = decltype(with_colsum)::value;
-    struct TnFrags { Frag<bf16> a[4], b[2], c; };
-    TnFrags f0, f1;
-    auto ld = [&](TnFrags& f, const lds_char* ta, const lds_char* tb, int ks) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) f.b[j] = load_frag_tr<bf16, 512, 1>(tb, ks, wq * 64 + j * 32);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) f.a[i] = load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + i * 32);
-      // bias gradient: Q wave wq sums the columns of P sub-tile wq (one more fragment read, one more MFMA)
-      if constexpr (CS) f.c = load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + wq * 32);
-    };
-    auto mm = [&](const TnFrags& f) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mma32(f.a[i], f.b[j], acc[i][j]);
-      if constexpr (CS) cs = mma32(f.c, ones, cs);
-    };
-    // stage t has landed for every wave (and every read of the slot it is about to overwrite has retired: wait_vm_barrier waits lgkmcnt(0));
-    // request stage t + TNB_NS - 1 into that slot; clear the rows past the end of a ragged last stage
-    auto enter_stage = [&](int t, int slot, int slot_next) {
-      wait_stage(min(nt - t - 1, TNB_NS - 2));
-      if (t + TNB_NS - 1 < nt) stage(slot_next, (t + TNB_NS - 1) * TNB_KT);
-      const int valid = rows_total - t * TNB_KT;
-      if (valid < TNB_KT) {
-        // (the DMA clamped its source rows.  A only: a zero A row contributes nothing whatever B holds there, and B's clamped rows are finite data)
-        LdsPtr ta = smem + slot * 2 * TNB_TILE;
-        for (int idx = threadIdx.x; idx < (TNB_KT - valid) * 32; idx += 512) {
-          const u32x4 z = {0u, 0u, 0u, 0u};
-          lds_write16(ta + (valid + idx / 32) * 512 + (idx % 32) * 16, z);
-        }
-        __syncthreads();
-      }
-    };
-    int slot = 0, slot_next = TNB_NS - 1;
-    enter_stage(0, slot, slot_next);
-    ld(f0, smem, smem + TNB_TILE, 0);
-    for (int t = 0; t < nt; ++t) {
-      const lds_char* ta = smem + slot * 2 * TNB_TILE;
-      const lds_char* tb = ta + TNB_TILE;
-      ld(f1, ta, tb, 16);
-      PFN_PIN_LDS_MFMA();
-      mm(f0);
-      PFN_PIN_LDS_MFMA();
-      if constexpr (TNB_KT == 64) {
-        ld(f0, ta, tb, 32);
-        PFN_PIN_LDS_MFMA();
-        mm(f1);
-        PFN_PIN_LDS_MFMA();
-        ld(f1, ta, tb, 48);
-        PFN_PIN_LDS_MFMA();
-        mm(f0);
-        PFN_PIN_LDS_MFMA();
-      }
-      slot_next = slot;
-      slot = slot + 1 == TNB_NS ? 0 : slot + 1;
-      if (t + 1 < nt) {
-        enter_stage(t + 1, slot, slot_next);
-        const lds_char* tan = smem + slot * 2 * TNB_TILE;
-        ld(f0, tan, tan + TNB_TILE, 0);
-      }
-      PFN_PIN_LDS_MFMA();
-      mm(f1);
-      PFN_PIN_LDS_MFMA();
-    }
-  };
-#else
   auto main_loop = [&](auto with_colsum) {
     constexpr bool CS = decltype(with_colsum)::value;
     int slot = 0, slot_next = TNB_NS - 1;
@@ -2015,32 +1662,32 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
       }
 #pragma unroll
       for (int ks = 0; ks < TNB_KT; ks += 16) {
-        Frag<bf16> fa[4], fb[2];
+        Frag<T> fa[4], fb[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = load_frag_tr<bf16, 512, 1>(tb, ks, wq * 64 + j * 32);
+        for (int j = 0; j < 2; ++j) fb[j] = load_frag_tr<T, 512, 1>(tb, ks, wq * 64 + j * 32);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + i * 32);
+        for (int i = 0; i < 4; ++i) fa[i] = load_frag_tr<T, 512, 1>(ta, ks, wp * 128 + i * 32);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = mma32(fa[i], fb[j], acc[i][j]);
         // bias gradient: Q wave wq sums the columns of P sub-tile wq (one more fragment read, one more MFMA)
-        if constexpr (CS) cs = mma32(load_frag_tr<bf16, 512, 1>(ta, ks, wp * 128 + wq * 32), ones, cs);
+        if constexpr (CS) cs = mma32(load_frag_tr<T, 512, 1>(ta, ks, wp * 128 + wq * 32), ones, cs);
       }
       slot_next = slot;
       slot = slot + 1 == TNB_NS ? 0 : slot + 1;
     }
   };
-#endif
   if (do_colsum) main_loop(std::true_type{});
   else main_loop(std::false_type{});
 
   const int pv = pr.Pv > 0 ? pr.Pv : pr.P;    // rows of C that exist (A may end in zero-padding columns)
+  const float osc = loss_scale_down(g.scale_amax);      // fp16 backward: the gradients leave unscaled (pfn_device.h)
   if (do_colsum && (lane & 31) == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int pp = p0 + wp * 128 + wq * 32 + acc_row(r, lane);
-      if (pp < pv) unsafeAtomicAdd(pr.colsum + pp, cs[r]);
+      if (pp < pv) unsafeAtomicAdd(pr.colsum + pp, cs[r] * osc);
     }
   }
   // always atomic: token splits add into the same tile, and concurrent backward passes (micro-batches on several
@@ -2056,8 +1703,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
         const int qq = q0 + wq * 64 + j * 32 + (lane & 31);
         float* c = pr.C + (long)pp * pr.ldc + qq;
         if (pp >= pv) continue;
-        if (atomic) unsafeAtomicAdd(c, acc[i][j][r]);
-        else *c += acc[i][j][r];
+        if (atomic) unsafeAtomicAdd(c, acc[i][j][r] * osc);
+        else *c += acc[i][j][r] * osc;
       }
 }
 
@@ -2069,13 +1716,13 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int g_tn_debug_wrap = 0;
 void set_gemm_tn_debug_wrap(int rows) { g_tn_debug_wrap = rows; }
 // 0: automatic, 1: only the generic 128x128 kernel, 2: the 256x256 LDS-DMA kernel whenever legal,
-// 3: the 128x256 LDS-DMA kernel whenever legal, 4: the 256x256 tile fed by a ring of four 32-deep stages (tests / profiling)
+// 3: the 128x256 LDS-DMA kernel whenever legal (tests / profiling)
 static int g_big_mode = 0;
 void set_gemm_nt_big_mode(int mode) { g_big_mode = mode; }
 // returns 0 (generic kernel), 1 (256x256) or 2 (128x256)
 static int gemm_nt_pick(const GemmNT& g) {
   if (g_big_mode == 1 || !g.vec_ok || g.K % 64 || g.N % 4) return 0;
-  if (g_big_mode == 2 || g_big_mode == 4) return 1;      // (4: the 256 x 256 tile fed by a four-stage ring, gemm_nt_ring_kernel)
+  if (g_big_mode == 2) return 1;
   if (g_big_mode == 3) return 2;
   const int ntail = g.N % BIG_BN;
   if (ntail && ntail < BIG_BN - BIG_BN / 8) return 0;   // no mostly-empty tile columns (1000 bars: the last of four is 232 wide)
@@ -2086,39 +1733,17 @@ static int gemm_nt_pick(const GemmNT& g) {
   return tiles256 >= 192 ? 1 : (tiles128 >= 192 ? 2 : 0);
 }
 
-static int g_nt_persist = 0;   // PFN_TUNE_GEMM_PERSIST: workgroups of the persistent kernel (0 = off)
-void set_gemm_nt_persist(int wgs) { g_nt_persist = wgs; }
-template <int FLAGS> static bool launch_persist_t(const GemmNT& g, hipStream_t stream) {
-  using C = BigCfg<2, 64>;
-  using P = PersistCfg<FLAGS>;
-  if (g_nt_persist <= 0 || (g.K / 64) % 2 || g.N % C::BN || !g.wide_t) return false;
-  if ((FLAGS & EPI_OUT_F32) && (g.ld_out_f32 % 4)) return false;
-  static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_persist_kernel<FLAGS>, P::LDS);
-  const int tiles = ((g.M + C::BM - 1) / C::BM) * (g.N / C::BN);
-  hipLaunchKernelGGL((gemm_nt_persist_kernel<FLAGS>), dim3(std::min(tiles, g_nt_persist)), dim3(512), P::LDS, stream, g);
-  return true;
-}
-template <int FLAGS> static bool launch_ring_t(const GemmNT& g, hipStream_t stream) {
-  using C = BigCfg<2, 32>;
-  if (g_big_mode != 4 || g.K % 32) return false;
-  static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_ring_kernel<FLAGS>, RING_NS * C::STAGE);
-  const int tiles = ((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
-  hipLaunchKernelGGL((gemm_nt_ring_kernel<FLAGS>), dim3(tiles), dim3(512), RING_NS * C::STAGE, stream, g);
-  return true;
-}
-template <int FLAGS, int NWM, int BK> static void launch_big_t(const GemmNT& g, hipStream_t stream) {
+template <typename T, int FLAGS, int NWM, int BK> static void launch_big_t(const GemmNT& g, hipStream_t stream) {
   using C = BigCfg<NWM, BK>;
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_big_kernel<FLAGS, NWM, BK>, 2 * C::STAGE);
+  allowance.ensure(gemm_nt_big_kernel<T, FLAGS, NWM, BK>, 2 * C::STAGE);
   const int tiles = ((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
-  hipLaunchKernelGGL((gemm_nt_big_kernel<FLAGS, NWM, BK>), dim3(tiles), dim3(C::NT), 2 * C::STAGE, stream, g);
+  hipLaunchKernelGGL((gemm_nt_big_kernel<T, FLAGS, NWM, BK>), dim3(tiles), dim3(C::NT), 2 * C::STAGE, stream, g);
 }
 // the epilogue flag combinations the encoder stack uses; anything else takes the generic kernel
-static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
+template <typename T> static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
   switch (g.flags) {
-#define PFN_BIG_CASE(F) case (F): if (small_tile) launch_big_t<(F), 1, 32>(g, stream); else if (!launch_ring_t<(F)>(g, stream) && !launch_persist_t<(F)>(g, stream)) launch_big_t<(F), 2, 64>(g, stream); return true;
+#define PFN_BIG_CASE(F) case (F): if (small_tile) launch_big_t<T, (F), 1, 32>(g, stream); else launch_big_t<T, (F), 2, 64>(g, stream); return true;
     PFN_BIG_CASE(EPI_BIAS | EPI_OUT_T)                            // q/k/v projection
     PFN_BIG_CASE(EPI_BIAS | EPI_RESID | EPI_OUT_F32)              // out_proj, linear2 (+ residual)
     PFN_BIG_CASE(EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T)    // linear1 + GELU
@@ -2138,7 +1763,7 @@ static bool launch_big(const GemmNT& g, bool small_tile, hipStream_t stream) {
 static void nt_prepare(GemmNT& g, int precision);
 bool gemm_nt_rowdot_fused(const GemmNT& g_in, int precision) {
   GemmNT g = g_in;
-  if (precision != PFN_PREC_BF16 || g.M <= 0 || g.flags != (EPI_OUT_T | EPI_ROWDOT) || g.N % 64 || g.rd_D % 64 || g.N % g.rd_D) return false;
+  if (!prec_is16(precision) || g.M <= 0 || g.flags != (EPI_OUT_T | EPI_ROWDOT) || g.N % 64 || g.rd_D % 64 || g.N % g.rd_D) return false;
   if ((g.lda * 2) % 16 || (g.ldb * 2) % 16 || !aligned16(g.A) || !aligned16(g.B)) return false;
   nt_prepare(g, precision);
   return gemm_nt_pick(g) == 1 && g.wide_t;      // the 256 x 256 tile only (the 4-wave 128 x 256 form has no registers left for the row sums: 56 bytes of scratch)
@@ -2146,21 +1771,21 @@ bool gemm_nt_rowdot_fused(const GemmNT& g_in, int precision) {
 int launch_gemm_nt(const GemmNT& g_in, int precision, hipStream_t stream) {
   GemmNT g = g_in;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return PFN_OK;
-  const size_t es = precision == PFN_PREC_BF16 ? 2 : 4;
+  const size_t es = prec_esize(precision);
   if ((g.lda * es) % 16 || (g.ldb * es) % 16 || !aligned16(g.A) || !aligned16(g.B)) return PFN_ERR_ALIGNMENT;
   nt_prepare(g, precision);
-  if (precision == PFN_PREC_BF16) {
+  if (prec_is16(precision)) {
     const int pick = gemm_nt_pick(g);
-    if (pick && launch_big(g, pick == 2, stream)) return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+    if (pick && (precision == PFN_PREC_FP16 ? launch_big<f16>(g, pick == 2, stream) : launch_big<bf16>(g, pick == 2, stream)))
+      return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
   }
   if (g.flags & EPI_ROWDOT) return PFN_ERR_UNSUPPORTED;      // (callers ask gemm_nt_rowdot_fused first)
   const int tiles = ((g.M + GEMM_BM - 1) / GEMM_BM) * ((g.N + GEMM_BN - 1) / GEMM_BN);
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, dim3(tiles), dim3(256), 65536, stream, g);
-  else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(tiles), dim3(256), 65536, stream, g);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(tiles), dim3(256), 65536, stream, g));
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 static void nt_prepare(GemmNT& g, int precision) {
-  const size_t es = precision == PFN_PREC_BF16 ? 2 : 4;
+  const size_t es = prec_esize(precision);
   // the epilogue moves 4 columns per lane when every stream it touches allows it
   bool vec = true;
   if ((g.flags & EPI_OUT_F32) && (g.ld_out_f32 % 4 || !aligned16(g.out_f32))) vec = false;
@@ -2175,7 +1800,7 @@ static void nt_prepare(GemmNT& g, int precision) {
 
 int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream) {
   if (g.M <= 0 || g.P <= 0 || g.Q <= 0) return PFN_OK;
-  const size_t es = precision == PFN_PREC_BF16 ? 2 : 4;
+  const size_t es = prec_esize(precision);
   if ((g.lda * es) % 16 || (g.ldb * es) % 16 || !aligned16(g.A) || !aligned16(g.B)) return PFN_ERR_ALIGNMENT;
   const int tp = (g.P + 127) / 128, tq = (g.Q + 127) / 128;
   int splits = (1024 + tp * tq - 1) / (tp * tq);
@@ -2189,8 +1814,7 @@ int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream) {
   splits = (g.M + chunk - 1) / chunk;
   g.m_chunk = chunk;
   const size_t lds = 4 * TN_BMK * 128 * es;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gemm_tn_kernel<bf16>, dim3(tq, tp, splits), dim3(256), lds, stream, g);
-  else hipLaunchKernelGGL(gemm_tn_kernel<float>, dim3(tq, tp, splits), dim3(256), lds, stream, g);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(tq, tp, splits), dim3(256), lds, stream, g));
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 
@@ -2199,34 +1823,32 @@ bool gemm_ln_supported(const GemmLN& g) {
          aligned16(g.A) && aligned16(g.B) && aligned16(g.bias) && aligned16(g.gamma) && aligned16(g.beta) && aligned16(g.y) && aligned16(g.x_t) &&
          (g.resid ? aligned16(g.resid) : (aligned16(g.ry) && aligned16(g.rgamma) && aligned16(g.rbeta)));
 }
-template <int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g, hipStream_t stream) {
+template <typename T, int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g, hipStream_t stream) {
   const size_t lds = std::max<size_t>(2 * (128 + NWN * 64) * (BK * 2), LnEpi<NWN>::BYTES);
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_ln_kernel<NWN, RL, BK>, lds);
-  hipLaunchKernelGGL((gemm_nt_ln_kernel<NWN, RL, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
+  allowance.ensure(gemm_nt_ln_kernel<T, NWN, RL, BK>, lds);
+  hipLaunchKernelGGL((gemm_nt_ln_kernel<T, NWN, RL, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
 }
 // PFN_TUNE_GEMM_LN_ROWS (test / profiling knob): 1 = the LayerNorm-fused GEMMs at N = 512 run on 64-ROW tiles (4 waves x (2 x 4) blocks, 32-deep stages:
 // 72 KiB of LDS, 256 registers per wave) so that TWO workgroups share a CU and one's HBM-bound epilogue can run under the other's MFMA loop; 0 = the
 // 128-row tiles that fill the CU's LDS alone
 static int g_ln_rows64 = 0;
 void set_gemm_ln_rows64(int on) { g_ln_rows64 = on; }
-template <int NWN, bool RL, int BK, int MI, int NJ> static void launch_gemm_ln_wide_t(const GemmLN& g, hipStream_t stream) {
+template <typename T, int NWN, bool RL, int BK, int MI, int NJ> static void launch_gemm_ln_wide_t(const GemmLN& g, hipStream_t stream) {
   constexpr int BM = MI * 32;
   const size_t lds = std::max<size_t>(2 * (BM + NWN * NJ * 32) * (BK * 2), LnEpiW<NWN, MI, NJ>::BYTES);
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_ln_wide_kernel<NWN, RL, BK, MI, NJ>, lds);
-  hipLaunchKernelGGL((gemm_nt_ln_wide_kernel<NWN, RL, BK, MI, NJ>), dim3((g.M + BM - 1) / BM), dim3(NWN * 64), lds, stream, g);
+  allowance.ensure(gemm_nt_ln_wide_kernel<T, NWN, RL, BK, MI, NJ>, lds);
+  hipLaunchKernelGGL((gemm_nt_ln_wide_kernel<T, NWN, RL, BK, MI, NJ>), dim3((g.M + BM - 1) / BM), dim3(NWN * 64), lds, stream, g);
 }
-int launch_gemm_ln(const GemmLN& g, hipStream_t stream) {
-  if (g.M <= 0) return PFN_OK;
-  if (!gemm_ln_supported(g)) return PFN_ERR_UNSUPPORTED;
+template <typename T> static int launch_gemm_ln_op(const GemmLN& g, hipStream_t stream) {
   const bool rl = g.resid == nullptr;
   // 64-deep stages (two of them fill the CU's 160 KiB of LDS at N = 512) whenever K allows, else 32-deep
 #define PFN_LN_CASE(NWN) \
-  if (g.K % 64 == 0) { if (rl) launch_gemm_ln_t<NWN, true, 64>(g, stream); else launch_gemm_ln_t<NWN, false, 64>(g, stream); } \
-  else { if (rl) launch_gemm_ln_t<NWN, true, 32>(g, stream); else launch_gemm_ln_t<NWN, false, 32>(g, stream); }
+  if (g.K % 64 == 0) { if (rl) launch_gemm_ln_t<T, NWN, true, 64>(g, stream); else launch_gemm_ln_t<T, NWN, false, 64>(g, stream); } \
+  else { if (rl) launch_gemm_ln_t<T, NWN, true, 32>(g, stream); else launch_gemm_ln_t<T, NWN, false, 32>(g, stream); }
   if (g.N == 512 && g_ln_rows64) {
-    if (rl) launch_gemm_ln_wide_t<4, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<4, false, 32, 2, 4>(g, stream);
+    if (rl) launch_gemm_ln_wide_t<T, 4, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<T, 4, false, 32, 2, 4>(g, stream);
     return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
   }
   switch (g.N / 64) {
@@ -2234,54 +1856,63 @@ int launch_gemm_ln(const GemmLN& g, hipStream_t stream) {
     case 4: PFN_LN_CASE(4) break;
     case 8: PFN_LN_CASE(8) break;
     default:   // N = 1024: 64 rows x (8 waves x 128 columns), 32-deep stages (two of them are 136 KiB)
-      if (rl) launch_gemm_ln_wide_t<8, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<8, false, 32, 2, 4>(g, stream);
+      if (rl) launch_gemm_ln_wide_t<T, 8, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<T, 8, false, 32, 2, 4>(g, stream);
       break;
   }
 #undef PFN_LN_CASE
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+int launch_gemm_ln(const GemmLN& g, int precision, hipStream_t stream) {
+  if (g.M <= 0) return PFN_OK;
+  if (!prec_is16(precision) || !gemm_ln_supported(g)) return PFN_ERR_UNSUPPORTED;
+  return precision == PFN_PREC_FP16 ? launch_gemm_ln_op<f16>(g, stream) : launch_gemm_ln_op<bf16>(g, stream);
 }
 
 bool gemm_lnbwd_supported(const GemmLNB& g) {
   return (g.N == 128 || g.N == 256 || g.N == 512 || g.N == 1024) && g.K % 32 == 0 && g.K >= 32 && (g.lda * 2) % 16 == 0 && (g.ldb * 2) % 16 == 0 &&
          aligned16(g.A) && aligned16(g.B) && aligned16(g.aux) && aligned16(g.y) && aligned16(g.gamma) && aligned16(g.dx_t) && g.dgamma && g.dbeta;
 }
-template <int NWN, int BK> static void launch_gemm_lnbwd_t(const GemmLNB& g, hipStream_t stream) {
+template <typename T, int NWN, int BK> static void launch_gemm_lnbwd_t(const GemmLNB& g, hipStream_t stream) {
   const size_t lds = LnbCfg<NWN, BK>::LDS;
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_lnbwd_kernel<NWN, BK>, lds);
-  hipLaunchKernelGGL((gemm_nt_lnbwd_kernel<NWN, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
+  allowance.ensure(gemm_nt_lnbwd_kernel<T, NWN, BK>, lds);
+  hipLaunchKernelGGL((gemm_nt_lnbwd_kernel<T, NWN, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
 }
-template <int NWN, int BK, int MI, int NJ> static void launch_gemm_lnbwd_wide_t(const GemmLNB& g, hipStream_t stream) {
+template <typename T, int NWN, int BK, int MI, int NJ> static void launch_gemm_lnbwd_wide_t(const GemmLNB& g, hipStream_t stream) {
   const size_t lds = LnbCfgW<NWN, BK, MI, NJ>::LDS;
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_lnbwd_wide_kernel<NWN, BK, MI, NJ>, lds);
-  hipLaunchKernelGGL((gemm_nt_lnbwd_wide_kernel<NWN, BK, MI, NJ>), dim3((g.M + MI * 32 - 1) / (MI * 32)), dim3(NWN * 64), lds, stream, g);
+  allowance.ensure(gemm_nt_lnbwd_wide_kernel<T, NWN, BK, MI, NJ>, lds);
+  hipLaunchKernelGGL((gemm_nt_lnbwd_wide_kernel<T, NWN, BK, MI, NJ>), dim3((g.M + MI * 32 - 1) / (MI * 32)), dim3(NWN * 64), lds, stream, g);
 }
-int launch_gemm_lnbwd(const GemmLNB& g, hipStream_t stream) {
-  if (g.M <= 0) return PFN_OK;
-  if (!gemm_lnbwd_supported(g)) return PFN_ERR_UNSUPPORTED;
-#define PFN_LNB_CASE(NWN) if (g.K % 64 == 0) launch_gemm_lnbwd_t<NWN, 64>(g, stream); else launch_gemm_lnbwd_t<NWN, 32>(g, stream);
+template <typename T> static int launch_gemm_lnbwd_op(const GemmLNB& g, hipStream_t stream) {
+#define PFN_LNB_CASE(NWN) if (g.K % 64 == 0) launch_gemm_lnbwd_t<T, NWN, 64>(g, stream); else launch_gemm_lnbwd_t<T, NWN, 32>(g, stream);
   if (g.N == 512 && g_ln_rows64) {
-    launch_gemm_lnbwd_wide_t<4, 32, 2, 4>(g, stream);
+    launch_gemm_lnbwd_wide_t<T, 4, 32, 2, 4>(g, stream);
     return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
   }
   switch (g.N / 64) {
     case 2: PFN_LNB_CASE(2) break;
     case 4: PFN_LNB_CASE(4) break;
     case 8: PFN_LNB_CASE(8) break;
-    default: launch_gemm_lnbwd_wide_t<8, 32, 2, 4>(g, stream); break;     // N = 1024: 64-row tiles, 32-deep stages
+    default: launch_gemm_lnbwd_wide_t<T, 8, 32, 2, 4>(g, stream); break;     // N = 1024: 64-row tiles, 32-deep stages
   }
 #undef PFN_LNB_CASE
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+}
+int launch_gemm_lnbwd(const GemmLNB& g, int precision, hipStream_t stream) {
+  if (g.M <= 0) return PFN_OK;
+  if (!prec_is16(precision) || !gemm_lnbwd_supported(g)) return PFN_ERR_UNSUPPORTED;
+  return precision == PFN_PREC_FP16 ? launch_gemm_lnbwd_op<f16>(g, stream) : launch_gemm_lnbwd_op<bf16>(g, stream);
 }
 
 bool gemm_tn_group_supported(const TnProblem& p) {
   return p.P % 256 == 0 && p.Q % 256 == 0 && (p.lda * 2) % 16 == 0 && (p.ldb * 2) % 16 == 0 && aligned16(p.A) && aligned16(p.B);
 }
 
-int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream) {
+int launch_gemm_tn_group(GemmTNGroup g, int precision, hipStream_t stream) {
   if (g.n <= 0 || g.M <= 0) return PFN_OK;
   if (g.n > TN_GROUP_MAX) return PFN_ERR_ARGUMENT;
+  if (!prec_is16(precision)) return PFN_ERR_UNSUPPORTED;
   int tiles = 0;
   for (int i = 0; i < g.n; ++i) {
     if (!gemm_tn_group_supported(g.p[i])) return PFN_ERR_UNSUPPORTED;
@@ -2307,9 +1938,14 @@ int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream) {
   g.splits = splits;
   g.m_chunk = chunk;
   g.debug_mask = g_tn_debug_wrap > 0 ? g_tn_debug_wrap - 1 : 0x7fffffff;
-  static LdsAllowance allowance;
-  allowance.ensure(gemm_tn_big_kernel, TNB_LDS);
-  hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(tiles * splits), dim3(512), TNB_LDS, stream, g);
+  static LdsAllowance allowance[2];
+  if (precision == PFN_PREC_FP16) {
+    allowance[1].ensure(gemm_tn_big_kernel<f16>, TNB_LDS);
+    hipLaunchKernelGGL(gemm_tn_big_kernel<f16>, dim3(tiles * splits), dim3(512), TNB_LDS, stream, g);
+  } else {
+    allowance[0].ensure(gemm_tn_big_kernel<bf16>, TNB_LDS);
+    hipLaunchKernelGGL(gemm_tn_big_kernel<bf16>, dim3(tiles * splits), dim3(512), TNB_LDS, stream, g);
+  }
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 

@@ -62,11 +62,11 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
-inline int esize(int prec) { return prec == PFN_PREC_BF16 ? 2 : 4; }
+inline int esize(int prec) { return prec_esize(prec); }
 
 int check_desc(const pfn_model_desc* d) {
   if (!d) return fail(PFN_ERR_ARGUMENT, "null model descriptor");
-  if (d->precision != PFN_PREC_BF16 && d->precision != PFN_PREC_F32) return fail(PFN_ERR_ARGUMENT, "bad precision %d", d->precision);
+  if (d->precision != PFN_PREC_BF16 && d->precision != PFN_PREC_F32 && d->precision != PFN_PREC_FP16) return fail(PFN_ERR_ARGUMENT, "bad precision %d", d->precision);
   if (d->num_features < 1 || d->emsize < 8 || d->nhead < 1 || d->nhid < 8 || d->nlayers < 0 || d->n_out < 0)
     return fail(PFN_ERR_ARGUMENT, "bad model dimensions");   // n_out == 0: no decoder -- the stack returns the encoder's test rows
   if (d->emsize % d->nhead) return fail(PFN_ERR_ARGUMENT, "emsize %d not divisible by nhead %d", d->emsize, d->nhead);
@@ -143,6 +143,7 @@ struct Ws {
   // the top layer on the test rows only (top_layer_on_test_rows below): compact [S - sep, B] row order
   char *top_ctx_t, *top_dy1_t, *top_dctx_t;   // attention output / LN1-input gradient / d(attention output) of the test rows
   float *top_ry, *top_rmean, *top_rrstd;      // the layer input (the residual of its first LayerNorm) of the test rows
+  float* lscale;                              // PFN_PREC_FP16: max|dlogits| of the running backward call, from which every kernel derives the loss scale (pfn_device.h)
   float* ln_part;                             // PFN_SCHED_DETERMINISTIC: per-workgroup column sums of the LayerNorm backward (launch_layernorm_bwd `partials`)
   int64_t bytes;
 };
@@ -182,6 +183,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   const int64_t Mtop = (d.nlayers > 0 && d.dropout == 0.f && !(d.schedule & PFN_SCHED_TOP_LAYER_ALL_ROWS)) ? (int64_t)B * (S - (S + 3) / 4) : 0;
   w.top_ctx_t = take(Mtop * E * es); w.top_dy1_t = take(Mtop * E * es); w.top_dctx_t = take(Mtop * E * es);
   w.top_ry = (float*)take(Mtop * E * 4); w.top_rmean = (float*)take(Mtop * 4); w.top_rrstd = (float*)take(Mtop * 4);
+  w.lscale = (float*)take(256);
   w.ln_part = (d.schedule & PFN_SCHED_DETERMINISTIC) ? (float*)take((int64_t)LNB_MAX_BLOCKS * 3 * E * 4) : nullptr;
   w.bytes = cur;
   return w;
@@ -248,7 +250,6 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_GEMM_NT_KERNEL: set_gemm_nt_big_mode(value); return PFN_OK;
     case PFN_TUNE_GEMM_TN_WRAP: set_gemm_tn_debug_wrap(value); return PFN_OK;
     case PFN_TUNE_FUSE_LNBWD: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_SEPARATE_LNBWD) : (g_default_schedule | PFN_SCHED_SEPARATE_LNBWD); return PFN_OK;
-    case PFN_TUNE_GEMM_PERSIST: set_gemm_nt_persist(value); return PFN_OK;
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
     case PFN_TUNE_GEMM_LN_ROWS: set_gemm_ln_rows64(value); return PFN_OK;
     case PFN_TUNE_GP_PLANES: g_gp_planes = value != 0; return PFN_OK;
@@ -383,7 +384,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   probe.A = w.x0_t; probe.lda = E; probe.B = sh; probe.ldb = E; probe.M = M; probe.N = E; probe.K = E;
   probe.bias = params; probe.gamma = params; probe.beta = params; probe.resid = w.x0; probe.y = w.x0; probe.x_t = w.x0_t;
   // (dropout sits between the bias and the residual add: it takes the unfused GEMM / LayerNorm kernels with an element-wise pass between)
-  const bool fuse_ln = prec == PFN_PREC_BF16 && gemm_ln_supported(probe) && F % 32 == 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));
+  const bool fuse_ln = prec_is16(prec) && gemm_ln_supported(probe) && F % 32 == 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));
   struct Resid { const float* plain; const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; };
   Resid res = {w.x0, nullptr, nullptr, nullptr, nullptr, nullptr};   // where the layer input lives in f32
   auto set_resid = [](GemmLN& g, const Resid& r) {
@@ -436,7 +437,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       set_resid(g, res);
       g.gamma = params + p.g1; g.beta = params + p.be1; g.eps = d->ln_eps;
       g.y = a.y1; g.mean = a.mean1; g.rstd = a.rstd1; g.x_t = a.x1_t;
-      PFN_TRY(launch_gemm_ln(g, s));
+      PFN_TRY(launch_gemm_ln(g, prec, s));
       res = Resid{nullptr, a.y1, a.mean1, a.rstd1, params + p.g1, params + p.be1};
     } else {
       {  // out_proj + residual  (dropout1: the product leaves alone and the element-wise pass adds the residual)
@@ -463,7 +464,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       g.gamma = params + p.g2; g.beta = params + p.be2; g.eps = d->ln_eps;
       g.y = a.y2; g.mean = a.mean2; g.rstd = a.rstd2; g.x_t = a.x2_t;
       g.x_f32 = (l == d->nlayers - 1) ? x2_f32 : nullptr;
-      PFN_TRY(launch_gemm_ln(g, s));
+      PFN_TRY(launch_gemm_ln(g, prec, s));
       res = Resid{nullptr, a.y2, a.mean2, a.rstd2, params + p.g2, params + p.be2};
     } else {
       {  // linear2 + residual  (dropout2 as above)
@@ -560,7 +561,8 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
   // PFN_SCHED_DETERMINISTIC: one writer per gradient element and launch -- no token splits in the weight-gradient GEMMs, the LayerNorm backward as its own
   // kernel with ordered partial sums, the embedding gradient from one workgroup per column block
   const bool det = (d->schedule & PFN_SCHED_DETERMINISTIC) != 0;
-  auto tn_det = [&](GemmTN g) { if (det) g.max_splits = 1; return g; };
+  const float* lsc = nullptr;      // fp16 operands: the device float the loss scale is derived from (set below, once the workspace is carved); else no scaling
+  auto tn_det = [&](GemmTN g) { if (det) g.max_splits = 1; g.scale_amax = lsc; return g; };
   auto dseed = [&](int layer, int site) { return dropout_site_seed(dropout_seed, layer, site); };
   if (!params || !shadow || !workspace || !grads) return fail(PFN_ERR_ARGUMENT, "null pointer");
   if (!dsrc_sbe && (!x || !y)) return fail(PFN_ERR_ARGUMENT, "need x and y (or dsrc_sbe)");
@@ -576,15 +578,22 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
   auto W = [&](int64_t off) { return (const void*)(sh + off * es); };
   auto WT = [&](int64_t off) { return (const void*)(sh + (L.total + off) * es); };
 
+  // fp16 operands: the backward chain runs on dlogits * 2^k, k from max|dlogits| on the device; every kernel that writes a parameter gradient takes 2^k out again
+  if (prec == PFN_PREC_FP16 && Mt > 0) {
+    if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
+    PFN_TRY(launch_absmax(dlogits, (long)Mt * (O > 0 ? O : E), w.lscale, s));
+    lsc = w.lscale;
+  }
   // ---- decoder ----
   const float* dxt = w.dxt;
   const char* xt_t = top_mode ? w.layer[d->nlayers - 1].x2_t : w.xt_t;      // the decoder's input rows (forward)
   if (Mt > 0 && O == 0) {
     if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
     dxt = dlogits;   // no decoder: the incoming gradient already is d(test rows) [Mt, E]
+    if (lsc) { PFN_TRY(launch_scale_copy(dlogits, w.dxt, (long)Mt * E, lsc, s)); dxt = w.dxt; }
   } else if (Mt > 0) {
     if (!dlogits) return fail(PFN_ERR_ARGUMENT, "null dlogits");
-    PFN_TRY(launch_cast_rows(dlogits, O, w.dlog_t, npad, Mt, O, prec, s));
+    PFN_TRY(launch_cast_rows(dlogits, O, w.dlog_t, npad, Mt, O, prec, s, lsc));
     // the decoder's two weight gradients: one grouped launch of 256 x 256 tiles when the shapes allow (bars padded to a multiple of
     // 256 by the zero columns of dlog_t: Pv bounds the rows that exist), else a split-K launch each
     TnProblem dp2; memset(&dp2, 0, sizeof(dp2));
@@ -592,7 +601,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     dp2.colsum = grads + L.dec2_b;
     TnProblem dp0; memset(&dp0, 0, sizeof(dp0));
     dp0.A = w.dd_t; dp0.lda = F; dp0.B = xt_t; dp0.ldb = E; dp0.C = grads + L.dec0_w; dp0.ldc = E; dp0.P = F; dp0.Q = E; dp0.colsum = grads + L.dec0_b;
-    const bool dec_grouped = prec == PFN_PREC_BF16 && gemm_tn_group_supported(dp2) && gemm_tn_group_supported(dp0);
+    const bool dec_grouped = prec_is16(prec) && gemm_tn_group_supported(dp2) && gemm_tn_group_supported(dp0);
     if (!dec_grouped) PFN_TRY(launch_gemm_tn(tn_det(tn(w.dlog_t, npad, w.dt, F, grads + L.dec2_w, F, Mt, O, F, grads + L.dec2_b)), prec, s));
     {
       // (contraction over the zero-padded width when that is whole 64-deep stages: the LDS-DMA kernel then takes it)
@@ -602,8 +611,8 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     }
     if (dec_grouped) {
       GemmTNGroup g; memset(&g, 0, sizeof(g));
-      g.n = 2; g.M = Mt; g.p[0] = dp2; g.p[1] = dp0; g.splits = det ? 1 : 0;
-      PFN_TRY(launch_gemm_tn_group(g, s));
+      g.n = 2; g.M = Mt; g.p[0] = dp2; g.p[1] = dp0; g.splits = det ? 1 : 0; g.scale_amax = lsc;
+      PFN_TRY(launch_gemm_tn_group(g, prec, s));
     } else {
       PFN_TRY(launch_gemm_tn(tn_det(tn(w.dd_t, F, xt_t, E, grads + L.dec0_w, E, Mt, F, E, grads + L.dec0_b)), prec, s));
     }
@@ -630,15 +639,15 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
                  const float* gamma, void* dx_t, float* dgamma, float* dbeta, int rows) {
     GemmLNB g; memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = Bw; g.ldb = ldb; g.M = rows; g.N = E; g.K = K; g.aux = aux;
-    g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta;
+    g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta; g.scale_amax = lsc;
     return g;
   };
   // The embedding's weight gradients d(src)^T . [x | masked y | train flag] are a (skinny) weight-gradient GEMM like the others:
   // embed_fwd left the augmented inputs in operand precision, the first layer's dx leaves in operand precision, and the
   // split-K TN kernel does the rest (the register kernel it replaces streamed d(src) at 0.7 TB/s).  Custom encoders
   // (dsrc_sbe), the exact-f32 mode and wide encoders keep the f32 path.
-  const bool emb_gemm = !dsrc_sbe && prec == PFN_PREC_BF16 && d->nlayers > 0 && d->num_features + 2 <= EMB_AUG && E % 8 == 0;
-  bool fuse_lnb = !det && !(d->schedule & PFN_SCHED_SEPARATE_LNBWD) && prec == PFN_PREC_BF16 && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
+  const bool emb_gemm = !dsrc_sbe && prec_is16(prec) && d->nlayers > 0 && d->num_features + 2 <= EMB_AUG && E % 8 == 0;
+  bool fuse_lnb = !det && !(d->schedule & PFN_SCHED_SEPARATE_LNBWD) && prec_is16(prec) && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
   if (fuse_lnb) {
     const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
     fuse_lnb = gemm_lnbwd_supported(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, a.dy1_t, grads + p.g1, grads + p.be1, M)) &&
@@ -665,7 +674,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
       add(a.dqkv_t, 3 * E, xin_t, E, grads + p.w_in, E, 3 * E, E, grads + p.b_in);
     }
     if (!probs_top.empty()) {
-      bool grouped_top = prec == PFN_PREC_BF16;
+      bool grouped_top = prec_is16(prec);
       for (const TnProblem& t : probs_top) grouped_top = grouped_top && gemm_tn_group_supported(t);
       if (grouped_top) {
         ProfScope ps(PFN_PROF_WGRAD + 1, s);
@@ -674,14 +683,15 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
         g.n = (int)probs_top.size();
         g.M = Mt;
         g.splits = det ? 1 : 0;
+        g.scale_amax = lsc;
         for (int i = 0; i < g.n; ++i) g.p[i] = probs_top[i];
-        PFN_TRY(launch_gemm_tn_group(g, s));
+        PFN_TRY(launch_gemm_tn_group(g, prec, s));
       } else {
         for (const TnProblem& t : probs_top)
           PFN_TRY(launch_gemm_tn(tn_det(tn(t.A, t.lda, t.B, t.ldb, t.C, t.ldc, Mt, t.P, t.Q, t.colsum)), prec, s));
       }
     }
-    bool grouped = prec == PFN_PREC_BF16;
+    bool grouped = prec_is16(prec);
     for (const TnProblem& t : probs) grouped = grouped && gemm_tn_group_supported(t);
     if (grouped) {
       for (size_t i0 = 0; i0 < probs.size(); i0 += TN_GROUP_MAX) {
@@ -691,8 +701,9 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
         g.n = (int)std::min<size_t>(TN_GROUP_MAX, probs.size() - i0);
         g.M = M;
         g.splits = det ? 1 : 0;
+        g.scale_amax = lsc;
         for (int i = 0; i < g.n; ++i) g.p[i] = probs[i0 + i];
-        PFN_TRY(launch_gemm_tn_group(g, s));
+        PFN_TRY(launch_gemm_tn_group(g, prec, s));
       }
     } else {  // exact-f32 parity mode and shapes outside the 256-tile kernel: one split-K launch per gradient
       for (const TnProblem& t : probs)
@@ -715,7 +726,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     // the residual path keeps the unmasked one, and the two bias gradients become column sums of the masked operands (weight-gradient launch)
     if (!fuse_lnb || l == d->nlayers - 1)
       PFN_TRY(launch_layernorm_bwd(top ? (const void*)dxt : (const void*)w.gA_t, top ? 0 : 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t,
-                                   grads + p.g2, grads + p.be2, pdrop > 0.f ? nullptr : grads + p.b2, Ml, E, prec, s, w.ln_part));
+                                   grads + p.g2, grads + p.be2, pdrop > 0.f ? nullptr : grads + p.b2, Ml, E, prec, s, w.ln_part, lsc));
     const char* dy2_op = a.dy2_t;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy2_t, a.dy2m_t, nullptr, nullptr, M, E, dseed(l, 3), pdrop, prec, s)); dy2_op = a.dy2m_t; }
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
@@ -726,7 +737,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     }
     if (fuse_lnb) {  // dy1 = LN1 backward of (dh . W1 + dy2)
       ProfScope ps(PFN_PROF_GEMM_DY1 + (top ? 1 : 0), s);
-      PFN_TRY(launch_gemm_lnbwd(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, dy1_t, grads + p.g1, grads + p.be1, Ml), s));
+      PFN_TRY(launch_gemm_lnbwd(lnb(a.dh_t, F, WT(t.w1), F, F, a.dy2_t, a.y1, a.mean1, a.rstd1, params + p.g1, dy1_t, grads + p.g1, grads + p.be1, Ml), prec, s));
     } else {
       {  // dx1 = dh . W1 + dy2
         GemmNT g = nt(a.dh_t, F, WT(t.w1), F, Ml, E, F, EPI_RESID_T | EPI_OUT_T);
@@ -734,7 +745,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
         PFN_TRY(launch_gemm_nt(g, prec, s));
       }
       PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, dy1_t, grads + p.g1, grads + p.be1,
-                                   pdrop > 0.f ? nullptr : grads + p.b_o, Ml, E, prec, s, w.ln_part));
+                                   pdrop > 0.f ? nullptr : grads + p.b_o, Ml, E, prec, s, w.ln_part, lsc));
     }
     const char* dy1_op = dy1_t;
     bool delta_fused = false;
@@ -787,7 +798,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
       const LayerP& pb = L.layer[l - 1];
       LayerWs& ab = w.layer[l - 1];
       PFN_TRY(launch_gemm_lnbwd(lnb(a.dqkv_t, 3 * E, WT(t.w_in), 3 * E, 3 * E, a.dy1_t, ab.y2, ab.mean2, ab.rstd2, params + pb.g2, ab.dy2_t,
-                                    grads + pb.g2, grads + pb.be2, M), s));
+                                    grads + pb.g2, grads + pb.be2, M), prec, s));
     } else {  // dx = dqkv . Win + dy1
       // the gradient stays in operand precision between layers; the embedding's gradient (layer 0) too when its weight
       // gradients are computed as a GEMM (emb_gemm below), else it leaves in f32
@@ -805,10 +816,11 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
   if (d->nlayers > 0) PFN_TRY(launch_weight_gradients(split_at >= 0 ? split_at - 1 : d->nlayers - 1, 0));
   // ---- embedding ----
   if (dsrc_sbe) {
-    PFN_TRY(launch_bse_to_sbe(w.gA, dsrc_sbe, S, B, E, s));
+    PFN_TRY(launch_bse_to_sbe(w.gA, dsrc_sbe, S, B, E, s, lsc));
   } else if (emb_gemm) {
     if (hipMemsetAsync(w.embacc, 0, sizeof(float) * E * EMB_AUG, s) != hipSuccess) return fail(PFN_ERR_LAUNCH, "memset");
     GemmTN g = tn(w.gA_t, E, w.xaug_t, EMB_AUG, w.embacc, EMB_AUG, M, E, EMB_AUG, grads + L.enc_b);
+    g.scale_amax = lsc;
     g.max_splits = det ? 1 : 128;      // a 512 x 32 result: measured 67 / 62 / 88 us with 64 / 128 / 256 splits (the partial sums are added atomically)
     PFN_TRY(launch_gemm_tn(g, prec, s));
     PFN_TRY(launch_embed_grad_scatter(w.embacc, grads + L.enc_w, grads + L.yenc_w, grads + L.yenc_b, E, d->num_features, s));
@@ -816,7 +828,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     EmbedBwdArgs e;
     e.dsrc = w.gA; e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;
     e.dwx = grads + L.enc_w; e.dbx = grads + L.enc_b; e.dwy = grads + L.yenc_w; e.dby = grads + L.yenc_b;
-    e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep; e.sep_of = sep_of; e.single_block = det ? 1 : 0;
+    e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep; e.sep_of = sep_of; e.single_block = det ? 1 : 0; e.scale_amax = lsc;
     PFN_TRY(launch_embed_bwd(e, s));
   }
   return PFN_OK;
@@ -929,7 +941,7 @@ int pfn_op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float
   return PFN_OK;
 }
 int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, float* const* C,
-                         const int64_t* ldc, const int32_t* P, const int32_t* Q, float* const* colsum, int M, int splits, void* stream) {
+                         const int64_t* ldc, const int32_t* P, const int32_t* Q, float* const* colsum, int M, int splits, int prec, void* stream) {
   if (n < 1 || n > TN_GROUP_MAX || !A || !lda || !B || !ldb || !C || !ldc || !P || !Q) return fail(PFN_ERR_ARGUMENT, "bad gemm_tn_group arguments");
   GemmTNGroup g;
   memset(&g, 0, sizeof(g));
@@ -939,28 +951,28 @@ int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const 
     t.A = A[i]; t.lda = lda[i]; t.B = B[i]; t.ldb = ldb[i]; t.C = C[i]; t.ldc = ldc[i]; t.P = P[i]; t.Q = Q[i];
     t.colsum = colsum ? colsum[i] : nullptr;
   }
-  PFN_TRY(launch_gemm_tn_group(g, (hipStream_t)stream));
+  PFN_TRY(launch_gemm_tn_group(g, prec, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
                    const float* resid, const float* ry, const float* rmean, const float* rrstd, const float* rgamma, const float* rbeta,
-                   const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd, void* x_t, void* stream) {
+                   const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd, void* x_t, int prec, void* stream) {
   GemmLN g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.bias = bias; g.resid = resid;
   g.ry = ry; g.rmean = rmean; g.rrstd = rrstd; g.rgamma = rgamma; g.rbeta = rbeta; g.gamma = gamma; g.beta = beta; g.eps = eps;
   g.y = y; g.mean = mean; g.rstd = rstd; g.x_t = x_t;
-  PFN_TRY(launch_gemm_ln(g, (hipStream_t)stream));
+  PFN_TRY(launch_gemm_ln(g, prec, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_gemm_lnbwd(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const void* aux,
                       const float* y, const float* mean, const float* rstd, const float* gamma,
-                      void* dx_t, float* dgamma, float* dbeta, void* stream) {
+                      void* dx_t, float* dgamma, float* dbeta, int prec, void* stream) {
   GemmLNB g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.aux = aux;
   g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta;
-  PFN_TRY(launch_gemm_lnbwd(g, (hipStream_t)stream));
+  PFN_TRY(launch_gemm_lnbwd(g, prec, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep, int prec, void* stream) {

@@ -27,11 +27,25 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// fp16 operands (round 6): 11-bit significand at the same MFMA rate and bytes as bf16 (v_mfma_f32_32x32x16_f16) -- the operand format that brings the
+// TIMED forward under the north star's 1e-3 (profiles/r06_operand_format_simulation.json); gradients travel under a power-of-two loss scale (LossScale below)
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// vector types of an operand element type (the 16-bit ones; float only so that discarded `if constexpr` branches still name a type)
+template <typename T> struct OpVec;
+template <> struct OpVec<bf16> { typedef bf16x8 x8; typedef bf16x4 x4; typedef bf16x2 x2; };
+template <> struct OpVec<f16> { typedef f16x8 x8; typedef f16x4 x4; typedef f16x2 x2; };
+template <> struct OpVec<float> { typedef f32x4 x8; typedef f32x4 x4; typedef f32x2 x2; };
+template <typename T> using X8 = typename OpVec<T>::x8;
+template <typename T> using X4 = typename OpVec<T>::x4;
+template <typename T> using X2 = typename OpVec<T>::x2;
 
 #define PFN_DEV __device__ __forceinline__
 // Scheduling fence for LDS and MFMA instructions only (vector / scalar ALU and global memory instructions may still
@@ -49,6 +63,10 @@ template <> struct Frag<bf16> {
   bf16x8 v;
   PFN_DEV void set(int e, float x) { v[e] = (bf16)x; }
 };
+template <> struct Frag<f16> {
+  f16x8 v;
+  PFN_DEV void set(int e, float x) { v[e] = (f16)x; }
+};
 template <> struct Frag<float> {
   float v[8];
   PFN_DEV void set(int e, float x) { v[e] = x; }
@@ -56,6 +74,9 @@ template <> struct Frag<float> {
 
 PFN_DEV f32x16 mma32(const Frag<bf16>& a, const Frag<bf16>& b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+}
+PFN_DEV f32x16 mma32(const Frag<f16>& a, const Frag<f16>& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, c, 0, 0, 0);
 }
 // exact-f32 path: eight 32x32x2 steps; step e contracts slots (0,e) and (1,e).
 PFN_DEV f32x16 mma32(const Frag<float>& a, const Frag<float>& b, f32x16 c) {
@@ -72,6 +93,9 @@ PFN_DEV f32x16 mma32(const Frag<float>& a, const Frag<float>& b, f32x16 c) {
 // epilogue that reads the accumulators first waits out the MFMA -> reader hazard (mma32_acc_drain).
 PFN_DEV void mma32_acc(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
   asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a.v), "v"(b.v));
+}
+PFN_DEV void mma32_acc(f32x16& acc, const Frag<f16>& a, const Frag<f16>& b) {
+  asm("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a.v), "v"(b.v));
 }
 PFN_DEV void mma32_acc(f32x16& acc, const Frag<float>& a, const Frag<float>& b) { acc = mma32(a, b, acc); }
 PFN_DEV void mma32_acc_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
@@ -132,7 +156,7 @@ template <typename T, int RB> PFN_DEV Frag<T> load_frag_row(const lds_char* tile
   Frag<T> f;
   if constexpr (sizeof(T) == 2) {
     u32x4 raw = lds_read16(tile + lds_off16<RB>(row, (k0 >> 3) + h));
-    f.v = __builtin_bit_cast(bf16x8, raw);
+    f.v = __builtin_bit_cast(typename OpVec<T>::x8, raw);
   } else {
     const int c = (k0 >> 2) + 2 * h;
     u32x4 r0 = lds_read16(tile + lds_off16<RB>(row, c));
@@ -144,8 +168,9 @@ template <typename T, int RB> PFN_DEV Frag<T> load_frag_row(const lds_char* tile
   return f;
 }
 
-PFN_DEV bf16x4 ds_read_tr16_b64(const lds_char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+template <typename T> PFN_DEV typename OpVec<T>::x4 ds_read_tr16_b64(const lds_char* p) {      // the same instruction for every 2-byte element type
+  return __builtin_bit_cast(typename OpVec<T>::x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p)));
 }
 
 // Transposed fragment from a swz64 tile whose ROWS are the contraction index and whose columns
@@ -160,8 +185,8 @@ template <typename T, int RB, int MAP> PFN_DEV Frag<T> load_frag_tr(const lds_ch
     const int colb = (col0 + 16 * g + 4 * (i & 3)) * 2;
     const int ra = (MAP == 1) ? (k0 + 8 * h) : (k0 + 4 * h);
     const int rb = (MAP == 1) ? (k0 + 8 * h + 4) : (k0 + 8 + 4 * h);
-    bf16x4 lo = ds_read_tr16_b64(tile + lds_off64<RB>(ra + (i >> 2), colb));
-    bf16x4 hi = ds_read_tr16_b64(tile + lds_off64<RB>(rb + (i >> 2), colb));
+    const auto lo = ds_read_tr16_b64<T>(tile + lds_off64<RB>(ra + (i >> 2), colb));
+    const auto hi = ds_read_tr16_b64<T>(tile + lds_off64<RB>(rb + (i >> 2), colb));
     f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   } else {
     const int colb = (col0 + (l & 31)) * 4;
@@ -194,7 +219,7 @@ template <typename T, int STRIDE> PFN_DEV Frag<T> load_frag_row_p(const lds_char
   Frag<T> f;
   if constexpr (sizeof(T) == 2) {
     u32x4 raw = lds_read16(tile + row * STRIDE + ((k0 >> 3) + h) * 16);
-    f.v = __builtin_bit_cast(bf16x8, raw);
+    f.v = __builtin_bit_cast(typename OpVec<T>::x8, raw);
   } else {
     const int c = (k0 >> 2) + 2 * h;
     u32x4 r0 = lds_read16(tile + row * STRIDE + c * 16);
@@ -214,8 +239,8 @@ template <typename T, int STRIDE, int MAP> PFN_DEV Frag<T> load_frag_tr_p(const 
     const int colb = (col0 + 16 * g + 4 * (i & 3)) * 2;
     const int ra = (MAP == 1) ? (k0 + 8 * h) : (k0 + 4 * h);
     const int rb = (MAP == 1) ? (k0 + 8 * h + 4) : (k0 + 8 + 4 * h);
-    bf16x4 lo = ds_read_tr16_b64(tile + (ra + (i >> 2)) * STRIDE + colb);
-    bf16x4 hi = ds_read_tr16_b64(tile + (rb + (i >> 2)) * STRIDE + colb);
+    const auto lo = ds_read_tr16_b64<T>(tile + (ra + (i >> 2)) * STRIDE + colb);
+    const auto hi = ds_read_tr16_b64<T>(tile + (rb + (i >> 2)) * STRIDE + colb);
     f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   } else {
     const int colb = (col0 + (l & 31)) * 4;
@@ -237,8 +262,9 @@ template <typename T> PFN_DEV void store_row_block(T* row_block, const float (&v
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      bf16x2 a0 = {(bf16)v[8 * p + 0], (bf16)v[8 * p + 1]}, a1 = {(bf16)v[8 * p + 2], (bf16)v[8 * p + 3]};
-      bf16x2 b0 = {(bf16)v[8 * p + 4], (bf16)v[8 * p + 5]}, b1 = {(bf16)v[8 * p + 6], (bf16)v[8 * p + 7]};
+      typedef typename OpVec<T>::x2 x2;
+      x2 a0 = {(T)v[8 * p + 0], (T)v[8 * p + 1]}, a1 = {(T)v[8 * p + 2], (T)v[8 * p + 3]};
+      x2 b0 = {(T)v[8 * p + 4], (T)v[8 * p + 5]}, b1 = {(T)v[8 * p + 6], (T)v[8 * p + 7]};
       const auto r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
       const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
       const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
@@ -488,6 +514,27 @@ PFN_DEV float wave_max(float v) {
   return v;
 }
 template <typename T> PFN_DEV float to_f(T x) { return (float)x; }
+
+// ---------------------------------------------------------------------------------------------
+// Loss scale of the fp16 backward (PFN_PREC_FP16).  fp16 spans 2^-14 .. 2^16 at full precision; the gradient of a mean loss over ~10^4 rows starts at
+// 1e-4 .. 1e-8 per element, so the backward chain runs on dlogits * 2^k and every kernel that WRITES a parameter gradient (or d(src)) multiplies by 2^-k
+// on the way out: the flat gradient buffer holds unscaled f32 values, exactly as in the other modes.  k is chosen per backward call ON THE DEVICE -- no host
+// round trip -- from amax = max|dlogits| (absmax_kernel, rowwise.hip) so that amax * 2^k lands in [64, 128): six binades of headroom below 65504 for what the
+// chain adds (|W|, |q|, |k| of a trained model), and 8-bit-or-better relative precision down to 2^-20 of the largest element.  Both factors are powers of
+// two: the scaling itself is exact.  A null pointer (the other precisions) means 1.
+// ---------------------------------------------------------------------------------------------
+constexpr int LOSS_SCALE_TARGET_LOG2 = 6;
+PFN_DEV float loss_scale_exp(const float* amax, int sign) {      // 2^(sign * k), k = 6 - floor(log2 amax), clamped to the range where both factors are normal f32
+  if (!amax) return 1.f;
+  const unsigned bits = __builtin_bit_cast(unsigned, *amax);
+  const int e = (int)((bits >> 23) & 255u) - 127;               // floor(log2 amax) for a normal value
+  int k = LOSS_SCALE_TARGET_LOG2 - e;
+  if (e == -127 || e == 128) k = 0;                             // zero / subnormal / inf / nan gradient: leave it alone
+  k = k < -60 ? -60 : (k > 60 ? 60 : k);
+  return __builtin_bit_cast(float, (unsigned)(127 + sign * k) << 23);
+}
+PFN_DEV float loss_scale_up(const float* amax) { return loss_scale_exp(amax, 1); }
+PFN_DEV float loss_scale_down(const float* amax) { return loss_scale_exp(amax, -1); }
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter = (index, stream), key = seed

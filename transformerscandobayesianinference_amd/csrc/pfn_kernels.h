@@ -24,6 +24,19 @@ struct LdsAllowance {
   }
 };
 
+// Operand element types (include/pfn_hip.h PFN_PREC_*): two 16-bit formats on the matrix cores at the same rate and bytes, and the exact-f32 parity mode.
+inline bool prec_is16(int p) { return p == PFN_PREC_BF16 || p == PFN_PREC_FP16; }
+inline int prec_esize(int p) { return prec_is16(p) ? 2 : 4; }
+// host-side dispatch of a statement over the operand type T (device code only sees the instantiations)
+#define PFN_DISPATCH_OP(prec, ...)                                                          \
+  do {                                                                                      \
+    if ((prec) == PFN_PREC_BF16) { using T = ::pfn::bf16_t; __VA_ARGS__; }                  \
+    else if ((prec) == PFN_PREC_FP16) { using T = ::pfn::f16_t; __VA_ARGS__; }              \
+    else { using T = float; __VA_ARGS__; }                                                  \
+  } while (0)
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
 // In-step kernel timing (test / profiling hook pfn_profile_*, pfn_api.hip): an event pair on the launch stream around the launches inside the scope;
 // a no-op unless profiling is enabled.
 bool prof_enabled();
@@ -100,7 +113,6 @@ int launch_gemm_nt(const GemmNT& g, int precision, hipStream_t stream);
 bool gemm_nt_rowdot_fused(const GemmNT& g, int precision);   // true: launch_gemm_nt(g) will run a kernel that implements EPI_ROWDOT (else the caller keeps attn_delta_kernel)
 // kernel selection knob (tests / profiling): 0 automatic, 1 only the 128x128 kernel, 2 the 256x256 kernel whenever legal
 void set_gemm_nt_big_mode(int mode);
-void set_gemm_nt_persist(int wgs);
 void set_gemm_ln_rows64(int on);
 
 struct GemmTN {
@@ -112,6 +124,7 @@ struct GemmTN {
   int m_chunk;              // filled by the launcher
   float* colsum;            // optional [P]: += column sums of A (bias gradient), atomically
   int max_splits;           // 0 = automatic; else an upper bound on the token-axis splits (small C: fewer atomic partial sums)
+  const float* scale_amax;  // fp16 backward: C and colsum receive the product times 2^-k (nullptr = 1)
 };
 int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream);
 
@@ -130,6 +143,7 @@ struct GemmTNGroup {
   int tile_start[TN_GROUP_MAX + 1];  // filled by the launcher
   int n, M, splits, m_chunk;
   int debug_mask;                    // all ones; profiling only (pfn_set_tuning key 1): 2^k - 1 wraps the token index
+  const float* scale_amax;           // fp16 backward: every C and colsum of the group receives its product times 2^-k (nullptr = 1)
 };
 void set_gemm_tn_debug_wrap(int rows);
 // GEMM + bias + residual + LayerNorm in one kernel (gemm_nt_ln_kernel): one workgroup owns 128 full rows of the
@@ -149,7 +163,7 @@ struct GemmLN {
   float* x_f32;                                    // optional: the LayerNorm output in f32 as well (last layer -> decoder)
 };
 bool gemm_ln_supported(const GemmLN& g);
-int launch_gemm_ln(const GemmLN& g, hipStream_t stream);
+int launch_gemm_ln(const GemmLN& g, int precision, hipStream_t stream);      // precision: one of the 16-bit formats
 
 // A data-gradient GEMM with the backward of the LayerNorm whose OUTPUT gradient it produces fused in (gemm_nt_lnbwd_kernel):
 //   v = A . B^T + aux;  dx_t = LayerNorm backward of v through (y, mean, rstd, gamma);  dgamma += sum_rows v xhat;  dbeta += sum_rows v
@@ -161,12 +175,13 @@ struct GemmLNB {
   const float* y; const float* mean; const float* rstd; const float* gamma;   // the LayerNorm's input [M,N], row statistics [M], weight [N]
   void* dx_t;                   // [M,N] bf16: gradient w.r.t. the LayerNorm input
   float* dgamma; float* dbeta;  // [N] f32, accumulated with atomics
+  const float* scale_amax;      // fp16 backward: dgamma / dbeta leave times 2^-k (dx_t stays in the scaled chain); nullptr = 1
 };
 bool gemm_lnbwd_supported(const GemmLNB& g);
-int launch_gemm_lnbwd(const GemmLNB& g, hipStream_t stream);
+int launch_gemm_lnbwd(const GemmLNB& g, int precision, hipStream_t stream);
 
 bool gemm_tn_group_supported(const TnProblem& p);
-int launch_gemm_tn_group(GemmTNGroup g, hipStream_t stream);
+int launch_gemm_tn_group(GemmTNGroup g, int precision, hipStream_t stream);
 
 // ---- attention (attention.hip) ---------------------------------------------------------------
 // qkv: [B, S, 3E] T (q | k | v, heads contiguous inside each E), ctx: [B, S, E] T,
@@ -212,7 +227,11 @@ void transpose_group_add(TransposeGroup& g, long src_off, long dst_off, int rows
 int launch_transpose_cast_group(const float* src, void* dst, const TransposeGroup& g, int precision, hipStream_t s);
 int launch_transpose_cast(const float* src, void* dst_t, int rows, int cols, long ld_dst, int precision, hipStream_t s);
 // dst[r, 0:C] = (T) src[r, 0:C], dst[r, C:ld_dst] = 0
-int launch_cast_rows(const float* src, long ld_src, void* dst_t, long ld_dst, long R, int C, int precision, hipStream_t s);
+int launch_cast_rows(const float* src, long ld_src, void* dst_t, long ld_dst, long R, int C, int precision, hipStream_t s, const float* scale_amax = nullptr);
+// ---- loss scale of the fp16 backward (pfn_device.h loss_scale_up / loss_scale_down): `scale_amax` arguments below point at ONE device float holding
+// max|incoming gradient| (launch_absmax), from which every kernel derives the same power of two; nullptr = no scaling (bf16 / f32) ----
+int launch_absmax(const float* x, long n, float* amax, hipStream_t s);                                   // amax[0] = max |x[i]| (x 16-byte aligned)
+int launch_scale_copy(const float* src, float* dst, long n, const float* scale_amax, hipStream_t s);    // dst = src * 2^k
 
 // x:[T,B,nf] (strides given in elements), y:[T,B]; out f32 + T in [B,S,E]
 struct EmbedArgs {
@@ -234,6 +253,7 @@ struct EmbedBwdArgs {
   int S, B, nf, E, sep;
   const int* sep_of;    // ragged batch: per-dataset eval positions [B] (nullptr = every dataset at `sep`)
   int single_block;     // 1: one workgroup per column block walks every token (one writer per gradient element: PFN_SCHED_DETERMINISTIC)
+  const float* scale_amax;   // fp16 backward: dsrc carries the loss scale, the gradients leave without it (nullptr = none)
 };
 int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s);
 // the GEMM form: acc[E, EMB_AUG] = d(src)^T . xaug (launch_gemm_tn) -> dwx += acc[:, :nf], dwy += acc[:, nf], dby += acc[:, nf + 1]
@@ -241,7 +261,7 @@ int launch_embed_grad_scatter(const float* acc, float* dwx, float* dwy, float* d
 
 // src given in the reference layout [S,B,E] f32 (custom encoders): copy into [B,S,E] f32 + T
 int launch_sbe_to_bse(const float* src, float* out_f32, void* out_t, int S, int B, int E, int precision, hipStream_t s);
-int launch_bse_to_sbe(const float* src_bse, float* dst_sbe, int S, int B, int E, hipStream_t s);
+int launch_bse_to_sbe(const float* src_bse, float* dst_sbe, int S, int B, int E, hipStream_t s, const float* scale_amax = nullptr);      // (* 2^-k)
 
 // y = LN(x) * gamma + beta over E; writes f32 and T copies, mean/rstd per row
 int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
@@ -250,7 +270,7 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 // accumulates colsum(dx) (the bias gradient of the linear that produced x's pre-LN sum).
 int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd,
                          float* dx_f32, void* dx_t, float* dgamma, float* dbeta, float* dbias_extra,
-                         long rows, int E, int precision, hipStream_t s, float* partials = nullptr);
+                         long rows, int E, int precision, hipStream_t s, float* partials = nullptr, const float* scale_amax = nullptr);      // scale_amax: dgamma / dbeta / dbias_extra leave times 2^-k
 // `partials` (PFN_SCHED_DETERMINISTIC): scratch of LNB_MAX_BLOCKS * 3 * E floats -- every workgroup leaves its column sums there and a second tiny launch adds
 // them to dgamma / dbeta / dbias_extra in block order (one writer per element, a fixed summation order) instead of the f32 atomics
 constexpr int LNB_MAX_BLOCKS = 512;

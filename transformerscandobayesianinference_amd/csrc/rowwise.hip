@@ -11,16 +11,16 @@ namespace pfn {
 
 template <typename T> PFN_DEV void st4(T* p, f32x4 x) {
   if constexpr (sizeof(T) == 2) {
-    bf16x4 v;
+    X4<T> v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (bf16)x[e];
-    *reinterpret_cast<bf16x4*>(p) = v;
+    for (int e = 0; e < 4; ++e) v[e] = (T)x[e];
+    *reinterpret_cast<X4<T>*>(p) = v;
   } else *reinterpret_cast<f32x4*>(p) = x;
 }
 template <typename T> PFN_DEV f32x4 ld4(const T* p) {
   f32x4 r;
   if constexpr (sizeof(T) == 2) {
-    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    X4<T> v = *reinterpret_cast<const X4<T>*>(p);
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = (float)v[e];
   } else r = *reinterpret_cast<const f32x4*>(p);
@@ -44,23 +44,60 @@ int launch_cast_params(const float* src, void* dst, long n, int precision, hipSt
   if (n % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = n / 4;
   if (n4 == 0) return PFN_OK;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(cast_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, n4);
-  else hipLaunchKernelGGL(cast_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, n4);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(cast_kernel<T>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (T*)dst, n4));
   return PFN_LAUNCH_OK();
 }
 
-template <typename T> __global__ __launch_bounds__(256) void cast_rows_kernel(const float* src, long ld_src, T* dst, long ld_dst, long R, int C) {
+template <typename T> __global__ __launch_bounds__(256) void cast_rows_kernel(const float* src, long ld_src, T* dst, long ld_dst, long R, int C, const float* scale_amax) {
   const long total = R * ld_dst;
+  const float sc = loss_scale_up(scale_amax);      // fp16 backward: the gradient enters the chain times 2^k (pfn_device.h)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / ld_dst; const int c = (int)(i % ld_dst);
-    dst[i] = (T)(c < C ? src[r * ld_src + c] : 0.f);
+    dst[i] = (T)(c < C ? src[r * ld_src + c] * sc : 0.f);
   }
 }
-int launch_cast_rows(const float* src, long ld_src, void* dst, long ld_dst, long R, int C, int precision, hipStream_t s) {
+int launch_cast_rows(const float* src, long ld_src, void* dst, long ld_dst, long R, int C, int precision, hipStream_t s, const float* scale_amax) {
   const long total = R * ld_dst;
   if (total == 0) return PFN_OK;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(cast_rows_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, ld_src, (bf16*)dst, ld_dst, R, C);
-  else hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, ld_src, (float*)dst, ld_dst, R, C);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(cast_rows_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, ld_src, (T*)dst, ld_dst, R, C, scale_amax));
+  return PFN_LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp16 backward: amax = max |x| over the incoming gradient (non-negative floats order like their bit patterns: one integer atomic per workgroup), and the
+// scaled f32 copy for the entry that has no cast in front of the chain (no decoder: the gradient of the test rows goes straight into the LayerNorm backward)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, unsigned* amax_bits) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));      // (fmaxf drops a NaN operand: a NaN gradient stays a NaN downstream, the scale stays sane)
+  }
+  if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(amax_bits, __builtin_bit_cast(unsigned, m));
+  }
+}
+int launch_absmax(const float* x, long n, float* amax, hipStream_t s) {
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return PFN_ERR_ALIGNMENT;
+  if (hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return PFN_ERR_LAUNCH;
+  if (n <= 0) return PFN_OK;
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4 + 1, 256 * 8, 1024)), dim3(256), 0, s, x, n, reinterpret_cast<unsigned*>(amax));
+  return PFN_LAUNCH_OK();
+}
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float* src, float* dst, long n, const float* scale_amax) {
+  const float sc = loss_scale_up(scale_amax);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i] * sc;
+}
+int launch_scale_copy(const float* src, float* dst, long n, const float* scale_amax, hipStream_t s) {
+  if (n <= 0) return PFN_OK;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, src, dst, n, scale_amax);
   return PFN_LAUNCH_OK();
 }
 
@@ -110,14 +147,12 @@ void transpose_group_add(TransposeGroup& g, long src_off, long dst_off, int rows
 }
 int launch_transpose_cast_group(const float* src, void* dst, const TransposeGroup& g, int precision, hipStream_t s) {
   if (g.n == 0) return PFN_OK;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(transpose_cast_group_kernel<bf16>, dim3(g.blocks), dim3(256), 0, s, src, (bf16*)dst, g);
-  else hipLaunchKernelGGL(transpose_cast_group_kernel<float>, dim3(g.blocks), dim3(256), 0, s, src, (float*)dst, g);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(transpose_cast_group_kernel<T>, dim3(g.blocks), dim3(256), 0, s, src, (T*)dst, g));
   return PFN_LAUNCH_OK();
 }
 int launch_transpose_cast(const float* src, void* dst, int rows, int cols, long ld_dst, int precision, hipStream_t s) {
   dim3 grid((cols + 31) / 32, (unsigned)((ld_dst + 31) / 32));
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(transpose_cast_kernel<bf16>, grid, dim3(256), 0, s, src, (bf16*)dst, rows, cols, ld_dst);
-  else hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, rows, cols, ld_dst);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(transpose_cast_kernel<T>, grid, dim3(256), 0, s, src, (T*)dst, rows, cols, ld_dst));
   return PFN_LAUNCH_OK();
 }
 
@@ -179,8 +214,7 @@ int launch_embed_fwd(const EmbedArgs& a, int precision, hipStream_t s) {
   const long ntok = (long)a.B * a.S;
   const int grid = (int)((ntok + EMB_TOK - 1) / EMB_TOK);
   const size_t lds = EMB_TOK * (a.nf + 2) * sizeof(float);
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(grid), dim3(256), lds, s, a);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(embed_fwd_kernel<T>, dim3(grid), dim3(256), lds, s, a));
   return PFN_LAUNCH_OK();
 }
 
@@ -247,6 +281,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs a) {
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) t += red[(q * 64 + c) * (NF8 + 1) + f];
+    t *= loss_scale_down(a.scale_amax);
     if (f < a.nf) unsafeAtomicAdd(a.dwx + (long)ee * a.nf + f, t);
     else if (f == a.nf) unsafeAtomicAdd(a.dwy + ee, t);
     else if (f == a.nf + 1) unsafeAtomicAdd(a.dby + ee, t);
@@ -274,6 +309,7 @@ __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(EmbedBwdArgs a) {
   }
   __syncthreads();
   const int ntk = (int)std::min<long>(128, ntok - t0);
+  const float osc = loss_scale_down(a.scale_amax);
   for (int e = threadIdx.x; e < a.E; e += 256) {
     float db = 0.f;
     for (int f0 = 0; f0 < nf8; f0 += 8) {
@@ -287,19 +323,19 @@ __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(EmbedBwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int f = f0 + j;
-        if (f < a.nf) unsafeAtomicAdd(a.dwx + (long)e * a.nf + f, acc[j]);
-        else if (f == a.nf) unsafeAtomicAdd(a.dwy + e, acc[j]);
-        else if (f == a.nf + 1) unsafeAtomicAdd(a.dby + e, acc[j]);
+        if (f < a.nf) unsafeAtomicAdd(a.dwx + (long)e * a.nf + f, acc[j] * osc);
+        else if (f == a.nf) unsafeAtomicAdd(a.dwy + e, acc[j] * osc);
+        else if (f == a.nf + 1) unsafeAtomicAdd(a.dby + e, acc[j] * osc);
       }
     }
-    unsafeAtomicAdd(a.dbx + e, db);
+    unsafeAtomicAdd(a.dbx + e, db * osc);
   }
 }
 __global__ __launch_bounds__(256) void embed_grad_scatter_kernel(const float* acc, float* dwx, float* dwy, float* dby, int E, int nf) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= E * (nf + 2)) return;
   const int e = i / (nf + 2), f = i % (nf + 2);
-  const float v = acc[e * EMB_AUG + f];
+  const float v = acc[e * EMB_AUG + f];      // (already unscaled: the GEMM that filled acc took the loss scale out)
   if (f < nf) unsafeAtomicAdd(dwx + (long)e * nf + f, v);
   else if (f == nf) unsafeAtomicAdd(dwy + e, v);
   else unsafeAtomicAdd(dby + e, v);
@@ -352,23 +388,23 @@ template <typename T> __global__ __launch_bounds__(256) void sbe_to_bse_kernel(c
 int launch_sbe_to_bse(const float* src, float* o32, void* ot, int S, int B, int E, int precision, hipStream_t s) {
   if (E % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = (long)S * B * E / 4;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(sbe_to_bse_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, o32, (bf16*)ot, S, B, E);
-  else hipLaunchKernelGGL(sbe_to_bse_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, o32, (float*)ot, S, B, E);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(sbe_to_bse_kernel<T>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, o32, (T*)ot, S, B, E));
   return PFN_LAUNCH_OK();
 }
-__global__ __launch_bounds__(256) void bse_to_sbe_kernel(const float* src, float* dst, int S, int B, int E) {
+__global__ __launch_bounds__(256) void bse_to_sbe_kernel(const float* src, float* dst, int S, int B, int E, const float* scale_amax) {
   const long n4 = (long)S * B * E / 4;
   const int e4 = E / 4;
+  const float osc = loss_scale_down(scale_amax);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const long tok = i / e4; const int c = (int)(i % e4) * 4;
     const long b = tok / S, sidx = tok % S;
-    *reinterpret_cast<f32x4*>(dst + (sidx * B + b) * E + c) = *reinterpret_cast<const f32x4*>(src + tok * E + c);
+    *reinterpret_cast<f32x4*>(dst + (sidx * B + b) * E + c) = *reinterpret_cast<const f32x4*>(src + tok * E + c) * osc;
   }
 }
-int launch_bse_to_sbe(const float* src, float* dst, int S, int B, int E, hipStream_t s) {
+int launch_bse_to_sbe(const float* src, float* dst, int S, int B, int E, hipStream_t s, const float* scale_amax) {
   if (E % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = (long)S * B * E / 4;
-  hipLaunchKernelGGL(bse_to_sbe_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, dst, S, B, E);
+  hipLaunchKernelGGL(bse_to_sbe_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, dst, S, B, E, scale_amax);
   return PFN_LAUNCH_OK();
 }
 
@@ -420,8 +456,7 @@ int launch_dropout_scale(const void* src, void* dst, const void* src2, void* dst
   if (n4 == 0) return PFN_OK;
   const unsigned thr = dropout_threshold(p);
   const float scale = 1.f / (1.f - p);
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(dropout_scale_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, (const bf16*)src2, (bf16*)dst2, n4, cols / 4, site_seed, thr, scale);
-  else hipLaunchKernelGGL(dropout_scale_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, (const float*)src, (float*)dst, (const float*)src2, (float*)dst2, n4, cols / 4, site_seed, thr, scale);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(dropout_scale_kernel<T>, dim3(grid_for(n4, 256)), dim3(256), 0, s, (const T*)src, (T*)dst, (const T*)src2, (T*)dst2, n4, cols / 4, site_seed, thr, scale));
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 
@@ -429,8 +464,7 @@ int launch_gather_test_rows(const float* src, void* dst, int S, int B, int E, in
   if (E % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = (long)(S - sep) * B * E / 4;
   if (n4 == 0) return PFN_OK;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gather_test_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep);
-  else hipLaunchKernelGGL(gather_test_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(gather_test_kernel<T>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (T*)dst, S, B, E, sep));
   return PFN_LAUNCH_OK();
 }
 template <typename T> __global__ __launch_bounds__(256) void scatter_test_kernel(const float* src, T* dst, int S, int B, int E, int sep) {
@@ -447,8 +481,7 @@ template <typename T> __global__ __launch_bounds__(256) void scatter_test_kernel
 int launch_scatter_test_rows(const float* src, void* dst, int S, int B, int E, int sep, int precision, hipStream_t s) {
   if (E % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = (long)S * B * E / 4;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(scatter_test_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep);
-  else hipLaunchKernelGGL(scatter_test_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(scatter_test_kernel<T>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (T*)dst, S, B, E, sep));
   return PFN_LAUNCH_OK();
 }
 
@@ -479,15 +512,13 @@ template <typename T> __global__ __launch_bounds__(256) void scatter_test_ragged
 int launch_gather_test_rows_ragged(const float* src, void* dst, int S, int B, int E, const int* sep_of, const long* row_off, int precision, hipStream_t s) {
   if (E % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = (long)S * B * E / 4;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(gather_test_ragged_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep_of, row_off);
-  else hipLaunchKernelGGL(gather_test_ragged_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep_of, row_off);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(gather_test_ragged_kernel<T>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (T*)dst, S, B, E, sep_of, row_off));
   return PFN_LAUNCH_OK();
 }
 int launch_scatter_test_rows_ragged(const float* src, void* dst, int S, int B, int E, const int* sep_of, const long* row_off, int precision, hipStream_t s) {
   if (E % 4) return PFN_ERR_ALIGNMENT;
   const long n4 = (long)S * B * E / 4;
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(scatter_test_ragged_kernel<bf16>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (bf16*)dst, S, B, E, sep_of, row_off);
-  else hipLaunchKernelGGL(scatter_test_ragged_kernel<float>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (float*)dst, S, B, E, sep_of, row_off);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(scatter_test_ragged_kernel<T>, dim3(grid_for(n4, 256)), dim3(256), 0, s, src, (T*)dst, S, B, E, sep_of, row_off));
   return PFN_LAUNCH_OK();
 }
 
@@ -662,7 +693,7 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
   const int grid = grid_for(rows, 4, 8192);
 #define LN_FWD(TT, NV) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, NV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, y32, (TT*)yt, mean, rstd, rows, E, eps)
 #define LN_FWD_NV(TT) do { if (E <= 256) LN_FWD(TT, 1); else if (E <= 512) LN_FWD(TT, 2); else if (E <= 1024) LN_FWD(TT, 4); else LN_FWD(TT, 8); } while (0)
-  if (precision == PFN_PREC_BF16) LN_FWD_NV(bf16); else LN_FWD_NV(float);
+  PFN_DISPATCH_OP(precision, LN_FWD_NV(T));
   return PFN_LAUNCH_OK();
 }
 
@@ -675,7 +706,7 @@ constexpr int LNB_WAVES = 8;
 // 16-byte one (bf16 dY loads and dX stores of 8 bytes per lane stream at little more than half the rate).
 template <typename T, int EV> PFN_DEV void ln_load(const T* p, float (&v)[EV]) {
   if constexpr (sizeof(T) == 2 && EV == 8) {
-    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+    const X8<T> t = *reinterpret_cast<const X8<T>*>(p);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
   } else {
@@ -689,10 +720,10 @@ template <typename T, int EV> PFN_DEV void ln_load(const T* p, float (&v)[EV]) {
 }
 template <typename T, int EV> PFN_DEV void ln_store(T* p, const float (&v)[EV]) {
   if constexpr (sizeof(T) == 2 && EV == 8) {
-    bf16x8 t;
+    X8<T> t;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = (bf16)v[e];
-    *reinterpret_cast<bf16x8*>(p) = t;
+    for (int e = 0; e < 8; ++e) t[e] = (T)v[e];
+    *reinterpret_cast<X8<T>*>(p) = t;
   } else {
 #pragma unroll
     for (int j = 0; j < EV; j += 4) st4<T>(p + j, f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]});
@@ -700,8 +731,9 @@ template <typename T, int EV> PFN_DEV void ln_store(T* p, const float (&v)[EV]) 
 }
 template <typename T, int NV, int EV, bool DY_T>
 __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const void* dy_any, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                                                      float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E, float* partials) {
+                                                                      float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E, float* partials, const float* scale_amax) {
   extern __shared__ __attribute__((aligned(16))) float part[];  // [LNB_WAVES][E]
+  const float osc = loss_scale_down(scale_amax);                // fp16 backward: the parameter gradients leave unscaled (pfn_device.h)
   const float* dy = reinterpret_cast<const float*>(dy_any);     // upstream gradient: f32, or operand precision when DY_T
   const T* dy_t = reinterpret_cast<const T*>(dy_any);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -789,6 +821,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const voi
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < LNB_WAVES; ++w) t += part[w * E + c];
+      t *= osc;
       // deterministic schedule (PFN_SCHED_DETERMINISTIC): the block's partial goes to scratch, ln_partials_reduce_kernel adds the blocks in index order
       if (partials) partials[((long)blockIdx.x * 3 + q) * E + c] = t;
       else unsafeAtomicAdd(out + c, t);
@@ -805,7 +838,7 @@ __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* pa
   out[c] += t;
 }
 int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, void* dxt,
-                         float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s, float* partials) {
+                         float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s, float* partials, const float* scale_amax) {
   if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
   if (rows == 0) return PFN_OK;
   const int grid = grid_for(rows, LNB_WAVES * 8, LNB_MAX_BLOCKS);
@@ -813,13 +846,13 @@ int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const floa
 #define LN_BWD_K(TT, NV, EV, DT) do { \
     static LdsAllowance allowance; \
     allowance.ensure(layernorm_bwd_kernel<TT, NV, EV, DT>, lds); \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, EV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E, partials); } while (0)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, EV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E, partials, scale_amax); } while (0)
 #define LN_BWD(TT, NV, EV) do { if (dy_is_t) LN_BWD_K(TT, NV, EV, true); else LN_BWD_K(TT, NV, EV, false); } while (0)
   // rows of >= 512 elements in 8-element lane chunks (16-byte operand-precision accesses), narrower rows in 4-element ones
 #define LN_BWD_NV(TT) do { \
     if (E % 8 == 0 && E >= 512) { if (E <= 512) LN_BWD(TT, 1, 8); else if (E <= 1024) LN_BWD(TT, 2, 8); else LN_BWD(TT, 4, 8); } \
     else if (E <= 256) LN_BWD(TT, 1, 4); else if (E <= 512) LN_BWD(TT, 2, 4); else if (E <= 1024) LN_BWD(TT, 4, 4); else LN_BWD(TT, 8, 4); } while (0)
-  if (precision == PFN_PREC_BF16) LN_BWD_NV(bf16); else LN_BWD_NV(float);
+  PFN_DISPATCH_OP(precision, LN_BWD_NV(T));
   if (partials) hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((E + 255) / 256, 3), dim3(256), 0, s, partials, grid, E, dgamma, dbeta, dbias);
   return PFN_LAUNCH_OK();
 }
@@ -857,12 +890,11 @@ template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const
 }
 int launch_colsum(const void* a, long lda, long rows, int cols, float* out, int precision, hipStream_t s) {
   if (rows == 0 || cols == 0) return PFN_OK;
-  const int es = precision == PFN_PREC_BF16 ? 2 : 4;
+  const int es = prec_esize(precision);
   if ((lda * es) % 8) return PFN_ERR_ALIGNMENT;
   const int cg = (cols + 3) / 4;
   dim3 grid((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (cg + 255) / 256);
-  if (precision == PFN_PREC_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)a, lda, rows, cols, out);
-  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)a, lda, rows, cols, out);
+  PFN_DISPATCH_OP(precision, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)a, lda, rows, cols, out));
   return PFN_LAUNCH_OK();
 }
 

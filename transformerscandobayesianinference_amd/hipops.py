@@ -4,7 +4,9 @@ import torch
 
 from transformerscandobayesianinference_amd import _hip
 
-TDT = {_hip.PREC_BF16: torch.bfloat16, _hip.PREC_F32: torch.float32}
+TDT = {_hip.PREC_BF16: torch.bfloat16, _hip.PREC_F32: torch.float32, _hip.PREC_FP16: torch.float16}
+PREC_OF = {v: k for k, v in TDT.items()}      # operand precision of a tensor's dtype
+MANGLED_OPERAND = {_hip.PREC_BF16: 'DF16b', _hip.PREC_FP16: 'DF16_', _hip.PREC_F32: 'f'}      # Itanium mangling of the kernels' operand-type template argument
 
 
 def sp():
@@ -29,7 +31,7 @@ def gemm_tn(A, B, C, prec, atomic=1):
 
 
 def gemm_tn_group(problems, splits=0):
-    """problems: list of (A[M,P], B[M,Q], C[P,Q], colsum[P] or None), all bf16 operands with the same M."""
+    """problems: list of (A[M,P], B[M,Q], C[P,Q], colsum[P] or None), all operands of ONE 16-bit dtype (bf16 / fp16) with the same M."""
     import ctypes
     n = len(problems)
     M = problems[0][0].shape[0]
@@ -39,7 +41,7 @@ def gemm_tn_group(problems, splits=0):
     C = VP(*[p[2].data_ptr() for p in problems]); ldc = L(*[p[2].stride(0) for p in problems])
     P = I(*[p[0].shape[1] for p in problems]); Q = I(*[p[1].shape[1] for p in problems])
     cs = VP(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems])
-    _hip.check(_hip.lib().pfn_op_gemm_tn_group(n, A, lda, B, ldb, C, ldc, P, Q, cs, M, splits, sp()), 'pfn_op_gemm_tn_group')
+    _hip.check(_hip.lib().pfn_op_gemm_tn_group(n, A, lda, B, ldb, C, ldc, P, Q, cs, M, splits, PREC_OF[problems[0][0].dtype], sp()), 'pfn_op_gemm_tn_group')
 
 
 def gemm_ln(A, B, bias, gamma, beta, eps, resid=None, prev=None, out=None):
@@ -50,14 +52,14 @@ def gemm_ln(A, B, bias, gamma, beta, eps, resid=None, prev=None, out=None):
     dev = A.device
     if out is None:
         y = torch.full((M + 2, N), float('nan'), device=dev)
-        x_t = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        x_t = torch.empty(M, N, dtype=A.dtype, device=dev)
         mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
     else:
         y, x_t, mean, rstd = out
     p = _hip.ptr
     pv = prev if prev is not None else (None,) * 5
     _hip.check(_hip.lib().pfn_op_gemm_ln(p(A), A.stride(0), p(B), B.stride(0), M, N, K, p(bias), p(resid), p(pv[0]), p(pv[1]), p(pv[2]), p(pv[3]), p(pv[4]),
-                                         p(gamma), p(beta), eps, p(y), p(mean), p(rstd), p(x_t), sp()), 'pfn_op_gemm_ln')
+                                         p(gamma), p(beta), eps, p(y), p(mean), p(rstd), p(x_t), PREC_OF[A.dtype], sp()), 'pfn_op_gemm_ln')
     if out is None:
         assert torch.isnan(y[M:]).all()
     return y[:M], x_t, mean, rstd
@@ -103,11 +105,11 @@ def gemm_lnbwd(A, B, aux, y, mean, rstd, gamma, out=None):
     M, K = A.shape
     N = B.shape[0]
     if out is None:
-        out = (torch.full((M + 2, N), float('nan'), dtype=torch.bfloat16, device=A.device), torch.zeros(N, device=A.device), torch.zeros(N, device=A.device))
+        out = (torch.full((M + 2, N), float('nan'), dtype=A.dtype, device=A.device), torch.zeros(N, device=A.device), torch.zeros(N, device=A.device))
     dx_t, dgamma, dbeta = out
     p = _hip.ptr
     _hip.check(_hip.lib().pfn_op_gemm_lnbwd(p(A), A.stride(0), p(B), B.stride(0), M, N, K, p(aux), p(y), p(mean), p(rstd), p(gamma),
-                                            p(dx_t), p(dgamma), p(dbeta), sp()), 'pfn_op_gemm_lnbwd')
+                                            p(dx_t), p(dgamma), p(dbeta), PREC_OF[A.dtype], sp()), 'pfn_op_gemm_lnbwd')
     return dx_t, dgamma, dbeta
 
 
@@ -116,11 +118,11 @@ def gemm_lnbwd(A, B, aux, y, mean, rstd, gamma, out=None):
 # it executes 5, the forward's S being recomputed once)
 ATTENTION_BWD_PARTS = [
     # (rocprofv3 prints these kernels by their mangled names: its demangler does not know the __bf16 template argument)
-    ('attn_bwd: delta = rowsum(dO * O)', '_ZN3pfn17attn_delta_kernelIDF16bEEvNS_8AttnArgsEi', 1, 0.0, 0.0),
-    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', '_ZN3pfn18attn_bwd_kv_kernelIDF16bLi{D}ELi0ELb0', 2, 3.0, 4.0),
-    ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', '_ZN3pfn18attn_bwd_dq_kernelIDF16bLi{D}ELb0', 4, 1.0, 1.0),      # (...ELb0: the variant without the dropout masks)
+    ('attn_bwd: delta = rowsum(dO * O)', '_ZN3pfn17attn_delta_kernelI{T}EEvNS_8AttnArgsEi', 1, 0.0, 0.0),
+    ('attn_bwd: key-block pass (S, dP, dV, dK products; stores dS^T)', '_ZN3pfn18attn_bwd_kv_kernelI{T}Li{D}ELi0ELb0', 2, 3.0, 4.0),
+    ('attn_bwd: query-block pass (dQ = dS K from the stored dS^T)', '_ZN3pfn18attn_bwd_dq_kernelI{T}Li{D}ELb0', 4, 1.0, 1.0),      # (...ELb0: the variant without the dropout masks)
 ]
-ATTENTION_FWD_ROCPROF = '_ZN3pfn15attn_fwd_kernelIDF16bLi{D}ELb0'
+ATTENTION_FWD_ROCPROF = '_ZN3pfn15attn_fwd_kernelI{T}Li{D}ELb0'
 # (round 2: head dim 256 ran the key-block pass as two launches with one more S product -- {256: 5.0}; round 3: one pass everywhere)
 ATTENTION_BWD_KV_EXECUTED_UNITS = {}
 _bwd_scratch = {}

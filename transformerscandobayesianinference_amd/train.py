@@ -285,7 +285,7 @@ def main(argv=None):
     parser.add_argument('--steps_per_epoch', default=10, type=int)
     parser.add_argument('--batch_size', default=1000, type=int)
     parser.add_argument('--lr', '--learning_rate', default=.001, type=float)
-    parser.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    parser.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'f32'])
     args, _ = _parse_args(config_parser, parser, argv)
     cfg = dict(args.__dict__)
     cfg.pop('config', None)

@@ -297,7 +297,7 @@ class TransformerModel(nn.Module):
 
     def _make_desc(self, precision=None):
         nf = self.encoder.in_features if self._fused_embedding() else 1
-        prec = {'bf16': _hip.PREC_BF16, 'f32': _hip.PREC_F32, 'fp32': _hip.PREC_F32}[precision or self.precision]
+        prec = _hip.PRECISIONS[precision or self.precision]
         # schedule: the library's defaults (0) unless a test / profiling run changed them (pfn_set_tuning) or the model carries its own bits; fixed per
         # descriptor, so a forward and the backward that reads its workspace always agree about the buffer layout (ABI 6)
         sched = getattr(self, 'schedule', None)       # (a model pickled whole before ABI 6 has no such attribute: ADVICE r4)
