@@ -74,6 +74,10 @@ enum { PFN_SCHED_TOP_LAYER_ALL_ROWS = 1, /* run the TOP encoder layer on every r
                                           * so that layer's train rows feed nothing (not with live dropout, not when sep < S / 4) */
        PFN_SCHED_FUSE_LN_WIDE = 2,       /* emsize 1024: LayerNorm-fused GEMMs on 64-row x 1024-column tiles (correct, measured slower: default off) */
        PFN_SCHED_SEPARATE_LNBWD = 4,     /* LayerNorm backward as its own kernels instead of inside the data-gradient GEMMs that feed it */
+       PFN_SCHED_NO_KEY_CENTERING = 16,  /* 16-bit operand formats centre the keys of every dataset before they are rounded: k' = k - W_k xbar with xbar a sample mean of the
+                                          * dataset's layer-input rows.  softmax_j(q_i . k_j) is invariant to one vector subtracted from every key, so outputs and gradients are the
+                                          * reference's (transformer.py:84) while the rounding of K stops being relative to the keys' common component (ABI 8; default on).
+                                          * This bit turns it off (the arithmetic of rounds 1-5). */
        PFN_SCHED_DETERMINISTIC = 8       /* bit-reproducible gradients (the reference's CPU loop is deterministic, train.py:58-110): every gradient element has
                                           * exactly ONE writer per launch and launches are stream-ordered -- weight-gradient GEMMs without token splits, LayerNorm
                                           * gamma / beta / bias gradients through per-workgroup partials summed in a fixed order (implies SEPARATE_LNBWD), the
@@ -342,6 +346,13 @@ int pfn_op_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const floa
                          const float* rstd, float* dx_f32, void* dx_t, float* dgamma, float* dbeta,
                          float* dbias_extra, int64_t rows, int E, int prec, void* stream);
 int pfn_op_cast(const float* src, void* dst, int64_t n, int prec, void* stream);
+/* The packed q|k|v projection of one encoder layer as the stack runs it (torch multi_head_attention_forward's in_proj: reference transformer.py:84):
+ *   qkv[b, t, :] = x[b, t, :] . w_in^T + b_in,   x [B, S, E] T,  w_in [3E, E] T,  b_in [3E] f32,  qkv [B, S, 3E] T
+ * and, when center != 0 (16-bit operands, E % 64 == 0), with the keys of every dataset centred before they are rounded (ABI 8, PFN_SCHED_NO_KEY_CENTERING clear):
+ *   k'[b, t, :] = k[b, t, :] - W_k . xbar[b],   xbar[b] = mean of <= 64 evenly spaced rows t' = i * (sep_b / ns) (i < ns = min(64, sep_b)) of x[b, 0 : sep_b, :]
+ * (sep_b = sep_of[b] when sep_of != NULL -- a device array -- else sep).  kshift_ws: B * E floats of scratch (receives W_k . xbar). */
+int pfn_op_qkv_projection(const void* x_t, const void* w_in_t, const float* b_in, void* qkv_t, float* kshift_ws,
+                          int B, int S, int E, int sep, const int32_t* sep_of, int center, int prec, void* stream);
 
 #ifdef __cplusplus
 }

@@ -181,6 +181,46 @@ def test_gemm_tn(M, P, Q, prec):
     assert relerr(C, ref) < 3e-6, relerr(C, ref)
 
 
+@pytest.mark.parametrize('gemm_mode', [0, 1], ids=['lds-dma-kernel', '128x128-kernel'])
+@pytest.mark.parametrize('B,S,E,seps', [(3, 700, 256, [600, 600, 600]), (2, 2000, 512, [1755, 1755]), (4, 300, 128, [257, 0, 1, 40]), (2, 130, 64, [130, 5])])
+def test_qkv_projection_with_centred_keys(B, S, E, seps, gemm_mode, op16):
+    """Key centring (pfn_op_qkv_projection, csrc/pfn_kernels.h launch_key_shift): the K block leaves the projection minus W_k . xbar[b], xbar the mean of <= 64
+    evenly spaced TRAIN rows of the dataset; q and v are the plain projection; a dataset without train rows is not shifted; per-dataset eval positions (ragged
+    batch) and the uniform one agree; the shifted keys give the SAME attention output (softmax is invariant to one vector subtracted from every key)."""
+    dt = hipops.TDT[op16]
+    x = rnd(B, S, E, dtype=dt, seed=60) + 1.5            # a common component, as in a trained model
+    w = rnd(3 * E, E, dtype=dt, seed=61, scale=0.1)
+    b = rnd(3 * E, seed=62)
+    uniform = len(set(seps)) == 1
+    sep_of = None if uniform else torch.tensor(seps, dtype=torch.int32, device=dev())
+    _hip.check(_hip.lib().pfn_set_tuning(0, gemm_mode), 'pfn_set_tuning')
+    try:
+        plain, _ = hipops.qkv_projection(x, w, b, max(seps), center=False)
+        got, ks = hipops.qkv_projection(x, w, b, max(seps), center=True, sep_of=sep_of)
+    finally:
+        _hip.lib().pfn_set_tuning(0, 0)
+    assert not torch.isnan(got.float()).any() and not torch.isnan(ks).any()
+    ref = x.double() @ w.double().t() + b.double()
+    tol_t = tol(op16, 4e-3, 5e-4, 0)
+    assert relerr(plain, ref) < tol_t
+    want_ks = torch.zeros(B, E, dtype=torch.float64, device=dev())
+    for i, sep in enumerate(seps):
+        if sep > 0:
+            ns = min(64, sep); st = sep // ns
+            want_ks[i] = x[i, 0:ns * st:st].double().mean(0) @ w[E:2 * E].double().t()
+    assert relerr(ks, want_ks) < 1e-5, relerr(ks, want_ks)
+    ref_c = ref.clone()
+    ref_c[:, :, E:2 * E] -= want_ks[:, None, :]
+    assert torch.equal(got[:, :, :E], plain[:, :, :E]) and torch.equal(got[:, :, 2 * E:], plain[:, :, 2 * E:])      # q and v untouched
+    # relative to the CENTRED keys' own norm -- the point of the exercise: the rounding is now relative to the part of k that differs between keys
+    assert relerr(got[:, :, E:2 * E], ref_c[:, :, E:2 * E]) < tol_t
+    if uniform:
+        H = max(1, E // 64)
+        ctx_p, lse_p = hipops.attention_fwd(plain, H, seps[0], op16)
+        ctx_c, lse_c = hipops.attention_fwd(got, H, seps[0], op16)
+        assert relerr(ctx_c, ctx_p) < 2.5 * tol_t
+
+
 @pytest.fixture(params=[0, 1], ids=['128-row-tiles', '64-row-tiles'])
 def ln_tile_rows(request):
     """PFN_TUNE_GEMM_LN_ROWS: the LayerNorm-fused GEMMs at N = 512 on 128-row tiles (default) or on 64-row tiles, two workgroups per CU."""

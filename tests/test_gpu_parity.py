@@ -85,9 +85,9 @@ def test_forward_loss_grads_vs_reference_golden(case, precision):
         within(f'{precision} logits rel l2', relerr(logits, want['logits']), tol3(precision, 1e-4, 1e-2))
         losses = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].flatten()).view(*logits.shape[:2])
         loss = losses.mean()
-        assert abs(loss.item() - want['loss'].item()) < tol3(precision, 1e-4, 1e-3) * abs(want['loss'].item()), (sep, loss.item(), want['loss'].item())
+        within(f'{precision} loss rel', abs(loss.item() - want['loss'].item()) / abs(want['loss'].item()), tol3(precision, 1e-4, 1e-3))
         means = model.criterion.mean(logits)
-        assert mean_err(means, want['mean'], y) < tol3(precision, 1e-5, 1e-3), (sep, mean_err(means, want['mean'], y))
+        within(f'{precision} means max / target range', mean_err(means, want['mean'], y), tol3(precision, 1e-5, 1e-3))
         within(f'{precision} means rel l2 (own norm)', relerr(means, want['mean']), tol3(precision, 1e-4, 4e-3))      # relative to the means' own norm: the logit error
         if 'grads' in want:
             loss.backward()
@@ -131,7 +131,7 @@ def test_two_training_steps_vs_reference_golden(precision):
         d_got = final[k].cpu().double() - rec['state_dict'][k].double()
         num += ((d_got - d_ref) ** 2).sum().item()
         den += (d_ref ** 2).sum().item()
-    within(f'{precision} two-step Adam update rel l2', math.sqrt(num / den), tol3(precision, 2e-2, 0.12))
+    within(f'{precision} two-step Adam update rel l2', math.sqrt(num / den), tol3(precision, 2e-2, 0.12, 7e-2))      # (fp16 measured 3.3e-2: Adam turns rounding-level gradients into O(lr) steps in every format)
 
 
 def random_model(cfg, precision, seed=0):
@@ -164,11 +164,11 @@ def test_config1_vs_oracle(precision):
         loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
         loss.backward()
         tight = precision == 'f32'
-        assert abs(loss.item() - loss_o.item()) < tol3(precision, 1e-4, 1e-3) * abs(loss_o.item()), (sep, loss.item(), loss_o.item())
+        within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3))
         within(f'{precision} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 1e-2))
         m_o = pfn_oracle.bar_mean(logits_o, sd['criterion.borders'])
         m_h = model.criterion.mean(logits)
-        assert mean_err(m_h, m_o, y) < tol3(precision, 1e-5, 1e-3)
+        within(f'{precision} means max / target range', mean_err(m_h, m_o, y), tol3(precision, 1e-5, 1e-3))
         within(f'{precision} means rel l2 (own norm)', relerr(m_h, m_o), tol3(precision, 1e-4, 4e-3))
         tot_err = math.sqrt(sum(((p.grad.double().cpu() - grads_o[k]) ** 2).sum().item() for k, p in model.named_parameters()))
         tot = math.sqrt(sum((g ** 2).sum().item() for g in grads_o.values()))
@@ -193,9 +193,9 @@ def test_config5_width_vs_oracle(precision, H):
     logits = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
     loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
     tight = precision == 'f32'
-    assert abs(loss.item() - loss_o.item()) < tol3(precision, 1e-4, 1e-3) * abs(loss_o.item()), (loss.item(), loss_o.item())
+    within(f'{precision} H{H} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3))
     within(f'{precision} H{H} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 1e-2))
-    assert mean_err(model.criterion.mean(logits), pfn_oracle.bar_mean(logits_o, sd['criterion.borders']), y) < tol3(precision, 1e-5, 1e-3)
+    within(f'{precision} H{H} means max / target range', mean_err(model.criterion.mean(logits), pfn_oracle.bar_mean(logits_o, sd['criterion.borders']), y), tol3(precision, 1e-5, 1e-3))
     # (exact-f32 at head dim 256, round 5: the backward runs the plain vector-ALU attention kernels -- csrc/attention.hip attn_bwd_plain_* -- and is held to the
     # same 2e-4 "any layout mistake fails" bound as every other f32 shape)
     loss.backward()
@@ -857,7 +857,7 @@ def test_config4_model_shape_vs_oracle(precision, sep):
     within(f'{precision} sep {sep} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-5, 1e-3))
     within(f'{precision} sep {sep} logits rel l2', relerr(lg, lo), tol3(precision, 1e-4, 1.1e-2))
     p_err = (torch.sigmoid(lg).double().cpu() - torch.sigmoid(lo)).abs().max().item()      # posterior-predictive mean of the label
-    assert p_err < tol3(precision, 1e-5, 1e-3), p_err
+    within(f'{precision} sep {sep} probability max abs', p_err, tol3(precision, 1e-5, 1e-3))
     got = {k: p.grad for k, p in model.named_parameters()}
     tot_err = math.sqrt(sum(((got[k].double().cpu() - v.grad) ** 2).sum().item() for k, v in leaves.items()))
     tot = math.sqrt(sum((v.grad ** 2).sum().item() for v in leaves.values()))
@@ -1022,7 +1022,7 @@ def test_validate_and_run_test_vs_oracle():
             want.append(((pfn_oracle.bar_mean(lo, borders)[0] - y[pos].double()) ** 2).mean())
         want = torch.stack(want)
         assert scores.shape == want.shape
-        assert relerr(scores, want) < tol3(precision, 1e-4, 5e-3), (precision, relerr(scores, want))
+        within(f'{precision} validate scores rel l2', relerr(scores, want), tol3(precision, 1e-4, 5e-3))
         # run_test(): same idea through its `get_batch` argument
         drawn = []
 
@@ -1045,8 +1045,8 @@ def test_validate_and_run_test_vs_oracle():
                 se.append(((pfn_oracle.bar_mean(lo, borders)[0] - yb[p].double()) ** 2).mean())
                 top = lo[0].argmax(-1)
                 me.append((((borders[top] + borders[top + 1]).double() / 2 - yb[p].double()) ** 2).mean())
-            assert abs(nll[j].item() - torch.cat(nl).mean().item()) < tol3(precision, 1e-4, 1e-3) * abs(torch.cat(nl).mean().item())
-            assert abs(mse[j].item() - torch.stack(se).mean().item()) < tol3(precision, 1e-4, 5e-3) * torch.stack(se).mean().item()
+            within(f'{precision} run_test nll rel', abs(nll[j].item() - torch.cat(nl).mean().item()) / abs(torch.cat(nl).mean().item()), tol3(precision, 1e-4, 1e-3))
+            within(f'{precision} run_test mse rel', abs(mse[j].item() - torch.stack(se).mean().item()) / torch.stack(se).mean().item(), tol3(precision, 1e-4, 5e-3))
             if tight:
                 assert abs(mode_mse[j].item() - torch.stack(me).mean().item()) < 1e-4 * torch.stack(me).mean().item()
 
@@ -1085,7 +1085,7 @@ def test_custom_decoder_module_vs_oracle(precision):
     loss.backward()
     tight = precision == 'f32'
     within(f'{precision} logits rel l2', relerr(logits, lo), tol3(precision, 1e-4, 1e-2))
-    assert abs(loss.item() - loss_o.item()) < tol3(precision, 1e-4, 1e-3) * abs(loss_o.item())
+    within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3))
     got = {k: p.grad for k, p in model.named_parameters()}
     tot_err = math.sqrt(sum(((got[k].double().cpu() - v.grad) ** 2).sum().item() for k, v in leaves.items()))
     tot = math.sqrt(sum((v.grad ** 2).sum().item() for v in leaves.values()))
@@ -1174,12 +1174,25 @@ def test_trained_checkpoint_parity():
     path = os.path.join(GOLD, 'trained_config1.pt')
     sd, _ = torch.load(path)
     cfg = dict(T=100, B=8, F=5, E=128, H=4, nhid=256, L=2, nbars=100)
-    model = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], 0.0,
-                             y_encoder=encoders.Linear(1, cfg['E']), precision='bf16')           # product defaults: inference in f32
-    model.criterion = bar_distribution.FullSupportBarDistribution(sd['criterion.borders'].clone())
-    model.load_state_dict(sd)
-    model.to(DEV)
     borders = sd['criterion.borders']
+
+    def build(precision, schedule):
+        m = TransformerModel(encoders.Linear(cfg['F'], cfg['E']), cfg['nbars'], cfg['E'], cfg['H'], cfg['nhid'], cfg['L'], 0.0,
+                             y_encoder=encoders.Linear(1, cfg['E']), precision=precision)           # product defaults: inference in f32
+        m.criterion = bar_distribution.FullSupportBarDistribution(borders.clone())
+        m.load_state_dict(sd)
+        m.schedule = schedule
+        return m.to(DEV)
+    # (path, operand format of the training forward, train mode, schedule bits, bounds on NLL / means (own norm) / logits)
+    # This checkpoint saw 9.6 M datasets: its attention is sharp (|q| up to 80, the keys of a dataset share a common component nine times their spread), and the
+    # forward amplifies operand rounding -- f32 kernels land at 2e-5 (untrained models: 1e-6).  Rounds 1-5's bf16 training forward: 3-6e-2.  Round 6: the keys are
+    # centred per dataset before they are rounded (same outputs in exact arithmetic: csrc/pfn_kernels.h launch_key_shift), and fp16 operands carry 3 more bits:
+    # profiles/r06_operand_format_simulation.json predicted 2e-2 (bf16, centred) and 2-3e-3 (fp16, centred) on the means.  Inference carries the north star's 1e-3.
+    variants = [('inference outputs (f32 kernels)', 'bf16', False, 0, (1e-3, 1e-3, 2e-4)),
+                ('bf16 training forward, keys not centred (the arithmetic of rounds 1-5)', 'bf16', True, _hip.SCHED_NO_KEY_CENTERING, (6e-2, 0.12, 0.12)),
+                ('bf16 training forward', 'bf16', True, 0, (3e-2, 6e-2, 6e-2)),
+                ('fp16 training forward', 'fp16', True, 0, (1.5e-2, 3e-2, 3e-2))]
+    models = {}
     gen = torch.Generator().manual_seed(2024)
     x, y, _ = pfn_oracle.get_batch_fast_gp(cfg['B'], cfg['T'], cfg['F'], {'noise': 1e-4, 'outputscale': 1., 'lengthscale': .6}, gen)
     params = {k: v for k, v in sd.items() if not k.startswith('criterion.')}
@@ -1189,21 +1202,17 @@ def test_trained_checkpoint_parity():
         mean_o = pfn_oracle.bar_mean(lo, borders)
         assert mean_o.pow(2).mean().sqrt().item() > 0.3          # a trained model: its means are not the prior mean 0
         assert relerr(mean_o, y[sep:]) < 0.7                      # ... they track the targets
-        for mode, train_mode in (('inference outputs (f32 kernels)', False), ('bf16 training forward', True)):
+        for mode, precision, train_mode, schedule, (b_nll, b_mean, b_logits) in variants:
+            model = models.setdefault((precision, schedule), build(precision, schedule))
             model.train(train_mode)
             with torch.no_grad():
                 lg = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
                 nll = model.criterion(lg.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean().item()
                 mean = model.criterion.mean(lg)
-            tight = not train_mode
             # (a trained model's NLL crosses zero as the train set grows, so the relative error is taken against max(|nll|, 0.5).)
-            # This checkpoint saw 9.6 M datasets: its attention is sharp, and the forward amplifies operand rounding -- f32 kernels land
-            # at 2e-5 (untrained models: 1e-6), the bf16 training forward at 3-6e-2 (after 640 k datasets it was 5e-3; at the benchmarked
-            # scale, trained for 512 k datasets, 1.2-1.5e-3: profiles/r03_trained_config{1,2}.json).  Inference carries the north star's
-            # 1e-3; the bf16 bounds are 2x the measured values.
-            within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3 if tight else 6e-2)
-            within(f'{mode}: means rel l2 (own norm)', relerr(mean, mean_o), 1e-3 if tight else 0.12)
-            within(f'{mode}: logits rel l2', relerr(lg, lo), 2e-4 if tight else 0.12)
+            within(f'{mode}: nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), b_nll)
+            within(f'{mode}: means rel l2 (own norm)', relerr(mean, mean_o), b_mean)
+            within(f'{mode}: logits rel l2', relerr(lg, lo), b_logits)
 
 
 @pytest.mark.parametrize('emsize', [64, 256, 512])       # head dims 32, 128 (the benchmarked kernels) and 256
@@ -1240,7 +1249,7 @@ def test_dropout_vs_oracle_with_the_same_masks(precision, emsize):
     assert relerr(logits_o, logits_plain) > 0.05                       # the masks do something
     tight = precision == 'f32'
     within(f'{precision} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 2e-2))
-    assert abs(loss.item() - loss_o.item()) < tol3(precision, 1e-4, 5e-3) * abs(loss_o.item()), (loss.item(), loss_o.item())
+    within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 5e-3))
     got = {k: p.grad for k, p in model.named_parameters()}
     tot_err = math.sqrt(sum(((got[k].double().cpu() - v) ** 2).sum().item() for k, v in grads_o.items()))
     tot = math.sqrt(sum((v ** 2).sum().item() for v in grads_o.values()))
@@ -1408,8 +1417,8 @@ def test_training_loop_vs_reference_train_golden(precision, aggregate_streams, a
     within(f'{precision} batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses, rec['batch_losses'])), tol3(precision, 1e-4, 2e-3))
     epoch = [sum(losses[e * cfg['steps_per_epoch']:(e + 1) * cfg['steps_per_epoch']]) / cfg['steps_per_epoch'] for e in range(cfg['epochs'])]
     within(f'{precision} epoch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(epoch, rec['epoch_losses'])), tol3(precision, 1e-4, 2e-3))
-    assert abs(total - rec['returned_total_loss']) < tol3(precision, 1e-4, 2e-3) * abs(rec['returned_total_loss'])
-    within(f'{precision} parameter update over the run, rel l2', replay.update_error(final, rec), tol3(precision, 1e-3, 0.1))
+    within(f'{precision} returned total loss rel', abs(total - rec['returned_total_loss']) / abs(rec['returned_total_loss']), tol3(precision, 1e-4, 2e-3))
+    within(f'{precision} parameter update over the run, rel l2', replay.update_error(final, rec), tol3(precision, 1e-3, 0.1, 6e-2))      # (fp16 measured 1.7-2.8e-2)
 
 
 def _two_gpus():
@@ -1622,7 +1631,7 @@ def test_deterministic_schedule_is_bit_reproducible(precision):
         assert torch.equal(final_a[k], final_b[k]), k
     tight = precision == 'f32'
     within(f'{precision} deterministic schedule: batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses_a, rec['batch_losses'])), tol3(precision, 1e-4, 2e-3))
-    within(f'{precision} deterministic schedule: parameter update over the run, rel l2', replay.update_error(final_a, rec), tol3(precision, 1e-3, 0.1))
+    within(f'{precision} deterministic schedule: parameter update over the run, rel l2', replay.update_error(final_a, rec), tol3(precision, 1e-3, 0.1, 4e-2))      # (fp16 measured 1.8e-2)
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16', 'f32'])

@@ -39,8 +39,9 @@ def rounder(fmt):
     raise ValueError(fmt)
 
 
-def forward(sd, x, y, sep, nhead, fmt_of, maxabs=None):
-    """fmt_of: dict operand class -> format name (missing = exact)."""
+def forward(sd, x, y, sep, nhead, fmt_of, maxabs=None, center=False):
+    """fmt_of: dict operand class -> format name (missing = exact).  center: the product's key centring (csrc/pfn_kernels.h launch_key_shift) -- k' = k - W_k xbar with
+    xbar the mean of <= 64 evenly spaced TRAIN rows of the (rounded) layer input, subtracted in f32 before k is rounded; exact arithmetic is unchanged by it."""
     dt = torch.float64
     p = {k: v.detach().to(dt) for k, v in sd.items() if not k.startswith('criterion.')}
     x, y = x.to(dt), y.to(dt)
@@ -65,8 +66,13 @@ def forward(sd, x, y, sep, nhead, fmt_of, maxabs=None):
     L = 1 + max(int(k.split('.')[2]) for k in p if k.startswith('transformer_encoder.layers.'))
     for l in range(L):
         pre = f'transformer_encoder.layers.{l}.'
-        qkv = O._linear(X(h), W(p[pre + 'self_attn.in_proj_weight']), p[pre + 'self_attn.in_proj_bias'])
+        xr, wr = X(h), W(p[pre + 'self_attn.in_proj_weight'])
+        qkv = O._linear(xr, wr, p[pre + 'self_attn.in_proj_bias'])
         q, k, v = qkv.split(E, -1)
+        if center and sep > 0:
+            ns = min(64, sep); st = sep // ns
+            xbar = xr[0:ns * st:st].mean(0, keepdim=True)                 # [1, B, E]
+            k = k - xbar @ wr[E:2 * E].t()
         q, k, v = R['Q'](note('Q', q)), R['K'](note('K', k)), R['V'](note('V', v))
         q, k, v = [t.reshape(T, B, nhead, D).permute(1, 2, 0, 3) for t in (q, k, v)]
         s = q @ k.transpose(-1, -2) / math.sqrt(D) + mask
@@ -90,6 +96,8 @@ def variants():
          ('weights fp16; rest bf16', dict(allc('bf16'), W='fp16')),
          ('all operands fp16', allc('fp16')),
          ('all operands fp16, subnormals flushed', allc('fp16-ftz'))]
+    v.append(('all operands bf16 + keys centred per dataset (round 6 bf16 path)', dict(allc('bf16'), _center=True)))
+    v.append(('all operands fp16 + keys centred per dataset (round 6 fp16 path)', dict(allc('fp16'), _center=True)))
     for c in CLASSES:
         v.append((f'only {c} bf16', {c: 'bf16'}))
     for c in CLASSES:
@@ -104,12 +112,14 @@ def evaluate(name, sd, x, y, seps, nhead, borders, nbars, rows_out):
         exact = forward(sd, x, y, sep, nhead, {}, mx)
         ref = O.forward({k: v for k, v in sd.items() if not k.startswith('criterion.')}, x, y, sep, nhead)
         assert rel(exact, ref.double()) < 1e-10, rel(exact, ref.double())          # the harness with nothing rounded IS the oracle
+        assert rel(forward(sd, x, y, sep, nhead, {}, center=True), exact) < 1e-9  # ... and centring the keys changes nothing in exact arithmetic
         nll = lambda lg: O.bar_nll(lg.reshape(-1, nbars), y[sep:].reshape(-1).double(), borders).mean().item()
         mean_o, nll_o = O.bar_mean(exact, borders), nll(exact)
         rows_out.append(dict(model=name, sep=sep, operand_ranges={k: float('%.4g' % v) for k, v in sorted(mx.items())}, nll_oracle=nll_o))
         print(json.dumps(rows_out[-1]), flush=True)
         for vname, fmt_of in variants():
-            lg = forward(sd, x, y, sep, nhead, fmt_of)
+            fmt_of = dict(fmt_of)
+            lg = forward(sd, x, y, sep, nhead, fmt_of, center=fmt_of.pop('_center', False))
             r = dict(model=name, sep=sep, variant=vname, logits_rel_l2=rel(lg, exact), mean_rel_l2_own_norm=rel(O.bar_mean(lg, borders), mean_o),
                      nll_rel=abs(nll(lg) - nll_o) / max(abs(nll_o), 0.5), finite=bool(torch.isfinite(lg).all()))
             rows_out.append(r)

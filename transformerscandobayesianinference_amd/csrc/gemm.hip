@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
     const bool full = (ncol + 3 < g.N) && g.vec_ok;
     if (full) {
       if (flags & EPI_BIAS) { f32x4 b = *reinterpret_cast<const f32x4*>(bias + ncol); v += b; }
+      if ((flags & EPI_ROWSHIFT) && ncol >= g.rs_n0 && ncol < g.rs_n1) v -= *reinterpret_cast<const f32x4*>(g.rowshift + (m / g.rs_S) * g.rs_ld + (ncol - g.rs_n0));
       if (flags & EPI_GELU_BWD) {
         float a[4];
         if constexpr (sizeof(T) == 2) { X4<T> t = *reinterpret_cast<const X4<T>*>(aux + m * g.ld_aux + ncol); for (int e = 0; e < 4; ++e) a[e] = (float)t[e]; }
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
         float x = v[e];
         const int n = ncol + e;
         if (flags & EPI_BIAS) x += bias[n];
+        if ((flags & EPI_ROWSHIFT) && n >= g.rs_n0 && n < g.rs_n1) x -= g.rowshift[(m / g.rs_S) * g.rs_ld + (n - g.rs_n0)];
         if (flags & EPI_GELU_BWD) x *= (float)aux[m * g.ld_aux + n];
         if (flags & EPI_RESID) x += g.resid[m * g.ld_resid + n];
         if (flags & EPI_RESID_T) x += (float)aux[m * g.ld_aux + n];
@@ -234,6 +236,15 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
       const long m = mvalid ? m_row : (long)g.M - 1;     // clamped for the loads; stores are guarded
       const int nb = n0 + wn * 64 + j * 32;              // first column of this 32-column block (wave-uniform)
       float pre[16], post[16];
+      // EPI_ROWSHIFT (key centring of the q|k|v projection): the lane's row selects its dataset's shift vector; rs_n0 / rs_n1 are multiples of 64, so a block is
+      // shifted as a whole or not at all (wave-uniform branch)
+      f32x4 shift_v[4];
+      const bool shifted = (flags & EPI_ROWSHIFT) && nb >= g.rs_n0 && nb < g.rs_n1;
+      if (shifted) {
+        const float* sp = g.rowshift + (m / g.rs_S) * g.rs_ld + (nb - g.rs_n0) + 4 * h;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) shift_v[gq] = *reinterpret_cast<const f32x4*>(sp + 8 * gq);
+      }
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = min(nb + 8 * gq + 4 * h, g.N - 4);
@@ -246,6 +257,7 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
           if constexpr (HAS_RES) res_v[bb][gq] = *reinterpret_cast<const f32x4*>(g.resid + m * g.ld_resid + n);
         }
         if (flags & EPI_BIAS) v += bias_v[j][gq];
+        if (shifted) v -= shift_v[gq];
         if (flags & EPI_GELU_BWD) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= (float)aux_v[HAS_AUX ? bb : 0][gq][e];
@@ -1745,6 +1757,7 @@ template <typename T> static bool launch_big(const GemmNT& g, bool small_tile, h
   switch (g.flags) {
 #define PFN_BIG_CASE(F) case (F): if (small_tile) launch_big_t<T, (F), 1, 32>(g, stream); else launch_big_t<T, (F), 2, 64>(g, stream); return true;
     PFN_BIG_CASE(EPI_BIAS | EPI_OUT_T)                            // q/k/v projection
+    PFN_BIG_CASE(EPI_BIAS | EPI_OUT_T | EPI_ROWSHIFT)             // ... with the keys centred per dataset (EPI_ROWSHIFT)
     PFN_BIG_CASE(EPI_BIAS | EPI_RESID | EPI_OUT_F32)              // out_proj, linear2 (+ residual)
     PFN_BIG_CASE(EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T)    // linear1 + GELU
     PFN_BIG_CASE(EPI_GELU_BWD | EPI_OUT_T)                        // d(hpre)
@@ -1773,6 +1786,7 @@ int launch_gemm_nt(const GemmNT& g_in, int precision, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return PFN_OK;
   const size_t es = prec_esize(precision);
   if ((g.lda * es) % 16 || (g.ldb * es) % 16 || !aligned16(g.A) || !aligned16(g.B)) return PFN_ERR_ALIGNMENT;
+  if ((g.flags & EPI_ROWSHIFT) && (!g.rowshift || g.rs_S <= 0 || g.rs_n0 % 64 || g.rs_n1 % 64 || g.rs_n0 < 0 || g.rs_n1 > g.N)) return PFN_ERR_ARGUMENT;
   nt_prepare(g, precision);
   if (prec_is16(precision)) {
     const int pick = gemm_nt_pick(g);
@@ -1794,6 +1808,7 @@ static void nt_prepare(GemmNT& g, int precision) {
   if ((g.flags & EPI_RESID) && (g.ld_resid % 4 || !aligned16(g.resid))) vec = false;
   if ((g.flags & (EPI_GELU_BWD | EPI_RESID_T | EPI_ROWDOT)) && ((g.ld_aux * es) % (4 * es) || !aligned16(g.aux))) vec = false;
   if ((g.flags & EPI_BIAS) && !aligned16(g.bias)) vec = false;
+  if ((g.flags & EPI_ROWSHIFT) && (!aligned16(g.rowshift) || g.rs_ld % 4 || g.rs_n0 % 4 || g.rs_n1 % 4)) vec = false;
   g.vec_ok = vec ? 1 : 0;
   g.wide_t = (!(g.flags & EPI_OUT_T) || g.ld_out_t % 8 == 0) && (!(g.flags & EPI_OUT2_T) || g.ld_out2 % 8 == 0) ? 1 : 0;   // 16-byte rows
 }

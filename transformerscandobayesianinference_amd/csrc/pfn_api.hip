@@ -76,7 +76,7 @@ int check_desc(const pfn_model_desc* d) {
   const bool ok = dh == 32 || dh == 64 || dh == 128 || dh == 256;
   if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128/256)", dh);
   if (d->emsize > 2048) return fail(PFN_ERR_UNSUPPORTED, "emsize > 2048 unsupported by the LayerNorm kernels");
-  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
+  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC | PFN_SCHED_NO_KEY_CENTERING)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
   if (!(d->dropout >= 0.f && d->dropout < 1.f)) return fail(PFN_ERR_ARGUMENT, "dropout %g outside [0, 1)", (double)d->dropout);
   return PFN_OK;
 }
@@ -143,6 +143,7 @@ struct Ws {
   // the top layer on the test rows only (top_layer_on_test_rows below): compact [S - sep, B] row order
   char *top_ctx_t, *top_dy1_t, *top_dctx_t;   // attention output / LN1-input gradient / d(attention output) of the test rows
   float *top_ry, *top_rmean, *top_rrstd;      // the layer input (the residual of its first LayerNorm) of the test rows
+  float* kshift;                              // [B, E] f32: the per-dataset key shift of the layer whose q|k|v projection runs next (16-bit operands; launch_key_shift)
   float* lscale;                              // PFN_PREC_FP16: max|dlogits| of the running backward call, from which every kernel derives the loss scale (pfn_device.h)
   float* ln_part;                             // PFN_SCHED_DETERMINISTIC: per-workgroup column sums of the LayerNorm backward (launch_layernorm_bwd `partials`)
   int64_t bytes;
@@ -183,6 +184,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   const int64_t Mtop = (d.nlayers > 0 && d.dropout == 0.f && !(d.schedule & PFN_SCHED_TOP_LAYER_ALL_ROWS)) ? (int64_t)B * (S - (S + 3) / 4) : 0;
   w.top_ctx_t = take(Mtop * E * es); w.top_dy1_t = take(Mtop * E * es); w.top_dctx_t = take(Mtop * E * es);
   w.top_ry = (float*)take(Mtop * E * 4); w.top_rmean = (float*)take(Mtop * 4); w.top_rrstd = (float*)take(Mtop * 4);
+  w.kshift = prec_is16(d.precision) && !(d.schedule & PFN_SCHED_NO_KEY_CENTERING) ? (float*)take((int64_t)B * E * 4) : nullptr;
   w.lscale = (float*)take(256);
   w.ln_part = (d.schedule & PFN_SCHED_DETERMINISTIC) ? (float*)take((int64_t)LNB_MAX_BLOCKS * 3 * E * 4) : nullptr;
   w.bytes = cur;
@@ -404,6 +406,12 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       ProfScope ps(PFN_PROF_GEMM_QKV, s);
       GemmNT g = nt(xin_t, E, W(p.w_in), E, M, 3 * E, E, EPI_BIAS | EPI_OUT_T);
       g.bias = params + p.b_in; g.out_t = a.qkv; g.ld_out_t = 3 * E;
+      // 16-bit operands: the keys leave centred per dataset, k' = k - W_k xbar (pfn_kernels.h launch_key_shift: the attention output and every gradient are those of
+      // the uncentred keys, the operand rounding of K is 9 x smaller on a trained model).  The shift is taken in f32 inside this GEMM's epilogue.
+      if (w.kshift && E % 64 == 0) {
+        PFN_TRY(launch_key_shift(xin_t, W(p.w_in + (int64_t)E * E), w.kshift, B, S, E, sep, sep_of, prec, s));
+        g.flags |= EPI_ROWSHIFT; g.rowshift = w.kshift; g.rs_ld = E; g.rs_S = S; g.rs_n0 = E; g.rs_n1 = 2 * E;
+      }
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
     {
@@ -1025,6 +1033,19 @@ int pfn_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 int pfn_op_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx_f32,
                          void* dx_t, float* dgamma, float* dbeta, float* dbias_extra, int64_t rows, int E, int prec, void* stream) {
   PFN_TRY(launch_layernorm_bwd(dy, dy_is_t, x, gamma, mean, rstd, dx_f32, dx_t, dgamma, dbeta, dbias_extra, rows, E, prec, (hipStream_t)stream));
+  return PFN_OK;
+}
+int pfn_op_qkv_projection(const void* x_t, const void* w_in_t, const float* b_in, void* qkv_t, float* kshift_ws,
+                          int B, int S, int E, int sep, const int32_t* sep_of, int center, int prec, void* stream) {
+  if (!x_t || !w_in_t || !b_in || !qkv_t || B < 1 || S < 1 || E < 8 || sep < 0 || sep > S) return fail(PFN_ERR_ARGUMENT, "bad qkv_projection arguments");
+  GemmNT g = nt(x_t, E, w_in_t, E, B * S, 3 * E, E, EPI_BIAS | EPI_OUT_T);
+  g.bias = b_in; g.out_t = qkv_t; g.ld_out_t = 3 * E;
+  if (center) {
+    if (!prec_is16(prec) || E % 64 || !kshift_ws) return fail(PFN_ERR_UNSUPPORTED, "key centring: 16-bit operands, emsize a multiple of 64, scratch of B * E floats");
+    PFN_TRY(launch_key_shift(x_t, (const char*)w_in_t + (int64_t)E * E * esize(prec), kshift_ws, B, S, E, sep, sep_of, prec, (hipStream_t)stream));
+    g.flags |= EPI_ROWSHIFT; g.rowshift = kshift_ws; g.rs_ld = E; g.rs_S = S; g.rs_n0 = E; g.rs_n1 = 2 * E;
+  }
+  PFN_TRY(launch_gemm_nt(g, prec, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_cast(const float* src, void* dst, int64_t n, int prec, void* stream) {

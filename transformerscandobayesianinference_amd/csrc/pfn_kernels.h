@@ -91,6 +91,9 @@ enum : int {
   // produces it (aux = the forward's context rows), with f32 atomics (two 64-column waves per head of 128: two addends, order-free; the caller zeroes rowdot);
   // the wave that owns a head's first columns also writes lse2 = lse * log2(e) behind it (what attn_delta_kernel did)
   EPI_ROWDOT = 512,
+  // out[m, n] -= rowshift[(m / rs_S) * rs_ld + (n - rs_n0)] for rs_n0 <= n < rs_n1: a per-DATASET shift of a column range, applied in f32 before the value is
+  // rounded to operand precision -- the key centring of the q|k|v projection (launch_key_shift below; pfn_api.hip).  rs_n0, rs_n1 multiples of 64.
+  EPI_ROWSHIFT = 1024,
 };
 
 struct GemmNT {
@@ -108,7 +111,19 @@ struct GemmNT {
   int wide_t;  // filled by the launcher: operand-precision outputs may be stored 16 bytes at a time
   // EPI_ROWDOT: rowdot [B, H, S] f32 (+ lse2 [B, H, S] behind it at rd_lse2_off), lse [B, H, S]; rows m = b * rd_S + i, heads of rd_D columns
   float* rowdot; const float* rd_lse; long rd_lse2_off; int rd_S, rd_H, rd_D;
+  // EPI_ROWSHIFT: rowshift [M / rs_S, rs_ld] f32
+  const float* rowshift; long rs_ld; int rs_S, rs_n0, rs_n1;
 };
+// Key centring (round 6).  softmax_j(q_i . k_j) does not change when ONE vector c is subtracted from every key of a (dataset, head): q_i . (k_j - c) = q_i . k_j - q_i . c,
+// a constant along j (the self key of a test row is shifted like the others).  In a trained PFN the keys of a dataset share a large common component (measured on
+// tests/golden/trained_config1.pt: |k| rms 6.6, |k - mean_j k| rms 0.73) and the 16-bit rounding of k is relative to |k|, not to the part that matters: storing
+// k' = k - c with c ~ the dataset's mean key makes the attention 9 x less sensitive to the operand rounding of K (profiles/r06_operand_format_simulation.json: bf16
+// forward 5e-2 -> 2e-2, fp16 7e-3 -> 2.5e-3 on that checkpoint).  The backward needs nothing: sum_j dS_ij = 0, so dK' = dK and d(c) = 0 (the reference's gradient).
+// c = W_k xbar with xbar the mean of a strided SAMPLE of the dataset's TRAIN rows of the layer input (any c is exact; this one removes the common part to ~ 1 / sqrt(samples);
+// train rows only, so that no test row reaches another row's output even at rounding level):
+//   kshift[b, n] = sum_e w_k[n, e] * mean_{t in sample} x[b, t, e]        x [B, S, E] T,  w_k [E, E] T (rows = the K block of in_proj_weight),  kshift [B, E] f32
+//   sep / sep_of: the eval position (sep_of [B] on the device for a ragged batch, else nullptr); a dataset without train rows gets a zero shift
+int launch_key_shift(const void* x_t, const void* w_k_t, float* kshift, int B, int S, int E, int sep, const int* sep_of, int precision, hipStream_t s);
 int launch_gemm_nt(const GemmNT& g, int precision, hipStream_t stream);
 bool gemm_nt_rowdot_fused(const GemmNT& g, int precision);   // true: launch_gemm_nt(g) will run a kernel that implements EPI_ROWDOT (else the caller keeps attn_delta_kernel)
 // kernel selection knob (tests / profiling): 0 automatic, 1 only the 128x128 kernel, 2 the 256x256 kernel whenever legal

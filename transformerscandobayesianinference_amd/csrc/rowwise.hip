@@ -157,6 +157,66 @@ int launch_transpose_cast(const float* src, void* dst, int rows, int cols, long 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Key centring (pfn_kernels.h launch_key_shift): kshift[b, n] = sum_e w_k[n, e] * xbar[b, e], xbar = the mean of KS_SAMPLES evenly spaced rows of dataset b's
+// layer input (train rows only).  One workgroup per (dataset, 64 outputs): the sample mean (64 rows x E, 16-byte loads, f32 sums through LDS), then a wave per output row of
+// w_k at a time (16 bytes per lane: a whole row of E <= 512 per instruction).  Reads 2 x 64 KB per workgroup at E = 512: a few microseconds per layer.
+// ---------------------------------------------------------------------------------------------
+constexpr int KS_SAMPLES = 64;
+template <typename T> __global__ __launch_bounds__(256) void key_shift_kernel(const T* x, const T* wk, float* kshift, int S, int E, int sep_all, const int* sep_of) {
+  __shared__ float part[2048];                       // [R row lanes][E] partial sums, then xbar in part[0 .. E)
+  const int b = blockIdx.y, n0 = blockIdx.x * 64;
+  // the sample is taken from the TRAIN rows [0, sep) only: they are the keys every query sees, and a test row must not reach any other row's output -- not even
+  // through a rounding-level shift (the reference's mask, transformer.py:34-41; tests pin the other test rows bit-identical when one changes)
+  const int sep = sep_of ? sep_of[b] : sep_all;
+  if (sep <= 0) {      // no train row: the only key of a query is its own
+    for (int o = threadIdx.x; o < 64 && n0 + o < E; o += 256) kshift[(long)b * E + n0 + o] = 0.f;
+    return;
+  }
+  const int ns = sep < KS_SAMPLES ? sep : KS_SAMPLES, stride = sep / ns;
+  const int G = E / 8, R = G >= 256 ? 1 : 256 / G;
+  const T* xb = x + (long)b * S * E;
+  for (int idx = threadIdx.x; idx < G * R; idx += 256) {
+    const int cg = idx % G, rl = idx / G;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = rl; r < ns; r += R) {
+      const X8<T> v = *reinterpret_cast<const X8<T>*>(xb + (long)r * stride * E + cg * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[rl * E + cg * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)ns;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float s = 0.f;
+    for (int rl = 0; rl < R; ++rl) s += part[rl * E + e];
+    part[e] = s * inv;                               // (row lane 0's slot: every thread reads its own column of the other lanes before writing)
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int o = 0; o < 16; ++o) {
+    const int n = n0 + wave * 16 + o;
+    if (n >= E) break;                               // (wave-uniform)
+    float s = 0.f;
+    for (int e0 = lane * 8; e0 < E; e0 += 512) {
+      const X8<T> w = *reinterpret_cast<const X8<T>*>(wk + (long)n * E + e0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)w[e] * part[e0 + e];
+    }
+    s = wave_sum(s);
+    if (lane == 0) kshift[(long)b * E + n] = s;
+  }
+}
+int launch_key_shift(const void* x_t, const void* w_k_t, float* kshift, int B, int S, int E, int sep, const int* sep_of, int precision, hipStream_t s) {
+  if (!prec_is16(precision) || E % 8 || E > 2048 || B < 1 || S < 1) return PFN_ERR_UNSUPPORTED;
+  const dim3 grid((E + 63) / 64, B);
+  if (precision == PFN_PREC_FP16) hipLaunchKernelGGL(key_shift_kernel<f16>, grid, dim3(256), 0, s, (const f16*)x_t, (const f16*)w_k_t, kshift, S, E, sep, sep_of);
+  else hipLaunchKernelGGL(key_shift_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x_t, (const bf16*)w_k_t, kshift, S, E, sep, sep_of);
+  return PFN_LAUNCH_OK();
+}
+
+// ---------------------------------------------------------------------------------------------
 // embedding: src[b,s,:] = Wx x[s,b,:] + bx  (+ Wy y[s,b] + by  when s < sep)
 // ---------------------------------------------------------------------------------------------
 constexpr int EMB_TOK = 16;

@@ -177,3 +177,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, prec, want_f32=True):
                                                dx32.data_ptr() if want_f32 else 0, dxt.data_ptr(), dg.data_ptr(), db.data_ptr(), dbias.data_ptr(),
                                                rows, E, prec, sp()), 'ln bwd')
     return dx32, dxt, dg, db, dbias
+
+
+def qkv_projection(x, w_in, b_in, sep, center=True, sep_of=None):
+    """x [B, S, E], w_in [3E, E] (one 16-bit dtype), b_in [3E] f32 -> (qkv [B, S, 3E], kshift [B, E] f32): the encoder layer's packed projection with the keys of every
+    dataset centred on a sample mean of its train rows (pfn_op_qkv_projection; center=False: the plain projection)."""
+    B, S, E = x.shape
+    qkv = torch.full((B, S, 3 * E), float('nan'), dtype=x.dtype, device=x.device)
+    ks = torch.full((B, E), float('nan'), dtype=torch.float32, device=x.device)
+    _hip.check(_hip.lib().pfn_op_qkv_projection(x.data_ptr(), w_in.data_ptr(), b_in.data_ptr(), qkv.data_ptr(), ks.data_ptr(), B, S, E, sep,
+                                                _hip.ptr(sep_of), int(center), PREC_OF[x.dtype], sp()), 'pfn_op_qkv_projection')
+    return qkv, ks
