@@ -244,7 +244,7 @@ int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
  * lengthscale [B,nf], outputscale [B], noise [B].  kernel: 0 = RBF, 1 / 2 / 3 = Matern nu = 2.5 / 1.5 / 0.5 (gpytorch MaternKernel's three closed forms).
  * K_ws: workspace of pfn_gp_workspace_bytes(B, S) bytes: the [B,S,S] f32 matrix, factored in place (SCRATCH: with the plane scratch attached only the
  * 256 x 256 diagonal blocks of the factor are left in it -- the panels below them are consumed from the planes and never stored), followed by the scratch of
- * the trailing update (the two scaled fp16 planes of the current outer block's solved panel: + 11 % at S = 2000).  K_ws_bytes (ABI 7): the size the caller allocated --
+ * the trailing update (TWO sets -- the solved panels of an even and an odd outer block, the delayed rank-512 update -- of two scaled fp16 planes each: + 23 % at S = 2000, + 39 % at 1000, + 50 % at 512; always size with pfn_gp_workspace_bytes).  K_ws_bytes (ABI 7): the size the caller allocated --
  * below B*S*S*4 the call returns PFN_ERR_ARGUMENT; between that and pfn_gp_workspace_bytes(B, S) the trailing update runs without the plane scratch
  * (same arithmetic, slower), so a caller sized for an older ABI cannot be written past.  info [B]: 0 or (index+1) of the first non-positive pivot. */
 int64_t pfn_gp_workspace_bytes(int B, int S);

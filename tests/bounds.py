@@ -19,6 +19,10 @@ def within(label, value, bound):
     return value
 
 
+def measure_only():
+    return bool(os.environ.get('PFN_BOUNDS_MEASURE_ONLY'))
+
+
 def dump():
     path = os.environ.get('PFN_RECORD_BOUNDS')
     if path and _measured:

@@ -38,3 +38,9 @@ def pytest_sessionfinish(session, exitstatus):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import bounds
     bounds.dump()
+    if bounds.measure_only():
+        # PFN_BOUNDS_MEASURE_ONLY turns every `within` bound into a recording: such a session must never read as a pass -- it ends with a failure
+        # status and says why, whatever the tests did
+        sys.stderr.write('\n' + '!' * 100 + '\nPFN_BOUNDS_MEASURE_ONLY is set: the tolerance bounds of this session were RECORDED, NOT ASSERTED -- this run is not a test result '
+                         '(exit status forced to 1)\n' + '!' * 100 + '\n')
+        session.exitstatus = 1

@@ -965,19 +965,26 @@ def test_failed_cholesky_is_repaired_with_jitter():
         fast_gp.gp_sample(1, 64, 2, DEV, 0.6, -1.0, 1e-9, x=xs)          # negative outputscale: no jitter of the ladder helps
 
 
-def test_bench_self_launches_two_ranks_on_one_device():
-    """`python bench.py --gpus 2` without a torchrun environment spawns the ranks itself; on a one-GPU box the PFN_DP_* hooks put
-    both ranks on device 0 over gloo (RCCL refuses two ranks per device) -- the line must say so and count both ranks."""
+@pytest.mark.parametrize('ranks', [2, 8])
+def test_bench_self_launches_the_ranks_on_one_device(ranks):
+    """`python bench.py --gpus N` without a torchrun environment spawns the ranks itself; on a one-GPU box the PFN_DP_* hooks put
+    every rank on device 0 over gloo (RCCL refuses two ranks per device) -- the line must say so, count every rank, carry the per-rank step times, the
+    all-reduce figures and the fallback count, and stay inside the 6 KB contract (N = 8: what the driver's scaling run launches)."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(PFN_DP_BACKEND='gloo', PFN_DP_SINGLE_DEVICE='1')
-    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '4'],
-                         capture_output=True, text=True, env=env, timeout=600)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(ranks), '--steps', '2', '--warmup', '1', '--batch', '4'],
+                         capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
-    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['ranks_share_device'] is True
-    assert line['config']['global_batch'] == 8 and line['allreduce_ms'] > 0 and line['value'] > 0
+    text = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+    assert len(text) <= 6 * 1024
+    line = json.loads(text)
+    assert line['n_gpus'] == ranks and line['ranks_seen'] == ranks and line['ranks_share_device'] is True and line['scaling'] == 'weak'
+    assert line['config']['global_batch'] == 4 * ranks and line['config']['parallelism'] == f'dp{ranks}' and line['allreduce_ms'] > 0 and line['value'] > 0
+    assert len(line['per_rank_ms_per_step']) == ranks and all(v > 0 for v in line['per_rank_ms_per_step'])
+    assert line['allreduce_overlapped']['fallback_steps'] == 0 and line['allreduce_overlapped']['in_timed_steps'] == 2
+    assert line['allreduce_overlapped']['overlapped_bytes'] + line['allreduce_overlapped']['exposed_bytes'] == line['allreduce_bytes']
 
 
 def test_train_cli_smoke(capsys):

@@ -340,6 +340,20 @@ class _OracleModel(nn.Module):
         self.transformer_encoder = _EncoderParams(ninp, nhid, nlayers)
         self.decoder = nn.Sequential(nn.Linear(ninp, nhid), nn.GELU(), nn.Linear(nhid, n_out))
         self._flat = self._grad = None
+        self.nlayers, self._custom_decoder, self._first_group_hook = nlayers, False, None      # what dp.OverlappedGradientReducer asks of a model
+
+    def _fused_embedding(self):
+        return True
+
+    def layer_offset(self, l):
+        """first element of encoder layer l in the flat buffers (state-dict order: embedding | layers | decoder), as TransformerModel.layer_offset"""
+        self.flat_parameters()
+        o = 0
+        for name, p in self.named_parameters():
+            if name.startswith(f'transformer_encoder.layers.{l}.') or (l >= self.nlayers and name.startswith('decoder.')):
+                return o
+            o += p.numel()
+        return o
 
     def flat_parameters(self):
         if self._flat is None:
@@ -436,23 +450,24 @@ import os, sys, random, torch
 sys.path.insert(0, sys.argv[1])
 from transformerscandobayesianinference_amd import dp
 rank, world, local = dp.init_from_env(backend='gloo')
-assert dp.world_size() == 2 and dp.rank() == rank and dp.local_batch_size(8) == 4
+W = int(os.environ['WORLD_SIZE'])
+assert world == W and dp.world_size() == W and dp.rank() == rank and dp.local_batch_size(8 * W) == 8
 seed = dp.seed_ranks()
 shared = [random.random() for _ in range(3)]           # python stream (single_eval_pos) is rank-shared
 own = torch.rand(3)                                    # torch stream (prior draws) is rank-distinct
-gathered = [None, None]
+gathered = [None] * W
 torch.distributed.all_gather_object(gathered, (shared, own.tolist()))
-assert gathered[0][0] == gathered[1][0] and gathered[0][1] != gathered[1][1]
+assert all(g[0] == gathered[0][0] for g in gathered) and len({tuple(g[1]) for g in gathered}) == W
 # gradient all-reduce of the flat buffer: mean over ranks == gradient of the global batch
 torch.manual_seed(0)
 w = torch.randn(5, requires_grad=True)
-data = torch.arange(16, dtype=torch.float32).view(8, 2)[rank * 4:(rank + 1) * 4]
+data = torch.arange(8 * W, dtype=torch.float32).view(4 * W, 2)[rank * 4:(rank + 1) * 4]
 loss = ((data @ w[:2]) ** 2).mean()
 loss.backward()
 flat = w.grad.clone()
 dp.all_reduce_gradients(flat)
 flat /= world
-full = torch.arange(16, dtype=torch.float32).view(8, 2)
+full = torch.arange(8 * W, dtype=torch.float32).view(4 * W, 2)
 w2 = w.detach().clone().requires_grad_(True)
 ((full @ w2[:2]) ** 2).mean().backward()
 assert torch.allclose(flat, w2.grad, rtol=1e-6), (flat, w2.grad)
@@ -462,24 +477,83 @@ red = dp.OverlappedGradientReducer(flat_grad=buf, split=6, first_group_layers=1)
 red.arm(1)
 assert red.armed()
 red.finish()
-assert torch.equal(buf, torch.arange(10, dtype=torch.float32) * 3) and not red.overlapped_last_step and not red.armed()
+assert torch.equal(buf, torch.arange(10, dtype=torch.float32) * (W * (W + 1) // 2)) and not red.overlapped_last_step and not red.armed()
 assert red.layout() == dict(total_bytes=40, overlapped_bytes=16, exposed_bytes=24, first_group_layers=1)
 whole = dp.OverlappedGradientReducer(flat_grad=torch.ones(4) * (rank + 1))      # no split: one collective
 whole.finish()
-assert torch.equal(whole.grad, torch.ones(4) * 3)
+assert torch.equal(whole.grad, torch.ones(4) * (W * (W + 1) // 2))
+
+# ---- the training loop itself on W ranks (CPU control path: the f64 oracle stands in for the HIP model, as in test_train_loop_plumbing_on_cpu) ----
+sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import test_host as th
+from oracle import pfn_oracle
+from transformerscandobayesianinference_amd import bar_distribution, encoders, utils, train as train_mod
+from transformerscandobayesianinference_amd.priors.utils import get_batch_to_dataloader
+train_mod.TransformerModel, train_mod.FusedClipAdam = th._OracleModel, th._TorchAdam
+
+class CpuBar(bar_distribution.FullSupportBarDistribution):
+    def forward(self, logits, y):
+        return pfn_oracle.bar_nll(logits, y, self.borders, True)
+
+seen = []      # (batch size this rank was asked for, first feature value of the draw)
+def get_batch(batch_size, seq_len, num_features, hyperparameters=None):
+    x, y, t = pfn_oracle.get_batch_fast_gp(batch_size, seq_len, num_features, hyperparameters)
+    seen.append((batch_size, float(x[0, 0, 0])))
+    return x, y, t
+DL = get_batch_to_dataloader(get_batch)
+DL.num_outputs = 1
+torch.manual_seed(5)
+borders = bar_distribution.get_bucket_limits(10, ys=pfn_oracle.get_batch_fast_gp(50, 10, 2)[1])      # (same on every rank: drawn before the ranks are seeded apart)
+dp.seed_ranks(1234)
+torch.manual_seed(99)      # ... but identical INITIAL weights come from the broadcast in train(), not from this seed: make the seeds differ on purpose below
+torch.manual_seed(99 + rank)
+random.seed(7)             # rank-shared eval positions
+loss, pos, model = train_mod.train(DL, CpuBar(borders), encoders.Linear, emsize=32, nhid=32, nlayers=2, nhead=1, dropout=0.0, y_encoder_generator=encoders.Linear,
+                                   extra_prior_kwargs_dict={'num_features': 2, 'fuse_x_y': False}, single_eval_pos_gen=utils.get_weighted_single_eval_pos_sampler(10),
+                                   bptt=12, verbose=False, epochs=2, steps_per_epoch=4, batch_size=2 * W, lr=1e-2, warmup_epochs=1, aggregate_k_gradients=2)
+assert all(b == 2 for b, _ in seen) and len(seen) == 8          # every rank draws batch_size / world datasets per step
+flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+everyone = [None] * W
+torch.distributed.all_gather_object(everyone, (flat.tolist(), [v for _, v in seen], loss))
+assert all(e[0] == everyone[0][0] for e in everyone), 'the ranks ended with different weights'      # same initial weights (broadcast) + same averaged gradients
+assert len({tuple(e[1]) for e in everyone}) == W, 'two ranks drew the same data'
+assert all(abs(e[2] - everyone[0][2]) < 1e-12 for e in everyone)                                     # the returned loss is the mean over ranks
+# one step by hand: the reducer's two collectives over W ranks give the gradient of the GLOBAL batch
+m = th._OracleModel(encoders.Linear(2, 32), 10, 32, 1, 32, 2, y_encoder=encoders.Linear(1, 32))
+fl, gr = m.flat_parameters()
+torch.distributed.broadcast(fl, 0)
+crit = CpuBar(borders)
+x, y, t = pfn_oracle.get_batch_fast_gp(3, 12, 2)      # this rank's shard (rank-distinct torch stream)
+red = dp.OverlappedGradientReducer(m)
+assert red.first_group_layers == 1 and red.split == m.layer_offset(1) and 0 < red.split < gr.numel()
+red.arm(1)
+crit(m((x, y), single_eval_pos=8).reshape(-1, 10), t[8:].flatten()).mean().backward()
+red.finish()
+shards = [None] * W
+torch.distributed.all_gather_object(shards, (x, y, t))
+m2 = th._OracleModel(encoders.Linear(2, 32), 10, 32, 1, 32, 2, y_encoder=encoders.Linear(1, 32))
+fl2, gr2 = m2.flat_parameters()
+fl2.copy_(fl)
+X, Y, T = (torch.cat([s[i] for s in shards], 1) for i in range(3))
+crit(m2((X, Y), single_eval_pos=8).reshape(-1, 10), T[8:].flatten()).mean().backward()
+assert torch.allclose(gr / W, gr2, rtol=1e-4, atol=1e-7), (gr / W - gr2).abs().max()
 print('rank', rank, 'ok')
 '''
 
 
-def test_data_parallel_helpers_over_gloo(tmp_path):
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_data_parallel_helpers_and_train_loop_over_gloo(tmp_path, world):
+    """SURVEY.md 8(e) on the CPU control path at world sizes 2, 4 and 8 (VERDICT r5 item 8): rank seeding (shared eval-position stream, distinct draws),
+    local_batch_size, the two-collective reducer, and train() itself -- every rank draws batch_size / world datasets per step, the ranks end with identical
+    weights, and one hand-run step's reduced gradient equals the gradient of the concatenated global batch."""
     script = tmp_path / 'dp_check.py'
     script.write_text(_DP_SCRIPT)
     _PORT = _free_port()      # (a fixed port collided once in a full-suite run: a listener of an earlier test was still closing)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_PORT)
-    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                          '--master-port', _PORT, str(script), ROOT], capture_output=True, text=True, env=env, timeout=240)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_PORT, OMP_NUM_THREADS='1')
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+                          '--master-port', _PORT, str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert res.stdout.count('ok') == 2
+    assert res.stdout.count('ok') == world
 
 
 def test_gp_mix_hyperprior_moments():

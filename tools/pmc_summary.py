@@ -46,8 +46,23 @@ def top_layer_dispatches(rows, grid_key):
 
 def main():
     import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = sys.argv[1]
     traffic = {}
+    # what was profiled: the bench line of the kernel-trace run (tools/profile_bench.sh puts it next to the traces)
+    meta = {}
+    try:
+        line = json.load(open(os.path.join(out, 'bench.json')))
+        meta = dict(config=line['config']['baseline_config'], batch=line['config']['per_gpu_batch'], streams=line['config']['micro_batch_streams'], precision=line['dtype'],
+                    workload=line['config']['workload'], datasets_per_s_under_the_profiler=line['value'])
+    except Exception as e:      # (older layouts: the defaults of configs[1])
+        meta = dict(config=2, batch=int(sys.argv[2]) if len(sys.argv) > 2 else 64, streams=2, precision='bf16', note_meta=f'bench.json unreadable: {e}')
+    try:
+        import torch  # noqa: F401
+        from transformerscandobayesianinference_amd import _hip
+        meta['abi'] = _hip.ABI_VERSION
+    except Exception:
+        pass
     st = find(os.path.join(out, 'stats'), '*kernel_stats.csv')
     if st:
         print('== rocprofv3 --kernel-trace --stats: bench.py --steps 10 --warmup 3 ==')
@@ -58,20 +73,21 @@ def main():
     tr = find(os.path.join(out, 'stats'), '*kernel_trace.csv')
     if tr:
         # the attention kernels' in-step durations, the top layer's short launches (queries >= sep only) apart from the others
-        rows = [r for r in csv.DictReader(open(tr)) if 'attn_' in r['Kernel_Name']]
-        top = top_layer_dispatches(rows, 'Grid_Size_X')
+        rows = [r for r in csv.DictReader(open(tr)) if 'pfn' in r['Kernel_Name']]      # every kernel of the library (the dominant one is a GEMM in some configurations)
+        top = top_layer_dispatches([r for r in rows if 'attn_' in r['Kernel_Name']], 'Grid_Size_X')
         agg = {}
         for r in rows:
             a = agg.setdefault((r['Kernel_Name'], r['Dispatch_Id'] in top), [0, 0.0])
             a[0] += 1
             a[1] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
-        print('== attention kernels inside the step (kernel trace of the same run), top-layer launches apart ==')
+        print('== kernels inside the step (kernel trace of the same run), the attention\'s top-layer launches apart ==')
         in_step = {}
         for (name, is_top), (n, ns) in sorted(agg.items()):
-            print(f'{short(name) + (TOP if is_top else ""):96s} n={n:5d} avg_us={ns / n / 1e3:10.2f}')
+            if 'attn_' in name or ns / 1e6 > 1.0:
+                print(f'{short(name) + (TOP if is_top else ""):96s} n={n:5d} avg_us={ns / n / 1e3:10.2f}')
             in_step[name + (TOP if is_top else '')] = {'calls': n, 'avg_us': ns / n / 1e3}
         json.dump({'note': 'rocprofv3 --kernel-trace of bench.py --steps 10 --warmup 3 (tools/profile_bench.sh): average in-step duration per attention kernel; the top '
-                           'encoder layer\'s launches (queries >= sep only, told by the grid of the forward / query-block pass) are listed apart', 'kernels': in_step},
+                           'encoder layer\'s launches (queries >= sep only, told by the grid of the forward / query-block pass) are listed apart', **meta, 'kernels': in_step},
                   open(os.path.join(out, 'in_step_attention.json'), 'w'), indent=1)
     for d in sorted(glob.glob(os.path.join(out, 'pmc_*'))):
         if not os.path.isdir(d):
@@ -99,8 +115,8 @@ def main():
                 traffic.setdefault(k, {})['write_bytes'] = avg * 1024
                 extra = f'  -> {avg / 1024:10.1f} MB/launch written (uncalibrated)'
             print(f'{k:66s} {c:28s} n={n:5d} avg={avg:16.1f}{extra}')
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    json.dump({'note': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB) per launch, bench.py --steps 3 --warmup 1 --batch {batch}; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported', 'config': 2, 'batch': batch, 'streams': 2, 'kernels': traffic}, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
+    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB) per launch, bench.py --steps 3 --warmup 1 of the configuration below; FETCH_SIZE doubled per MI355X_MICROARCH.md '
+                       '(gfx950 counts 128-B requests at 64 B), WRITE_SIZE as reported', **meta, 'kernels': traffic}, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -232,11 +232,11 @@ def evaluate(x, y, y_non_noisy, use_mse=False, hyperparameters={}, get_model_on_
     return ls.to('cpu'), per_t.to('cpu'), time.time() - start_time
 DataLoader.prefetch = True        # draws run ahead of the training steps on a side stream (priors/utils.py)
 DataLoader.prefetch_group = 10    # ... ten steps' worth of datasets per sampler call (MI355X, bptt 2000: 64 us per dataset at 4 x 32, 54 us at 10 x 32;
-                                  # 16 MB of factorisation workspace per dataset: 5 GB of the 288)
+                                  # 16 MB of matrix + 3.7 MB of plane scratch per dataset at bptt 2000: 6.3 GB of the 288)
 DataLoader.prefetch_group_datasets = 640    # ... and at least this many datasets per call when the batches are small (priors/utils.py)
 DataLoader.prefetch_memory_share = 0.125    # ... but never more than an eighth of the free device memory per group (two groups are alive at a time)
 def workspace_bytes_per_dataset(kw):
-    """K_ws per dataset as the library sizes it (the [Tp, Tp] f32 matrix + the plane scratch: +11 % at bptt 2000, +20 % at 1000, +25 % at 512 -- ADVICE r4: not a constant factor)."""
+    """K_ws per dataset as the library sizes it (the [Tp, Tp] f32 matrix + the plane scratch -- two plane sets of two fp16 planes since round 5: +23 % at bptt 2000, +39 % at 1000, +50 % at 512; ADVICE r4 / r5: not a constant factor, always asked of pfn_gp_workspace_bytes)."""
     Tp = (kw.get('seq_len', 0) + 3) // 4 * 4
     return int(_hip.lib().pfn_gp_workspace_bytes(1, Tp)) if Tp > 0 else 0
 

@@ -95,6 +95,23 @@ class MicroBatchStreams:
     # and run as one launch set in which every dataset carries its own eval position (TransformerModel.forward_batches, pfn_stack_forward_ragged):
     # the launches are as large as a big batch's.  The batches of a step are split into `groups` contiguous chunks, one per stream.
     MAX_GROUP_DATASETS = 64      # datasets per launch set (the activation workspace grows with it: ~0.34 GB per dataset at the north-star shape)
+    WORKSPACE_MEMORY_SHARE = 0.5  # ... and never more datasets than fit this share of the device's FREE memory over the streams' concurrent launch sets
+
+    def max_group_datasets(self, model, seq_len, n_concurrent):
+        """Datasets per launch set: MAX_GROUP_DATASETS, lowered until `n_concurrent` workspaces of that many datasets (pfn_workspace_bytes for this model's
+        descriptor: the activations the backward re-reads) fit WORKSPACE_MEMORY_SHARE of the free device memory -- a larger model or a smaller GPU then runs
+        smaller launch sets instead of running out of memory where the reference's one-batch-at-a-time loop fits."""
+        import ctypes
+        n = self.MAX_GROUP_DATASETS
+        try:
+            desc = model._operands(_hip.stream_ptr(model.flat_parameters()[0].device), False)[0]
+            free, _ = torch.cuda.mem_get_info(model.flat_parameters()[0].device)
+        except Exception:      # (no descriptor yet / not a cuda device: the constant stands)
+            return n
+        budget = self.WORKSPACE_MEMORY_SHARE * free / max(1, n_concurrent)
+        while n > 1 and _hip.lib().pfn_workspace_bytes(ctypes.byref(desc), n, seq_len) > budget:
+            n //= 2
+        return n
 
     def can_stack(self, model):
         return getattr(model, 'can_forward_batches', lambda: False)()
@@ -105,7 +122,8 @@ class MicroBatchStreams:
         loss_fn(output_k, targets_k, sep_k) -> losses [T - sep_k, b_k].  before(n_groups): called once ahead of the first launch set with the number of backward
         passes that follow (data-parallel runs arm their reducer for that many)."""
         total = sum(b[0][0].shape[1] for b in batches)
-        n_groups = max(1, -(-total // self.MAX_GROUP_DATASETS))
+        concurrent = self.n if (self.streams and not getattr(model, 'deterministic', False)) else 1
+        n_groups = max(1, -(-total // self.max_group_datasets(model, batches[0][0][0].shape[0], concurrent)))
         if self.streams and not getattr(model, 'deterministic', False):
             n_groups = max(n_groups, min(self.n, len(batches)))
         n_groups = min(n_groups, len(batches))

@@ -115,6 +115,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     # gradient accumulation over SMALL batches (the notebooks' batch_size 4 x aggregate_k_gradients 25): the batches of one optimizer step run whole, round-robin on
     # `aggregate_streams` HIP streams, instead of each being split into column groups (streams.py; measured in bench.py's batch_sweep).  None = automatic.
     explicit_streams = aggregate_streams is not None and aggregate_streams > 1
+    plain_schedule_requested = aggregate_streams is not None and aggregate_streams <= 1      # aggregate_streams=0: the caller asked for the plain sequential schedule
     if aggregate_streams is None:
         # (one MI355X, configs[1]: batch 4 x 25 batches 956 datasets/s as column groups, 1680 / 1688 / 1927 on 2 / 4 / 8 alternating streams; batch 8 x 4:
         # 1637 -> 2066; batch 16 x 4: 2175 -> 2346 -- gpurun call 3 of round 4, profiles/r04_small_batch_streams.txt)
@@ -125,7 +126,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
     # model whose embedding and decoder run inside the HIP stack, and no explicit aggregate_streams request), True / False = forced.
     small_batches = aggregate_k_gradients >= 2 and dp.local_batch_size(batch_size) * bptt <= 16 * 2048
     if aggregate_stacked is None:
-        aggregate_stacked = small_batches and not explicit_streams
+        aggregate_stacked = small_batches and not explicit_streams and not plain_schedule_requested
     stacked = bool(aggregate_stacked) and aggregate_k_gradients >= 2 and str(device).startswith('cuda') and micro.can_stack(model)
     # data-parallel runs: the flat gradient buffer is all-reduced as two collectives, the upper layers' half under the backward
     reducer = dp.OverlappedGradientReducer(model) if world > 1 and hasattr(model, 'flat_parameters') else None
@@ -200,7 +201,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
                     if last_micro_step and pending:
                         # one stack + one scatter-add for the whole optimizer step (25 batches at the notebooks' recipe: three tiny launches each added up)
                         lks = torch.stack([losses_k.mean() for _, losses_k in pending])
-                        idx = torch.tensor([sep_k for sep_k, _ in pending], dtype=torch.long)
+                        idx = torch.tensor([sep_k % bptt if sep_k < 0 else sep_k for sep_k, _ in pending], dtype=torch.long)      # (negative positions count from the end, as in model.forward; index_add_ takes none)
                         total_loss += lks.sum()
                         positional_sum.index_add_(0, idx.to(device, non_blocking=True), lks)
                         positional_cnt.index_add_(0, idx, torch.ones(len(pending)))
