@@ -78,6 +78,11 @@ enum { PFN_SCHED_TOP_LAYER_ALL_ROWS = 1, /* run the TOP encoder layer on every r
                                           * dataset's layer-input rows.  softmax_j(q_i . k_j) is invariant to one vector subtracted from every key, so outputs and gradients are the
                                           * reference's (transformer.py:84) while the rounding of K stops being relative to the keys' common component (ABI 8; default on).
                                           * This bit turns it off (the arithmetic of rounds 1-5). */
+       PFN_SCHED_FUSE_Q_PROJECTION = 32, /* the Q projection runs INSIDE the attention forward kernel (north_star: "QKV projection + scaled-dot-product attention + softmax ... as one
+                                          * fused kernel"): a workgroup forms its 256 queries' head slice x W_q[h]^T + b_q[h] on the matrix cores in its prologue, the GEMM in
+                                          * front projects k | v only (shared by every query block of a head: they stay a GEMM).  Same Q bits as the GEMM's; 16-bit operands,
+                                          * head dim <= 128, emsize % 128 == 0, no live dropout -- otherwise ignored.  Built and measured in round 6 (ABI 8); default off:
+                                          * profiles/r06_fused_q_projection.txt */
        PFN_SCHED_DETERMINISTIC = 8       /* bit-reproducible gradients (the reference's CPU loop is deterministic, train.py:58-110): every gradient element has
                                           * exactly ONE writer per launch and launches are stream-ordered -- weight-gradient GEMMs without token splits, LayerNorm
                                           * gamma / beta / bias gradients through per-workgroup partials summed in a fixed order (implies SEPARATE_LNBWD), the
@@ -90,7 +95,7 @@ int pfn_default_schedule(void);
 int pfn_abi_version(void);
 const char* pfn_last_error_string(void);
 /* TEST / PROFILING ONLY: process-wide kernel-selection knobs (results are identical up to rounding order; not synchronised -- set them
- * while no call is in flight).  Keys 2, 5 and 6 do not act on calls directly: they change what pfn_default_schedule() hands to NEW
+ * while no call is in flight).  Keys 2, 5, 6, 12 and 13 do not act on calls directly: they change what pfn_default_schedule() hands to NEW
  * descriptors (pfn_model_desc::schedule), so a forward / backward pair can never disagree about them.
  * PFN_TUNE_GEMM_NT_KERNEL: 0 automatic (default), 1 always the 128x128 register-staged
  * kernel, 2 the 256x256 LDS-DMA kernel whenever the shape is legal for it, 3 the 128x256 one.
@@ -106,6 +111,11 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_FUSE_DELTA = 9,    /* 1 (default): on the full-sequence layers of the bf16 stack the attention backward's delta = rowsum(dO . O) is taken in the epilogue of the GEMM that
                                     * produces dO (f32 atomics into a zeroed scratch: two addends per element at head dim 128); 0: a pass of its own over dO and O (attn_delta_kernel) */
        PFN_TUNE_GEMM_LN_ROWS = 7,  /* 1: the LayerNorm-fused GEMMs at emsize 512 run on 64-row tiles, two workgroups per CU (gemm.hip g_ln_rows64); 0 (default): 128-row tiles */
+       PFN_TUNE_ATTN_BWD_GROUP = 10, /* > 0: the attention backward's key-block / query-block pass pair runs for that many datasets at a time, every group through the front of
+                                      * the dS^T scratch (which then stays in the 256 MB memory-side cache between the two passes); 0 (default): one pair per call */
+       PFN_TUNE_WGRAD_SPLITS = 11,   /* > 0: token-axis splits of the grouped weight-gradient launch where the stack leaves them automatic; 0 (default): the occupancy rule */
+       PFN_TUNE_FUSE_Q_PROJECTION = 12, /* 1: new descriptors carry PFN_SCHED_FUSE_Q_PROJECTION (default 0) */
+       PFN_TUNE_KEY_CENTERING = 13,     /* 0: new descriptors carry PFN_SCHED_NO_KEY_CENTERING (default 1: keys centred) */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
                                     * returns output[single_eval_pos:] (transformer.py:91), so that layer's train rows feed nothing; 0: every layer on every row */ };
 int pfn_set_tuning(int key, int value);

@@ -983,7 +983,7 @@ def test_bench_self_launches_the_ranks_on_one_device(ranks):
     assert line['n_gpus'] == ranks and line['ranks_seen'] == ranks and line['ranks_share_device'] is True and line['scaling'] == 'weak'
     assert line['config']['global_batch'] == 4 * ranks and line['config']['parallelism'] == f'dp{ranks}' and line['allreduce_ms'] > 0 and line['value'] > 0
     assert len(line['per_rank_ms_per_step']) == ranks and all(v > 0 for v in line['per_rank_ms_per_step'])
-    assert line['allreduce_overlapped']['fallback_steps'] == 0 and line['allreduce_overlapped']['in_timed_steps'] == 2
+    assert line['allreduce_overlapped']['fallback_steps'] == 0 and line['allreduce_overlapped']['in_timed_steps'] is True      # every armed step overlapped its early collective
     assert line['allreduce_overlapped']['overlapped_bytes'] + line['allreduce_overlapped']['exposed_bytes'] == line['allreduce_bytes']
 
 
@@ -1757,3 +1757,35 @@ def test_forward_batches_equals_separate_forwards(precision, seps):
         outs_e = model.forward_batches(batches, seps)
         for got, (x, y), sep in zip(outs_e, batches, seps):
             assert torch.equal(got, model((x, y), single_eval_pos=sep))
+
+
+
+@pytest.mark.parametrize('E,H', [(128, 4), (256, 4), (512, 4)], ids=['head-dim-32', 'head-dim-64', 'head-dim-128'])
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_q_projection_inside_the_attention_kernel_equals_the_gemm_projection(precision, E, H):
+    """PFN_SCHED_FUSE_Q_PROJECTION (north_star: "QKV projection + scaled-dot-product attention + softmax ... as one fused kernel"; the half that can exist -- K and V are
+    shared by every query block of a head and stay a GEMM): the attention forward forms its queries' head slice x W_q[h]^T + b_q[h] on the matrix cores in its prologue.
+    Same operands in the same contraction order as the GEMM: the forward must agree to the last bit -- uniform and ragged batches, the top layer on the test rows or on
+    every row -- and so must the gradients up to the atomics' summation order."""
+    cfg = dict(T=600, B=3, F=4, E=E, H=H, nhid=2 * E, L=2, nbars=20)
+    g = torch.Generator().manual_seed(17)
+    x, y = torch.rand(cfg['T'], cfg['B'], cfg['F'], generator=g).to(DEV), torch.randn(cfg['T'], cfg['B'], generator=g).to(DEV)
+    out = {}
+    for fused in (False, True):
+        model = random_model(cfg, precision, seed=11)
+        model.schedule = _hip.SCHED_FUSE_Q_PROJECTION if fused else 0
+        model = model.to(DEV).train()
+        res = []
+        for sep in (520, 100):                                   # the top layer on the test rows / on every row (sep < T / 4)
+            model.zero_grad()
+            lg = model((x, y), single_eval_pos=sep)
+            model.criterion(lg.reshape(-1, cfg['nbars']), y[sep:].flatten()).mean().backward()
+            res.append((lg.detach().clone(), model.flat_parameters()[1].clone()))
+        with torch.no_grad():
+            rag = model.forward_batches([(x[:, :2], y[:, :2]), (x[:, 2:], y[:, 2:])], [517, 300])
+        out[fused] = (res, [r.clone() for r in rag])
+    for (lg0, g0), (lg1, g1) in zip(out[False][0], out[True][0]):
+        assert torch.equal(lg1, lg0), relerr(lg1, lg0)
+        within(f'{precision} fused vs GEMM Q projection: gradient rel l2', relerr(g1, g0), 1e-5)
+    for r0, r1 in zip(out[False][1], out[True][1]):
+        assert torch.equal(r1, r0)

@@ -199,7 +199,27 @@ constexpr float RESCALE_THR = 6.f;  // log2 units: lazily raised running max of 
 // and a full V tile of 256 columns do not fit the LDS side by side (2 x 33 KB + 4 x 34 KB), a K tile and a half V tile do.  The softmax
 // statistics are recomputed per slice (identical values; slice 0 writes lse).  1.5 x the matrix work of an unsplit kernel, for a pass
 // that is not the throughput path (reference transformer.py:55-91 under model.eval(), priors/fast_gp_mix.py:139-153 validate).
-template <typename T, int D, bool DROP = false, int DV = D>
+// A 32 x 32 accumulator tile whose ROWS are the contraction index of the next product (rows acc_row(r) = accumulator order, lane = column) as the operand fragment of
+// contraction chunk c (rows 16 c .. 16 c + 15) in MEMORY order (mapping M1: slot (h, e) = row 16 c + 8 h + e): the half-waves exchange their middle quads
+// (v_permlane32_swap, as store_row_block does for its 16-byte stores), `add8` is added in f32 first (add8[4 g + e] belongs to row 16 c + 8 g + 4 h + e).
+template <typename T> PFN_DEV Frag<T> acc_to_frag_m1(const f32x16& acc, int c, const float (&add8)[8]) {
+  static_assert(sizeof(T) == 2, "16-bit operands");
+  typedef X2<T> x2;
+  const x2 a0 = {(T)(acc[8 * c + 0] + add8[0]), (T)(acc[8 * c + 1] + add8[1])}, a1 = {(T)(acc[8 * c + 2] + add8[2]), (T)(acc[8 * c + 3] + add8[3])};
+  const x2 b0 = {(T)(acc[8 * c + 4] + add8[4]), (T)(acc[8 * c + 5] + add8[5])}, b1 = {(T)(acc[8 * c + 6] + add8[6]), (T)(acc[8 * c + 7] + add8[7])};
+  const auto r0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
+  const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+  Frag<T> f;
+  f.v = __builtin_bit_cast(X8<T>, w);
+  return f;
+}
+
+// FUSEQ (AttnArgs::xq): the workgroup's Q slice is formed here instead of read from qkv -- see AttnArgs.  Q^T[d][query] = W_q[h] x^T as "swapped" MFMAs (A = 32 rows
+// of W_q[h], B = the wave's 32 x rows), so a lane ends up with its own query's 128 values, 16 per accumulator tile in accumulator order; acc_to_frag_m1 turns them
+// into the very fragments the K.Q^T product wants.  W_q[h] ([D, E], 128 KB at emsize 512) goes through the K / V tile buffers (not yet in use) in chunks of 128
+// columns, double-buffered; the x rows come straight from global memory, 16 bytes per lane and k-step (whole 1-KiB rows over the prologue).
+template <typename T, int D, bool DROP = false, int DV = D, bool FUSEQ = false>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs a) {
   using C = AttnCfg<T, D>;
   using CV = AttnCfg<T, DV>;      // the V / O side: CV::NDB column blocks, CV::CIMG bytes per tile image
@@ -242,8 +262,54 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs 
   const unsigned dthr = DROP ? dropout_threshold(a.p_drop) : 0u;
 
   Frag<T> qf[C::NKK];
+  if constexpr (FUSEQ) {
+    static_assert(sizeof(T) == 2 && D <= 128 && C::NW == 8, "fused Q projection: the 8-wave 16-bit configurations");
+    constexpr int EC = 128, WS = EC * 2 + 16, WIMG = D * WS;      // W_q chunk image: D rows x 128 columns, padded row stride (conflict-free ds_read_b128 along rows)
+    static_assert(2 * WIMG <= 2 * C::RIMG + 4 * CV::CIMG, "W_q chunk buffers must fit the (idle) K / V tile buffers");
+    const T* xrow = reinterpret_cast<const T*>(a.xq) + ((long)b * a.S + qc) * a.E;
+    const T* wq_h = reinterpret_cast<const T*>(a.wq) + (long)(hd * D) * a.E;
+    f32x16 qa[C::NDB];
 #pragma unroll
-  for (int kk = 0; kk < C::NKK; ++kk) qf[kk] = load_frag_global<T>(Qp + (long)qc * rs + kk * 16 + 8 * h);
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qa[db][r] = 0.f;
+    TileStage<T, D, EC * 2, C::NT> sw;
+    const int nch = a.E / EC;
+    sw.issue(wq_h, a.E, D, EC);
+    sw.template commit_p<WS>(smem);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+      const lds_char* wimg = smem + (ch & 1) * WIMG;
+      if (ch + 1 < nch) sw.issue(wq_h + (ch + 1) * EC, a.E, D, EC);      // the next chunk's loads stay in flight under this chunk's products
+      Frag<T> xf[EC / 16];
+#pragma unroll
+      for (int ks = 0; ks < EC / 16; ++ks) xf[ks] = load_frag_global<T>(xrow + ch * EC + ks * 16 + 8 * h);
+#pragma unroll
+      for (int ks = 0; ks < EC / 16; ++ks) {
+        Frag<T> wf[C::NDB];
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) wf[db] = load_frag_row_p<T, WS>(wimg, db * 32 + li, ks * 16);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) qa[db] = mma32(wf[db], xf[ks], qa[db]);
+      }
+      if (ch + 1 < nch) sw.template commit_p<WS>(smem + ((ch + 1) & 1) * WIMG);
+      __syncthreads();
+    }
+    const float* bq = a.bq + hd * D;
+    T* qout = reinterpret_cast<T*>(const_cast<void*>(a.qkv)) + (long)b * a.S * rs + hd * D + (long)qc * rs;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bq + db * 32 + 16 * c + 4 * h), b1 = *reinterpret_cast<const f32x4*>(bq + db * 32 + 16 * c + 8 + 4 * h);
+        const float add8[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        qf[2 * db + c] = acc_to_frag_m1<T>(qa[db], c, add8);
+        if (a.q_store && qvalid) *reinterpret_cast<X8<T>*>(qout + (2 * db + c) * 16 + 8 * h) = qf[2 * db + c].v;      // the backward reads Q from qkv
+      }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < C::NKK; ++kk) qf[kk] = load_frag_global<T>(Qp + (long)qc * rs + kk * 16 + 8 * h);
+  }
 
   // initial state: the self key for test rows, empty for train rows.  The self K / V rows are only fetched by waves
   // that hold a test row at all (wave-uniform branch): 7 of 8 waves at the north star skip 24 loads per lane.
@@ -558,7 +624,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
 
   // (ragged batch: the grid has ceil(max position / 256) blocks per (dataset, head); a dataset's blocks past ITS position leave at once)
   const AttnBlock wg = a.sep_of ? attn_block((a.sep + C::QBLK - 1) / C::QBLK, a.H) : attn_block_ragged_last((a.sep + C::QBLK - 1) / C::QBLK, a.sep / C::QBLK, a.H);
-  const int b = wg.b, hd = wg.hd;
+  const int b = wg.b + a.b0, hd = wg.hd;      // (b0: this launch's first dataset, AttnArgs)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
   const long rs = 3L * a.E;
   const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.S * rs;
@@ -589,7 +655,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnAr
   // dS^T of this (dataset, head): 32 x 32 blocks, block (key / 32, query / 32) at ((key / 32) * (ds_ld / 32) + query / 32) blocks
   // (store_frag_pair_blocked); the wave owns block row key / 32
   constexpr int DSBLK = 32 * 32;   // elements per block
-  T* dsT = reinterpret_cast<T*>(a.ds) + ((long)b * a.H + hd) * a.ds_rows * a.ds_ld + (long)(key0 / 32 + wave) * (a.ds_ld / 32) * DSBLK;
+  T* dsT = reinterpret_cast<T*>(a.ds) + ((long)(b - a.b0) * a.H + hd) * a.ds_rows * a.ds_ld + (long)(key0 / 32 + wave) * (a.ds_ld / 32) * DSBLK;
   const bool ds_row_live = key0 + wave * 32 < a.ds_rows;   // wave-uniform: this wave's block row exists in the buffer
 
   Frag<T> kf[C::NKK], vf[(K::VLDS || !DO_DK) ? 1 : C::NKK];
@@ -969,7 +1035,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
 
   AttnBlock wg = attn_block((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK, a.H);
   wg.blk += a.q_begin / C::QBLK;    // (q_begin: AttnArgs; the launcher zero-fills the dQ rows below it)
-  wg.b = a.B - 1 - wg.b;            // most recently written dS^T first (see above)
+  wg.b = a.b0 + a.bg - 1 - wg.b;    // most recently written dS^T first (see above); datasets [b0, b0 + bg) of this launch
   wg.hd = a.H - 1 - wg.hd;
   const int b = wg.b, hd = wg.hd;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, li = lane & 31;
@@ -998,7 +1064,7 @@ __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnAr
   // pass stored zeros for them (dS^T), the descriptor's range ends at sep (K).  At the top of tile t the K tile t+1 and then the
   // dS^T tile t+2 are issued; the end of tile t waits for everything EXCEPT that last dS^T tile (vmcnt = its instruction count:
   // loads return in order), so a dS^T fetch has two tile times to arrive.  (One tile ahead, the pass ran at 3.4 TB/s.)
-  const long ds_bh = ((long)b * a.H + hd) * a.ds_rows * a.ds_ld;
+  const long ds_bh = ((long)(b - a.b0) * a.H + hd) * a.ds_rows * a.ds_ld;
   const DmaRsrc rd = make_dma_rsrc(reinterpret_cast<const T*>(a.ds) + ds_bh, (long)a.ds_rows * a.ds_ld * (long)sizeof(T));
   const DmaRsrc rk = make_dma_rsrc(Kp, ((long)(sep - 1) * rs + D) * (long)sizeof(T));   // rows >= sep read as zero
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -1402,17 +1468,35 @@ __global__ __launch_bounds__(256) void attn_bwd_plain_dq_kernel(AttnArgs a) {
 // =============================================================================================
 // launchers
 // =============================================================================================
+static int g_attn_bwd_group = 0;      // PFN_TUNE_ATTN_BWD_GROUP (launch_bwd_k)
+void set_attn_bwd_group(int datasets) { g_attn_bwd_group = datasets; }
+bool attn_fwd_can_fuse_q(int E, int H, int precision) {
+  const int D = H > 0 ? E / H : 0;
+  return prec_is16(precision) && (D == 32 || D == 64 || D == 128) && E % 128 == 0;
+}
 template <typename T, int D, bool DROP> static int launch_fwd_k(const AttnArgs& a, hipStream_t s) {
   using C = AttnCfg<T, D>;
   // exact-f32 at head dim 256: the V / O columns in two slices of 128 (attn_fwd_kernel, DV)
   constexpr int DV = (sizeof(T) == 4 && D == 256) ? 128 : D;
   constexpr size_t lds = 2 * C::RIMG + 4 * AttnCfg<T, DV>::CIMG;
   static_assert(lds <= 160 * 1024, "attention forward: tile buffers exceed the CU's LDS");
+  if ((a.S + C::QBLK - 1) / C::QBLK <= a.q_begin / C::QBLK) return PFN_OK;      // no query at or above q_begin
+  const dim3 grid(((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK) * a.H * a.B, D / DV);
+  if constexpr (sizeof(T) == 2 && D <= 128 && !DROP) {
+    if (a.xq) {      // the Q projection inside the kernel (AttnArgs::xq)
+      if (!a.wq || !a.bq || a.E % 128) return PFN_ERR_ARGUMENT;
+      static LdsAllowance allowance_q;
+      allowance_q.ensure(attn_fwd_kernel<T, D, false, DV, true>, lds);
+      ProfScope ps(PFN_PROF_ATTN_FWD + (a.q_begin > 0 ? 1 : 0), s);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, D, false, DV, true>), grid, dim3(C::NT), lds, s, a);
+      return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+    }
+  }
+  if (a.xq) return PFN_ERR_UNSUPPORTED;
   static LdsAllowance allowance;
   allowance.ensure(attn_fwd_kernel<T, D, DROP, DV>, lds);
-  if ((a.S + C::QBLK - 1) / C::QBLK <= a.q_begin / C::QBLK) return PFN_OK;      // no query at or above q_begin
   ProfScope ps(PFN_PROF_ATTN_FWD + (a.q_begin > 0 ? 1 : 0), s);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, D, DROP, DV>), dim3(((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK) * a.H * a.B, D / DV), dim3(C::NT), lds, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, D, DROP, DV>), grid, dim3(C::NT), lds, s, a);
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 template <typename T, int D> static int launch_fwd_t(const AttnArgs& a, hipStream_t s) {
@@ -1432,10 +1516,38 @@ template <typename T, int D, bool DROP> static int launch_bwd_k(const AttnArgs& 
   static LdsAllowance allow_kv[3], allow_dq;      // (per device; hipFuncSetAttribute costs tens of microseconds of host time per call)
   auto run_kv = [&](auto kernel, LdsAllowance& allow, const AttnArgs& ac) {
     allow.ensure(kernel, lds_kv);
-    hipLaunchKernelGGL(kernel, dim3(((ac.sep + C::QBLK - 1) / C::QBLK) * ac.H * ac.B), dim3(C::NT), lds_kv, s, ac);
+    hipLaunchKernelGGL(kernel, dim3(((ac.sep + C::QBLK - 1) / C::QBLK) * ac.H * ac.bg), dim3(C::NT), lds_kv, s, ac);
   };
   // (Launching the pair for a few datasets at a time into one scratch, so that dS^T -- 436 MB per 16 datasets -- stays in the
   // 256 MB memory-side cache, was measured: 432 vs 436 us with two chunks, slower with more: each launch ends in a partial round.)
+  // PFN_TUNE_ATTN_BWD_GROUP (round 6 experiment): the key-block / query-block pair for `group` datasets at a time, every group through the front of
+  // the dS^T scratch (25.7 MB per dataset at the north star), so that the query-block pass finds what the key-block pass just wrote in the 256 MB memory-side cache
+  // instead of in HBM.  0 = one pair for the whole call.  (Measured: profiles/r06_attention_bwd_groups.txt.)
+  const int group = (g_attn_bwd_group > 0 && g_attn_bwd_group < a.B && (parts & ATTN_BWD_KV) && (parts & ATTN_BWD_DQ)) ? g_attn_bwd_group : a.B;
+  const bool dq_runs = (parts & ATTN_BWD_DQ) && (a.S + C::QBLK - 1) / C::QBLK > a.q_begin / C::QBLK;
+  if (group < a.B) {
+    if (a.q_from_sep) {
+      const int rc = launch_zero_row_prefix_ragged(a.dqkv, a.S, a.B, a.sep_of, 3L * a.E * (long)sizeof(T), (long)a.E * (long)sizeof(T), s);
+      if (rc != PFN_OK) return rc;
+    } else if (a.q_begin > 0) {
+      const int rc = launch_zero_row_prefix(a.dqkv, a.S, a.B, a.q_begin, 3L * a.E * (long)sizeof(T), (long)a.E * (long)sizeof(T), s);
+      if (rc != PFN_OK) return rc;
+    }
+    allow_dq.ensure(attn_bwd_dq_kernel<T, D, DROP>, lds_dq);
+    for (int b0 = 0; b0 < a.B; b0 += group) {
+      AttnArgs ag = a;
+      ag.b0 = b0; ag.bg = std::min(group, a.B - b0);
+      if (a.sep > 0) {
+        ProfScope ps(PFN_PROF_ATTN_BWD_KV + (a.q_begin > 0 ? 1 : 0), s);
+        run_kv(attn_bwd_kv_kernel<T, D, 0, DROP>, allow_kv[0], ag);
+      }
+      if (dq_runs) {
+        ProfScope ps(PFN_PROF_ATTN_BWD_DQ + (a.q_begin > 0 ? 1 : 0), s);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, DROP>), dim3(((a.S + C::QBLK - 1) / C::QBLK - a.q_begin / C::QBLK) * a.H * ag.bg), dim3(C::NT), lds_dq, s, ag);
+      }
+    }
+    return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+  }
   if ((parts & ATTN_BWD_KV) && a.sep > 0) {
     ProfScope ps(PFN_PROF_ATTN_BWD_KV + (a.q_begin > 0 ? 1 : 0), s);
     if constexpr (BwdKvCfg<T, D>::SPLIT && !DROP) {      // (A/B builds only: -DPFN_KV_SPLIT_D256=1)
@@ -1561,6 +1673,7 @@ int launch_attn_bwd(const AttnArgs& a_in, int precision, hipStream_t s) {
   AttnArgs a = a_in;
   attn_bwd_ds_dims(a.S, a.sep, &a.ds_rows, &a.ds_ld);
   a.q_begin = a.q_begin / 256 * 256;
+  a.b0 = 0; a.bg = a.B;
   PFN_ATTN_DISPATCH(launch_bwd_t, return (launch_bwd_plain_f32<256>(a, s)))
 }
 

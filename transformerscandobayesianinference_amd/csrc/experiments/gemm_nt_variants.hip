@@ -1,3 +1,18 @@
+// EXPERIMENTS, NOT PART OF libpfn_hip.so (hygiene): two main-loop structures of the 256 x 256 NT GEMM that round 5 built, tested and measured
+// SLOWER than the shipped kernel (profiles/r05_gemm_experiments.txt) -- kept here, out of the product binary, as the record of what was tried:
+//   gemm_nt_ring_kernel    : the operand stream as a ring of four 32-deep stages, three in flight              (-4 ... 9 %)
+//   gemm_nt_persist_kernel : one workgroup per CU walking tiles, the next tile's first stage requested early    (within noise, more code)
+// The third one, software-pipelined fragment reads (-DPFN_GEMM_FRAG_PIPE=1 bodies inside the big / LayerNorm-fused / grouped-TN kernels), lived in
+// gemm.hip up to commit 9097de4 (round 5's last) and is in the git history only.
+// This translation unit INCLUDES the product's gemm.hip (tile configuration, epilogue, launch helpers) and adds the two kernels plus one C entry point; it builds
+// into its own library and never into the product:
+//     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -shared -o libpfn_gemm_experiments.so experiments/gemm_nt_variants.hip
+// bf16 operands only (the experiments predate the fp16 instantiations).
+#include <cstring>
+#include "../gemm.hip"
+
+namespace pfn {
+
 // ---------------------------------------------------------------------------------------------
 // gemm_nt_ring_kernel (round 5 experiment, PFN_TUNE_GEMM_NT_KERNEL = 4): the 256 x 256 tile with its operand stream as a RING of four 32-deep stages
 // (4 x 32 KiB = the same 128 KiB as two 64-deep stages), three of them in flight under the one being multiplied.  The big kernel has ONE stage in flight and ends
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ring_kernel(GemmNT g) {
     slot = slot + 1 == RING_NS ? 0 : slot + 1;
   }
   wait_vm_barrier<0>();      // every wave is done reading the ring before the epilogue's strips go there
-  nt_big_epilogue<FLAGS, 2>(g, acc, m0, n0, wave, lane, smem);
+  nt_big_epilogue<bf16, FLAGS, 2>(g, acc, m0, n0, wave, lane, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -189,8 +204,61 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(GemmNT g) {
     // every wave is done reading the last stage (buffer 1) before the epilogue's strips go there; the next tile's first stage
     // (buffer 0) stays in flight
     asm volatile("s_barrier" ::: "memory");
-    nt_big_epilogue<FLAGS, 2>(g, acc, m0, n0, wave, lane, smem + P::EP_OFF);
+    nt_big_epilogue<bf16, FLAGS, 2>(g, acc, m0, n0, wave, lane, smem + P::EP_OFF);
     stores_pending = m0 + C::BM <= g.M && g.wide_t;
     m0 = m0n; n0 = n0n;
+  }
+}
+
+
+static int g_nt_persist = 0;   // workgroups of the persistent kernel
+static int g_exp_variant = 0;
+template <int FLAGS> static bool launch_persist_t(const GemmNT& g, hipStream_t stream) {
+  using C = BigCfg<2, 64>;
+  using P = PersistCfg<FLAGS>;
+  if (g_nt_persist <= 0 || (g.K / 64) % 2 || g.N % C::BN || !g.wide_t) return false;
+  if ((FLAGS & EPI_OUT_F32) && (g.ld_out_f32 % 4)) return false;
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_persist_kernel<FLAGS>, P::LDS);
+  const int tiles = ((g.M + C::BM - 1) / C::BM) * (g.N / C::BN);
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<FLAGS>), dim3(std::min(tiles, g_nt_persist)), dim3(512), P::LDS, stream, g);
+  return true;
+}
+template <int FLAGS> static bool launch_ring_t(const GemmNT& g, hipStream_t stream) {
+  using C = BigCfg<2, 32>;
+  if (g_exp_variant != 1 || g.K % 32) return false;
+  static LdsAllowance allowance;
+  allowance.ensure(gemm_nt_ring_kernel<FLAGS>, RING_NS * C::STAGE);
+  const int tiles = ((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<FLAGS>), dim3(tiles), dim3(512), RING_NS * C::STAGE, stream, g);
+  return true;
+}
+
+}  // namespace pfn
+
+// variant 1: ring, variant 2: persistent with `wgs` workgroups.  Flags: the epilogue combinations of the product's launch_big; returns 0 / -1 (unsupported shape or flags).
+extern "C" int pfn_exp_gemm_nt(int variant, int wgs, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int flags, const float* bias,
+                               const void* aux, int64_t ld_aux, const float* resid, int64_t ld_resid, float* out_f32, int64_t ld_out_f32, void* out_t, int64_t ld_out_t,
+                               void* out2_t, int64_t ld_out2, void* stream) {
+  using namespace pfn;
+  GemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.flags = flags; g.bias = bias; g.aux = aux; g.ld_aux = ld_aux; g.resid = resid; g.ld_resid = ld_resid;
+  g.out_f32 = out_f32; g.ld_out_f32 = ld_out_f32; g.out_t = out_t; g.ld_out_t = ld_out_t; g.out2_t = out2_t; g.ld_out2 = ld_out2;
+  nt_prepare(g, PFN_PREC_BF16);
+  if (!g.vec_ok || g.K % 64 || g.N % 4) return -1;
+  g_exp_variant = variant; g_nt_persist = wgs;
+  hipStream_t s = (hipStream_t)stream;
+  switch (flags) {
+#define PFN_EXP_CASE(F) case (F): return (variant == 1 ? launch_ring_t<(F)>(g, s) : launch_persist_t<(F)>(g, s)) ? 0 : -1;
+    PFN_EXP_CASE(EPI_BIAS | EPI_OUT_T)
+    PFN_EXP_CASE(EPI_BIAS | EPI_GELU | EPI_OUT_T | EPI_OUT2_T)
+    PFN_EXP_CASE(EPI_GELU_BWD | EPI_OUT_T)
+    PFN_EXP_CASE(EPI_RESID_T | EPI_OUT_T)
+    PFN_EXP_CASE(EPI_RESID_T | EPI_OUT_F32)
+    PFN_EXP_CASE(EPI_OUT_T)
+    PFN_EXP_CASE(EPI_OUT_F32)
+#undef PFN_EXP_CASE
+    default: return -1;
   }
 }

@@ -1727,6 +1727,8 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 static int g_tn_debug_wrap = 0;
 void set_gemm_tn_debug_wrap(int rows) { g_tn_debug_wrap = rows; }
+static int g_tn_group_splits = 0;
+void set_gemm_tn_group_splits(int splits) { g_tn_group_splits = splits; }
 // 0: automatic, 1: only the generic 128x128 kernel, 2: the 256x256 LDS-DMA kernel whenever legal,
 // 3: the 128x256 LDS-DMA kernel whenever legal (tests / profiling)
 static int g_big_mode = 0;
@@ -1938,6 +1940,7 @@ int launch_gemm_tn_group(GemmTNGroup g, int precision, hipStream_t stream) {
   // split the token axis only when the group cannot occupy the chip by itself
   // automatic: the smallest split count (<= 8) whose workgroup count fills whole rounds of the 256 CUs to >= 90 %
   int splits = g.splits;
+  if (splits <= 0 && g_tn_group_splits > 0) splits = g_tn_group_splits;      // (test / profiling knob)
   if (splits <= 0) {
     splits = 8;
     for (int sp = 1; sp <= 8; ++sp) {   // (a 256 x 256 partial tile is 65536 atomics: more than 8 splits cost more than they fill)

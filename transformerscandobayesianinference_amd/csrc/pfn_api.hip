@@ -76,7 +76,7 @@ int check_desc(const pfn_model_desc* d) {
   const bool ok = dh == 32 || dh == 64 || dh == 128 || dh == 256;
   if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128/256)", dh);
   if (d->emsize > 2048) return fail(PFN_ERR_UNSUPPORTED, "emsize > 2048 unsupported by the LayerNorm kernels");
-  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC | PFN_SCHED_NO_KEY_CENTERING)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
+  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC | PFN_SCHED_NO_KEY_CENTERING | PFN_SCHED_FUSE_Q_PROJECTION)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
   if (!(d->dropout >= 0.f && d->dropout < 1.f)) return fail(PFN_ERR_ARGUMENT, "dropout %g outside [0, 1)", (double)d->dropout);
   return PFN_OK;
 }
@@ -253,6 +253,10 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_GEMM_TN_WRAP: set_gemm_tn_debug_wrap(value); return PFN_OK;
     case PFN_TUNE_FUSE_LNBWD: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_SEPARATE_LNBWD) : (g_default_schedule | PFN_SCHED_SEPARATE_LNBWD); return PFN_OK;
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
+    case PFN_TUNE_ATTN_BWD_GROUP: set_attn_bwd_group(value); return PFN_OK;
+    case PFN_TUNE_WGRAD_SPLITS: set_gemm_tn_group_splits(value); return PFN_OK;
+    case PFN_TUNE_FUSE_Q_PROJECTION: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_Q_PROJECTION) : (g_default_schedule & ~PFN_SCHED_FUSE_Q_PROJECTION); return PFN_OK;
+    case PFN_TUNE_KEY_CENTERING: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_NO_KEY_CENTERING) : (g_default_schedule | PFN_SCHED_NO_KEY_CENTERING); return PFN_OK;
     case PFN_TUNE_GEMM_LN_ROWS: set_gemm_ln_rows64(value); return PFN_OK;
     case PFN_TUNE_GP_PLANES: g_gp_planes = value != 0; return PFN_OK;
     case PFN_TUNE_FUSE_DELTA: g_fuse_delta = value != 0; return PFN_OK;
@@ -393,6 +397,8 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
     g.resid = r.plain; g.ry = r.y; g.rmean = r.mean; g.rrstd = r.rstd; g.rgamma = r.gamma; g.rbeta = r.beta;
   };
   const bool top_mode = rg ? top_layer_on_test_rows_ragged(*d, S, *rg, pdrop) : top_layer_on_test_rows(*d, S, sep, pdrop);
+  // north_star's "QKV projection + attention as one kernel", the half that can exist (PFN_SCHED_FUSE_Q_PROJECTION; measured, not the default: DESIGN.md section 3)
+  const bool fuse_q = (d->schedule & PFN_SCHED_FUSE_Q_PROJECTION) && pdrop == 0.f && attn_fwd_can_fuse_q(E, H, prec);
   // the top layer's row moves (token order -> the decoder's compact rows): (t - sep) B + b, or dataset-major for a ragged batch
   auto gather_top = [&](const void* src, void* dst, long row_bytes) {
     return rg ? launch_gather_rows_ragged(src, dst, S, B, row_bytes, rg->sep_of, (const long*)rg->row_off, s) : launch_gather_rows(src, dst, S, B, row_bytes, sep, s);
@@ -406,11 +412,14 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       ProfScope ps(PFN_PROF_GEMM_QKV, s);
       GemmNT g = nt(xin_t, E, W(p.w_in), E, M, 3 * E, E, EPI_BIAS | EPI_OUT_T);
       g.bias = params + p.b_in; g.out_t = a.qkv; g.ld_out_t = 3 * E;
+      if (fuse_q) {      // PFN_SCHED_FUSE_Q_PROJECTION: only k | v here, q inside the attention kernel (below)
+        g.B = W(p.w_in + (int64_t)E * E); g.N = 2 * E; g.bias = params + p.b_in + E; g.out_t = a.qkv + (int64_t)E * es;
+      }
       // 16-bit operands: the keys leave centred per dataset, k' = k - W_k xbar (pfn_kernels.h launch_key_shift: the attention output and every gradient are those of
       // the uncentred keys, the operand rounding of K is 9 x smaller on a trained model).  The shift is taken in f32 inside this GEMM's epilogue.
       if (w.kshift && E % 64 == 0) {
         PFN_TRY(launch_key_shift(xin_t, W(p.w_in + (int64_t)E * E), w.kshift, B, S, E, sep, sep_of, prec, s));
-        g.flags |= EPI_ROWSHIFT; g.rowshift = w.kshift; g.rs_ld = E; g.rs_S = S; g.rs_n0 = E; g.rs_n1 = 2 * E;
+        g.flags |= EPI_ROWSHIFT; g.rowshift = w.kshift; g.rs_ld = E; g.rs_S = S; g.rs_n0 = fuse_q ? 0 : E; g.rs_n1 = g.rs_n0 + E;
       }
       PFN_TRY(launch_gemm_nt(g, prec, s));
     }
@@ -420,6 +429,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       at.p_drop = pdrop; at.drop_seed = dseed(l, 0);
       at.q_begin = top ? (rg ? rg->sep_min : sep) : 0;
       at.q_from_sep = (top && rg) ? 1 : 0;
+      if (fuse_q) { at.xq = xin_t; at.wq = W(p.w_in); at.bq = params + p.b_in; at.q_store = 1; }      // (q_store: the backward reads Q from qkv)
       PFN_TRY(launch_attn_fwd(at, prec, s));
     }
     const char* ctx_in = a.ctx;

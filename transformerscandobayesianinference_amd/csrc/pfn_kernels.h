@@ -161,6 +161,7 @@ struct GemmTNGroup {
   const float* scale_amax;           // fp16 backward: every C and colsum of the group receives its product times 2^-k (nullptr = 1)
 };
 void set_gemm_tn_debug_wrap(int rows);
+void set_gemm_tn_group_splits(int splits);      // PFN_TUNE_WGRAD_SPLITS: token-axis splits of the grouped weight-gradient launch when the caller leaves them automatic (0 = the occupancy rule)
 // GEMM + bias + residual + LayerNorm in one kernel (gemm_nt_ln_kernel): one workgroup owns 128 full rows of the
 // N = emsize columns, so the row statistics are taken straight from the accumulators:
 //     v = A . B^T + bias + r,   y = v (f32, kept for the LayerNorm backward),   x_t = (T) ((v - mean) rstd gamma + beta)
@@ -216,6 +217,17 @@ struct AttnArgs {
   int parts;  // backward launches to run, bit mask over ATTN_BWD_*; 0 = all (profiling entry point pfn_op_attention_bwd_parts)
   int zero_delta;  // the query-block pass (the last reader's successor) leaves delta[b, head, its queries] = 0: the next layer's GEMM epilogue ADDS into it (EPI_ROWDOT)
   int pingpong;  // filled by the launcher (PFN_TUNE_ATTN_PINGPONG): bit 0 forward, bit 1 key-block pass
+  // filled by the launcher: the backward's key-block / query-block pair may run for a GROUP of datasets at a time (PFN_TUNE_ATTN_BWD_GROUP) -- datasets [b0, b0 + bg) of the
+  // B in this call; every group re-uses the front of the dS^T scratch, so what the key-block pass wrote is still in the 256 MB memory-side cache when the query-block pass reads it
+  int b0, bg;
+  // forward with the Q PROJECTION FUSED IN (north_star's "QKV projection + attention as one kernel", the half that can exist: K and V are shared by every query block
+  // of a head and stay a GEMM).  xq != nullptr (16-bit operands, head dim <= 128, E % 128 == 0): the workgroup forms its 256 queries' head slice q = x W_q[h]^T + b_q[h]
+  // on the matrix cores in the prologue -- W_q[h] through LDS in 128-column chunks, x rows straight from global -- instead of reading them from qkv;
+  // q_store != 0 also writes them to qkv's Q columns (training: the backward reads them there).
+  const void* xq;      // [B, S, E] T: the layer input (operand copy)
+  const void* wq;      // [E, E] T: the Q block of in_proj_weight (rows h * D .. of head h)
+  const float* bq;     // [E] f32: the Q block of in_proj_bias
+  int q_store;
   // Queries below q_begin are skipped: their context rows / dQ rows are not written and they add nothing to dK and dV (the top encoder
   // layer, whose train rows feed nothing: pfn_api.hip).  The launcher rounds it down to a multiple of 256 (whole query blocks / tiles of every
   // kernel); the caller hands in dctx rows that are ZERO in [that multiple, its own first live row).
@@ -225,9 +237,11 @@ struct AttnArgs {
   unsigned drop_seed;      // site seed of this layer's attention (dropout_site_seed(call seed, layer, 0)); the kernels mix (dataset, head) in
 };
 void set_attn_pingpong(int mask);
+void set_attn_bwd_group(int datasets);      // 0 = all datasets of a call in one launch pair
 enum : int { ATTN_BWD_DELTA = 1, ATTN_BWD_KV = 2, ATTN_BWD_DQ = 4 };
 int64_t attn_bwd_ds_bytes(int B, int S, int H, int precision);   // size of AttnArgs::ds for any sep <= S
 int launch_attn_fwd(const AttnArgs& a, int precision, hipStream_t stream);
+bool attn_fwd_can_fuse_q(int E, int H, int precision);      // shapes for which AttnArgs::xq is implemented (16-bit operands, head dim <= 128, E % 128 == 0, no dropout)
 int launch_attn_bwd(const AttnArgs& a, int precision, hipStream_t stream);
 
 // ---- row-wise / element-wise kernels (rowwise.hip) --------------------------------------------
