@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libpfn_hip.so
-SRCS="pfn_api.hip gemm.hip attention.hip rowwise.hip bar.hip optim.hip gp_prior.hip mlp_prior.hip"
+SRCS="pfn_api.hip gemm.hip gemm_tn.hip attention.hip rowwise.hip bar.hip optim.hip gp_prior.hip mlp_prior.hip"
 mkdir -p ../_build
 pids=()
 for f in $SRCS; do
@@ -17,5 +17,5 @@ for f in $SRCS; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/pfn_api.o ../_build/gemm.o ../_build/attention.o ../_build/rowwise.o ../_build/bar.o ../_build/optim.o ../_build/gp_prior.o ../_build/mlp_prior.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/pfn_api.o ../_build/gemm.o ../_build/gemm_tn.o ../_build/attention.o ../_build/rowwise.o ../_build/bar.o ../_build/optim.o ../_build/gp_prior.o ../_build/mlp_prior.o
 echo "built $(realpath $OUT)"
