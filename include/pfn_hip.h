@@ -114,6 +114,7 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_ATTN_BWD_GROUP = 10, /* > 0: the attention backward's key-block / query-block pass pair runs for that many datasets at a time, every group through the front of
                                       * the dS^T scratch (which then stays in the 256 MB memory-side cache between the two passes); 0 (default): one pair per call */
        PFN_TUNE_WGRAD_SPLITS = 11,   /* > 0: token-axis splits of the grouped weight-gradient launch where the stack leaves them automatic; 0 (default): the occupancy rule */
+       PFN_TUNE_WGRAD_WAVES = 14,       /* waves per 256 x 256 tile of the grouped weight-gradient launch: 8 (128 x 64 each) or 4 (128 x 128 each, the whole register file per wave) */
        PFN_TUNE_FUSE_Q_PROJECTION = 12, /* 1: new descriptors carry PFN_SCHED_FUSE_Q_PROJECTION (default 0) */
        PFN_TUNE_KEY_CENTERING = 13,     /* 0: new descriptors carry PFN_SCHED_NO_KEY_CENTERING (default 1: keys centred) */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference

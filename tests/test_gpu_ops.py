@@ -284,8 +284,16 @@ def test_gemm_lnbwd_fused(M, N, K, ln_tile_rows, op16):
     assert relerr(dgamma, 2 * gd.grad) < tol(op16, 2e-3, 2.5e-4, 0) and relerr(dbeta, 2 * bd.grad) < 1e-4
 
 
-@pytest.mark.parametrize('M,splits', [(64, 1), (1000, 1), (1000, 0), (4100, 3), (37, 1)])
-def test_gemm_tn_group(M, splits, op16):
+@pytest.fixture(params=[8, 4], ids=['8-waves-128x64', '4-waves-128x128'])
+def wgrad_waves(request):
+    """PFN_TUNE_WGRAD_WAVES: the grouped weight-gradient launch as eight waves of 128 x 64 (gemm_tn_big_kernel) or four of 128 x 128 (gemm_tn_wide_kernel)."""
+    _hip.check(_hip.lib().pfn_set_tuning(14, request.param), 'pfn_set_tuning')
+    yield request.param
+    _hip.check(_hip.lib().pfn_set_tuning(14, 8), 'pfn_set_tuning')
+
+
+@pytest.mark.parametrize('M,splits', [(64, 1), (1000, 1), (1000, 0), (4100, 3), (37, 1), (130, 1)])
+def test_gemm_tn_group(M, splits, op16, wgrad_waves):
     """Grouped 256x256 weight-gradient kernel: several problems in one launch, ragged token tail, fused bias gradient."""
     shapes = [(512, 256), (256, 768), (256, 256)]
     probs, refs = [], []
@@ -302,7 +310,7 @@ def test_gemm_tn_group(M, splits, op16):
             assert relerr(cs, rs) < 3e-6, relerr(cs, rs)
 
 
-def test_gemm_tn_group_asymmetric(op16):
+def test_gemm_tn_group_asymmetric(op16, wgrad_waves):
     M = 256
     A = torch.zeros(M, 256, dtype=hipops.TDT[op16], device=dev()); A[torch.arange(M), torch.arange(M)] = 1
     B = (torch.arange(M * 512, device=dev()).float().view(M, 512) % 127 / 8).to(hipops.TDT[op16])

@@ -243,12 +243,12 @@ PFN_DEV void nt_big_epilogue(const GemmNT& g, f32x16 (&acc)[4][2], int m0, int n
       const bool shifted = (flags & EPI_ROWSHIFT) && nb >= g.rs_n0 && nb < g.rs_n1;
       if (shifted) {
         if (shift_lds) {      // the tile's shift rows wait in LDS (gemm_nt_big_kernel put them there before its main loop): no global load between this epilogue's stores
-          const int which = min((int)(m / g.rs_S) - (int)(m0 / g.rs_S), 1);
+          const int which = min((int)((unsigned)m / (unsigned)g.rs_S) - (int)((unsigned)m0 / (unsigned)g.rs_S), 1);      // (32-bit: a 64-bit division is ~150 instructions, eight times per wave)
           const lds_char* sp = shift_lds + (which * BIG_BN + (nb - n0) + 4 * h) * 4;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) shift_v[gq] = __builtin_bit_cast(f32x4, lds_read16(sp + 32 * gq));
         } else {
-          const float* sp = g.rowshift + (m / g.rs_S) * g.rs_ld + (nb - g.rs_n0) + 4 * h;
+          const float* sp = g.rowshift + (long)((unsigned)m / (unsigned)g.rs_S) * g.rs_ld + (nb - g.rs_n0) + 4 * h;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) shift_v[gq] = *reinterpret_cast<const f32x4*>(sp + 8 * gq);
         }

@@ -325,6 +325,163 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(GemmTNGroup g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_tn_wide_kernel (round 6): the same grouped product on the same 256 x 256 tile with FOUR waves of 128 x 128 instead of eight of 128 x 64.
+// Why: both operands are token-major, so every fragment is a transposing LDS read of 8 bytes per lane (ds_read_b64_tr_b16) -- 12 of them per 8 MFMAs in the 8-wave
+// shape.  Counted per CU and 16-token step that is 96 LDS read instructions + the DMA's own 16 KiB of LDS writes against 512 cycles of MFMA per SIMD: the LDS port,
+// not the matrix pipe, is what the 8-wave kernel runs at (838 TF/s = a third of the MFMA rate, whatever the depth of the operand ring: gemm_tn_big_kernel's header).
+// A wave that owns 128 x 128 reads (128 + 128) columns for twice the MFMAs: 64 read instructions per CU and step, a third less LDS traffic per flop.
+// Price: the 16 accumulator tiles are 256 registers, so a wave needs the whole register file (one wave per SIMD: no second wave to cover its LDS round trips) --
+// the fragments of step s + 1 are therefore requested before the MFMAs of step s (two fragment sets, PFN_PIN_LDS_MFMA keeps the machine scheduler from sinking the
+// reads back to their consumers), the first step of the next stage right behind the stage barrier.
+// ---------------------------------------------------------------------------------------------
+constexpr int TNW_NW = 4;                              // waves: 2 (P) x 2 (Q), each 128 x 128
+constexpr int TNW_PW = TNB_KT / 2 / TNW_NW;            // 1-KiB DMA pieces per wave per operand per stage
+static_assert(TNB_KT == 64 && TNB_NS == 2, "gemm_tn_wide_kernel is written for two 64-token stages");
+template <typename T>
+__global__ __launch_bounds__(TNW_NW * 64, 1) void gemm_tn_wide_kernel(GemmTNGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LdsPtr smem = lds_cast(smem_raw);
+  const int ntiles = g.tile_start[g.n];
+  const int id = xcd_remap(blockIdx.x, ntiles * g.splits);
+  const int split = id / ntiles, tile = id % ntiles;
+  int pi = 0;
+  while (tile >= g.tile_start[pi + 1]) ++pi;
+  const TnProblem& pr = g.p[pi];
+  const int tq = pr.Q / 256;
+  const int tl = tile - g.tile_start[pi];
+  const int p0 = (tl / tq) * 256, q0 = (tl % tq) * 256;
+  const long mbeg = (long)split * g.m_chunk;
+  const long mend = min((long)g.M, mbeg + g.m_chunk);
+  const int rows_total = (int)(mend - mbeg);
+  if (rows_total <= 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wp = wave >> 1, wq = wave & 1;
+
+  // DMA sources: piece i of this wave = token rows (wave + 4 i) * 2 + (lane >> 5); the swizzled column depends on row & 3 only, i.e. not on i (8 i = 0 mod 4):
+  // ONE pointer per operand, the row offset added per piece (sixteen 64-bit pointers would not fit beside 256 accumulator registers)
+  const int prow0 = wave * 2 + (lane >> 5);
+  const int pcol = ((((lane & 31) >> 2) ^ (prow0 & 3)) * 32) + (lane & 3) * 8;
+  const T* pa = reinterpret_cast<const T*>(pr.A) + mbeg * pr.lda + p0 + pcol;
+  const T* pb = reinterpret_cast<const T*>(pr.B) + mbeg * pr.ldb + q0 + pcol;
+  const long lda = pr.lda, ldb = pr.ldb;
+  auto stage = [&](int slot, int r0) {
+    LdsPtr ta = smem + slot * 2 * TNB_TILE + wave * 1024;
+    LdsPtr tb = ta + TNB_TILE;
+#pragma unroll
+    for (int i = 0; i < TNW_PW; ++i) {
+      const long r = min(r0 + prow0 + 2 * TNW_NW * i, rows_total - 1) & g.debug_mask;
+      dma16_global(pa + r * lda, ta + i * TNW_NW * 1024);
+      dma16_global(pb + r * ldb, tb + i * TNW_NW * 1024);
+    }
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // bias gradient (column sums of A over the tokens): on the vector ALU, straight from the A fragments the products read anyway -- lane l holds 8 tokens of column
+  // l & 31 of each of its 4 sub-tiles; Q wave wq sums sub-tiles 2 wq and 2 wq + 1 (64 adds per step under 512 cycles of MFMA; two more accumulator tiles do not fit)
+  float cs[2] = {0.f, 0.f};
+  const bool do_colsum = pr.colsum != nullptr && q0 == 0;
+
+  const int nt = (rows_total + TNB_KT - 1) / TNB_KT;
+  struct Frs { Frag<T> a[4], b[4]; };
+  auto main_loop = [&](auto with_colsum) {
+    constexpr bool CS = decltype(with_colsum)::value;
+    Frs f0, f1;
+    auto ld = [&](Frs& f, const lds_char* ta, const lds_char* tb, int ks) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.b[j] = load_frag_tr<T, 512, 1>(tb, ks, wq * 128 + j * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.a[i] = load_frag_tr<T, 512, 1>(ta, ks, wp * 128 + i * 32);
+    };
+    auto mm = [&](const Frs& f) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mma32(f.a[i], f.b[j], acc[i][j]);
+      // bias gradient: Q wave wq sums the columns of the wave's P sub-tiles 2 wq and 2 wq + 1 (their fragments are in registers already)
+      if constexpr (CS) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[c] += (float)(wq ? f.a[2 + c] : f.a[c]).v[e];
+      }
+    };
+    // stage t has landed for every wave and every read of the slot it is about to overwrite has retired (wait_vm_barrier waits lgkmcnt(0) too);
+    // request stage t + 1 into the other slot; clear the rows past the end of a ragged last stage
+    auto enter_stage = [&](int t, int slot) {
+      wait_vm_barrier<0>();
+      if (t + 1 < nt) stage(slot ^ 1, (t + 1) * TNB_KT);
+      const int valid = rows_total - t * TNB_KT;
+      if (valid < TNB_KT) {
+        LdsPtr ta = smem + slot * 2 * TNB_TILE;
+        for (int idx = threadIdx.x; idx < (TNB_KT - valid) * 32; idx += TNW_NW * 64) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          lds_write16(ta + (valid + idx / 32) * 512 + (idx % 32) * 16, z);
+        }
+        __syncthreads();
+      }
+    };
+    int slot = 0;
+    enter_stage(0, slot);
+    ld(f0, smem, smem + TNB_TILE, 0);
+    for (int t = 0; t < nt; ++t) {
+      const lds_char* ta = smem + slot * 2 * TNB_TILE;
+      const lds_char* tb = ta + TNB_TILE;
+      ld(f1, ta, tb, 16);
+      PFN_PIN_LDS_MFMA();
+      mm(f0);
+      PFN_PIN_LDS_MFMA();
+      ld(f0, ta, tb, 32);
+      PFN_PIN_LDS_MFMA();
+      mm(f1);
+      PFN_PIN_LDS_MFMA();
+      ld(f1, ta, tb, 48);
+      PFN_PIN_LDS_MFMA();
+      mm(f0);
+      PFN_PIN_LDS_MFMA();
+      slot ^= 1;
+      if (t + 1 < nt) {
+        enter_stage(t + 1, slot);
+        const lds_char* tan = smem + slot * 2 * TNB_TILE;
+        ld(f0, tan, tan + TNB_TILE, 0);
+      }
+      PFN_PIN_LDS_MFMA();
+      mm(f1);
+      PFN_PIN_LDS_MFMA();
+    }
+  };
+  stage(0, 0);
+  if (do_colsum) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
+
+  const int pv = pr.Pv > 0 ? pr.Pv : pr.P;
+  const float osc = loss_scale_down(g.scale_amax);
+  if (do_colsum) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float s = cs[c] + __shfl_xor(cs[c], 32, 64);      // the two half-waves hold the other 8 tokens of every step
+      const int pp = p0 + wp * 128 + (2 * wq + c) * 32 + (lane & 31);
+      if (lane < 32 && pp < pv) unsafeAtomicAdd(pr.colsum + pp, s * osc);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pp = p0 + wp * 128 + i * 32 + acc_row(r, lane);
+        const int qq = q0 + wq * 128 + j * 32 + (lane & 31);
+        if (pp < pv) unsafeAtomicAdd(pr.C + (long)pp * pr.ldc + qq, acc[i][j][r] * osc);
+      }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -333,6 +490,8 @@ static int g_tn_debug_wrap = 0;
 void set_gemm_tn_debug_wrap(int rows) { g_tn_debug_wrap = rows; }
 static int g_tn_group_splits = 0;
 void set_gemm_tn_group_splits(int splits) { g_tn_group_splits = splits; }
+static bool g_tn_wide = false;
+void set_gemm_tn_group_waves(int waves) { g_tn_wide = waves == 4; }
 
 int launch_gemm_tn(GemmTN g, int precision, hipStream_t stream) {
   if (g.M <= 0 || g.P <= 0 || g.Q <= 0) return PFN_OK;
@@ -388,6 +547,17 @@ int launch_gemm_tn_group(GemmTNGroup g, int precision, hipStream_t stream) {
   g.splits = splits;
   g.m_chunk = chunk;
   g.debug_mask = g_tn_debug_wrap > 0 ? g_tn_debug_wrap - 1 : 0x7fffffff;
+  if (g_tn_wide) {      // PFN_TUNE_WGRAD_WAVES = 4: four waves of 128 x 128 (gemm_tn_wide_kernel)
+    static LdsAllowance allow_w[2];
+    if (precision == PFN_PREC_FP16) {
+      allow_w[1].ensure(gemm_tn_wide_kernel<f16>, TNB_LDS);
+      hipLaunchKernelGGL(gemm_tn_wide_kernel<f16>, dim3(tiles * splits), dim3(TNW_NW * 64), TNB_LDS, stream, g);
+    } else {
+      allow_w[0].ensure(gemm_tn_wide_kernel<bf16>, TNB_LDS);
+      hipLaunchKernelGGL(gemm_tn_wide_kernel<bf16>, dim3(tiles * splits), dim3(TNW_NW * 64), TNB_LDS, stream, g);
+    }
+    return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
+  }
   static LdsAllowance allowance[2];
   if (precision == PFN_PREC_FP16) {
     allowance[1].ensure(gemm_tn_big_kernel<f16>, TNB_LDS);

@@ -255,6 +255,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_ATTN_PINGPONG: set_attn_pingpong(value); return PFN_OK;
     case PFN_TUNE_ATTN_BWD_GROUP: set_attn_bwd_group(value); return PFN_OK;
     case PFN_TUNE_WGRAD_SPLITS: set_gemm_tn_group_splits(value); return PFN_OK;
+    case PFN_TUNE_WGRAD_WAVES: set_gemm_tn_group_waves(value); return PFN_OK;
     case PFN_TUNE_FUSE_Q_PROJECTION: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_Q_PROJECTION) : (g_default_schedule & ~PFN_SCHED_FUSE_Q_PROJECTION); return PFN_OK;
     case PFN_TUNE_KEY_CENTERING: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_NO_KEY_CENTERING) : (g_default_schedule | PFN_SCHED_NO_KEY_CENTERING); return PFN_OK;
     case PFN_TUNE_GEMM_LN_ROWS: set_gemm_ln_rows64(value); return PFN_OK;

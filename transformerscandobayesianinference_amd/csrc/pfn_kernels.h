@@ -161,6 +161,7 @@ struct GemmTNGroup {
   const float* scale_amax;           // fp16 backward: every C and colsum of the group receives its product times 2^-k (nullptr = 1)
 };
 void set_gemm_tn_debug_wrap(int rows);
+void set_gemm_tn_group_waves(int waves);       // PFN_TUNE_WGRAD_WAVES: 8 = gemm_tn_big_kernel (eight waves of 128 x 64), 4 = gemm_tn_wide_kernel (four of 128 x 128)
 void set_gemm_tn_group_splits(int splits);      // PFN_TUNE_WGRAD_SPLITS: token-axis splits of the grouped weight-gradient launch when the caller leaves them automatic (0 = the occupancy rule)
 // GEMM + bias + residual + LayerNorm in one kernel (gemm_nt_ln_kernel): one workgroup owns 128 full rows of the
 // N = emsize columns, so the row statistics are taken straight from the accumulators:

@@ -175,13 +175,21 @@ template <typename T> __global__ __launch_bounds__(256) void key_shift_kernel(co
   const int ns = sep < KS_SAMPLES ? sep : KS_SAMPLES, stride = sep / ns;
   const int G = E / 8, R = G >= 256 ? 1 : 256 / G;
   const T* xb = x + (long)b * S * E;
+  // (every load of a batch is issued before the first is used: written as "load, add" per row the loop is a chain of memory round trips -- 17 us for this
+  // kernel in its first form, gpurun_out/r06c5)
   for (int idx = threadIdx.x; idx < G * R; idx += 256) {
     const int cg = idx % G, rl = idx / G;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = rl; r < ns; r += R) {
-      const X8<T> v = *reinterpret_cast<const X8<T>*>(xb + (long)r * stride * E + cg * 8);
+    for (int r0 = rl; r0 < ns; r0 += 8 * R) {
+      X8<T> v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const X8<T>*>(xb + (long)min(r0 + u * R, ns - 1) * stride * E + cg * 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + u * R < ns) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[rl * E + cg * 8 + e] = acc[e];
@@ -195,17 +203,28 @@ template <typename T> __global__ __launch_bounds__(256) void key_shift_kernel(co
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int o = 0; o < 16; ++o) {
-    const int n = n0 + wave * 16 + o;
-    if (n >= E) break;                               // (wave-uniform)
-    float s = 0.f;
-    for (int e0 = lane * 8; e0 < E; e0 += 512) {
-      const X8<T> w = *reinterpret_cast<const X8<T>*>(wk + (long)n * E + e0);
+  for (int pass = 0; pass * 512 < E; ++pass) {       // (one pass at E <= 512; every lane walks every pass: the wave-wide sum below wants all 64)
+    const int e0 = pass * 512 + lane * 8;
+    const bool live = e0 < E;
+    const int ec = live ? e0 : 0;
+    X8<T> w[16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += (float)w[e] * part[e0 + e];
+    for (int o = 0; o < 16; ++o) w[o] = *reinterpret_cast<const X8<T>*>(wk + (long)min(n0 + wave * 16 + o, E - 1) * E + ec);
+    float xv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[e] = live ? part[ec + e] : 0.f;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)w[o][e] * xv[e];
+      s = wave_sum(s);
+      const int n = n0 + wave * 16 + o;
+      if (lane == 0 && n < E) {
+        if (pass == 0) kshift[(long)b * E + n] = s;
+        else kshift[(long)b * E + n] += s;           // (E > 512: the later passes add their part, same lane, program order)
+      }
     }
-    s = wave_sum(s);
-    if (lane == 0) kshift[(long)b * E + n] = s;
   }
 }
 int launch_key_shift(const void* x_t, const void* w_k_t, float* kshift, int B, int S, int E, int sep, const int* sep_of, int precision, hipStream_t s) {
