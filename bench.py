@@ -889,6 +889,9 @@ def compact_line(result):
         line['val_bar_nll'] = v if not isinstance(v, dict) else _pick(v, ('bar_nll', 'value', 'n', 'sep'))
     for name, e in result.get('other_configs', {}).items():
         line.setdefault('other_configs', {})[name] = dict(value=e['value'], ms_per_step=e['ms_per_step'], per_gpu_batch=e['per_gpu_batch'], frac=e['step_roofline']['frac'])
+    if 'also_bf16' in result:
+        e = result['also_bf16']
+        line['also_bf16'] = dict(value=e['value'], ms_per_step=e['ms_per_step'], **{k: e['parity_timed_path'][k] for k in ('nll_rel', 'mean_rel_l2') if 'parity_timed_path' in e})
     if 'batch_sweep' in result:
         line['batch_sweep'] = [dict(b=e['per_gpu_batch'], k=e['aggregate_k_gradients'], schedule=e['schedule'].split(' (')[0], value=e['value']) for e in result['batch_sweep']]
     for k in ('ranks_seen', 'per_rank_ms_per_step', 'allreduce_ms', 'allreduce_bytes', 'collective_backend', 'devices_visible', 'ranks_share_device'):
@@ -933,7 +936,9 @@ def main():
     ap.add_argument('--aggregate-streams', type=int, default=0, help='> 1: the aggregate_k batches of a step run whole, round-robin on that many streams (small batches)')
     ap.add_argument('--aggregate-stacked', action='store_true', help='the aggregate_k batches of a step stacked into one launch set per micro-batch stream, every dataset with its own eval position (what train() picks for small batches since round 5)')
     ap.add_argument('--streams', type=int, default=None, help='concurrent micro-batches per step (column groups of the batch on separate HIP streams)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'f32'], help='operand format of the TIMED (training) path; recorded as `dtype`')
+    ap.add_argument('--precision', default='fp16', choices=['bf16', 'fp16', 'f32'],
+                    help='operand format of the TIMED (training) path, recorded as `dtype`.  fp16 (round 6): the 16-bit format whose training forward holds the north star\'s 1e-3 on NLL and '
+                         'posterior means (same MFMA rate and bytes as bf16; gradients under a device-side loss scale); the bf16 figures ride along as `also_bf16`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-kernel-breakdown', action='store_true')
@@ -1104,6 +1109,21 @@ def main():
             result['other_configs'][f'configs[{cfg - 1}]'] = entry
             release(rc)
             del rc
+        # the same configuration with bf16 operands (rounds 1-5's timed path; BASELINE configs[1] says "bf16"): throughput and timed-path parity beside the fp16 line
+        if args.precision != 'bf16':
+            t0 = time.time()
+            rb16 = run_config(2, device, 0, 1, 'bf16', steps=10, warmup=3)
+            tb16 = throughput_fields(rb16, 1)
+            entry = dict(dtype='bf16', value=tb16['value'], unit='datasets/s', ms_per_step=tb16['ms_per_step'], steps=10, warmup=3, per_gpu_batch=rb16['batch'],
+                         step_roofline_frac=tb16['frac'])
+            if not args.no_parity:
+                par16, _ = parity_check(rb16['model'], CONFIGS[2], device, 'bf16')
+                tf16 = par16['training_forward']
+                entry['parity_timed_path'] = dict(precision='bf16', nll_rel=tf16['nll_rel'], mean_rel_l2=tf16['mean_rel_l2'], logits_rel_l2=tf16['logits_rel_l2'])
+            entry['seconds'] = time.time() - t0
+            result['also_bf16'] = entry
+            release(rb16)
+            del rb16
         # the small-batch regime of the reference's notebooks (SetupForGPFittingExperiments.ipynb:143-149 trains configs[1] at batch_size 4 with
         # aggregate_k_gradients 25): per-GPU batch 4 x 25 batches per optimizer step, then 8 / 16 / 32 with one batch per step
         result['batch_sweep'] = []

@@ -74,10 +74,12 @@ enum { PFN_SCHED_TOP_LAYER_ALL_ROWS = 1, /* run the TOP encoder layer on every r
                                           * so that layer's train rows feed nothing (not with live dropout, not when sep < S / 4) */
        PFN_SCHED_FUSE_LN_WIDE = 2,       /* emsize 1024: LayerNorm-fused GEMMs on 64-row x 1024-column tiles (correct, measured slower: default off) */
        PFN_SCHED_SEPARATE_LNBWD = 4,     /* LayerNorm backward as its own kernels instead of inside the data-gradient GEMMs that feed it */
-       PFN_SCHED_NO_KEY_CENTERING = 16,  /* 16-bit operand formats centre the keys of every dataset before they are rounded: k' = k - W_k xbar with xbar a sample mean of the
-                                          * dataset's layer-input rows.  softmax_j(q_i . k_j) is invariant to one vector subtracted from every key, so outputs and gradients are the
-                                          * reference's (transformer.py:84) while the rounding of K stops being relative to the keys' common component (ABI 8; default on).
-                                          * This bit turns it off (the arithmetic of rounds 1-5). */
+       PFN_SCHED_NO_KEY_CENTERING = 16,  /* KEY CENTRING (ABI 8): the keys of every dataset are centred before they are rounded to 16 bits: k' = k - W_k xbar with xbar a sample mean
+                                          * of the dataset's TRAIN rows of the layer input.  softmax_j(q_i . k_j) is invariant to one vector subtracted from every key, so outputs and
+                                          * gradients are the reference's (transformer.py:84) while the rounding of K stops being relative to the keys' common component (nine
+                                          * times their spread on a trained model).  Default: ON with PFN_PREC_FP16 -- this bit turns it off -- and OFF with PFN_PREC_BF16 (the
+                                          * arithmetic of rounds 1-5) -- PFN_SCHED_KEY_CENTERING turns it on.  Costs one small kernel + a shifted GEMM epilogue per layer: 0.5 % of the step. */
+       PFN_SCHED_KEY_CENTERING = 64,
        PFN_SCHED_FUSE_Q_PROJECTION = 32, /* the Q projection runs INSIDE the attention forward kernel (north_star: "QKV projection + scaled-dot-product attention + softmax ... as one
                                           * fused kernel"): a workgroup forms its 256 queries' head slice x W_q[h]^T + b_q[h] on the matrix cores in its prologue, the GEMM in
                                           * front projects k | v only (shared by every query block of a head: they stay a GEMM).  Same Q bits as the GEMM's; 16-bit operands,
@@ -116,7 +118,7 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_WGRAD_SPLITS = 11,   /* > 0: token-axis splits of the grouped weight-gradient launch where the stack leaves them automatic; 0 (default): the occupancy rule */
        PFN_TUNE_WGRAD_WAVES = 14,       /* waves per 256 x 256 tile of the grouped weight-gradient launch: 8 (128 x 64 each) or 4 (128 x 128 each, the whole register file per wave) */
        PFN_TUNE_FUSE_Q_PROJECTION = 12, /* 1: new descriptors carry PFN_SCHED_FUSE_Q_PROJECTION (default 0) */
-       PFN_TUNE_KEY_CENTERING = 13,     /* 0: new descriptors carry PFN_SCHED_NO_KEY_CENTERING (default 1: keys centred) */
+       PFN_TUNE_KEY_CENTERING = 13,     /* 1: new descriptors carry PFN_SCHED_KEY_CENTERING, 0: PFN_SCHED_NO_KEY_CENTERING, -1 (default): neither (centred with fp16, not with bf16) */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
                                     * returns output[single_eval_pos:] (transformer.py:91), so that layer's train rows feed nothing; 0: every layer on every row */ };
 int pfn_set_tuning(int key, int value);

@@ -76,7 +76,7 @@ int check_desc(const pfn_model_desc* d) {
   const bool ok = dh == 32 || dh == 64 || dh == 128 || dh == 256;
   if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128/256)", dh);
   if (d->emsize > 2048) return fail(PFN_ERR_UNSUPPORTED, "emsize > 2048 unsupported by the LayerNorm kernels");
-  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC | PFN_SCHED_NO_KEY_CENTERING | PFN_SCHED_FUSE_Q_PROJECTION)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
+  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC | PFN_SCHED_NO_KEY_CENTERING | PFN_SCHED_FUSE_Q_PROJECTION | PFN_SCHED_KEY_CENTERING)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
   if (!(d->dropout >= 0.f && d->dropout < 1.f)) return fail(PFN_ERR_ARGUMENT, "dropout %g outside [0, 1)", (double)d->dropout);
   return PFN_OK;
 }
@@ -153,6 +153,13 @@ struct Ws {
 // own eval position.  sep_of [B] int32 and row_off [B + 1] int64 live on the device; row_off[b] = first compact test row of dataset b, row_off[B] = test_rows.
 struct Ragged { const int32_t* sep_of; const int64_t* row_off; int64_t test_rows; int sep_min; };
 
+// Key centring of the q|k|v projection (pfn_kernels.h launch_key_shift): on by default with fp16 operands (the format chosen for its accuracy: 0.5 % of the step buys
+// 1.3 - 1.7 x on a sharply trained model), opt-in with bf16 (whose error is dominated by its 8-bit significand everywhere else; PFN_SCHED_KEY_CENTERING keeps rounds 1-5's
+// arithmetic the default there)
+static bool key_centering(const pfn_model_desc& d) {
+  return (d.precision == PFN_PREC_FP16 && !(d.schedule & PFN_SCHED_NO_KEY_CENTERING)) || (d.precision == PFN_PREC_BF16 && (d.schedule & PFN_SCHED_KEY_CENTERING));
+}
+
 Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   Ws w;
   const int64_t M = (int64_t)B * S, E = d.emsize, F = d.nhid, es = esize(d.precision);
@@ -184,7 +191,7 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   const int64_t Mtop = (d.nlayers > 0 && d.dropout == 0.f && !(d.schedule & PFN_SCHED_TOP_LAYER_ALL_ROWS)) ? (int64_t)B * (S - (S + 3) / 4) : 0;
   w.top_ctx_t = take(Mtop * E * es); w.top_dy1_t = take(Mtop * E * es); w.top_dctx_t = take(Mtop * E * es);
   w.top_ry = (float*)take(Mtop * E * 4); w.top_rmean = (float*)take(Mtop * 4); w.top_rrstd = (float*)take(Mtop * 4);
-  w.kshift = prec_is16(d.precision) && !(d.schedule & PFN_SCHED_NO_KEY_CENTERING) ? (float*)take((int64_t)B * E * 4) : nullptr;
+  w.kshift = key_centering(d) ? (float*)take((int64_t)B * E * 4) : nullptr;
   w.lscale = (float*)take(256);
   w.ln_part = (d.schedule & PFN_SCHED_DETERMINISTIC) ? (float*)take((int64_t)LNB_MAX_BLOCKS * 3 * E * 4) : nullptr;
   w.bytes = cur;
@@ -257,7 +264,10 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_WGRAD_SPLITS: set_gemm_tn_group_splits(value); return PFN_OK;
     case PFN_TUNE_WGRAD_WAVES: set_gemm_tn_group_waves(value); return PFN_OK;
     case PFN_TUNE_FUSE_Q_PROJECTION: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_Q_PROJECTION) : (g_default_schedule & ~PFN_SCHED_FUSE_Q_PROJECTION); return PFN_OK;
-    case PFN_TUNE_KEY_CENTERING: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_NO_KEY_CENTERING) : (g_default_schedule | PFN_SCHED_NO_KEY_CENTERING); return PFN_OK;
+    case PFN_TUNE_KEY_CENTERING:      // 1: on for both 16-bit formats, 0: off for both, -1: the defaults (on with fp16, off with bf16)
+      g_default_schedule &= ~(PFN_SCHED_NO_KEY_CENTERING | PFN_SCHED_KEY_CENTERING);
+      if (value > 0) g_default_schedule |= PFN_SCHED_KEY_CENTERING; else if (value == 0) g_default_schedule |= PFN_SCHED_NO_KEY_CENTERING;
+      return PFN_OK;
     case PFN_TUNE_GEMM_LN_ROWS: set_gemm_ln_rows64(value); return PFN_OK;
     case PFN_TUNE_GP_PLANES: g_gp_planes = value != 0; return PFN_OK;
     case PFN_TUNE_FUSE_DELTA: g_fuse_delta = value != 0; return PFN_OK;
