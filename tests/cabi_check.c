@@ -73,9 +73,21 @@ int main(int argc, char** argv) {
     const int64_t plain = workspace_bytes(&d, 8, 2000);
     d.schedule = PFN_SCHED_DETERMINISTIC;
     CHECK(workspace_bytes(&d, 8, 2000) > plain);
-    d.schedule = 64;
+    d.schedule = 1 << 20;                          /* an unknown bit is refused */
     CHECK(workspace_bytes(&d, 8, 2000) < 0 && strstr(last_error(), "schedule") != 0);
     d.schedule = 0;
+    /* ABI 8: fp16 operands -- same workspace as bf16 plus the per-dataset key shift (keys centred by default with fp16; PFN_SCHED_NO_KEY_CENTERING drops it,
+     * PFN_SCHED_KEY_CENTERING adds it to bf16) */
+    d.precision = PFN_PREC_FP16;
+    CHECK(workspace_bytes(&d, 8, 2000) > plain && shadow_bytes(&d) > 0);
+    {
+      const int64_t centred = workspace_bytes(&d, 8, 2000);
+      d.schedule = PFN_SCHED_NO_KEY_CENTERING;
+      CHECK(workspace_bytes(&d, 8, 2000) == plain);
+      d.precision = PFN_PREC_BF16; d.schedule = PFN_SCHED_KEY_CENTERING;
+      CHECK(workspace_bytes(&d, 8, 2000) == centred);
+      d.schedule = 0;
+    }
   }
   /* ragged batches (ABI 7): the arguments are checked before anything is launched -- missing per-dataset arrays or an impossible row count are refused */
   {

@@ -145,7 +145,7 @@ def test_top_layer_row_rule_and_flop_accounting():
     finally:
         lib.pfn_set_tuning(6, 1)
     assert lib.pfn_default_schedule() == 0
-    bad_bits = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5, 0.0, 64)
+    bad_bits = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5, 0.0, 1 << 20)
     assert rows(1604, 0, bad_bits) < 0
     with_dropout = _hip.ModelDesc(18, 512, 4, 1024, 6, 1000, _hip.PREC_BF16, 1e-5, 0.2)
     assert rows(1604, 1, with_dropout) == B * S and rows(1604, 0, with_dropout) == B * S   # dropout keeps the full-layout row indices (the compact-row buffers are not carved)

@@ -125,13 +125,18 @@ def parity_of(sd, w, device, seps=None):
     """The trained state dict through the product model (training precision bf16, inference precision f32) against the f64 oracle on
     the same inputs: `outputs` = model.eval() under no_grad, `training_forward` = the bf16 forward of the training path."""
     out = {}
-    model = bench.build_model(device, 'bf16', w, criterion=_criterion_from(sd))
-    model.load_state_dict(sd)
-    model.to(device)
-    for sep in (seps or [w['parity_sep']]):
-        res, _ = bench.parity_check(model, dict(w, parity_sep=sep), device, 'bf16')
-        res.pop('against', None); res.pop('inputs', None)
-        out[f'sep{sep}'] = res
+    for prec in ('bf16', 'fp16'):      # round 6: both 16-bit training formats on the same trained weights
+        model = bench.build_model(device, prec, w, criterion=_criterion_from(sd))
+        model.load_state_dict(sd)
+        model.to(device)
+        for sep in (seps or [w['parity_sep']]):
+            res, _ = bench.parity_check(model, dict(w, parity_sep=sep), device, prec)
+            res.pop('against', None); res.pop('inputs', None)
+            if prec == 'bf16':
+                out[f'sep{sep}'] = res
+            else:
+                out[f'sep{sep}']['training_forward_fp16'] = res['training_forward']
+        del model
     return out
 
 
@@ -141,6 +146,9 @@ def log_parity(parity, log):
         log(f"  {k}: outputs ({v['precision']}) nll_rel {v['nll_rel']:.2e} mean_rel_l2 {v['mean_rel_l2']:.2e} logits_rel_l2 {v['logits_rel_l2']:.2e} | "
             f"training forward ({t['precision']}) nll_rel {t['nll_rel']:.2e} mean_rel_l2 {t['mean_rel_l2']:.2e} mean_max_over_range {t['mean_max_over_range']:.2e} "
             f"logits_rel_l2 {t['logits_rel_l2']:.2e}  (means rms {v['mean_ref_rms']:.3f}, targets rms {v['y_test_rms']:.3f})")
+        if 'training_forward_fp16' in v:
+            t = v['training_forward_fp16']
+            log(f"  {k}: training forward (fp16) nll_rel {t['nll_rel']:.2e} mean_rel_l2 {t['mean_rel_l2']:.2e} mean_max_over_range {t['mean_max_over_range']:.2e} logits_rel_l2 {t['logits_rel_l2']:.2e}")
 
 
 def _criterion_from(sd):
@@ -202,11 +210,13 @@ def stage_config2(args, device, log, shape='config2'):
 def stage_curves(args, device, log):
     w = SHAPES['config2']
     out = {}
-    for prec in ('bf16', 'f32'):
+    for prec in ('bf16', 'fp16', 'f32'):
         log(f'curves: {prec}')
         _, curve, seconds = run_training(w, device, prec, args.curve_epochs, args.curve_steps, args.curve_batch, args.lr, args.seed, log, streams=1)
         out[prec] = dict(loss=[c['loss'] for c in curve], seconds=seconds)
     a, b = np.array(out['bf16']['loss']), np.array(out['f32']['loss'])
+    h = np.array(out['fp16']['loss'])
+    out['fp16_vs_f32'] = dict(max_abs_diff=float(np.abs(h - b).max()), mean_abs_diff=float(np.abs(h - b).mean()))
     out['max_abs_diff'] = float(np.abs(a - b).max())
     out['mean_abs_diff'] = float(np.abs(a - b).mean())
     out['last_quarter_mean'] = dict(bf16=float(a[-len(a) // 4:].mean()), f32=float(b[-len(b) // 4:].mean()))
