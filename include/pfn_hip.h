@@ -117,6 +117,8 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
                                       * the dS^T scratch (which then stays in the 256 MB memory-side cache between the two passes); 0 (default): one pair per call */
        PFN_TUNE_WGRAD_SPLITS = 11,   /* > 0: token-axis splits of the grouped weight-gradient launch where the stack leaves them automatic; 0 (default): the occupancy rule */
        PFN_TUNE_WGRAD_WAVES = 14,       /* waves per 256 x 256 tile of the grouped weight-gradient launch: 8 (128 x 64 each) or 4 (128 x 128 each, the whole register file per wave) */
+       PFN_TUNE_LOSS_SCALE_TARGET = 15, /* PFN_PREC_FP16 backward: log2 of the value max|dlogits| is scaled to (power-of-two loss scale chosen on the device per call; default 2,
+                                         * range -8 .. 12).  16 - target binades of headroom for what the chain adds; overflowing elements saturate at +-65504 */
        PFN_TUNE_FUSE_Q_PROJECTION = 12, /* 1: new descriptors carry PFN_SCHED_FUSE_Q_PROJECTION (default 0) */
        PFN_TUNE_KEY_CENTERING = 13,     /* 1: new descriptors carry PFN_SCHED_KEY_CENTERING, 0: PFN_SCHED_NO_KEY_CENTERING, -1 (default): neither (centred with fp16, not with bf16) */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
@@ -243,7 +245,9 @@ int pfn_bar_mean(const float* logits, int64_t ld, const float* borders, int64_t 
 /* ---- optimizer: replaces clip_grad_norm_(params, 1.) + Adam.step() + zero_grad()
  * (train.py:55,95-97).  One fused pass over the flat buffers; the clip coefficient is computed on
  * the device (no host sync).  grad_scale multiplies g first (1/world for DP averaging).
- * scratch: >= 8192 bytes; scratch[0] (f32) receives the global gradient norm before clipping.
+ * scratch: >= 8192 bytes, zeroed once by the caller; scratch[0] (f32) receives the global gradient norm before clipping.
+ * A non-finite norm (inf / NaN anywhere in g) SKIPS the step: params and moments are left as they are, g is still cleared when zero_grad != 0, and
+ * scratch[1025] (f32) counts the skipped steps -- GradScaler's found_inf behaviour; the reference's loop would write NaN into every parameter.
  * zero_grad != 0 clears g after the update. */
 int pfn_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float max_norm,

@@ -508,3 +508,30 @@ def test_clip_adam_matches_torch():
         assert abs(scratch[0].item() - norm_ref.item()) < 1e-3 * norm_ref.item()
         assert gg.abs().max().item() == 0.0
         assert maxerr(p, ref_p.detach()) < 2e-6
+
+
+def test_clip_adam_skips_a_step_whose_gradient_is_not_finite():
+    """pfn_clip_adam_step: an inf / NaN anywhere in the gradient leaves parameters and moments untouched, clears the gradient when asked and counts the step in
+    scratch[1025] (GradScaler's found_inf behaviour; include/pfn_hip.h) -- the next finite step runs as if the skipped ones had not happened."""
+    n = 70_000
+    p0, g0 = rnd(n, seed=42), rnd(n, seed=43) * 0.05
+    p, m, v = p0.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    scratch = torch.zeros(2048, device=dev())
+
+    def step(pp, g, mm, vv, k, sc):
+        _hip.check(_hip.lib().pfn_clip_adam_step(pp.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1.0, k, 1,
+                                                 sc.data_ptr(), _hip.stream_ptr()), 'adam')
+    step(p, g0.clone(), m, v, 1, scratch)
+    p1, m1, v1 = p.clone(), m.clone(), v.clone()
+    assert scratch[1025].item() == 0 and not torch.equal(p1, p0)
+    for bad in (float('inf'), float('-inf'), float('nan')):
+        g = g0.clone()
+        g[n // 2 + 3] = bad
+        step(p, g, m, v, 2, scratch)
+        assert torch.equal(p, p1) and torch.equal(m, m1) and torch.equal(v, v1)
+        assert g.abs().max().item() == 0.0 and not math.isfinite(scratch[0].item())
+    assert scratch[1025].item() == 3
+    ref, rm, rv = p1.clone(), m1.clone(), v1.clone()       # the same finite step on a copy that never saw the bad ones
+    step(ref, g0 * 2, rm, rv, 2, torch.zeros(2048, device=dev()))
+    step(p, g0 * 2, m, v, 2, scratch)
+    assert torch.equal(p, ref) and torch.equal(m, rm) and torch.equal(v, rv) and scratch[1025].item() == 3

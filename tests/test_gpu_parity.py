@@ -175,6 +175,40 @@ def test_config1_vs_oracle(precision):
         within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2))
 
 
+@pytest.mark.parametrize('target', [9, 12])
+def test_fp16_backward_saturates_where_the_loss_scale_leaves_no_headroom(target):
+    """fp16 backward with the loss-scale target pushed up (PFN_TUNE_LOSS_SCALE_TARGET): max|dlogits| lands at 2^9 or 2^12 -- seven or four binades below 65504 --
+    so gradients along the chain leave the format.  Every kernel that stores fp16 runs with MODE.FP16_OVFL set (pfn_device.h operand_store_mode): the
+    overflowing elements saturate at +-65504 and every parameter gradient stays finite -- without it they are inf, and NaN one product later (round 6: the
+    GP-fitting recipe's weights were all NaN at epoch 68).  At the default target the same batch matches the oracle (test_config1_vs_oracle)."""
+    cfg = dict(T=100, B=8, F=5, E=128, H=4, nhid=256, L=2, nbars=100)
+    model = random_model(cfg, 'fp16', seed=3).to(DEV).train()
+    with torch.no_grad():
+        model.decoder[2].weight.mul_(40.)      # a confident head: d(hidden) = W^T dlogits is 40 x larger against max|dlogits|
+    model.mark_params_updated()
+    gen = torch.Generator().manual_seed(5)
+    x, y, _ = pfn_oracle.get_batch_fast_gp(cfg['B'], cfg['T'], cfg['F'], {'noise': 1e-4, 'outputscale': 1., 'lengthscale': .6}, gen)
+    lib = _hip.lib()
+    assert lib.pfn_set_tuning(15, 13) != 0 and lib.pfn_set_tuning(15, -9) != 0      # outside -8 .. 12: refused
+    grads = {}
+    try:
+        for tg in (2, target):
+            _hip.check(lib.pfn_set_tuning(15, tg), 'pfn_set_tuning')
+            for sep in (81, 1):
+                model.zero_grad()
+                logits = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
+                loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
+                loss.backward()
+                g = torch.cat([p.grad.flatten() for p in model.parameters()])
+                assert torch.isfinite(g).all(), (tg, sep)
+                grads[tg, sep] = g.clone()
+    finally:
+        _hip.check(lib.pfn_set_tuning(15, 2), 'pfn_set_tuning')
+    for sep in (81, 1):       # the saturated gradient still points the way of the exact one
+        a, b = grads[2, sep].double(), grads[target, sep].double()
+        within(f'1 - cosine of the target-{target} gradient and the default one, sep {sep}', 1. - (a @ b / (a.norm() * b.norm())).item(), 0.5)
+
+
 @pytest.mark.parametrize('H', [4, 16])
 @pytest.mark.parametrize('precision', ['f32', 'bf16', 'fp16'])
 def test_config5_width_vs_oracle(precision, H):

@@ -389,6 +389,9 @@ class _TorchAdam(torch.optim.Adam):
             for p in self.model.parameters():
                 p.grad.zero_()
 
+    def skipped_steps(self):      # (FusedClipAdam's counter of steps with a non-finite gradient: train() reads it once per epoch)
+        return 0
+
 
 def _cpu_train(monkeypatch, **kw):
     from transformerscandobayesianinference_amd import bar_distribution, encoders, train as train_mod

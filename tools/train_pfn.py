@@ -168,6 +168,10 @@ def stage_config2(args, device, log, shape='config2'):
     positions = sorted(set(positions))
     log('paired evaluation (trained)')
     trained = paired_curves(model, w, device, positions, args.eval_datasets, seed=777)
+    if args.light:
+        log(f"  trained  : PFN bar NLL {trained['summary']['pfn_bar_nll']:.4f}  exact GP {trained['summary']['exact_gp_nll']:.4f}  prior {trained['summary']['prior_nll']:.4f}  skipped steps {getattr(model, 'optimizer_steps_skipped', None)}")
+        return dict(recipe=dict(shape=shape, epochs=args.epochs, steps_per_epoch=args.steps_per_epoch, batch_size=args.batch, lr=args.lr, precision=args.precision, seed=args.seed, tune=args.tune),
+                    training_seconds=seconds, optimizer_steps_skipped=getattr(model, 'optimizer_steps_skipped', None), loss_curve=curve, paired_eval_trained=trained)
     fresh = bench.build_model(device, args.precision, w, criterion=_criterion_from(sd))
     with torch.no_grad():   # the reference's fresh model: zero-initialised residual branches (transformer.py:49-53)
         for layer in fresh.transformer_encoder.layers:
@@ -198,6 +202,7 @@ def stage_config2(args, device, log, shape='config2'):
                               warmup_epochs=args.epochs // 4, schedule='get_cosine_schedule_with_warmup, stepped per epoch (lr 0 in epoch 1, reference quirk Q5)',
                               eval_pos='get_weighted_single_eval_pos_sampler(2000)', precision=args.precision, seed=args.seed,
                               datasets=args.epochs * args.steps_per_epoch * args.batch),
+                  tune=args.tune, optimizer_steps_skipped=getattr(model, 'optimizer_steps_skipped', None),
                   training_seconds=seconds, datasets_per_second=args.epochs * args.steps_per_epoch * args.batch / seconds,
                   loss_curve=curve, paired_eval_trained=trained, paired_eval_untrained=untrained, api_sweeps=api, parity_trained=parity,
                   val_bar_nll=dict(value=val['value'], datasets=val['datasets'], eval_position=val['eval_position'], seed=val['seed']))
@@ -266,10 +271,15 @@ def main():
     ap.add_argument('--ckpt-bf16', action='store_true')
     ap.add_argument('--ckpt1', default=None, help='save the config-1 state dict here (1.3 MB)')
     ap.add_argument('--out', default='gpurun_out/r03_trained.json')
+    ap.add_argument('--tune', default='', help='comma-separated key=value pairs for pfn_set_tuning (include/pfn_hip.h), e.g. 15=6: the fp16 loss-scale target')
+    ap.add_argument('--light', action='store_true', help='config2 / notebook5: loss curve + paired evaluation of the trained model only')
     args = ap.parse_args()
     device = torch.device('cuda:0')
     torch.cuda.set_device(device)
     log = lambda s: print(s, flush=True)
+    from transformerscandobayesianinference_amd import _hip
+    for kv in filter(None, args.tune.split(',')):
+        _hip.check(_hip.lib().pfn_set_tuning(*[int(v) for v in kv.split('=')]), 'pfn_set_tuning')
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     result = json.load(open(args.out)) if os.path.exists(args.out) else {}
     for stage in args.stage:

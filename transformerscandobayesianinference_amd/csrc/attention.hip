@@ -221,6 +221,7 @@ template <typename T> PFN_DEV Frag<T> acc_to_frag_m1(const f32x16& acc, int c, c
 // columns, double-buffered; the x rows come straight from global memory, 16 bytes per lane and k-step (whole 1-KiB rows over the prologue).
 template <typename T, int D, bool DROP = false, int DV = D, bool FUSEQ = false>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_fwd_kernel(AttnArgs a) {
+  operand_store_mode<T>();
   using C = AttnCfg<T, D>;
   using CV = AttnCfg<T, DV>;      // the V / O side: CV::NDB column blocks, CV::CIMG bytes per tile image
   static_assert(C::KVB == CV::KVB && D % DV == 0, "V slices share the K tile's key count");
@@ -609,6 +610,7 @@ template <typename T, int D> struct BwdKvCfg {
 // dK, dS^T) -- six product units for the backward instead of five.
 template <typename T, int D, int MODE, bool DROP = false>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_kv_kernel(AttnArgs a) {
+  operand_store_mode<T>();
   using C = AttnCfg<T, D>;
   using K = BwdKvCfg<T, D>;
   constexpr bool DO_DK = MODE != 2, DO_DV = MODE != 1;
@@ -1027,6 +1029,7 @@ template <typename T> PFN_DEV Frag<T> load_frag_ds_blocked(const lds_char* block
 
 template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__((AttnCfg<T, D>::NT)) void attn_bwd_dq_kernel(AttnArgs a) {
+  operand_store_mode<T>();
   using C = AttnCfg<T, D>;
   using Q = BwdDqCfg<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];

@@ -27,6 +27,7 @@ constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_RB = 128;  // RB: bytes of cont
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT g) {
+  operand_store_mode<T>();
   constexpr int BK = GEMM_RB / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
@@ -413,6 +414,7 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 
 template <typename T, int FLAGS, int NWM, int BK>
 __global__ __launch_bounds__((BigCfg<NWM, BK>::NT), (BigCfg<NWM, BK>::MIN_BLOCKS)) void gemm_nt_big_kernel(GemmNT g) {
+  operand_store_mode<T>();
   using C = BigCfg<NWM, BK>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LdsPtr smem = lds_cast(smem_raw);
@@ -520,6 +522,7 @@ template <int NWN> struct LnEpi {   // LDS of gemm_nt_ln_kernel's epilogue: row 
 };
 template <typename T, int NWN, bool RESID_LN, int BK>
 __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
+  operand_store_mode<T>();
   constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
   constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
   constexpr int TILE_A = BM * RB, STAGE = TILE_A + BN * RB;
@@ -734,6 +737,7 @@ template <int NWN, int MI, int NJ> struct LnEpiW {   // LDS of gemm_nt_ln_kernel
 };
 template <typename T, int NWN, bool RESID_LN, int BK, int MI, int NJ>
 __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_kernel(GemmLN g) {      // (4-wave tiles: two workgroups per CU, 256 registers per wave)
+  operand_store_mode<T>();
   constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
   constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
   constexpr int TILE_A = BM * RB, STAGE = TILE_A + BN * RB;
@@ -980,6 +984,7 @@ template <int NWN, int BK> struct LnbCfg {
 
 template <typename T, int NWN, int BK>
 __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
+  operand_store_mode<T>();
   using C = LnbCfg<NWN, BK>;
   constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
   constexpr int PA = BM / RPP / NWN > 0 ? BM / RPP / NWN : 1, PB = BN / RPP / NWN;
@@ -1211,6 +1216,7 @@ template <int NWN, int BK, int MI, int NJ> struct LnbCfgW {
 
 template <typename T, int NWN, int BK, int MI, int NJ>
 __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wide_kernel(GemmLNB g) {
+  operand_store_mode<T>();
   using C = LnbCfgW<NWN, BK, MI, NJ>;
   constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
   constexpr int JH = NJ / 2, NU = MI * JH, NHB = MI * NJ;

@@ -11,6 +11,7 @@
 namespace pfn {
 
 constexpr int NORM_BLOCKS = 1024;
+constexpr int SKIPPED_AT = 1 + NORM_BLOCKS;      // scratch[SKIPPED_AT]: number of skipped (non-finite gradient) steps since the caller zeroed the scratch
 
 __global__ __launch_bounds__(256) void grad_sqsum_kernel(const float* g, long n4, float gscale, float* partial) {
   __shared__ float red[4];
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(256) void grad_sqsum_kernel(const float* g, long n4
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a, long n4, int nparts, int zero_grad) {
   __shared__ float s_coef;
+  __shared__ int s_skip;
   {
     // every block re-reduces the (<= 1024) partials in the same order: deterministic, no atomics
     float s = 0.f;
@@ -41,11 +43,23 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a, long n4, int
       // clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
       float coef = a.max_norm > 0.f ? a.max_norm / (norm + 1e-6f) : 1.f;
       s_coef = fminf(coef, 1.f) * a.grad_scale;
-      if (blockIdx.x == 0) a.scratch[0] = norm;
+      // A gradient with an inf / NaN in it (an overflow the fp16 backward's saturation did not catch, a bad batch) would turn every parameter into NaN through
+      // the clip coefficient: the step is SKIPPED instead -- parameters and moments untouched, the gradient cleared as asked -- and counted in
+      // scratch[SKIPPED_AT] (what torch.cuda.amp.GradScaler.step does with its found_inf flag; the reference itself has no such guard).
+      s_skip = !(norm <= 3.0e38f);
+      if (blockIdx.x == 0) {
+        a.scratch[0] = norm;
+        if (s_skip) a.scratch[SKIPPED_AT] += 1.f;
+      }
     }
     __syncthreads();
   }
   const float coef = s_coef;
+  if (s_skip) {
+    if (zero_grad)
+      for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) *reinterpret_cast<f32x4*>(a.g + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   const float bc1 = 1.f - powf(a.beta1, (float)a.step);
   const float bc2 = 1.f - powf(a.beta2, (float)a.step);
   const float step_size = a.lr / bc1;

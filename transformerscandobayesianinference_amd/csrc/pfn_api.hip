@@ -131,8 +131,8 @@ struct LayerWs {
 };
 struct Ws {
   float* x0; char* x0_t;
-  char* xaug_t;              // [M, EMB_AUG] operand precision: the embedding's augmented inputs (embed_fwd -> the backward's GEMM)
-  float* embacc;             // [E, EMB_AUG] f32: that GEMM's result before it is scattered into the encoder gradients
+  char* xaug_t;              // [M, emb_aug_width(nf)] operand precision: the embedding's augmented inputs (embed_fwd -> the backward's GEMM)
+  float* embacc;             // [E, emb_aug_width(nf)] f32: that GEMM's result before it is scattered into the encoder gradients
   std::vector<LayerWs> layer;
   char *xt_t, *dpre, *dt;
   // backward scratch
@@ -167,7 +167,8 @@ Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
   int64_t cur = 0;
   auto take = [&](int64_t nbytes) { char* p = base ? base + cur : nullptr; cur = align_up(cur + nbytes, 256); return p; };
   w.x0 = (float*)take(M * E * 4); w.x0_t = take(M * E * es);
-  w.xaug_t = take(M * EMB_AUG * es); w.embacc = (float*)take(E * EMB_AUG * 4);
+  const int64_t aug = emb_aug_width(d.num_features) > 0 ? emb_aug_width(d.num_features) : 32;
+  w.xaug_t = take(M * aug * es); w.embacc = (float*)take(E * aug * 4);
   w.layer.resize(d.nlayers);
   for (auto& l : w.layer) {
     l.qkv = take(M * 3 * E * es); l.ctx = take(M * E * es); l.lse = (float*)take((int64_t)B * d.nhead * S * 4);
@@ -263,6 +264,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_ATTN_BWD_GROUP: set_attn_bwd_group(value); return PFN_OK;
     case PFN_TUNE_WGRAD_SPLITS: set_gemm_tn_group_splits(value); return PFN_OK;
     case PFN_TUNE_WGRAD_WAVES: set_gemm_tn_group_waves(value); return PFN_OK;
+    case PFN_TUNE_LOSS_SCALE_TARGET: return set_loss_scale_target(value);
     case PFN_TUNE_FUSE_Q_PROJECTION: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_Q_PROJECTION) : (g_default_schedule & ~PFN_SCHED_FUSE_Q_PROJECTION); return PFN_OK;
     case PFN_TUNE_KEY_CENTERING:      // 1: on for both 16-bit formats, 0: off for both, -1: the defaults (on with fp16, off with bf16)
       g_default_schedule &= ~(PFN_SCHED_NO_KEY_CENTERING | PFN_SCHED_KEY_CENTERING);
@@ -389,7 +391,8 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
     e.x = x; e.x_st = x_st; e.x_sb = x_sb; e.y = y; e.y_st = y_st; e.y_sb = y_sb;
     e.wx = params + L.enc_w; e.bx = params + L.enc_b; e.wy = params + L.yenc_w; e.by = params + L.yenc_b;
     e.out_f32 = w.x0; e.out_t = w.x0_t; e.S = S; e.B = B; e.nf = d->num_features; e.E = E; e.sep = sep; e.sep_of = sep_of;
-    e.xaug_t = d->num_features + 2 <= EMB_AUG ? w.xaug_t : nullptr;
+    e.xaug_ld = emb_aug_width(d->num_features);
+    e.xaug_t = e.xaug_ld > 0 ? w.xaug_t : nullptr;
     PFN_TRY(launch_embed_fwd(e, prec, s));
   }
   const float* xin = w.x0;
@@ -675,7 +678,8 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
   // embed_fwd left the augmented inputs in operand precision, the first layer's dx leaves in operand precision, and the
   // split-K TN kernel does the rest (the register kernel it replaces streamed d(src) at 0.7 TB/s).  Custom encoders
   // (dsrc_sbe), the exact-f32 mode and wide encoders keep the f32 path.
-  const bool emb_gemm = !dsrc_sbe && prec_is16(prec) && d->nlayers > 0 && d->num_features + 2 <= EMB_AUG && E % 8 == 0;
+  const int aug = emb_aug_width(d->num_features);
+  const bool emb_gemm = !dsrc_sbe && prec_is16(prec) && d->nlayers > 0 && aug > 0 && E % 8 == 0;
   bool fuse_lnb = !det && !(d->schedule & PFN_SCHED_SEPARATE_LNBWD) && prec_is16(prec) && d->nlayers > 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));   // (dropout: masked and unmasked LayerNorm-input gradients both exist)
   if (fuse_lnb) {
     const LayerP& p = L.layer[0]; const LayerP& t = L.layer_t[0]; LayerWs& a = w.layer[0];
@@ -847,8 +851,8 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
   if (dsrc_sbe) {
     PFN_TRY(launch_bse_to_sbe(w.gA, dsrc_sbe, S, B, E, s, lsc));
   } else if (emb_gemm) {
-    if (hipMemsetAsync(w.embacc, 0, sizeof(float) * E * EMB_AUG, s) != hipSuccess) return fail(PFN_ERR_LAUNCH, "memset");
-    GemmTN g = tn(w.gA_t, E, w.xaug_t, EMB_AUG, w.embacc, EMB_AUG, M, E, EMB_AUG, grads + L.enc_b);
+    if (hipMemsetAsync(w.embacc, 0, sizeof(float) * E * aug, s) != hipSuccess) return fail(PFN_ERR_LAUNCH, "memset");
+    GemmTN g = tn(w.gA_t, E, w.xaug_t, aug, w.embacc, aug, M, E, aug, grads + L.enc_b);
     g.scale_amax = lsc;
     g.max_splits = det ? 1 : 128;      // a 512 x 32 result: measured 67 / 62 / 88 us with 64 / 128 / 256 splits (the partial sums are added atomically)
     PFN_TRY(launch_gemm_tn(g, prec, s));

@@ -515,16 +515,27 @@ PFN_DEV float wave_max(float v) {
 }
 template <typename T> PFN_DEV float to_f(T x) { return (float)x; }
 
+// First statement of every kernel that converts f32 to the operand type: with fp16 operands the wave's MODE.FP16_OVFL bit (23) is set, under which an fp16 VALU
+// result beyond the format's range is +-65504 instead of +-inf (probed on gfx950: tools/probe_fp16.hip); true infinities and NaNs still pass through.
+template <typename T> PFN_DEV void operand_store_mode() {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, bf16)) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Loss scale of the fp16 backward (PFN_PREC_FP16).  fp16 spans 2^-14 .. 2^16 at full precision; the gradient of a mean loss over ~10^4 rows starts at
 // 1e-4 .. 1e-8 per element, so the backward chain runs on dlogits * 2^k and every kernel that WRITES a parameter gradient (or d(src)) multiplies by 2^-k
 // on the way out: the flat gradient buffer holds unscaled f32 values, exactly as in the other modes.  k is chosen per backward call ON THE DEVICE -- no host
-// round trip -- from amax = max|dlogits| (absmax_kernel, rowwise.hip) so that amax * 2^k lands in [64, 128): six binades of headroom below 65504 for what the
-// chain adds (|W|, |q|, |k| of a trained model), and 8-bit-or-better relative precision down to 2^-20 of the largest element.  Both factors are powers of
-// two: the scaling itself is exact.  A null pointer (the other precisions) means 1.
+// round trip -- from amax = max|dlogits| (absmax_kernel, rowwise.hip) so that amax * 2^k lands in [2^t, 2^(t+1)), t = the loss-scale target
+// (PFN_TUNE_LOSS_SCALE_TARGET, default rowwise.hip g_loss_scale_target): 16 - t binades of headroom below 65504 for what the chain adds -- |W|, |q|, |k| of a
+// trained model, and the SUMS over up to bptt query rows in dK / dV when few keys take all the attention (bptt x the row gradients when they agree) -- and full
+// precision down to 2^-(14+t) of the largest element.  The target enters through the stored value (absmax_kernel writes amax * 2^(6 - t)), so the readers below
+// keep one constant.  Both factors are powers of two: the scaling itself is exact.  A null pointer (the other precisions) means 1.
+// What still overflows SATURATES: every kernel that stores fp16 runs with MODE.FP16_OVFL set (operand_store_mode below), so a conversion beyond 65504 gives
+// +-65504 -- an element-wise clip of an outlier gradient ahead of the global-norm clip -- instead of an inf that the next product turns into NaN weights
+// (round 6: the GP-fitting recipe trained to a bar NLL of -2.42 by epoch 67 and was all-NaN at epoch 68 without it).
 // ---------------------------------------------------------------------------------------------
 constexpr int LOSS_SCALE_TARGET_LOG2 = 6;
-PFN_DEV float loss_scale_exp(const float* amax, int sign) {      // 2^(sign * k), k = 6 - floor(log2 amax), clamped to the range where both factors are normal f32
+PFN_DEV float loss_scale_exp(const float* amax, int sign) {      // 2^(sign * k), k = 6 - floor(log2 stored value), clamped to the range where both factors are normal f32
   if (!amax) return 1.f;
   const unsigned bits = __builtin_bit_cast(unsigned, *amax);
   const int e = (int)((bits >> 23) & 255u) - 127;               // floor(log2 amax) for a normal value

@@ -260,7 +260,8 @@ int launch_transpose_cast(const float* src, void* dst_t, int rows, int cols, lon
 int launch_cast_rows(const float* src, long ld_src, void* dst_t, long ld_dst, long R, int C, int precision, hipStream_t s, const float* scale_amax = nullptr);
 // ---- loss scale of the fp16 backward (pfn_device.h loss_scale_up / loss_scale_down): `scale_amax` arguments below point at ONE device float holding
 // max|incoming gradient| (launch_absmax), from which every kernel derives the same power of two; nullptr = no scaling (bf16 / f32) ----
-int launch_absmax(const float* x, long n, float* amax, hipStream_t s);                                   // amax[0] = max |x[i]| (x 16-byte aligned)
+int launch_absmax(const float* x, long n, float* amax, hipStream_t s);
+int set_loss_scale_target(int log2_target);      // PFN_TUNE_LOSS_SCALE_TARGET                                   // amax[0] = max |x[i]| (x 16-byte aligned)
 int launch_scale_copy(const float* src, float* dst, long n, const float* scale_amax, hipStream_t s);    // dst = src * 2^k
 
 // x:[T,B,nf] (strides given in elements), y:[T,B]; out f32 + T in [B,S,E]
@@ -270,11 +271,14 @@ struct EmbedArgs {
   const float* wx; const float* bx;  // [E,nf], [E]
   const float* wy; const float* by;  // [E,1],  [E]
   float* out_f32; void* out_t;
-  void* xaug_t;   // optional [B*S, EMB_AUG] T: the token's features, masked y, train flag, zero padding -- the B operand of the backward's GEMM
+  void* xaug_t;   // optional [B*S, xaug_ld] T: the token's features, masked y, train flag, zero padding -- the B operand of the backward's GEMM
+  int xaug_ld;    // columns of xaug_t: emb_aug_width(nf)
   int S, B, nf, E, sep;
   const int* sep_of;   // ragged batch: per-dataset eval positions [B] on the device (then `sep` is unused); nullptr = every dataset at `sep`
 };
-constexpr int EMB_AUG = 32;   // columns of xaug_t (num_features + 2 <= EMB_AUG for the GEMM form of the backward)
+// columns of xaug_t / of the [E, aug] gradient accumulator: num_features + 2 rounded up to 32, 64 or 128 (the GEMM form of the embedding backward; 0 = wider
+// encoders keep the register kernel).  Round 6: 64 and 128 added -- BASELINE configs[3] has 60 features and spent 9 % of its kernel time in embed_bwd_wide_kernel
+__host__ __device__ inline int emb_aug_width(int nf) { return nf + 2 <= 32 ? 32 : nf + 2 <= 64 ? 64 : nf + 2 <= 128 ? 128 : 0; }
 int launch_embed_fwd(const EmbedArgs& a, int precision, hipStream_t s);
 // backward: dsrc [B,S,E] f32 -> dwx, dbx, dwy, dby (accumulated, f32)
 struct EmbedBwdArgs {
@@ -286,7 +290,7 @@ struct EmbedBwdArgs {
   const float* scale_amax;   // fp16 backward: dsrc carries the loss scale, the gradients leave without it (nullptr = none)
 };
 int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s);
-// the GEMM form: acc[E, EMB_AUG] = d(src)^T . xaug (launch_gemm_tn) -> dwx += acc[:, :nf], dwy += acc[:, nf], dby += acc[:, nf + 1]
+// the GEMM form: acc[E, aug] = d(src)^T . xaug (launch_gemm_tn), aug = emb_aug_width(nf) -> dwx += acc[:, :nf], dwy += acc[:, nf], dby += acc[:, nf + 1]
 int launch_embed_grad_scatter(const float* acc, float* dwx, float* dwy, float* dby, int E, int nf, hipStream_t s);
 
 // src given in the reference layout [S,B,E] f32 (custom encoders): copy into [B,S,E] f32 + T

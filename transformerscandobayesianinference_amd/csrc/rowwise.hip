@@ -37,6 +37,7 @@ static int grid_for(long work_items, int per_block, int cap = 4096) {
 // f32 -> T casts
 // ---------------------------------------------------------------------------------------------
 template <typename T> __global__ __launch_bounds__(256) void cast_kernel(const float* src, T* dst, long n4) {
+  operand_store_mode<T>();
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
     st4<T>(dst + 4 * i, *reinterpret_cast<const f32x4*>(src + 4 * i));
 }
@@ -49,6 +50,7 @@ int launch_cast_params(const float* src, void* dst, long n, int precision, hipSt
 }
 
 template <typename T> __global__ __launch_bounds__(256) void cast_rows_kernel(const float* src, long ld_src, T* dst, long ld_dst, long R, int C, const float* scale_amax) {
+  operand_store_mode<T>();
   const long total = R * ld_dst;
   const float sc = loss_scale_up(scale_amax);      // fp16 backward: the gradient enters the chain times 2^k (pfn_device.h)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -67,7 +69,7 @@ int launch_cast_rows(const float* src, long ld_src, void* dst, long ld_dst, long
 // fp16 backward: amax = max |x| over the incoming gradient (non-negative floats order like their bit patterns: one integer atomic per workgroup), and the
 // scaled f32 copy for the entry that has no cast in front of the chain (no decoder: the gradient of the test rows goes straight into the LayerNorm backward)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, unsigned* amax_bits) {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, unsigned* amax_bits, float bias) {
   __shared__ float red[4];
   float m = 0.f;
   const long n4 = n / 4;
@@ -81,14 +83,21 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, long n, uns
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (m > 0.f) atomicMax(amax_bits, __builtin_bit_cast(unsigned, m));
+    if (m > 0.f) atomicMax(amax_bits, __builtin_bit_cast(unsigned, m * bias));      // bias = 2^(6 - target): see loss_scale_exp (pfn_device.h)
   }
+}
+static int g_loss_scale_target = 2;      // log2 of where max|dlogits| lands after scaling (PFN_TUNE_LOSS_SCALE_TARGET; pfn_device.h)
+int set_loss_scale_target(int t) {
+  if (t < -8 || t > 12) return PFN_ERR_ARGUMENT;
+  g_loss_scale_target = t;
+  return PFN_OK;
 }
 int launch_absmax(const float* x, long n, float* amax, hipStream_t s) {
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return PFN_ERR_ALIGNMENT;
   if (hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return PFN_ERR_LAUNCH;
   if (n <= 0) return PFN_OK;
-  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4 + 1, 256 * 8, 1024)), dim3(256), 0, s, x, n, reinterpret_cast<unsigned*>(amax));
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4 + 1, 256 * 8, 1024)), dim3(256), 0, s, x, n, reinterpret_cast<unsigned*>(amax),
+                     ldexpf(1.f, LOSS_SCALE_TARGET_LOG2 - g_loss_scale_target));
   return PFN_LAUNCH_OK();
 }
 __global__ __launch_bounds__(256) void scale_copy_kernel(const float* src, float* dst, long n, const float* scale_amax) {
@@ -104,6 +113,7 @@ int launch_scale_copy(const float* src, float* dst, long n, const float* scale_a
 // dst[c, r] = (T) src[r, c], dst row stride ld_dst >= rows (padding columns zeroed by the caller's
 // memset-free contract: they are written here as zero)   (32x32 LDS tile transpose)
 template <typename T> __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, T* dst, int rows, int cols, long ld_dst) {
+  operand_store_mode<T>();
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -119,6 +129,7 @@ template <typename T> __global__ __launch_bounds__(256) void transpose_cast_kern
 }
 // every transposed operand copy of a model in ONE launch (pfn_prepare_params runs after each optimizer step: 26 launches of a few microseconds each before)
 template <typename T> __global__ __launch_bounds__(256) void transpose_cast_group_kernel(const float* src, T* dst, TransposeGroup g) {
+  operand_store_mode<T>();
   __shared__ float tile[32][33];
   int e = 0;
   while (e + 1 < g.n && (int)blockIdx.x >= g.first_block[e + 1]) ++e;
@@ -240,6 +251,7 @@ int launch_key_shift(const void* x_t, const void* w_k_t, float* kshift, int B, i
 // ---------------------------------------------------------------------------------------------
 constexpr int EMB_TOK = 16;
 template <typename T> __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a) {
+  operand_store_mode<T>();
   extern __shared__ float xs[];  // [EMB_TOK][nf + 1]  (last column: y or 0, plus flag in sign-free form)
   const long ntok = (long)a.B * a.S;
   const long t0 = (long)blockIdx.x * EMB_TOK;
@@ -259,11 +271,12 @@ template <typename T> __global__ __launch_bounds__(256) void embed_fwd_kernel(Em
   }
   __syncthreads();
   T* out_t = reinterpret_cast<T*>(a.out_t);
-  if (a.xaug_t) {   // the same values in operand precision, EMB_AUG columns per token (zero padded)
+  if (a.xaug_t) {   // the same values in operand precision, xaug_ld columns per token (zero padded)
     T* xa = reinterpret_cast<T*>(a.xaug_t);
-    for (int i = threadIdx.x; i < EMB_TOK * EMB_AUG; i += 256) {
-      const int tk = i / EMB_AUG, f = i % EMB_AUG;
-      if (t0 + tk < ntok) xa[(t0 + tk) * EMB_AUG + f] = (T)(f < nfp ? xs[tk * nfp + f] : 0.f);
+    const int aug = a.xaug_ld;
+    for (int i = threadIdx.x; i < EMB_TOK * aug; i += 256) {
+      const int tk = i / aug, f = i % aug;
+      if (t0 + tk < ntok) xa[(t0 + tk) * aug + f] = (T)(f < nfp ? xs[tk * nfp + f] : 0.f);
     }
   }
   for (int e = threadIdx.x; e < a.E; e += 256) {
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(256) void embed_grad_scatter_kernel(const float* ac
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= E * (nf + 2)) return;
   const int e = i / (nf + 2), f = i % (nf + 2);
-  const float v = acc[e * EMB_AUG + f];      // (already unscaled: the GEMM that filled acc took the loss scale out)
+  const float v = acc[e * emb_aug_width(nf) + f];      // (already unscaled: the GEMM that filled acc took the loss scale out)
   if (f < nf) unsafeAtomicAdd(dwx + (long)e * nf + f, v);
   else if (f == nf) unsafeAtomicAdd(dwy + e, v);
   else unsafeAtomicAdd(dby + e, v);
@@ -454,6 +467,7 @@ int launch_embed_bwd(const EmbedBwdArgs& a, hipStream_t s) {
 // layout copies between the reference [S,B,E] and the internal [B,S,E]
 // ---------------------------------------------------------------------------------------------
 template <typename T> __global__ __launch_bounds__(256) void sbe_to_bse_kernel(const float* src, float* o32, T* ot, int S, int B, int E) {
+  operand_store_mode<T>();
   const long n4 = (long)S * B * E / 4;
   const int e4 = E / 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -489,6 +503,7 @@ int launch_bse_to_sbe(const float* src, float* dst, int S, int B, int E, hipStre
 
 // gather / scatter of the test rows (s >= sep) into the decoder's compact [(S-sep)*B, E] matrix
 template <typename T> __global__ __launch_bounds__(256) void gather_test_kernel(const float* src, T* dst, int S, int B, int E, int sep) {
+  operand_store_mode<T>();
   const int e4 = E / 4;
   const long n4 = (long)(S - sep) * B * e4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -516,6 +531,7 @@ int launch_dropout_add(float* y, const float* resid, long rows, int cols, unsign
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
 }
 template <typename T> __global__ __launch_bounds__(256) void dropout_scale_kernel(const T* src, T* dst, const T* src2, T* dst2, long n4, int cols4, unsigned seed, unsigned thr, float scale) {
+  operand_store_mode<T>();
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const unsigned r = (unsigned)(i / cols4), c = (unsigned)(i % cols4) * 4;
     f32x4 v = ld4<T>(src + i * 4), w = {0.f, 0.f, 0.f, 0.f};
@@ -547,6 +563,7 @@ int launch_gather_test_rows(const float* src, void* dst, int S, int B, int E, in
   return PFN_LAUNCH_OK();
 }
 template <typename T> __global__ __launch_bounds__(256) void scatter_test_kernel(const float* src, T* dst, int S, int B, int E, int sep) {
+  operand_store_mode<T>();
   const int e4 = E / 4;
   const long n4 = (long)S * B * e4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -567,6 +584,7 @@ int launch_scatter_test_rows(const float* src, void* dst, int S, int B, int E, i
 // ragged batch (round 5: the micro-batches of one optimizer step in ONE launch set, each dataset with its own eval position): the decoder's compact rows are
 // dataset-major, row_off[b] + (s - sep_of[b]).  Both kernels walk the [B, S] token order.
 template <typename T> __global__ __launch_bounds__(256) void gather_test_ragged_kernel(const float* src, T* dst, int S, int B, int E, const int* sep_of, const long* row_off) {
+  operand_store_mode<T>();
   const int e4 = E / 4;
   const long n4 = (long)S * B * e4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -577,6 +595,7 @@ template <typename T> __global__ __launch_bounds__(256) void gather_test_ragged_
   }
 }
 template <typename T> __global__ __launch_bounds__(256) void scatter_test_ragged_kernel(const float* src, T* dst, int S, int B, int E, const int* sep_of, const long* row_off) {
+  operand_store_mode<T>();
   const int e4 = E / 4;
   const long n4 = (long)S * B * e4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -727,6 +746,7 @@ int launch_zero_row_prefix(void* base, int S, int B, int nrows, long row_bytes, 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, const float* gamma, const float* beta, float* y32, T* yt,
                                                             float* mean_o, float* rstd_o, long rows, int E, float eps) {
+  operand_store_mode<T>();
   const int lane = threadIdx.x & 63;
   const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const float invE = 1.f / (float)E;
@@ -811,6 +831,7 @@ template <typename T, int EV> PFN_DEV void ln_store(T* p, const float (&v)[EV]) 
 template <typename T, int NV, int EV, bool DY_T>
 __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const void* dy_any, const float* x, const float* gamma, const float* mean, const float* rstd,
                                                                       float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E, float* partials, const float* scale_amax) {
+  operand_store_mode<T>();
   extern __shared__ __attribute__((aligned(16))) float part[];  // [LNB_WAVES][E]
   const float osc = loss_scale_down(scale_amax);                // fp16 backward: the parameter gradients leave unscaled (pfn_device.h)
   const float* dy = reinterpret_cast<const float*>(dy_any);     // upstream gradient: f32, or operand precision when DY_T

@@ -70,6 +70,10 @@ class FusedClipAdam(torch.optim.Optimizer):
         _, grad = self._buffers()
         grad.zero_()
 
+    def skipped_steps(self):
+        """Steps the kernel skipped because the gradient held an inf / NaN (csrc/optim.hip; parameters and moments untouched); forces a device sync."""
+        return 0 if self._scratch is None else int(self._scratch[1025].item())
+
     def last_grad_norm(self):
         """Global gradient norm seen by the last step (before clipping); forces a device sync."""
         return float(self._scratch[0].item())

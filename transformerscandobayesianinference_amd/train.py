@@ -14,6 +14,7 @@ the model is returned on the CPU (Q8).  Removed: the per-step host syncs `loss.i
 """
 import argparse
 import time
+import warnings
 
 import torch
 import yaml
@@ -223,6 +224,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
 
     total_loss = float('inf')
     total_positional_losses = float('inf')
+    skipped = 0
     for epoch in range(1, epochs + 1):
         epoch_start_time = time.time()
         total_loss, total_positional_losses, time_to_get_batch, forward_time, step_time = train_epoch()
@@ -240,11 +242,15 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
                 f' data time {time_to_get_batch:5.2f} step time {step_time:5.2f}'
                 f' forward time {forward_time:5.2f}' + (f'val score {val_score}' if val_score is not None else ''))
             print('-' * 89)
+        skipped, skipped_before = optimizer.skipped_steps(), skipped      # (the epoch's loss has just been read back: no extra wait)
+        if skipped > skipped_before:
+            warnings.warn(f'epoch {epoch}: {skipped - skipped_before} optimizer step(s) skipped -- the gradient held an inf / NaN (csrc/optim.hip)', RuntimeWarning)
         if epoch_callback is not None:      # (model, epoch, mean loss, learning rate of the epoch, seconds): loss curves / checkpoints
             epoch_callback(model, epoch, total_loss, scheduler.get_last_lr()[0], time.time() - epoch_start_time)
         scheduler.step()
     if reducer is not None:
         reducer.detach()      # the returned model carries no reference to the reducer, its stream or the GPU gradient buffer
+    model.optimizer_steps_skipped = skipped      # steps whose gradient held an inf / NaN (warned about per epoch above)
     return total_loss, total_positional_losses, model.to('cpu')
 
 
