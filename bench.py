@@ -260,9 +260,10 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None,
             return True
         A, B_ = r(M, k), r(E, k)
         bias, gamma, beta, resid = f32(E), f32(E), f32(E), f32(M, E)
-        bufs = (torch.empty(M + 2, E, device=dev), torch.empty(M, E, dtype=bf, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev))
+        sums16 = precision == 'fp16'      # (fp16 models keep the pre-LayerNorm sums in operand precision: PFN_OP_SUMS_16BIT, what the step launches)
+        bufs = (torch.empty(M + 2, E, dtype=bf if sums16 else torch.float32, device=dev), torch.empty(M, E, dtype=bf, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev))
         try:
-            t = time_kernel(lambda: hipops.gemm_ln(A, B_, bias, gamma, beta, 1e-5, resid=resid, out=bufs))
+            t = time_kernel(lambda: hipops.gemm_ln(A, B_, bias, gamma, beta, 1e-5, resid=resid, out=bufs, sums16=sums16))
         except _hip.HipExtensionError:   # shape outside the fused kernel (emsize 1024): the step runs GEMM + LayerNorm kernels there
             return False
         nbytes = sum(v.numel() * v.element_size() for v in (A, B_, resid) + bufs)     # operands, f32 residual in, f32 sum + bf16 LN output + statistics out
@@ -278,6 +279,8 @@ def kernel_breakdown(batch, sep, w=WORKLOAD, fused_ln_wide=False, top_rows=None,
         A, B_, aux = r(M, k), r(E, k), r(M, E)
         y, gamma = f32(M, E), f32(E)
         mean, rstd = y.mean(1), 1 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
+        if precision == 'fp16':
+            y = y.to(bf)
         bufs = (torch.empty(M, E, dtype=bf, device=dev), torch.zeros(E, device=dev), torch.zeros(E, device=dev))
         try:
             t = time_kernel(lambda: hipops.gemm_lnbwd(A, B_, aux, y, mean, rstd, gamma, out=bufs))

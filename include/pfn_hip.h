@@ -80,6 +80,9 @@ enum { PFN_SCHED_TOP_LAYER_ALL_ROWS = 1, /* run the TOP encoder layer on every r
                                           * times their spread on a trained model).  Default: ON with PFN_PREC_FP16 -- this bit turns it off -- and OFF with PFN_PREC_BF16 (the
                                           * arithmetic of rounds 1-5) -- PFN_SCHED_KEY_CENTERING turns it on.  Costs one small kernel + a shifted GEMM epilogue per layer: 0.5 % of the step. */
        PFN_SCHED_KEY_CENTERING = 64,
+       PFN_SCHED_F32_RESIDUAL = 128,     /* PFN_PREC_FP16 keeps the pre-LayerNorm sums (the residual the next block adds, the LayerNorm backward's input) in f32 as bf16 does.
+                                          * Default (bit clear, fp16, no dropout, emsize 128 / 256 / 512): they are stored in fp16 -- the LayerNorm-fused GEMMs are bound by their
+                                          * epilogue's HBM streams and this halves the two f32 ones; LayerNorm itself, its statistics and the operand copy still come from f32 registers */
        PFN_SCHED_FUSE_Q_PROJECTION = 32, /* the Q projection runs INSIDE the attention forward kernel (north_star: "QKV projection + scaled-dot-product attention + softmax ... as one
                                           * fused kernel"): a workgroup forms its 256 queries' head slice x W_q[h]^T + b_q[h] on the matrix cores in its prologue, the GEMM in
                                           * front projects k | v only (shared by every query block of a head: they stay a GEMM).  Same Q bits as the GEMM's; 16-bit operands,
@@ -119,6 +122,7 @@ enum { PFN_TUNE_GEMM_NT_KERNEL = 0,
        PFN_TUNE_WGRAD_WAVES = 14,       /* waves per 256 x 256 tile of the grouped weight-gradient launch: 8 (128 x 64 each) or 4 (128 x 128 each, the whole register file per wave) */
        PFN_TUNE_LOSS_SCALE_TARGET = 15, /* PFN_PREC_FP16 backward: log2 of the value max|dlogits| is scaled to (power-of-two loss scale chosen on the device per call; default 2,
                                          * range -8 .. 12).  16 - target binades of headroom for what the chain adds; overflowing elements saturate at +-65504 */
+       PFN_TUNE_RESIDUAL16 = 16,        /* 0: new descriptors carry PFN_SCHED_F32_RESIDUAL; 1 (default): they do not */
        PFN_TUNE_FUSE_Q_PROJECTION = 12, /* 1: new descriptors carry PFN_SCHED_FUSE_Q_PROJECTION (default 0) */
        PFN_TUNE_KEY_CENTERING = 13,     /* 1: new descriptors carry PFN_SCHED_KEY_CENTERING, 0: PFN_SCHED_NO_KEY_CENTERING, -1 (default): neither (centred with fp16, not with bf16) */
        PFN_TUNE_TOP_LAYER_TEST_ROWS = 6 /* 1 (default): the top encoder layer runs everything behind its K / V projection on the test rows only -- the reference
@@ -318,7 +322,10 @@ int pfn_op_gemm_tn_group(int n, const void* const* A, const int64_t* lda, const 
  *   v = A[M,K] . B[N,K]^T + bias + r;  y = v (f32);  mean / rstd of v per row;  x_t = bf16((v - mean) rstd gamma + beta)
  * r = resid[M,N] (f32) when resid != NULL, else the previous LayerNorm's output recomputed as
  * (ry - rmean) rrstd rgamma + rbeta.  Replaces `x = norm(x + dropout(sublayer(x)))` of torch's TransformerEncoderLayer
- * (nn/modules/transformer.py:952-957) for the out_proj and linear2 sublayers. */
+ * (nn/modules/transformer.py:952-957) for the out_proj and linear2 sublayers.
+ * prec | PFN_OP_SUMS_16BIT (PFN_PREC_FP16 only): y is WRITTEN, and ry READ, in operand precision (the pointers then address fp16 rows) -- what the stack does for
+ * fp16 models unless PFN_SCHED_F32_RESIDUAL is set; pfn_op_gemm_lnbwd takes the same flag for its y. */
+#define PFN_OP_SUMS_16BIT 256
 int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const float* bias,
                    const float* resid, const float* ry, const float* rmean, const float* rrstd,
                    const float* rgamma, const float* rbeta, const float* gamma, const float* beta, float eps,

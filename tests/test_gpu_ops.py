@@ -284,6 +284,49 @@ def test_gemm_lnbwd_fused(M, N, K, ln_tile_rows, op16):
     assert relerr(dgamma, 2 * gd.grad) < tol(op16, 2e-3, 2.5e-4, 0) and relerr(dbeta, 2 * bd.grad) < 1e-4
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 512, 512), (1000, 512, 1024), (333, 128, 96), (2050, 256, 64), (300, 1024, 1024), (1, 1024, 64)])
+def test_gemm_ln_and_lnbwd_with_sums_in_operand_precision(M, N, K, ln_tile_rows):
+    """PFN_OP_SUMS_16BIT (fp16 operands): the LayerNorm-fused GEMM writes its pre-LN sums, and reads the previous LayerNorm's, as fp16 rows -- statistics, the
+    LayerNorm and its operand copy still come from the f32 values in the registers; the LayerNorm-backward GEMM reads such rows.  bf16 refuses the flag."""
+    if ln_tile_rows and N != 512:
+        pytest.skip('the 64-row tiles exist at N = 512 only')
+    dt = torch.float16
+    A, B = rnd(M, K, dtype=dt, seed=40), rnd(N, K, dtype=dt, seed=41, scale=0.1)
+    bias, gamma, beta = rnd(N, seed=42), rnd(N, seed=43) + 1, rnd(N, seed=44)
+    resid = rnd(M, N, seed=45)
+    v = A.double() @ B.double().t() + bias.double() + resid.double()
+    y, x_t, mean, rstd = hipops.gemm_ln(A, B, bias, gamma, beta, 1e-5, resid=resid, sums16=True)
+    y32, x32, mean32, rstd32 = hipops.gemm_ln(A, B, bias, gamma, beta, 1e-5, resid=resid)
+    assert y.dtype == dt and torch.equal(y, y32.to(dt))                        # the stored sums ARE the f32 sums, rounded once
+    assert torch.equal(x_t, x32) and torch.equal(mean, mean32) and torch.equal(rstd, rstd32)     # everything else is untouched by the flag
+    # residual = the previous LayerNorm's output recomputed from ITS 16-bit sums and (f32) statistics
+    ry32 = rnd(M, N, seed=46) * 2 + 0.3
+    ry = ry32.to(dt)
+    rg, rb = rnd(N, seed=47) + 1, rnd(N, seed=48)
+    rmean, rrstd = ry32.double().mean(1), 1 / torch.sqrt(ry32.double().var(1, unbiased=False) + 1e-5)      # statistics of the unrounded sums, as the producing kernel leaves them
+    r2 = (ry.double() - rmean[:, None]) * rrstd[:, None] * rg.double() + rb.double()
+    v2 = A.double() @ B.double().t() + bias.double() + r2
+    y2, x2, _, _ = hipops.gemm_ln(A, B, bias, gamma, beta, 1e-5, prev=(ry, rmean.float(), rrstd.float(), rg, rb), sums16=True)
+    assert relerr(y2, v2) < 5e-4 and relerr(x2, torch.nn.functional.layer_norm(v2, (N,), gamma.double(), beta.double(), 1e-5)) < 5e-4
+    with pytest.raises(_hip.HipExtensionError):
+        hipops.gemm_ln(A.to(torch.bfloat16), B.to(torch.bfloat16), bias, gamma, beta, 1e-5, resid=resid, sums16=True)
+    # LayerNorm backward inside the data-gradient GEMM, from 16-bit rows
+    aux = rnd(M, N, dtype=dt, seed=52)
+    yd = ry.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = torch.zeros(N, dtype=torch.float64, device=dev(), requires_grad=True)
+    Kb = K
+    Ab, Bb = rnd(M, Kb, dtype=dt, seed=50), rnd(N, Kb, dtype=dt, seed=51, scale=0.1)
+    vb = Ab.double() @ Bb.double().t() + aux.double()
+    m16, r16 = ry.double().mean(1), 1 / torch.sqrt(ry.double().var(1, unbiased=False) + 1e-5)
+    torch.nn.functional.layer_norm(yd, (N,), gd, bd, 1e-5).backward(vb)
+    dx_t, dgamma, dbeta = hipops.gemm_lnbwd(Ab, Bb, aux, ry, m16.float(), r16.float(), gamma)
+    assert torch.isnan(dx_t[M:].float()).all()
+    assert relerr(dx_t[:M], yd.grad) < 5e-4 and relerr(dgamma, gd.grad) < 2.5e-4 and relerr(dbeta, bd.grad) < 1e-4
+    dx32, dg32, db32 = hipops.gemm_lnbwd(Ab, Bb, aux, ry.float(), m16.float(), r16.float(), gamma)      # the same rows handed over as f32: the same arithmetic
+    assert torch.equal(dx32[:M], dx_t[:M])
+
+
 @pytest.fixture(params=[8, 4], ids=['8-waves-128x64', '4-waves-128x128'])
 def wgrad_waves(request):
     """PFN_TUNE_WGRAD_WAVES: the grouped weight-gradient launch as eight waves of 128 x 64 (gemm_tn_big_kernel) or four of 128 x 128 (gemm_tn_wide_kernel)."""

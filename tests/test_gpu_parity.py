@@ -175,6 +175,37 @@ def test_config1_vs_oracle(precision):
         within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2))
 
 
+@pytest.mark.parametrize('E,H', [(128, 4), (512, 4)])
+def test_fp16_pre_layernorm_sums_in_operand_precision_vs_f32(E, H):
+    """fp16 operands store the pre-LayerNorm sums -- the residual the next block adds, the LayerNorm backward's input -- in fp16 by default (GemmLN::y16: half the
+    bytes of the LayerNorm-fused GEMMs' two f32 streams); PFN_SCHED_F32_RESIDUAL keeps them in f32 as in bf16.  Both against the f64 oracle, and against each other:
+    the 16-bit sums add less than the operand rounding that is there anyway."""
+    cfg = dict(T=160, B=4, F=5, E=E, H=H, nhid=2 * E, L=3, nbars=100)
+    ref = random_model(cfg, 'fp16', seed=11)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    gen = torch.Generator().manual_seed(6)
+    x, y, _ = pfn_oracle.get_batch_fast_gp(cfg['B'], cfg['T'], cfg['F'], {'noise': 1e-4, 'outputscale': 1., 'lengthscale': .6}, gen)
+    for sep in (120, 30):       # (the top layer on the test rows only / on every row)
+        loss_o, logits_o, grads_o = pfn_oracle.loss_and_grads(sd, x, y, y, sep, cfg['H'], sd['criterion.borders'])
+        tot = math.sqrt(sum((g ** 2).sum().item() for g in grads_o.values()))
+        out = {}
+        for name, bits in (('fp16 sums', 0), ('f32 sums', _hip.SCHED_F32_RESIDUAL)):
+            model = random_model(cfg, 'fp16', seed=11)
+            model.schedule = bits
+            model = model.to(DEV).train()
+            logits = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
+            loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
+            loss.backward()
+            g = {k: p.grad.double().cpu() for k, p in model.named_parameters()}
+            err = math.sqrt(sum(((g[k] - grads_o[k]) ** 2).sum().item() for k in g)) / tot
+            within(f'{name}, sep {sep}: logits rel l2 vs oracle', relerr(logits, logits_o), 2.5e-3)
+            within(f'{name}, sep {sep}: loss rel vs oracle', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), 2.5e-4)
+            within(f'{name}, sep {sep}: global gradient rel l2 vs oracle', err, 3e-3)
+            out[name] = (logits.detach(), g)
+        within(f'sep {sep}: logits, fp16 sums vs f32 sums, rel l2', relerr(out['fp16 sums'][0], out['f32 sums'][0]), 2.5e-3)
+        assert not torch.equal(out['fp16 sums'][0], out['f32 sums'][0])      # (the bit does select another arithmetic)
+
+
 @pytest.mark.parametrize('target', [9, 12])
 def test_fp16_backward_saturates_where_the_loss_scale_leaves_no_headroom(target):
     """fp16 backward with the loss-scale target pushed up (PFN_TUNE_LOSS_SCALE_TARGET): max|dlogits| lands at 2^9 or 2^12 -- seven or four binades below 65504 --

@@ -3,7 +3,9 @@
 VERDICT round 5, next-round item 1(a).  The f64 oracle forward (oracle/pfn_oracle.py) is re-run with the HIP stack's operand roundings emulated -- every GEMM /
 attention operand the product path keeps in 16 bits (weights W, the layer-input copy X, the projected q|k|v QKV, the softmax numerators P entering P.V, the
 attention output CTX, the GELU output ACT) is rounded to the format under test and back; residual stream, LayerNorm arithmetic and accumulations stay exact (f32 in
-the kernels: orders of magnitude below the operand rounding).  Formats:
+the kernels: orders of magnitude below the operand rounding).  Class Y (round 6, second half): the pre-LayerNorm sums as the NEXT block's residual add sees them --
+r = (round(v) - mean) rstd gamma + beta with mean / rstd of the unrounded v, the form gemm_nt_ln_kernel<..., Y16> recomputes; the LayerNorm output that becomes the
+GEMM operand X still comes from the unrounded v.  Formats:
 
     bf16      8-bit significand (round 1-5's product path)
     fp16      11-bit significand, 5-bit exponent: same MFMA rate and bytes on gfx950 (v_mfma_f32_32x32x16_f16); range 6.1e-5 (normal) .. 65504
@@ -21,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import pfn_oracle as O
 
-CLASSES = ('W', 'X', 'Q', 'K', 'V', 'P', 'CTX', 'ACT')
+CLASSES = ('W', 'X', 'Q', 'K', 'V', 'P', 'CTX', 'ACT', 'Y')
 
 
 def rounder(fmt):
@@ -61,12 +63,17 @@ def forward(sd, x, y, sep, nhead, fmt_of, maxabs=None, center=False):
     X = lambda a: R['X'](note('X', a))
     emb = O._linear(x, p['encoder.weight'], p['encoder.bias'])
     h = torch.cat([emb[:sep] + O._linear(y.unsqueeze(-1), p['y_encoder.weight'], p['y_encoder.bias'])[:sep], emb[sep:]], 0)   # embedding: f32 FMAs in the kernel
+    hx = h       # hx: the LayerNorm output the operands are cut from; h: the same rows as the next residual add reads them (class Y)
+
+    def ln_pair(v, g, b):
+        mean, rstd = v.mean(-1, keepdim=True), (v.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        return (v - mean) * rstd * g + b, (R['Y'](note('Y', v)) - mean) * rstd * g + b
     E = h.shape[-1]; D = E // nhead
     mask = O.d_q_mask(T, sep, dt, h.device)
     L = 1 + max(int(k.split('.')[2]) for k in p if k.startswith('transformer_encoder.layers.'))
     for l in range(L):
         pre = f'transformer_encoder.layers.{l}.'
-        xr, wr = X(h), W(p[pre + 'self_attn.in_proj_weight'])
+        xr, wr = X(hx), W(p[pre + 'self_attn.in_proj_weight'])
         qkv = O._linear(xr, wr, p[pre + 'self_attn.in_proj_bias'])
         q, k, v = qkv.split(E, -1)
         if center and sep > 0:
@@ -80,15 +87,15 @@ def forward(sd, x, y, sep, nhead, fmt_of, maxabs=None, center=False):
         pu = torch.exp(s - mx)                                  # flash kernel: unnormalised P rounded for P.V, divided by the f32 row sum afterwards
         ctx = (R['P'](pu) @ v) / pu.sum(-1, keepdim=True)
         ctx = R['CTX'](note('CTX', ctx.permute(2, 0, 1, 3).reshape(T, B, E)))
-        h = O._layer_norm(h + O._linear(ctx, W(p[pre + 'self_attn.out_proj.weight']), p[pre + 'self_attn.out_proj.bias']), p[pre + 'norm1.weight'], p[pre + 'norm1.bias'])
-        act = R['ACT'](note('ACT', O._gelu(O._linear(X(h), W(p[pre + 'linear1.weight']), p[pre + 'linear1.bias']))))
-        h = O._layer_norm(h + O._linear(act, W(p[pre + 'linear2.weight']), p[pre + 'linear2.bias']), p[pre + 'norm2.weight'], p[pre + 'norm2.bias'])
-    d = R['ACT'](note('ACT', O._gelu(O._linear(X(h[sep:]), W(p['decoder.0.weight']), p['decoder.0.bias']))))
+        hx, h = ln_pair(h + O._linear(ctx, W(p[pre + 'self_attn.out_proj.weight']), p[pre + 'self_attn.out_proj.bias']), p[pre + 'norm1.weight'], p[pre + 'norm1.bias'])
+        act = R['ACT'](note('ACT', O._gelu(O._linear(X(hx), W(p[pre + 'linear1.weight']), p[pre + 'linear1.bias']))))
+        hx, h = ln_pair(h + O._linear(act, W(p[pre + 'linear2.weight']), p[pre + 'linear2.bias']), p[pre + 'norm2.weight'], p[pre + 'norm2.bias'])
+    d = R['ACT'](note('ACT', O._gelu(O._linear(X(hx[sep:]), W(p['decoder.0.weight']), p['decoder.0.bias']))))
     return O._linear(d, W(p['decoder.2.weight']), p['decoder.2.bias'])
 
 
 def variants():
-    allc = lambda f: {c: f for c in CLASSES}
+    allc = lambda f: {c: (f if c != 'Y' else None) for c in CLASSES}      # (the pre-LayerNorm sums stay f32 unless a variant says otherwise)
     v = [('all operands bf16 (rounds 1-5 timed path)', allc('bf16')),
          ('q, k fp16; rest bf16', dict(allc('bf16'), Q='fp16', K='fp16')),
          ('q, k, P fp16; rest bf16', dict(allc('bf16'), Q='fp16', K='fp16', P='fp16')),
@@ -98,6 +105,8 @@ def variants():
          ('all operands fp16, subnormals flushed', allc('fp16-ftz'))]
     v.append(('all operands bf16 + keys centred per dataset (round 6 bf16 path)', dict(allc('bf16'), _center=True)))
     v.append(('all operands fp16 + keys centred per dataset (round 6 fp16 path)', dict(allc('fp16'), _center=True)))
+    v.append(('... + pre-LayerNorm sums stored in fp16 (round 6 fp16 path, PFN_SCHED_F32_RESIDUAL clear)', dict(allc('fp16'), Y='fp16', _center=True)))
+    v.append(('all operands bf16 + keys centred + pre-LayerNorm sums stored in bf16 (not built: what it would cost)', dict(allc('bf16'), Y='bf16', _center=True)))
     for c in CLASSES:
         v.append((f'only {c} bf16', {c: 'bf16'}))
     for c in CLASSES:

@@ -19,7 +19,7 @@ PREC_BF16 = 0
 PREC_F32 = 1
 PREC_FP16 = 2      # fp16 MFMA operands under a device-side loss scale (include/pfn_hip.h): the timed path that holds the north star's 1e-3
 PRECISIONS = {'bf16': PREC_BF16, 'f32': PREC_F32, 'fp32': PREC_F32, 'fp16': PREC_FP16, 'f16': PREC_FP16}
-SCHED_TOP_LAYER_ALL_ROWS, SCHED_FUSE_LN_WIDE, SCHED_SEPARATE_LNBWD, SCHED_DETERMINISTIC, SCHED_NO_KEY_CENTERING, SCHED_FUSE_Q_PROJECTION, SCHED_KEY_CENTERING = 1, 2, 4, 8, 16, 32, 64     # pfn_model_desc.schedule bits (include/pfn_hip.h)
+SCHED_TOP_LAYER_ALL_ROWS, SCHED_FUSE_LN_WIDE, SCHED_SEPARATE_LNBWD, SCHED_DETERMINISTIC, SCHED_NO_KEY_CENTERING, SCHED_FUSE_Q_PROJECTION, SCHED_KEY_CENTERING, SCHED_F32_RESIDUAL = 1, 2, 4, 8, 16, 32, 64, 128     # pfn_model_desc.schedule bits (include/pfn_hip.h)
 
 # GEMM epilogue flags (csrc/pfn_kernels.h)
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESID, EPI_OUT_F32, EPI_OUT_T, EPI_OUT2_T, EPI_ACCUM, EPI_RESID_T = 1, 2, 4, 8, 16, 32, 64, 128, 256

@@ -520,7 +520,7 @@ template <int NWN> struct LnEpi {   // LDS of gemm_nt_ln_kernel's epilogue: row 
   static constexpr int WAVE = 32 * 272 + 32 * 144;
   static constexpr int BYTES = STRIPS + NWN * WAVE;
 };
-template <typename T, int NWN, bool RESID_LN, int BK>
+template <typename T, int NWN, bool RESID_LN, int BK, bool Y16>
 __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
   operand_store_mode<T>();
   constexpr int BM = 128, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * 64;
@@ -603,21 +603,28 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
     const float c2 = g.bias[n], c3 = g.gamma[n], c4 = g.beta[n];
     cvec[n] = c0; cvec[BN + n] = c1; cvec[2 * BN + n] = c2; cvec[3 * BN + n] = c3; cvec[4 * BN + n] = c4;
   }
-  const float* rsrc = RESID_LN ? g.ry : g.resid;
+  // Y16 (GemmLN::y16, fp16 operands): the pre-LN sums are stored -- and the previous LayerNorm's read back -- in operand precision, 2 instead of 4 bytes per
+  // element on the two f32 streams of this HBM-bound epilogue; statistics, outputs and the LayerNorm itself still come from the f32 values in the registers.
+  typedef typename std::conditional<Y16 && RESID_LN, X4<T>, f32x4>::type RV;      // a residual group as it is fetched
+  const float* rsrc = RESID_LN ? reinterpret_cast<const float*>(g.ry) : g.resid;
   // (32-bit row indices, the 64-bit element offsets formed where they are used; the residual rows' LayerNorm statistics travel with the rows, one block
   // ahead, instead of all four blocks' up front: this epilogue sits at the 256-register limit and a handful of long-lived values is a spill)
   float rm[2], rr[2];
   int mrow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) mrow[i] = min(m0 + i * 32 + li, g.M - 1);
-  f32x4 rv[2][8];
-  auto fetch_rows = [&](int i, f32x4 (&dst)[8]) {
+  RV rv[2][8];
+  auto fetch_rows = [&](int i, RV (&dst)[8]) {
     rm[i & 1] = 0.f; rr[i & 1] = 1.f;
     if constexpr (RESID_LN) { rm[i & 1] = g.rmean[mrow[i]]; rr[i & 1] = g.rrstd[mrow[i]]; }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) dst[j * 4 + gq] = *reinterpret_cast<const f32x4*>(rsrc + (long)mrow[i] * BN + wave * 64 + j * 32 + 8 * gq + 4 * h);
+      for (int gq = 0; gq < 4; ++gq) {
+        const long off = (long)mrow[i] * BN + wave * 64 + j * 32 + 8 * gq + 4 * h;
+        if constexpr (Y16 && RESID_LN) dst[j * 4 + gq] = *reinterpret_cast<const X4<T>*>(reinterpret_cast<const T*>(g.ry) + off);
+        else dst[j * 4 + gq] = *reinterpret_cast<const f32x4*>(rsrc + off);
+      }
   };
   fetch_rows(0, rv[0]);
   __syncthreads();                                          // cvec visible
@@ -632,7 +639,9 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int n = wave * 64 + j * 32 + 8 * gq + 4 * h;
-        f32x4 r = rv[i & 1][j * 4 + gq];
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (float)rv[i & 1][j * 4 + gq][e];
         if constexpr (RESID_LN) {
           const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + n), be = *reinterpret_cast<const f32x4*>(cvec + BN + n);
 #pragma unroll
@@ -702,18 +711,34 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_ln_kernel(GemmLN g) {
           xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
           xt[e] = (T)xo[e];
         }
-        lds_write16(sf + li * 272 + (j * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
+        if constexpr (Y16) {
+          X4<T> vt;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vt[e] = (T)v[e];
+          *reinterpret_cast<lds_tx4*>(sf + li * 144 + (j * 4 + gq) * 16 + h * 8) = vt;
+        } else {
+          lds_write16(sf + li * 272 + (j * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
+        }
         *reinterpret_cast<lds_tx4*>(st + li * 144 + (j * 4 + gq) * 16 + h * 8) = xt;
         if (g.x_f32 && mvalid) *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;   // (last layer only)
       }
     }
     __builtin_amdgcn_wave_barrier();
     const long mb = (long)m0 + i * 32;
+    if constexpr (Y16) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int rr = it * 4 + (lane >> 4), c = lane & 15;
-      const u32x4 q = lds_read16(sf + rr * 272 + c * 16);
-      if (mb + rr < g.M) *reinterpret_cast<u32x4*>(g.y + (mb + rr) * BN + wave * 64 + c * 4) = q;
+      for (int it = 0; it < 4; ++it) {
+        const int rr = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 q = lds_read16(sf + rr * 144 + c * 16);
+        if (mb + rr < g.M) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(g.y) + (mb + rr) * BN + wave * 64 + c * 8) = q;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rr = it * 4 + (lane >> 4), c = lane & 15;
+        const u32x4 q = lds_read16(sf + rr * 272 + c * 16);
+        if (mb + rr < g.M) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(g.y) + (mb + rr) * BN + wave * 64 + c * 4) = q;
+      }
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -735,7 +760,7 @@ template <int NWN, int MI, int NJ> struct LnEpiW {   // LDS of gemm_nt_ln_kernel
   static constexpr int WAVE = 32 * 272 + 32 * 144;
   static constexpr int BYTES = STRIPS + NWN * WAVE;
 };
-template <typename T, int NWN, bool RESID_LN, int BK, int MI, int NJ>
+template <typename T, int NWN, bool RESID_LN, int BK, int MI, int NJ, bool Y16>
 __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_kernel(GemmLN g) {      // (4-wave tiles: two workgroups per CU, 256 registers per wave)
   operand_store_mode<T>();
   constexpr int BM = MI * 32, WN = NJ * 32, RB = BK * 2, CPR = RB / 16, RPP = 1024 / RB, BN = NWN * WN;
@@ -818,7 +843,8 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
     const float c2 = g.bias[n], c3 = g.gamma[n], c4 = g.beta[n];
     cvec[n] = c0; cvec[BN + n] = c1; cvec[2 * BN + n] = c2; cvec[3 * BN + n] = c3; cvec[4 * BN + n] = c4;
   }
-  const float* rsrc = RESID_LN ? g.ry : g.resid;
+  typedef typename std::conditional<Y16 && RESID_LN, X4<T>, f32x4>::type RV;      // (Y16: see gemm_nt_ln_kernel)
+  const float* rsrc = RESID_LN ? reinterpret_cast<const float*>(g.ry) : g.resid;
   float rm[MI], rr[MI];
   long mrow[MI];
 #pragma unroll
@@ -827,13 +853,16 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
     rm[i] = 0.f; rr[i] = 1.f;
     if constexpr (RESID_LN) { rm[i] = g.rmean[mrow[i]]; rr[i] = g.rrstd[mrow[i]]; }
   }
-  f32x4 rv[2][8];
-  auto fetch_unit = [&](int u, f32x4 (&dst)[8]) {           // unit u = (row block u / JH, column blocks 2 (u % JH) and + 1)
+  RV rv[2][8];
+  auto fetch_unit = [&](int u, RV (&dst)[8]) {              // unit u = (row block u / JH, column blocks 2 (u % JH) and + 1)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        dst[jj * 4 + gq] = *reinterpret_cast<const f32x4*>(rsrc + mrow[u / JH] * BN + wave * WN + ((u % JH) * 2 + jj) * 32 + 8 * gq + 4 * h);
+      for (int gq = 0; gq < 4; ++gq) {
+        const long off = mrow[u / JH] * BN + wave * WN + ((u % JH) * 2 + jj) * 32 + 8 * gq + 4 * h;
+        if constexpr (Y16 && RESID_LN) dst[jj * 4 + gq] = *reinterpret_cast<const X4<T>*>(reinterpret_cast<const T*>(g.ry) + off);
+        else dst[jj * 4 + gq] = *reinterpret_cast<const f32x4*>(rsrc + off);
+      }
   };
   fetch_unit(0, rv[0]);
   __syncthreads();                                          // cvec visible
@@ -851,7 +880,9 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
       for (int gq = 0; gq < 4; ++gq) {
         const int j = jh * 2 + jj;
         const int n = wave * WN + j * 32 + 8 * gq + 4 * h;
-        f32x4 r = rv[u & 1][jj * 4 + gq];
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (float)rv[u & 1][jj * 4 + gq][e];
         if constexpr (RESID_LN) {
           const f32x4 ga = *reinterpret_cast<const f32x4*>(cvec + n), be = *reinterpret_cast<const f32x4*>(cvec + BN + n);
 #pragma unroll
@@ -926,7 +957,14 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
           xo[e] = (v[e] - mean[i]) * rstd[i] * ga[e] + be[e];
           xt[e] = (T)xo[e];
         }
-        lds_write16(sf + li * 272 + (jj * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
+        if constexpr (Y16) {
+          X4<T> vt;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vt[e] = (T)v[e];
+          *reinterpret_cast<lds_tx4*>(sf + li * 144 + (jj * 4 + gq) * 16 + h * 8) = vt;
+        } else {
+          lds_write16(sf + li * 272 + (jj * 8 + gq * 2 + h) * 16, __builtin_bit_cast(u32x4, v));
+        }
         *reinterpret_cast<lds_tx4*>(st + li * 144 + (jj * 4 + gq) * 16 + h * 8) = xt;
         if (g.x_f32 && mvalid) *reinterpret_cast<f32x4*>(g.x_f32 + m * BN + n) = xo;   // (last layer only)
       }
@@ -934,11 +972,20 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_ln_wide_
     __builtin_amdgcn_wave_barrier();
     const long mb = (long)m0 + i * 32;
     const int cb = wave * WN + jh * 64;                     // first column of the unit
+    if constexpr (Y16) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int rr_ = it * 4 + (lane >> 4), c = lane & 15;
-      const u32x4 q = lds_read16(sf + rr_ * 272 + c * 16);
-      if (mb + rr_ < g.M) *reinterpret_cast<u32x4*>(g.y + (mb + rr_) * BN + cb + c * 4) = q;
+      for (int it = 0; it < 4; ++it) {
+        const int rr_ = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 q = lds_read16(sf + rr_ * 144 + c * 16);
+        if (mb + rr_ < g.M) *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(g.y) + (mb + rr_) * BN + cb + c * 8) = q;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rr_ = it * 4 + (lane >> 4), c = lane & 15;
+        const u32x4 q = lds_read16(sf + rr_ * 272 + c * 16);
+        if (mb + rr_ < g.M) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(g.y) + (mb + rr_) * BN + cb + c * 4) = q;
+      }
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -982,7 +1029,7 @@ template <int NWN, int BK> struct LnbCfg {
   static constexpr int LDS = STAGES > EPI ? STAGES : EPI;
 };
 
-template <typename T, int NWN, int BK>
+template <typename T, int NWN, int BK, bool Y16>
 __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   operand_store_mode<T>();
   using C = LnbCfg<NWN, BK>;
@@ -1070,13 +1117,15 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
   }
   // y rows and the residual-branch gradient: one half row block (a 32-column block of the lane's row) ahead of its use -- a whole
   // block ahead does not fit the registers.  v = product + that gradient replaces the accumulator; rows past M hold zeros.
-  f32x4 yv[2][4];
+  typedef typename std::conditional<Y16, X4<T>, f32x4>::type YV;      // (GemmLNB::y16: the LayerNorm's input rows as gemm_nt_ln_kernel<..., Y16> stored them)
+  YV yv[2][4];
   X4<T> av[2][4];
-  auto fetch_half = [&](int hb, f32x4 (&dy)[4], X4<T> (&da)[4]) {           // hb = 2 i + j
+  auto fetch_half = [&](int hb, YV (&dy)[4], X4<T> (&da)[4]) {              // hb = 2 i + j
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const long off = (long)mrow[hb >> 1] * BN + wave * 64 + (hb & 1) * 32 + 8 * gq + 4 * h;
-      dy[gq] = *reinterpret_cast<const f32x4*>(g.y + off);
+      if constexpr (Y16) dy[gq] = *reinterpret_cast<const X4<T>*>(reinterpret_cast<const T*>(g.y) + off);
+      else dy[gq] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.y) + off);
       da[gq] = *reinterpret_cast<const X4<T>*>(aux + off);
     }
   };
@@ -1099,7 +1148,7 @@ __global__ __launch_bounds__(NWN * 64) void gemm_nt_lnbwd_kernel(GemmLNB g) {
       for (int e = 0; e < 4; ++e) {
         const float v = mvalid[i] ? acc[i][j][4 * gq + e] + (float)av[hb & 1][gq][e] : 0.f;
         acc[i][j][4 * gq + e] = v;
-        const float xh = (yv[hb & 1][gq][e] - mu[i]) * rs[i];
+        const float xh = ((float)yv[hb & 1][gq][e] - mu[i]) * rs[i];
         const float gv = ga[e] * v;
         s1 += gv;
         s2 += gv * xh;
@@ -1214,7 +1263,7 @@ template <int NWN, int BK, int MI, int NJ> struct LnbCfgW {
   static constexpr int LDS = STAGES > EPI ? STAGES : EPI;
 };
 
-template <typename T, int NWN, int BK, int MI, int NJ>
+template <typename T, int NWN, int BK, int MI, int NJ, bool Y16>
 __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wide_kernel(GemmLNB g) {
   operand_store_mode<T>();
   using C = LnbCfgW<NWN, BK, MI, NJ>;
@@ -1303,13 +1352,15 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
   }
   // y rows and the residual-branch gradient: one half row block (a 32-column block of the lane's row) ahead of its use -- a whole
   // block ahead does not fit the registers.  v = product + that gradient replaces the accumulator; rows past M hold zeros.
-  f32x4 yv[2][4];
+  typedef typename std::conditional<Y16, X4<T>, f32x4>::type YV;
+  YV yv[2][4];
   X4<T> av[2][4];
-  auto fetch_half = [&](int hb, f32x4 (&dy)[4], X4<T> (&da)[4]) {           // hb = NJ i + j
+  auto fetch_half = [&](int hb, YV (&dy)[4], X4<T> (&da)[4]) {              // hb = NJ i + j
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const long off = (long)mrow[hb / NJ] * BN + wave * WN + (hb % NJ) * 32 + 8 * gq + 4 * h;
-      dy[gq] = *reinterpret_cast<const f32x4*>(g.y + off);
+      if constexpr (Y16) dy[gq] = *reinterpret_cast<const X4<T>*>(reinterpret_cast<const T*>(g.y) + off);
+      else dy[gq] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.y) + off);
       da[gq] = *reinterpret_cast<const X4<T>*>(aux + off);
     }
   };
@@ -1332,7 +1383,7 @@ __global__ __launch_bounds__(NWN * 64, (NWN <= 4 ? 2 : 1)) void gemm_nt_lnbwd_wi
       for (int e = 0; e < 4; ++e) {
         const float v = mvalid[i] ? acc[i][j][4 * gq + e] + (float)av[hb & 1][gq][e] : 0.f;
         acc[i][j][4 * gq + e] = v;
-        const float xh = (yv[hb & 1][gq][e] - mu[i]) * rs[i];
+        const float xh = ((float)yv[hb & 1][gq][e] - mu[i]) * rs[i];
         const float gv = ga[e] * v;
         s1 += gv;
         s2 += gv * xh;
@@ -1537,32 +1588,32 @@ bool gemm_ln_supported(const GemmLN& g) {
          aligned16(g.A) && aligned16(g.B) && aligned16(g.bias) && aligned16(g.gamma) && aligned16(g.beta) && aligned16(g.y) && aligned16(g.x_t) &&
          (g.resid ? aligned16(g.resid) : (aligned16(g.ry) && aligned16(g.rgamma) && aligned16(g.rbeta)));
 }
-template <typename T, int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g, hipStream_t stream) {
+template <typename T, bool Y, int NWN, bool RL, int BK> static void launch_gemm_ln_t(const GemmLN& g, hipStream_t stream) {
   const size_t lds = std::max<size_t>(2 * (128 + NWN * 64) * (BK * 2), LnEpi<NWN>::BYTES);
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_ln_kernel<T, NWN, RL, BK>, lds);
-  hipLaunchKernelGGL((gemm_nt_ln_kernel<T, NWN, RL, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
+  allowance.ensure(gemm_nt_ln_kernel<T, NWN, RL, BK, Y>, lds);
+  hipLaunchKernelGGL((gemm_nt_ln_kernel<T, NWN, RL, BK, Y>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
 }
 // PFN_TUNE_GEMM_LN_ROWS (test / profiling knob): 1 = the LayerNorm-fused GEMMs at N = 512 run on 64-ROW tiles (4 waves x (2 x 4) blocks, 32-deep stages:
 // 72 KiB of LDS, 256 registers per wave) so that TWO workgroups share a CU and one's HBM-bound epilogue can run under the other's MFMA loop; 0 = the
 // 128-row tiles that fill the CU's LDS alone
 static int g_ln_rows64 = 0;
 void set_gemm_ln_rows64(int on) { g_ln_rows64 = on; }
-template <typename T, int NWN, bool RL, int BK, int MI, int NJ> static void launch_gemm_ln_wide_t(const GemmLN& g, hipStream_t stream) {
+template <typename T, bool Y, int NWN, bool RL, int BK, int MI, int NJ> static void launch_gemm_ln_wide_t(const GemmLN& g, hipStream_t stream) {
   constexpr int BM = MI * 32;
   const size_t lds = std::max<size_t>(2 * (BM + NWN * NJ * 32) * (BK * 2), LnEpiW<NWN, MI, NJ>::BYTES);
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_ln_wide_kernel<T, NWN, RL, BK, MI, NJ>, lds);
-  hipLaunchKernelGGL((gemm_nt_ln_wide_kernel<T, NWN, RL, BK, MI, NJ>), dim3((g.M + BM - 1) / BM), dim3(NWN * 64), lds, stream, g);
+  allowance.ensure(gemm_nt_ln_wide_kernel<T, NWN, RL, BK, MI, NJ, Y>, lds);
+  hipLaunchKernelGGL((gemm_nt_ln_wide_kernel<T, NWN, RL, BK, MI, NJ, Y>), dim3((g.M + BM - 1) / BM), dim3(NWN * 64), lds, stream, g);
 }
-template <typename T> static int launch_gemm_ln_op(const GemmLN& g, hipStream_t stream) {
+template <typename T, bool Y> static int launch_gemm_ln_op(const GemmLN& g, hipStream_t stream) {
   const bool rl = g.resid == nullptr;
   // 64-deep stages (two of them fill the CU's 160 KiB of LDS at N = 512) whenever K allows, else 32-deep
 #define PFN_LN_CASE(NWN) \
-  if (g.K % 64 == 0) { if (rl) launch_gemm_ln_t<T, NWN, true, 64>(g, stream); else launch_gemm_ln_t<T, NWN, false, 64>(g, stream); } \
-  else { if (rl) launch_gemm_ln_t<T, NWN, true, 32>(g, stream); else launch_gemm_ln_t<T, NWN, false, 32>(g, stream); }
+  if (g.K % 64 == 0) { if (rl) launch_gemm_ln_t<T, Y, NWN, true, 64>(g, stream); else launch_gemm_ln_t<T, Y, NWN, false, 64>(g, stream); } \
+  else { if (rl) launch_gemm_ln_t<T, Y, NWN, true, 32>(g, stream); else launch_gemm_ln_t<T, Y, NWN, false, 32>(g, stream); }
   if (g.N == 512 && g_ln_rows64) {
-    if (rl) launch_gemm_ln_wide_t<T, 4, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<T, 4, false, 32, 2, 4>(g, stream);
+    if (rl) launch_gemm_ln_wide_t<T, Y, 4, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<T, Y, 4, false, 32, 2, 4>(g, stream);
     return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
   }
   switch (g.N / 64) {
@@ -1570,7 +1621,7 @@ template <typename T> static int launch_gemm_ln_op(const GemmLN& g, hipStream_t 
     case 4: PFN_LN_CASE(4) break;
     case 8: PFN_LN_CASE(8) break;
     default:   // N = 1024: 64 rows x (8 waves x 128 columns), 32-deep stages (two of them are 136 KiB)
-      if (rl) launch_gemm_ln_wide_t<T, 8, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<T, 8, false, 32, 2, 4>(g, stream);
+      if (rl) launch_gemm_ln_wide_t<T, Y, 8, true, 32, 2, 4>(g, stream); else launch_gemm_ln_wide_t<T, Y, 8, false, 32, 2, 4>(g, stream);
       break;
   }
 #undef PFN_LN_CASE
@@ -1579,36 +1630,37 @@ template <typename T> static int launch_gemm_ln_op(const GemmLN& g, hipStream_t 
 int launch_gemm_ln(const GemmLN& g, int precision, hipStream_t stream) {
   if (g.M <= 0) return PFN_OK;
   if (!prec_is16(precision) || !gemm_ln_supported(g)) return PFN_ERR_UNSUPPORTED;
-  return precision == PFN_PREC_FP16 ? launch_gemm_ln_op<f16>(g, stream) : launch_gemm_ln_op<bf16>(g, stream);
+  if (g.y16) return precision == PFN_PREC_FP16 ? launch_gemm_ln_op<f16, true>(g, stream) : PFN_ERR_UNSUPPORTED;      // (bf16 keeps its f32 sums: 8 bits on the residual path cost parity)
+  return precision == PFN_PREC_FP16 ? launch_gemm_ln_op<f16, false>(g, stream) : launch_gemm_ln_op<bf16, false>(g, stream);
 }
 
 bool gemm_lnbwd_supported(const GemmLNB& g) {
   return (g.N == 128 || g.N == 256 || g.N == 512 || g.N == 1024) && g.K % 32 == 0 && g.K >= 32 && (g.lda * 2) % 16 == 0 && (g.ldb * 2) % 16 == 0 &&
          aligned16(g.A) && aligned16(g.B) && aligned16(g.aux) && aligned16(g.y) && aligned16(g.gamma) && aligned16(g.dx_t) && g.dgamma && g.dbeta;
 }
-template <typename T, int NWN, int BK> static void launch_gemm_lnbwd_t(const GemmLNB& g, hipStream_t stream) {
+template <typename T, bool Y, int NWN, int BK> static void launch_gemm_lnbwd_t(const GemmLNB& g, hipStream_t stream) {
   const size_t lds = LnbCfg<NWN, BK>::LDS;
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_lnbwd_kernel<T, NWN, BK>, lds);
-  hipLaunchKernelGGL((gemm_nt_lnbwd_kernel<T, NWN, BK>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
+  allowance.ensure(gemm_nt_lnbwd_kernel<T, NWN, BK, Y>, lds);
+  hipLaunchKernelGGL((gemm_nt_lnbwd_kernel<T, NWN, BK, Y>), dim3((g.M + 127) / 128), dim3(NWN * 64), lds, stream, g);
 }
-template <typename T, int NWN, int BK, int MI, int NJ> static void launch_gemm_lnbwd_wide_t(const GemmLNB& g, hipStream_t stream) {
+template <typename T, bool Y, int NWN, int BK, int MI, int NJ> static void launch_gemm_lnbwd_wide_t(const GemmLNB& g, hipStream_t stream) {
   const size_t lds = LnbCfgW<NWN, BK, MI, NJ>::LDS;
   static LdsAllowance allowance;
-  allowance.ensure(gemm_nt_lnbwd_wide_kernel<T, NWN, BK, MI, NJ>, lds);
-  hipLaunchKernelGGL((gemm_nt_lnbwd_wide_kernel<T, NWN, BK, MI, NJ>), dim3((g.M + MI * 32 - 1) / (MI * 32)), dim3(NWN * 64), lds, stream, g);
+  allowance.ensure(gemm_nt_lnbwd_wide_kernel<T, NWN, BK, MI, NJ, Y>, lds);
+  hipLaunchKernelGGL((gemm_nt_lnbwd_wide_kernel<T, NWN, BK, MI, NJ, Y>), dim3((g.M + MI * 32 - 1) / (MI * 32)), dim3(NWN * 64), lds, stream, g);
 }
-template <typename T> static int launch_gemm_lnbwd_op(const GemmLNB& g, hipStream_t stream) {
-#define PFN_LNB_CASE(NWN) if (g.K % 64 == 0) launch_gemm_lnbwd_t<T, NWN, 64>(g, stream); else launch_gemm_lnbwd_t<T, NWN, 32>(g, stream);
+template <typename T, bool Y> static int launch_gemm_lnbwd_op(const GemmLNB& g, hipStream_t stream) {
+#define PFN_LNB_CASE(NWN) if (g.K % 64 == 0) launch_gemm_lnbwd_t<T, Y, NWN, 64>(g, stream); else launch_gemm_lnbwd_t<T, Y, NWN, 32>(g, stream);
   if (g.N == 512 && g_ln_rows64) {
-    launch_gemm_lnbwd_wide_t<T, 4, 32, 2, 4>(g, stream);
+    launch_gemm_lnbwd_wide_t<T, Y, 4, 32, 2, 4>(g, stream);
     return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
   }
   switch (g.N / 64) {
     case 2: PFN_LNB_CASE(2) break;
     case 4: PFN_LNB_CASE(4) break;
     case 8: PFN_LNB_CASE(8) break;
-    default: launch_gemm_lnbwd_wide_t<T, 8, 32, 2, 4>(g, stream); break;     // N = 1024: 64-row tiles, 32-deep stages
+    default: launch_gemm_lnbwd_wide_t<T, Y, 8, 32, 2, 4>(g, stream); break;     // N = 1024: 64-row tiles, 32-deep stages
   }
 #undef PFN_LNB_CASE
   return hipGetLastError() == hipSuccess ? PFN_OK : PFN_ERR_LAUNCH;
@@ -1616,7 +1668,8 @@ template <typename T> static int launch_gemm_lnbwd_op(const GemmLNB& g, hipStrea
 int launch_gemm_lnbwd(const GemmLNB& g, int precision, hipStream_t stream) {
   if (g.M <= 0) return PFN_OK;
   if (!prec_is16(precision) || !gemm_lnbwd_supported(g)) return PFN_ERR_UNSUPPORTED;
-  return precision == PFN_PREC_FP16 ? launch_gemm_lnbwd_op<f16>(g, stream) : launch_gemm_lnbwd_op<bf16>(g, stream);
+  if (g.y16) return precision == PFN_PREC_FP16 ? launch_gemm_lnbwd_op<f16, true>(g, stream) : PFN_ERR_UNSUPPORTED;
+  return precision == PFN_PREC_FP16 ? launch_gemm_lnbwd_op<f16, false>(g, stream) : launch_gemm_lnbwd_op<bf16, false>(g, stream);
 }
 
 }  // namespace pfn

@@ -76,7 +76,7 @@ int check_desc(const pfn_model_desc* d) {
   const bool ok = dh == 32 || dh == 64 || dh == 128 || dh == 256;
   if (!ok) return fail(PFN_ERR_UNSUPPORTED, "head dim %d unsupported (32/64/128/256)", dh);
   if (d->emsize > 2048) return fail(PFN_ERR_UNSUPPORTED, "emsize > 2048 unsupported by the LayerNorm kernels");
-  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC | PFN_SCHED_NO_KEY_CENTERING | PFN_SCHED_FUSE_Q_PROJECTION | PFN_SCHED_KEY_CENTERING)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
+  if (d->schedule & ~(PFN_SCHED_TOP_LAYER_ALL_ROWS | PFN_SCHED_FUSE_LN_WIDE | PFN_SCHED_SEPARATE_LNBWD | PFN_SCHED_DETERMINISTIC | PFN_SCHED_NO_KEY_CENTERING | PFN_SCHED_FUSE_Q_PROJECTION | PFN_SCHED_KEY_CENTERING | PFN_SCHED_F32_RESIDUAL)) return fail(PFN_ERR_ARGUMENT, "unknown schedule bits 0x%x", d->schedule);
   if (!(d->dropout >= 0.f && d->dropout < 1.f)) return fail(PFN_ERR_ARGUMENT, "dropout %g outside [0, 1)", (double)d->dropout);
   return PFN_OK;
 }
@@ -158,6 +158,24 @@ struct Ragged { const int32_t* sep_of; const int64_t* row_off; int64_t test_rows
 // arithmetic the default there)
 static bool key_centering(const pfn_model_desc& d) {
   return (d.precision == PFN_PREC_FP16 && !(d.schedule & PFN_SCHED_NO_KEY_CENTERING)) || (d.precision == PFN_PREC_BF16 && (d.schedule & PFN_SCHED_KEY_CENTERING));
+}
+
+// The pre-LayerNorm sums (y1 / y2 of every layer: the residual the NEXT block adds, and the LayerNorm backward's input) in operand precision instead of f32
+// (GemmLN::y16, PFN_SCHED_F32_RESIDUAL clear): the LayerNorm-fused GEMMs are bound by their epilogue's HBM streams -- A in, residual in, sums out, operand copy
+// out -- and this halves the two f32 ones (392 -> 260 MB per out_proj launch at configs[1]).  fp16 only (11 bits; emulated on trained and untrained weights before
+// it was built: tools/sim_operand_formats.py class Y), and only where the fused kernels run on every layer: no dropout in the descriptor, widths they cover.
+// (The buffers keep their f32 size: a descriptor-only rule must not decide a layout the pointer-alignment probe in the forward can still overrule.)
+static bool residual16(const pfn_model_desc& d) {
+  const int E = d.emsize;
+  return d.precision == PFN_PREC_FP16 && !(d.schedule & PFN_SCHED_F32_RESIDUAL) && d.nlayers > 0 && d.dropout == 0.f && d.nhid % 32 == 0 &&
+         (E == 128 || E == 256 || E == 512 || (E == 1024 && (d.schedule & PFN_SCHED_FUSE_LN_WIDE)));
+}
+// can out_proj / linear2 run as gemm_nt_ln_kernel at all (shapes, 16-byte alignment of every stream)?  The forward and the backward ask the same question.
+static bool ln_gemm_probe(const pfn_model_desc& d, const Ws& w, const float* params, const void* sh, int M) {
+  GemmLN probe; memset(&probe, 0, sizeof(probe));
+  probe.A = w.x0_t; probe.lda = d.emsize; probe.B = sh; probe.ldb = d.emsize; probe.M = M; probe.N = d.emsize; probe.K = d.emsize;
+  probe.bias = params; probe.gamma = params; probe.beta = params; probe.resid = w.x0; probe.y = w.x0; probe.x_t = w.x0_t;
+  return gemm_ln_supported(probe);
 }
 
 Ws carve(const pfn_model_desc& d, int B, int S, char* base) {
@@ -265,6 +283,7 @@ int pfn_set_tuning(int key, int value) {
     case PFN_TUNE_WGRAD_SPLITS: set_gemm_tn_group_splits(value); return PFN_OK;
     case PFN_TUNE_WGRAD_WAVES: set_gemm_tn_group_waves(value); return PFN_OK;
     case PFN_TUNE_LOSS_SCALE_TARGET: return set_loss_scale_target(value);
+    case PFN_TUNE_RESIDUAL16: g_default_schedule = value ? (g_default_schedule & ~PFN_SCHED_F32_RESIDUAL) : (g_default_schedule | PFN_SCHED_F32_RESIDUAL); return PFN_OK;
     case PFN_TUNE_FUSE_Q_PROJECTION: g_default_schedule = value ? (g_default_schedule | PFN_SCHED_FUSE_Q_PROJECTION) : (g_default_schedule & ~PFN_SCHED_FUSE_Q_PROJECTION); return PFN_OK;
     case PFN_TUNE_KEY_CENTERING:      // 1: on for both 16-bit formats, 0: off for both, -1: the defaults (on with fp16, off with bf16)
       g_default_schedule &= ~(PFN_SCHED_NO_KEY_CENTERING | PFN_SCHED_KEY_CENTERING);
@@ -400,12 +419,11 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   // out_proj and linear2 run fused with their residual add and LayerNorm (gemm_nt_ln_kernel) when the shape allows:
   // the f32 LayerNorm output is then never stored -- the next residual add recomputes it from the pre-LN sum and the
   // row statistics -- except after the last layer, whose f32 output feeds the decoder gather.
-  GemmLN probe; memset(&probe, 0, sizeof(probe));
-  probe.A = w.x0_t; probe.lda = E; probe.B = sh; probe.ldb = E; probe.M = M; probe.N = E; probe.K = E;
-  probe.bias = params; probe.gamma = params; probe.beta = params; probe.resid = w.x0; probe.y = w.x0; probe.x_t = w.x0_t;
   // (dropout sits between the bias and the residual add: it takes the unfused GEMM / LayerNorm kernels with an element-wise pass between)
-  const bool fuse_ln = prec_is16(prec) && gemm_ln_supported(probe) && F % 32 == 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));
-  struct Resid { const float* plain; const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; };
+  const bool ln_ok = ln_gemm_probe(*d, w, params, sh, M);
+  const bool fuse_ln = prec_is16(prec) && ln_ok && F % 32 == 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));
+  const bool y16 = residual16(*d) && ln_ok;      // (implies fuse_ln: the descriptor's dropout is 0, so is pdrop)
+  struct Resid { const float* plain; const void* y; const float* mean; const float* rstd; const float* gamma; const float* beta; };
   Resid res = {w.x0, nullptr, nullptr, nullptr, nullptr, nullptr};   // where the layer input lives in f32
   auto set_resid = [](GemmLN& g, const Resid& r) {
     g.resid = r.plain; g.ry = r.y; g.rmean = r.mean; g.rrstd = r.rstd; g.rgamma = r.gamma; g.rbeta = r.beta;
@@ -451,7 +469,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       PFN_TRY(gather_top(a.ctx, w.top_ctx_t, (long)E * es));
       ctx_in = w.top_ctx_t;
       if (fuse_ln && !res.plain) {
-        PFN_TRY(gather_top(res.y, w.top_ry, (long)E * 4));
+        PFN_TRY(gather_top(res.y, w.top_ry, (long)E * (y16 ? es : 4)));
         PFN_TRY(gather_top(res.mean, w.top_rmean, 4));
         PFN_TRY(gather_top(res.rstd, w.top_rrstd, 4));
         res = Resid{nullptr, w.top_ry, w.top_rmean, w.top_rrstd, res.gamma, res.beta};
@@ -468,7 +486,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       g.A = ctx_in; g.lda = E; g.B = W(p.w_o); g.ldb = E; g.M = Ml; g.N = E; g.K = E; g.bias = params + p.b_o;
       set_resid(g, res);
       g.gamma = params + p.g1; g.beta = params + p.be1; g.eps = d->ln_eps;
-      g.y = a.y1; g.mean = a.mean1; g.rstd = a.rstd1; g.x_t = a.x1_t;
+      g.y = a.y1; g.mean = a.mean1; g.rstd = a.rstd1; g.x_t = a.x1_t; g.y16 = y16;
       PFN_TRY(launch_gemm_ln(g, prec, s));
       res = Resid{nullptr, a.y1, a.mean1, a.rstd1, params + p.g1, params + p.be1};
     } else {
@@ -494,7 +512,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       g.A = a.h; g.lda = F; g.B = W(p.w2); g.ldb = F; g.M = Ml; g.N = E; g.K = F; g.bias = params + p.b2;
       set_resid(g, res);
       g.gamma = params + p.g2; g.beta = params + p.be2; g.eps = d->ln_eps;
-      g.y = a.y2; g.mean = a.mean2; g.rstd = a.rstd2; g.x_t = a.x2_t;
+      g.y = a.y2; g.mean = a.mean2; g.rstd = a.rstd2; g.x_t = a.x2_t; g.y16 = y16;
       g.x_f32 = (l == d->nlayers - 1) ? x2_f32 : nullptr;
       PFN_TRY(launch_gemm_ln(g, prec, s));
       res = Resid{nullptr, a.y2, a.mean2, a.rstd2, params + p.g2, params + p.be2};
@@ -609,6 +627,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
   const char* sh = (const char*)shadow;
   auto W = [&](int64_t off) { return (const void*)(sh + off * es); };
   auto WT = [&](int64_t off) { return (const void*)(sh + (L.total + off) * es); };
+  const bool y16 = residual16(*d) && ln_gemm_probe(*d, w, params, sh, M);      // the forward stored the pre-LayerNorm sums in operand precision (same rule, same pointers)
 
   // fp16 operands: the backward chain runs on dlogits * 2^k, k from max|dlogits| on the device; every kernel that writes a parameter gradient takes 2^k out again
   if (prec == PFN_PREC_FP16 && Mt > 0) {
@@ -667,11 +686,11 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
   // The two GEMMs whose output is the gradient w.r.t. a LayerNorm output (dx1 -> LN1, dx -> the previous layer's LN2) run that
   // LayerNorm's backward in their epilogue (gemm_nt_lnbwd_kernel) when the shape allows: the sum never reaches HBM, and the
   // bias gradient of the Linear in front of the LayerNorm moves to the weight-gradient GEMM that reads the same operand.
-  auto lnb = [&](const void* A, long lda, const void* Bw, long ldb, int K, const void* aux, const float* y, const float* mean, const float* rstd,
+  auto lnb = [&](const void* A, long lda, const void* Bw, long ldb, int K, const void* aux, const void* y, const float* mean, const float* rstd,
                  const float* gamma, void* dx_t, float* dgamma, float* dbeta, int rows) {
     GemmLNB g; memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = Bw; g.ldb = ldb; g.M = rows; g.N = E; g.K = K; g.aux = aux;
-    g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta; g.scale_amax = lsc;
+    g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta; g.scale_amax = lsc; g.y16 = y16;
     return g;
   };
   // The embedding's weight gradients d(src)^T . [x | masked y | train flag] are a (skinny) weight-gradient GEMM like the others:
@@ -759,7 +778,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
     // the residual path keeps the unmasked one, and the two bias gradients become column sums of the masked operands (weight-gradient launch)
     if (!fuse_lnb || l == d->nlayers - 1)
       PFN_TRY(launch_layernorm_bwd(top ? (const void*)dxt : (const void*)w.gA_t, top ? 0 : 1, a.y2, params + p.g2, a.mean2, a.rstd2, nullptr, a.dy2_t,
-                                   grads + p.g2, grads + p.be2, pdrop > 0.f ? nullptr : grads + p.b2, Ml, E, prec, s, w.ln_part, lsc));
+                                   grads + p.g2, grads + p.be2, pdrop > 0.f ? nullptr : grads + p.b2, Ml, E, prec, s, w.ln_part, lsc, y16));
     const char* dy2_op = a.dy2_t;
     if (pdrop > 0.f) { PFN_TRY(launch_dropout_scale(a.dy2_t, a.dy2m_t, nullptr, nullptr, M, E, dseed(l, 3), pdrop, prec, s)); dy2_op = a.dy2m_t; }
     {  // d(hpre) = (dy2 . W2) * gelu'(hpre)
@@ -778,7 +797,7 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
         PFN_TRY(launch_gemm_nt(g, prec, s));
       }
       PFN_TRY(launch_layernorm_bwd(w.gA_t, 1, a.y1, params + p.g1, a.mean1, a.rstd1, nullptr, dy1_t, grads + p.g1, grads + p.be1,
-                                   pdrop > 0.f ? nullptr : grads + p.b_o, Ml, E, prec, s, w.ln_part, lsc));
+                                   pdrop > 0.f ? nullptr : grads + p.b_o, Ml, E, prec, s, w.ln_part, lsc, y16));
     }
     const char* dy1_op = dy1_t;
     bool delta_fused = false;
@@ -994,8 +1013,8 @@ int pfn_op_gemm_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M
   memset(&g, 0, sizeof(g));
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.bias = bias; g.resid = resid;
   g.ry = ry; g.rmean = rmean; g.rrstd = rrstd; g.rgamma = rgamma; g.rbeta = rbeta; g.gamma = gamma; g.beta = beta; g.eps = eps;
-  g.y = y; g.mean = mean; g.rstd = rstd; g.x_t = x_t;
-  PFN_TRY(launch_gemm_ln(g, prec, (hipStream_t)stream));
+  g.y = y; g.mean = mean; g.rstd = rstd; g.x_t = x_t; g.y16 = (prec & PFN_OP_SUMS_16BIT) ? 1 : 0;
+  PFN_TRY(launch_gemm_ln(g, prec & ~PFN_OP_SUMS_16BIT, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_gemm_lnbwd(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, const void* aux,
@@ -1004,8 +1023,8 @@ int pfn_op_gemm_lnbwd(const void* A, int64_t lda, const void* B, int64_t ldb, in
   GemmLNB g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.aux = aux;
-  g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta;
-  PFN_TRY(launch_gemm_lnbwd(g, prec, (hipStream_t)stream));
+  g.y = y; g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.dx_t = dx_t; g.dgamma = dgamma; g.dbeta = dbeta; g.y16 = (prec & PFN_OP_SUMS_16BIT) ? 1 : 0;
+  PFN_TRY(launch_gemm_lnbwd(g, prec & ~PFN_OP_SUMS_16BIT, (hipStream_t)stream));
   return PFN_OK;
 }
 int pfn_op_attention_fwd(const void* qkv, void* ctx, float* lse, int B, int S, int E, int H, int sep, int prec, void* stream) {

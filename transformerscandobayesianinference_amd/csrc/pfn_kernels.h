@@ -174,10 +174,11 @@ struct GemmLN {
   int M, N, K;
   const float* bias;            // [N]
   const float* resid;           // [M,N] f32, or nullptr to use the recomputed form below
-  const float* ry; const float* rmean; const float* rrstd; const float* rgamma; const float* rbeta;
+  const void* ry; const float* rmean; const float* rrstd; const float* rgamma; const float* rbeta;      // ry: f32, or operand precision when y16
   const float* gamma; const float* beta; float eps;
-  float* y; float* mean; float* rstd; void* x_t;   // outputs
+  void* y; float* mean; float* rstd; void* x_t;    // outputs (y: f32, or operand precision when y16)
   float* x_f32;                                    // optional: the LayerNorm output in f32 as well (last layer -> decoder)
+  int y16;                                         // fp16 only: y is written, and ry read, in operand precision (half the bytes of this HBM-bound epilogue's two f32 streams)
 };
 bool gemm_ln_supported(const GemmLN& g);
 int launch_gemm_ln(const GemmLN& g, int precision, hipStream_t stream);      // precision: one of the 16-bit formats
@@ -189,10 +190,11 @@ struct GemmLNB {
   const void* B; long ldb;      // [N,K] bf16
   int M, N, K;
   const void* aux;              // [M,N] bf16 (row pitch N): the residual-branch gradient added to the product
-  const float* y; const float* mean; const float* rstd; const float* gamma;   // the LayerNorm's input [M,N], row statistics [M], weight [N]
+  const void* y; const float* mean; const float* rstd; const float* gamma;    // the LayerNorm's input [M,N] (f32, or operand precision when y16), row statistics [M], weight [N]
   void* dx_t;                   // [M,N] bf16: gradient w.r.t. the LayerNorm input
   float* dgamma; float* dbeta;  // [N] f32, accumulated with atomics
   const float* scale_amax;      // fp16 backward: dgamma / dbeta leave times 2^-k (dx_t stays in the scaled chain); nullptr = 1
+  int y16;                      // y as GemmLN::y16 stored it
 };
 bool gemm_lnbwd_supported(const GemmLNB& g);
 int launch_gemm_lnbwd(const GemmLNB& g, int precision, hipStream_t stream);
@@ -302,9 +304,9 @@ int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
                          float* mean, float* rstd, long rows, int E, float eps, int precision, hipStream_t s);
 // dx = LN'(dy) (dy f32, or T when dy_is_t); dx written f32 + T; dgamma/dbeta accumulated with atomics; optional dbias_extra
 // accumulates colsum(dx) (the bias gradient of the linear that produced x's pre-LN sum).
-int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd,
+int launch_layernorm_bwd(const void* dy, int dy_is_t, const void* x, const float* gamma, const float* mean, const float* rstd,
                          float* dx_f32, void* dx_t, float* dgamma, float* dbeta, float* dbias_extra,
-                         long rows, int E, int precision, hipStream_t s, float* partials = nullptr, const float* scale_amax = nullptr);      // scale_amax: dgamma / dbeta / dbias_extra leave times 2^-k
+                         long rows, int E, int precision, hipStream_t s, float* partials = nullptr, const float* scale_amax = nullptr, int x_is_t = 0);      // x_is_t: x in operand precision (GemmLN::y16);      // scale_amax: dgamma / dbeta / dbias_extra leave times 2^-k
 // `partials` (PFN_SCHED_DETERMINISTIC): scratch of LNB_MAX_BLOCKS * 3 * E floats -- every workgroup leaves its column sums there and a second tiny launch adds
 // them to dgamma / dbeta / dbias_extra in block order (one writer per element, a fixed summation order) instead of the f32 atomics
 constexpr int LNB_MAX_BLOCKS = 512;

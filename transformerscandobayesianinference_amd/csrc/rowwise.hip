@@ -829,13 +829,15 @@ template <typename T, int EV> PFN_DEV void ln_store(T* p, const float (&v)[EV]) 
   }
 }
 template <typename T, int NV, int EV, bool DY_T>
-__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const void* dy_any, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                                                      float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E, float* partials, const float* scale_amax) {
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const void* dy_any, const void* x_any, const float* gamma, const float* mean, const float* rstd,
+                                                                      float* dx32, T* dxt, float* dgamma, float* dbeta, float* dbias, long rows, int E, float* partials, const float* scale_amax, int x_is_t) {
   operand_store_mode<T>();
   extern __shared__ __attribute__((aligned(16))) float part[];  // [LNB_WAVES][E]
   const float osc = loss_scale_down(scale_amax);                // fp16 backward: the parameter gradients leave unscaled (pfn_device.h)
   const float* dy = reinterpret_cast<const float*>(dy_any);     // upstream gradient: f32, or operand precision when DY_T
   const T* dy_t = reinterpret_cast<const T*>(dy_any);
+  const float* x = reinterpret_cast<const float*>(x_any);      // the LayerNorm's input rows: f32, or operand precision when x_is_t (GemmLN::y16 stored them)
+  const T* x_t = reinterpret_cast<const T*>(x_any);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wave0 = (long)blockIdx.x * LNB_WAVES + wave;
   const long wstride = (long)gridDim.x * LNB_WAVES;
@@ -861,7 +863,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const voi
       for (int k = 0; k < NV; ++k) {
         const int c = (k * 64 + lane) * EV;
         if (c < E) {
-          ln_load<float, EV>(x + r * E + c, xv[u][k]);
+          if (x_is_t) ln_load<T, EV>(x_t + r * E + c, xv[u][k]);
+          else ln_load<float, EV>(x + r * E + c, xv[u][k]);
           if constexpr (DY_T) ln_load<T, EV>(dy_t + r * E + c, dv[u][k]);
           else ln_load<float, EV>(dy + r * E + c, dv[u][k]);
         }
@@ -937,16 +940,16 @@ __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* pa
   for (int b = 0; b < nblocks; ++b) t += partials[((long)b * 3 + q) * E + c];
   out[c] += t;
 }
-int launch_layernorm_bwd(const void* dy, int dy_is_t, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx32, void* dxt,
-                         float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s, float* partials, const float* scale_amax) {
-  if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
+int launch_layernorm_bwd(const void* dy, int dy_is_t, const void* x, const float* gamma, const float* mean, const float* rstd, float* dx32, void* dxt,
+                         float* dgamma, float* dbeta, float* dbias, long rows, int E, int precision, hipStream_t s, float* partials, const float* scale_amax, int x_is_t) {
+  if (E % 4 || E > 2048 || (x_is_t && !prec_is16(precision))) return PFN_ERR_UNSUPPORTED;
   if (rows == 0) return PFN_OK;
   const int grid = grid_for(rows, LNB_WAVES * 8, LNB_MAX_BLOCKS);
   const size_t lds = LNB_WAVES * E * sizeof(float);
 #define LN_BWD_K(TT, NV, EV, DT) do { \
     static LdsAllowance allowance; \
     allowance.ensure(layernorm_bwd_kernel<TT, NV, EV, DT>, lds); \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, EV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E, partials, scale_amax); } while (0)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NV, EV, DT>), dim3(grid), dim3(LNB_WAVES * 64), lds, s, dy, x, gamma, mean, rstd, dx32, (TT*)dxt, dgamma, dbeta, dbias, rows, E, partials, scale_amax, x_is_t); } while (0)
 #define LN_BWD(TT, NV, EV) do { if (dy_is_t) LN_BWD_K(TT, NV, EV, true); else LN_BWD_K(TT, NV, EV, false); } while (0)
   // rows of >= 512 elements in 8-element lane chunks (16-byte operand-precision accesses), narrower rows in 4-element ones
 #define LN_BWD_NV(TT) do { \

@@ -44,22 +44,27 @@ def gemm_tn_group(problems, splits=0):
     _hip.check(_hip.lib().pfn_op_gemm_tn_group(n, A, lda, B, ldb, C, ldc, P, Q, cs, M, splits, PREC_OF[problems[0][0].dtype], sp()), 'pfn_op_gemm_tn_group')
 
 
-def gemm_ln(A, B, bias, gamma, beta, eps, resid=None, prev=None, out=None):
+SUMS_16BIT = 256      # include/pfn_hip.h PFN_OP_SUMS_16BIT
+
+
+def gemm_ln(A, B, bias, gamma, beta, eps, resid=None, prev=None, out=None, sums16=False):
     """prev = (ry, rmean, rrstd, rgamma, rbeta) when the residual is the previous LayerNorm's (recomputed) output.
-    out = (y[M+2,N], x_t, mean, rstd) pre-allocated buffers (timing loops)."""
+    out = (y[M+2,N], x_t, mean, rstd) pre-allocated buffers (timing loops).
+    sums16 (fp16 operands): y leaves -- and prev's ry arrives -- in operand precision (PFN_OP_SUMS_16BIT: what the stack does for fp16 models)."""
     M, K = A.shape
     N = B.shape[0]
     dev = A.device
     if out is None:
-        y = torch.full((M + 2, N), float('nan'), device=dev)
+        y = torch.full((M + 2, N), float('nan'), dtype=A.dtype if sums16 else torch.float32, device=dev)
         x_t = torch.empty(M, N, dtype=A.dtype, device=dev)
         mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
     else:
         y, x_t, mean, rstd = out
     p = _hip.ptr
     pv = prev if prev is not None else (None,) * 5
+    assert y.dtype == (A.dtype if sums16 else torch.float32) and (pv[0] is None or pv[0].dtype == y.dtype)
     _hip.check(_hip.lib().pfn_op_gemm_ln(p(A), A.stride(0), p(B), B.stride(0), M, N, K, p(bias), p(resid), p(pv[0]), p(pv[1]), p(pv[2]), p(pv[3]), p(pv[4]),
-                                         p(gamma), p(beta), eps, p(y), p(mean), p(rstd), p(x_t), PREC_OF[A.dtype], sp()), 'pfn_op_gemm_ln')
+                                         p(gamma), p(beta), eps, p(y), p(mean), p(rstd), p(x_t), PREC_OF[A.dtype] | (SUMS_16BIT if sums16 else 0), sp()), 'pfn_op_gemm_ln')
     if out is None:
         assert torch.isnan(y[M:]).all()
     return y[:M], x_t, mean, rstd
@@ -101,7 +106,8 @@ def scatter_rows(src, B, S, sep, zero_from, fill=float('nan'), out=None):
 
 
 def gemm_lnbwd(A, B, aux, y, mean, rstd, gamma, out=None):
-    """dx_t, dgamma, dbeta of  v = A . B^T + aux  pushed back through the LayerNorm (y, mean, rstd, gamma)  (pfn_op_gemm_lnbwd)."""
+    """dx_t, dgamma, dbeta of  v = A . B^T + aux  pushed back through the LayerNorm (y, mean, rstd, gamma)  (pfn_op_gemm_lnbwd).
+    y in operand precision (fp16) selects PFN_OP_SUMS_16BIT."""
     M, K = A.shape
     N = B.shape[0]
     if out is None:
@@ -109,7 +115,7 @@ def gemm_lnbwd(A, B, aux, y, mean, rstd, gamma, out=None):
     dx_t, dgamma, dbeta = out
     p = _hip.ptr
     _hip.check(_hip.lib().pfn_op_gemm_lnbwd(p(A), A.stride(0), p(B), B.stride(0), M, N, K, p(aux), p(y), p(mean), p(rstd), p(gamma),
-                                            p(dx_t), p(dgamma), p(dbeta), PREC_OF[A.dtype], sp()), 'pfn_op_gemm_lnbwd')
+                                            p(dx_t), p(dgamma), p(dbeta), PREC_OF[A.dtype] | (SUMS_16BIT if y.dtype == A.dtype else 0), sp()), 'pfn_op_gemm_lnbwd')
     return dx_t, dgamma, dbeta
 
 
