@@ -82,19 +82,19 @@ def test_forward_loss_grads_vs_reference_golden(case, precision):
         model.zero_grad()
         logits = model((x, y), single_eval_pos=sep)
         assert logits.shape == want['logits'].shape
-        within(f'{precision} logits rel l2', relerr(logits, want['logits']), tol3(precision, 1e-4, 1e-2))
+        within(f'{precision} logits rel l2', relerr(logits, want['logits']), tol3(precision, 1e-4, 1e-2, 1.2e-3))
         losses = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].flatten()).view(*logits.shape[:2])
         loss = losses.mean()
-        within(f'{precision} loss rel', abs(loss.item() - want['loss'].item()) / abs(want['loss'].item()), tol3(precision, 1e-4, 1e-3))
+        within(f'{precision} loss rel', abs(loss.item() - want['loss'].item()) / abs(want['loss'].item()), tol3(precision, 1e-4, 1e-3, 1.0e-4))
         means = model.criterion.mean(logits)
-        within(f'{precision} means max / target range', mean_err(means, want['mean'], y), tol3(precision, 1e-5, 1e-3))
-        within(f'{precision} means rel l2 (own norm)', relerr(means, want['mean']), tol3(precision, 1e-4, 4e-3))      # relative to the means' own norm: the logit error
+        within(f'{precision} means max / target range', mean_err(means, want['mean'], y), tol3(precision, 1e-5, 1e-3, 2.0e-5))
+        within(f'{precision} means rel l2 (own norm)', relerr(means, want['mean']), tol3(precision, 1e-4, 4e-3, 7.1e-4))      # relative to the means' own norm: the logit error
         if 'grads' in want:
             loss.backward()
             got = {k: p.grad for k, p in model.named_parameters()}
             tot_err = math.sqrt(sum(((got[k].double().cpu() - g.double()) ** 2).sum().item() for k, g in want['grads'].items()))
             tot = math.sqrt(sum((g.double() ** 2).sum().item() for g in want['grads'].values()))
-            within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2))
+            within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2, 1.2e-3))
             if tight:
                 for k, g in want['grads'].items():
                     if g.norm() > 1e-6:
@@ -164,15 +164,15 @@ def test_config1_vs_oracle(precision):
         loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
         loss.backward()
         tight = precision == 'f32'
-        within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3))
-        within(f'{precision} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 1e-2))
+        within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3, 1.0e-4))
+        within(f'{precision} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 1e-2, 1.3e-3))
         m_o = pfn_oracle.bar_mean(logits_o, sd['criterion.borders'])
         m_h = model.criterion.mean(logits)
-        within(f'{precision} means max / target range', mean_err(m_h, m_o, y), tol3(precision, 1e-5, 1e-3))
-        within(f'{precision} means rel l2 (own norm)', relerr(m_h, m_o), tol3(precision, 1e-4, 4e-3))
+        within(f'{precision} means max / target range', mean_err(m_h, m_o, y), tol3(precision, 1e-5, 1e-3, 1.9e-5))
+        within(f'{precision} means rel l2 (own norm)', relerr(m_h, m_o), tol3(precision, 1e-4, 4e-3, 2.1e-4))
         tot_err = math.sqrt(sum(((p.grad.double().cpu() - grads_o[k]) ** 2).sum().item() for k, p in model.named_parameters()))
         tot = math.sqrt(sum((g ** 2).sum().item() for g in grads_o.values()))
-        within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2))
+        within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2, 1.3e-3))
 
 
 @pytest.mark.parametrize('E,H', [(128, 4), (512, 4)])
@@ -198,11 +198,11 @@ def test_fp16_pre_layernorm_sums_in_operand_precision_vs_f32(E, H):
             loss.backward()
             g = {k: p.grad.double().cpu() for k, p in model.named_parameters()}
             err = math.sqrt(sum(((g[k] - grads_o[k]) ** 2).sum().item() for k in g)) / tot
-            within(f'{name}, sep {sep}: logits rel l2 vs oracle', relerr(logits, logits_o), 2.5e-3)
-            within(f'{name}, sep {sep}: loss rel vs oracle', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), 2.5e-4)
-            within(f'{name}, sep {sep}: global gradient rel l2 vs oracle', err, 3e-3)
+            within(f'{name}, sep {sep}: logits rel l2 vs oracle', relerr(logits, logits_o), 1.5e-3)       # (measured: 5.8e-4 with f32 sums, 7.3e-4 with fp16 sums)
+            within(f'{name}, sep {sep}: loss rel vs oracle', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), 2.5e-5)
+            within(f'{name}, sep {sep}: global gradient rel l2 vs oracle', err, 1.2e-3)
             out[name] = (logits.detach(), g)
-        within(f'sep {sep}: logits, fp16 sums vs f32 sums, rel l2', relerr(out['fp16 sums'][0], out['f32 sums'][0]), 2.5e-3)
+        within(f'sep {sep}: logits, fp16 sums vs f32 sums, rel l2', relerr(out['fp16 sums'][0], out['f32 sums'][0]), 1.3e-3)
         assert not torch.equal(out['fp16 sums'][0], out['f32 sums'][0])      # (the bit does select another arithmetic)
 
 
@@ -237,7 +237,7 @@ def test_fp16_backward_saturates_where_the_loss_scale_leaves_no_headroom(target)
         _hip.check(lib.pfn_set_tuning(15, 2), 'pfn_set_tuning')
     for sep in (81, 1):       # the saturated gradient still points the way of the exact one
         a, b = grads[2, sep].double(), grads[target, sep].double()
-        within(f'1 - cosine of the target-{target} gradient and the default one, sep {sep}', 1. - (a @ b / (a.norm() * b.norm())).item(), 0.5)
+        within(f'1 - cosine of the target-{target} gradient and the default one, sep {sep}', 1. - (a @ b / (a.norm() * b.norm())).item(), 8e-3)      # (measured 3.7e-3 at target 12, sep 1; 1e-11 where nothing saturates)
 
 
 @pytest.mark.parametrize('H', [4, 16])
@@ -258,15 +258,15 @@ def test_config5_width_vs_oracle(precision, H):
     logits = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
     loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
     tight = precision == 'f32'
-    within(f'{precision} H{H} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3))
-    within(f'{precision} H{H} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 1e-2))
-    within(f'{precision} H{H} means max / target range', mean_err(model.criterion.mean(logits), pfn_oracle.bar_mean(logits_o, sd['criterion.borders']), y), tol3(precision, 1e-5, 1e-3))
+    within(f'{precision} H{H} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3, 1.0e-4))
+    within(f'{precision} H{H} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 1e-2, 1.4e-3))
+    within(f'{precision} H{H} means max / target range', mean_err(model.criterion.mean(logits), pfn_oracle.bar_mean(logits_o, sd['criterion.borders']), y), tol3(precision, 1e-5, 1e-3, 2.4e-5))
     # (exact-f32 at head dim 256, round 5: the backward runs the plain vector-ALU attention kernels -- csrc/attention.hip attn_bwd_plain_* -- and is held to the
     # same 2e-4 "any layout mistake fails" bound as every other f32 shape)
     loss.backward()
     tot_err = math.sqrt(sum(((p.grad.double().cpu() - grads_o[k]) ** 2).sum().item() for k, p in model.named_parameters()))
     tot = math.sqrt(sum((g ** 2).sum().item() for g in grads_o.values()))
-    within(f'{precision} H{H} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2))
+    within(f'{precision} H{H} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2, 1.3e-3))
 
 
 def test_full_size_properties_bf16():
@@ -891,10 +891,10 @@ def test_config2_full_shape_vs_oracle(precision):
     tight = precision == 'f32'
     tf = par['training_forward']
     assert tf['precision'] == precision
-    within(f'{precision} training forward: nll rel', tf['nll_rel'], tol3(precision, 1e-5, 1e-3))
-    within(f'{precision} training forward: means max / target range', tf['mean_max_over_y_range'], tol3(precision, 1e-6, 1e-3))
-    within(f'{precision} training forward: means rel l2 vs targets', tf['mean_rel_l2_vs_targets'], tol3(precision, 1e-6, 1e-3))
-    within(f'{precision} training forward: logits rel l2', tf['logits_rel_l2'], tol3(precision, 1e-4, 1e-2))
+    within(f'{precision} training forward: nll rel', tf['nll_rel'], tol3(precision, 1e-5, 1e-3, 1.1e-5))
+    within(f'{precision} training forward: means max / target range', tf['mean_max_over_y_range'], tol3(precision, 1e-6, 1e-3, 6.4e-6))
+    within(f'{precision} training forward: means rel l2 vs targets', tf['mean_rel_l2_vs_targets'], tol3(precision, 1e-6, 1e-3, 1.7e-5))
+    within(f'{precision} training forward: logits rel l2', tf['logits_rel_l2'], tol3(precision, 1e-4, 1e-2, 1.7e-3))
 
 
 @pytest.mark.parametrize('sep', [437, 500])
@@ -919,14 +919,14 @@ def test_config4_model_shape_vs_oracle(precision, sep):
     loss = model.criterion(lg.squeeze(-1), yd[sep:]).mean()
     loss.backward()
     tight = precision == 'f32'
-    within(f'{precision} sep {sep} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-5, 1e-3))
-    within(f'{precision} sep {sep} logits rel l2', relerr(lg, lo), tol3(precision, 1e-4, 1.1e-2))
+    within(f'{precision} sep {sep} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-5, 1e-3, 1.2e-5))
+    within(f'{precision} sep {sep} logits rel l2', relerr(lg, lo), tol3(precision, 1e-4, 1.1e-2, 2.3e-3))
     p_err = (torch.sigmoid(lg).double().cpu() - torch.sigmoid(lo)).abs().max().item()      # posterior-predictive mean of the label
     within(f'{precision} sep {sep} probability max abs', p_err, tol3(precision, 1e-5, 1e-3))
     got = {k: p.grad for k, p in model.named_parameters()}
     tot_err = math.sqrt(sum(((got[k].double().cpu() - v.grad) ** 2).sum().item() for k, v in leaves.items()))
     tot = math.sqrt(sum((v.grad ** 2).sum().item() for v in leaves.values()))
-    within(f'{precision} sep {sep} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2))
+    within(f'{precision} sep {sep} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2, 1.6e-3))
     if tight:
         for k, v in leaves.items():
             if v.grad.norm() > 1e-7:
@@ -1094,7 +1094,7 @@ def test_validate_and_run_test_vs_oracle():
             want.append(((pfn_oracle.bar_mean(lo, borders)[0] - y[pos].double()) ** 2).mean())
         want = torch.stack(want)
         assert scores.shape == want.shape
-        within(f'{precision} validate scores rel l2', relerr(scores, want), tol3(precision, 1e-4, 5e-3))
+        within(f'{precision} validate scores rel l2', relerr(scores, want), tol3(precision, 1e-4, 5e-3, 1.6e-4))
         # run_test(): same idea through its `get_batch` argument
         drawn = []
 
@@ -1117,8 +1117,8 @@ def test_validate_and_run_test_vs_oracle():
                 se.append(((pfn_oracle.bar_mean(lo, borders)[0] - yb[p].double()) ** 2).mean())
                 top = lo[0].argmax(-1)
                 me.append((((borders[top] + borders[top + 1]).double() / 2 - yb[p].double()) ** 2).mean())
-            within(f'{precision} run_test nll rel', abs(nll[j].item() - torch.cat(nl).mean().item()) / abs(torch.cat(nl).mean().item()), tol3(precision, 1e-4, 1e-3))
-            within(f'{precision} run_test mse rel', abs(mse[j].item() - torch.stack(se).mean().item()) / torch.stack(se).mean().item(), tol3(precision, 1e-4, 5e-3))
+            within(f'{precision} run_test nll rel', abs(nll[j].item() - torch.cat(nl).mean().item()) / abs(torch.cat(nl).mean().item()), tol3(precision, 1e-4, 1e-3, 1.0e-4))
+            within(f'{precision} run_test mse rel', abs(mse[j].item() - torch.stack(se).mean().item()) / torch.stack(se).mean().item(), tol3(precision, 1e-4, 5e-3, 1.0e-4))
             if tight:
                 assert abs(mode_mse[j].item() - torch.stack(me).mean().item()) < 1e-4 * torch.stack(me).mean().item()
 
@@ -1156,12 +1156,12 @@ def test_custom_decoder_module_vs_oracle(precision):
     loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
     loss.backward()
     tight = precision == 'f32'
-    within(f'{precision} logits rel l2', relerr(logits, lo), tol3(precision, 1e-4, 1e-2))
-    within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3))
+    within(f'{precision} logits rel l2', relerr(logits, lo), tol3(precision, 1e-4, 1e-2, 3.2e-4))
+    within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3, 1.0e-4))
     got = {k: p.grad for k, p in model.named_parameters()}
     tot_err = math.sqrt(sum(((got[k].double().cpu() - v.grad) ** 2).sum().item() for k, v in leaves.items()))
     tot = math.sqrt(sum((v.grad ** 2).sum().item() for v in leaves.values()))
-    within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2))
+    within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2, 5.9e-4))
     # a custom decoder runs in PyTorch (AccumulateGrad's += on views of the shared flat buffer): such a model is NOT split over micro-batch
     # streams, a plain one is -- and the unsplit pass through MicroBatchStreams reproduces the gradients above
     from transformerscandobayesianinference_amd.streams import MicroBatchStreams
@@ -1225,13 +1225,13 @@ def test_top_layer_on_the_test_rows_equals_every_layer_on_every_row(precision, L
     tight = precision == 'f32'
     # (bf16: the row-wise products are the same instructions on the same rows; what differs is the f32 decoder gradient entering the top LayerNorm's
     # backward unrounded, and the summation order of the weight gradients over fewer rows)
-    within(f'{precision} top-layer schedules: logits rel l2', relerr(results[1][0], results[0][0]), tol3(precision, 1e-6, 1e-5))
-    within(f'{precision} top-layer schedules: inference logits rel l2', relerr(results[1][1], results[0][1]), tol3(precision, 1e-6, 1e-5))
+    within(f'{precision} top-layer schedules: logits rel l2', relerr(results[1][0], results[0][0]), tol3(precision, 1e-6, 1e-5, 1.0e-6))
+    within(f'{precision} top-layer schedules: inference logits rel l2', relerr(results[1][1], results[0][1]), tol3(precision, 1e-6, 1e-5, 1.0e-6))
     for k, g0 in results[0][2].items():
         if g0.norm() < 1e-12:
             assert results[1][2][k].norm() < 1e-9, k
             continue
-        within(f'{precision} top-layer schedules: gradient rel l2', relerr(results[1][2][k], g0), tol3(precision, 1e-5, 3.5e-3))
+        within(f'{precision} top-layer schedules: gradient rel l2', relerr(results[1][2][k], g0), tol3(precision, 1e-5, 3.5e-3, 4.7e-4))
     # short train parts keep every row (nothing to gain) and dropout does too (its masks are indexed by the full-layout row)
     assert _hip.lib().pfn_top_layer_rows(ctypes.byref(desc), cfg['B'], cfg['T'], cfg['T'] // 4 - 1, 0) == cfg['T'] * cfg['B']
     assert _hip.lib().pfn_top_layer_rows(ctypes.byref(desc), cfg['B'], cfg['T'], cfg['T'], 0) == cfg['T'] * cfg['B']
@@ -1324,12 +1324,12 @@ def test_dropout_vs_oracle_with_the_same_masks(precision, emsize):
     _, logits_plain, _ = pfn_oracle.loss_and_grads(sd, x, y, y, sep, cfg['H'], borders)
     assert relerr(logits_o, logits_plain) > 0.05                       # the masks do something
     tight = precision == 'f32'
-    within(f'{precision} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 2e-2))
-    within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 5e-3))
+    within(f'{precision} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 2e-2, 1.3e-3))
+    within(f'{precision} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 5e-3, 1.0e-4))
     got = {k: p.grad for k, p in model.named_parameters()}
     tot_err = math.sqrt(sum(((got[k].double().cpu() - v) ** 2).sum().item() for k, v in grads_o.items()))
     tot = math.sqrt(sum((v ** 2).sum().item() for v in grads_o.values()))
-    within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 2e-2))
+    within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 2e-2, 1.2e-3))
     if tight:
         for k, v in grads_o.items():
             if v.norm() > 1e-7:
@@ -1340,7 +1340,7 @@ def test_dropout_vs_oracle_with_the_same_masks(precision, emsize):
     model.eval()
     with torch.no_grad():
         lg_eval = model((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
-    within(f'{precision} eval-mode logits rel l2 (no dropout)', relerr(lg_eval, logits_plain), tol3(precision, 1e-4, 2e-2))
+    within(f'{precision} eval-mode logits rel l2 (no dropout)', relerr(lg_eval, logits_plain), tol3(precision, 1e-4, 2e-2, 1.3e-3))
     # the keep rate of a mask is 1 - p
     keep = pfn_oracle.dropout_keep_mask(pfn_oracle.dropout_site_seed(seed, 0, 1), range(400), range(64), pdrop)
     assert abs(keep.float().mean().item() - (1 - pdrop)) < 0.01
@@ -1481,9 +1481,9 @@ def test_trained_head_dim_256_inference_parity():
             lg = m16((x.to(DEV), y.to(DEV)), single_eval_pos=sep)
             nll = m16.criterion(lg.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean().item()
             mean = m16.criterion.mean(lg)
-        within('fp16 training forward (head dim 256): nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 1e-3)
-        within('fp16 training forward (head dim 256): means rel l2 (own norm)', relerr(mean, mean_o), 1e-3)
-        within('fp16 training forward (head dim 256): logits rel l2', relerr(lg, lo), 1e-3)
+        within('fp16 training forward (head dim 256): nll rel', abs(nll - nll_o) / max(abs(nll_o), 0.5), 4e-4)      # (2 x measured: 1.9e-4 / 8.0e-5 / 1.7e-4; bf16: 1.7e-3 / 7.0e-4 / 1.4e-3)
+        within('fp16 training forward (head dim 256): means rel l2 (own norm)', relerr(mean, mean_o), 1.6e-4)
+        within('fp16 training forward (head dim 256): logits rel l2', relerr(lg, lo), 3.4e-4)
 
 
 @pytest.mark.parametrize('precision,aggregate_streams,aggregate_stacked', [('f32', 0, False), ('bf16', 0, False), ('fp16', 0, False), ('f32', 2, False), ('f32', 0, True), ('bf16', 0, True), ('fp16', 0, True)])
@@ -1505,10 +1505,10 @@ def test_training_loop_vs_reference_train_golden(precision, aggregate_streams, a
     assert lrs == pytest.approx(rec['batch_lr'], rel=1e-12, abs=0) and lrs[0] == 0.0
     tight = precision == 'f32'
     # (measured: f32 5.4e-7 / 2.4e-7 / 2.6e-4, bf16 7.5e-4 / 1.3e-4 / 4.2e-2 -- profiles/r04_parity_measured.json)
-    within(f'{precision} batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses, rec['batch_losses'])), tol3(precision, 1e-4, 2e-3))
+    within(f'{precision} batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses, rec['batch_losses'])), tol3(precision, 1e-4, 2e-3, 3.0e-4))
     epoch = [sum(losses[e * cfg['steps_per_epoch']:(e + 1) * cfg['steps_per_epoch']]) / cfg['steps_per_epoch'] for e in range(cfg['epochs'])]
-    within(f'{precision} epoch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(epoch, rec['epoch_losses'])), tol3(precision, 1e-4, 2e-3))
-    within(f'{precision} returned total loss rel', abs(total - rec['returned_total_loss']) / abs(rec['returned_total_loss']), tol3(precision, 1e-4, 2e-3))
+    within(f'{precision} epoch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(epoch, rec['epoch_losses'])), tol3(precision, 1e-4, 2e-3, 1.0e-4))
+    within(f'{precision} returned total loss rel', abs(total - rec['returned_total_loss']) / abs(rec['returned_total_loss']), tol3(precision, 1e-4, 2e-3, 1.0e-4))
     within(f'{precision} parameter update over the run, rel l2', replay.update_error(final, rec), tol3(precision, 1e-3, 0.1, 6e-2))      # (fp16 measured 1.7-2.8e-2)
 
 
@@ -1725,7 +1725,7 @@ def test_deterministic_schedule_is_bit_reproducible(precision):
     for k in final_a:
         assert torch.equal(final_a[k], final_b[k]), k
     tight = precision == 'f32'
-    within(f'{precision} deterministic schedule: batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses_a, rec['batch_losses'])), tol3(precision, 1e-4, 2e-3))
+    within(f'{precision} deterministic schedule: batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses_a, rec['batch_losses'])), tol3(precision, 1e-4, 2e-3, 1.4e-4))
     within(f'{precision} deterministic schedule: parameter update over the run, rel l2', replay.update_error(final_a, rec), tol3(precision, 1e-3, 0.1, 4e-2))      # (fp16 measured 1.8e-2)
 
 
@@ -1759,7 +1759,7 @@ def test_deterministic_schedule_gradients_at_a_benchmark_like_shape(precision):
     g1, g2 = grad(md), grad(md)
     assert torch.equal(g1, g2)
     g0 = grad(build(False))
-    within(f'{precision} deterministic vs default schedule: gradient rel l2', relerr(g1, g0), tol3(precision, 1e-5, 5e-3))
+    within(f'{precision} deterministic vs default schedule: gradient rel l2', relerr(g1, g0), tol3(precision, 1e-5, 5e-3, 2.6e-4))
 
 
 @pytest.mark.parametrize('E,H', [(256, 4), (512, 4), (1024, 4)], ids=['head-dim-64', 'head-dim-128', 'head-dim-256'])
@@ -1838,7 +1838,7 @@ def test_forward_batches_equals_separate_forwards(precision, seps):
         assert got.shape == ref.shape == (cfg['T'] - sep, w, cfg['nbars'])
         assert torch.equal(got, ref), (sep, relerr(got, ref) if ref.numel() else 0)
     sum(loss_of(o, y, sep) for o, (_, y), sep in zip(outs, batches, seps) if sep < cfg['T']).backward()
-    within(f'{precision} stacked vs sequential accumulation: gradient rel l2', relerr(grad, g_seq), tol3(precision, 1e-5, 5e-3))
+    within(f'{precision} stacked vs sequential accumulation: gradient rel l2', relerr(grad, g_seq), tol3(precision, 1e-5, 5e-3, 5.3e-4))
     # and the inference pass (eval mode, no_grad) takes the same route
     model.eval()
     with torch.no_grad():
