@@ -82,7 +82,8 @@ enum { PFN_SCHED_TOP_LAYER_ALL_ROWS = 1, /* run the TOP encoder layer on every r
        PFN_SCHED_KEY_CENTERING = 64,
        PFN_SCHED_F32_RESIDUAL = 128,     /* PFN_PREC_FP16 keeps the pre-LayerNorm sums (the residual the next block adds, the LayerNorm backward's input) in f32 as bf16 does.
                                           * Default (bit clear, fp16, no dropout, emsize 128 / 256 / 512): they are stored in fp16 -- the LayerNorm-fused GEMMs are bound by their
-                                          * epilogue's HBM streams and this halves the two f32 ones; LayerNorm itself, its statistics and the operand copy still come from f32 registers */
+                                          * epilogue's HBM streams and this halves the two f32 ones; LayerNorm itself, its statistics and the operand copy still come from f32 registers.
+                                          * Other widths (the LayerNorm as its own kernel): the GEMM ahead of it adds the residual from the operand-precision copy and stores an fp16 sum */
        PFN_SCHED_FUSE_Q_PROJECTION = 32, /* the Q projection runs INSIDE the attention forward kernel (north_star: "QKV projection + scaled-dot-product attention + softmax ... as one
                                           * fused kernel"): a workgroup forms its 256 queries' head slice x W_q[h]^T + b_q[h] on the matrix cores in its prologue, the GEMM in
                                           * front projects k | v only (shared by every query block of a head: they stay a GEMM).  Same Q bits as the GEMM's; 16-bit operands,

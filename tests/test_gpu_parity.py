@@ -175,11 +175,12 @@ def test_config1_vs_oracle(precision):
         within(f'{precision} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2, 1.3e-3))
 
 
-@pytest.mark.parametrize('E,H', [(128, 4), (512, 4)])
+@pytest.mark.parametrize('E,H', [(128, 4), (512, 4), (1024, 4)])      # LayerNorm-fused GEMMs (128, 512) / the LayerNorm as its own kernel (1024 = configs[4])
 def test_fp16_pre_layernorm_sums_in_operand_precision_vs_f32(E, H):
     """fp16 operands store the pre-LayerNorm sums -- the residual the next block adds, the LayerNorm backward's input -- in fp16 by default (GemmLN::y16: half the
     bytes of the LayerNorm-fused GEMMs' two f32 streams); PFN_SCHED_F32_RESIDUAL keeps them in f32 as in bf16.  Both against the f64 oracle, and against each other:
-    the 16-bit sums add less than the operand rounding that is there anyway."""
+    the 16-bit sums add less than the operand rounding that is there anyway.  At emsize 1024, where the LayerNorm is its own kernel, the GEMM ahead of it adds the
+    residual from the operand-precision copy of the layer input and stores an fp16 sum (launch_layernorm_fwd x_is_t)."""
     cfg = dict(T=160, B=4, F=5, E=E, H=H, nhid=2 * E, L=3, nbars=100)
     ref = random_model(cfg, 'fp16', seed=11)
     sd = {k: v.clone() for k, v in ref.state_dict().items()}

@@ -1,6 +1,6 @@
 """Sets the fp16 argument of every `tol3(precision, f32, bf16)` bound in tests/test_gpu_parity.py to 2 x the largest value a recorded GPU session measured for it
 (PFN_RECORD_BOUNDS=... pytest -m gpu  ->  profiles/r06_parity_measured.json), never below the exact-f32 bound and never above the default (a quarter of the bf16 bound).
-Bounds that already carry an explicit fp16 value are left alone unless --all.
+A bound that already carries an fp16 value is recomputed unless its line has a comment (set by hand).
 
     python tools/tighten_fp16_bounds.py profiles/r06_parity_measured.json [more records ...] [--write]
 """
@@ -25,8 +25,8 @@ def main():
         m = re.match(r'def (test_\w+)\(', line)
         if m:
             test = m.group(1)
-        m = re.search(r"within\(f'\{precision\} (.*?)', .*tol3\(precision, ([0-9.e-]+), ([0-9.e-]+)\)\)", line)
-        if not m or test is None:
+        m = re.search(r"within\(f'\{precision\} (.*?)', .*tol3\(precision, ([0-9.e-]+), ([0-9.e-]+)(, [0-9.e-]+)?\)\)", line)
+        if not m or test is None or '#' in line:      # (a bound with a comment was set by hand)
             continue
         label, f32, bf16 = m.group(1), float(m.group(2)), float(m.group(3))
         pat = re.compile(re.escape(test) + r'(\[.*\])? :: fp16 ' + re.sub(r'\\\{.*?\\\}', '.*?', re.escape(label)) + '$')
@@ -36,10 +36,10 @@ def main():
             continue
         default = max(f32, bf16 / 4)
         new = min(default, max(f32, round_up(2 * max(vals)) if max(vals) > 0 else f32))
-        if new >= default:
+        if new >= default and not m.group(4):
             continue
         s = ('%.1e' % new).replace('e-0', 'e-')
-        lines[i] = line.replace(f'tol3(precision, {m.group(2)}, {m.group(3)})', f'tol3(precision, {m.group(2)}, {m.group(3)}, {s})')
+        lines[i] = line.replace(f'tol3(precision, {m.group(2)}, {m.group(3)}{m.group(4) or ""})', f'tol3(precision, {m.group(2)}, {m.group(3)}, {s})' if new < default else f'tol3(precision, {m.group(2)}, {m.group(3)})')
         print(f'{test}: "{label}"  measured {max(vals):.2e} (n={len(vals)})  default {default:.1e} -> {s}')
         changed += 1
     print(changed, 'bounds tightened')

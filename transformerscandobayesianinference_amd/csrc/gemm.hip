@@ -1534,6 +1534,7 @@ template <typename T> static bool launch_big(const GemmNT& g, bool small_tile, h
     PFN_BIG_CASE(EPI_RESID | EPI_OUT_F32)
     PFN_BIG_CASE(EPI_RESID_T | EPI_OUT_F32)                       // dx = dgrad + residual gradient (kept in operand precision)
     PFN_BIG_CASE(EPI_RESID_T | EPI_OUT_T)                         // ... between layers the sum stays in operand precision too
+    PFN_BIG_CASE(EPI_BIAS | EPI_RESID_T | EPI_OUT_T)              // out_proj / linear2 + residual where the LayerNorm is its own kernel, fp16 sums (emsize 1024)
     PFN_BIG_CASE(EPI_OUT_T)                                       // d(ctx)
     PFN_BIG_CASE(EPI_OUT_T | EPI_ROWDOT)                          // d(ctx) + the attention backward's delta
     PFN_BIG_CASE(EPI_OUT_F32)

@@ -170,6 +170,14 @@ static bool residual16(const pfn_model_desc& d) {
   return d.precision == PFN_PREC_FP16 && !(d.schedule & PFN_SCHED_F32_RESIDUAL) && d.nlayers > 0 && d.dropout == 0.f && d.nhid % 32 == 0 &&
          (E == 128 || E == 256 || E == 512 || (E == 1024 && (d.schedule & PFN_SCHED_FUSE_LN_WIDE)));
 }
+// ... and where the LayerNorm stays its own kernel (emsize 1024 by default: the wide fused kernels lose there) an fp16 model runs the same streams in fp16: the GEMM in
+// front takes its residual from the operand-precision copy of the LayerNorm output and stores the sum in fp16, layernorm_fwd reads that and writes the operand copy
+// only (the f32 LayerNorm output survives for the last layer, which feeds the decoder gather) -- 8 instead of 18 bytes per element around every LayerNorm.
+static bool residual16_separate_ln(const pfn_model_desc& d, bool ln_fusable) {
+  // (from emsize 1024 on: there the streams are the kernels' bound.  Narrow unfusable widths keep f32 -- nothing to gain, and here the ROUNDED sum is what the
+  // LayerNorm normalises, so the rounding reaches the operands and not only the residual path: measured 1.3 x on the logits at emsize 1024, 4 x at 64)
+  return d.precision == PFN_PREC_FP16 && !(d.schedule & PFN_SCHED_F32_RESIDUAL) && d.nlayers > 0 && d.dropout == 0.f && d.emsize >= 1024 && d.emsize % 8 == 0 && !ln_fusable;
+}
 // can out_proj / linear2 run as gemm_nt_ln_kernel at all (shapes, 16-byte alignment of every stream)?  The forward and the backward ask the same question.
 static bool ln_gemm_probe(const pfn_model_desc& d, const Ws& w, const float* params, const void* sh, int M) {
   GemmLN probe; memset(&probe, 0, sizeof(probe));
@@ -423,6 +431,7 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
   const bool ln_ok = ln_gemm_probe(*d, w, params, sh, M);
   const bool fuse_ln = prec_is16(prec) && ln_ok && F % 32 == 0 && pdrop == 0.f && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE));
   const bool y16 = residual16(*d) && ln_ok;      // (implies fuse_ln: the descriptor's dropout is 0, so is pdrop)
+  const bool y16u = residual16_separate_ln(*d, ln_ok && F % 32 == 0 && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE)));      // (implies !fuse_ln)
   struct Resid { const float* plain; const void* y; const float* mean; const float* rstd; const float* gamma; const float* beta; };
   Resid res = {w.x0, nullptr, nullptr, nullptr, nullptr, nullptr};   // where the layer input lives in f32
   auto set_resid = [](GemmLN& g, const Resid& r) {
@@ -474,7 +483,8 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
         PFN_TRY(gather_top(res.rstd, w.top_rrstd, 4));
         res = Resid{nullptr, w.top_ry, w.top_rmean, w.top_rrstd, res.gamma, res.beta};
       } else {
-        PFN_TRY(gather_top(fuse_ln ? res.plain : xin, w.top_ry, (long)E * 4));
+        if (y16u) PFN_TRY(gather_top(xin_t, w.top_ry, (long)E * es));      // (the residual of this layer's out_proj is read in operand precision)
+        else PFN_TRY(gather_top(fuse_ln ? res.plain : xin, w.top_ry, (long)E * 4));
         res = Resid{w.top_ry, nullptr, nullptr, nullptr, nullptr, nullptr};
         xin = w.top_ry;
       }
@@ -493,10 +503,13 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       {  // out_proj + residual  (dropout1: the product leaves alone and the element-wise pass adds the residual)
         GemmNT g = nt(ctx_in, E, W(p.w_o), E, Ml, E, E, EPI_BIAS | (pdrop > 0.f ? 0 : EPI_RESID) | EPI_OUT_F32);
         g.bias = params + p.b_o; g.resid = xin; g.ld_resid = E; g.out_f32 = a.y1; g.ld_out_f32 = E;
+        if (y16u) {      // residual from the operand-precision layer input (the gathered test rows in top mode), sum out in operand precision
+          g.flags = EPI_BIAS | EPI_RESID_T | EPI_OUT_T; g.aux = top ? (const void*)w.top_ry : (const void*)xin_t; g.ld_aux = E; g.out_t = a.y1; g.ld_out_t = E;
+        }
         PFN_TRY(launch_gemm_nt(g, prec, s));
         if (pdrop > 0.f) PFN_TRY(launch_dropout_add(a.y1, xin, M, E, dseed(l, 1), pdrop, s));
       }
-      PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, a.x1, a.x1_t, a.mean1, a.rstd1, Ml, E, d->ln_eps, prec, s));
+      PFN_TRY(launch_layernorm_fwd(a.y1, params + p.g1, params + p.be1, y16u ? nullptr : a.x1, a.x1_t, a.mean1, a.rstd1, Ml, E, d->ln_eps, prec, s, y16u));
     }
     {  // linear1 + GELU (pre-activation kept for the backward)
       ProfScope ps(PFN_PROF_GEMM_LIN1 + (top ? 1 : 0), s);
@@ -520,10 +533,13 @@ static int stack_forward_impl(const pfn_model_desc* d, const float* params, cons
       {  // linear2 + residual  (dropout2 as above)
         GemmNT g = nt(a.h, F, W(p.w2), F, Ml, E, F, EPI_BIAS | (pdrop > 0.f ? 0 : EPI_RESID) | EPI_OUT_F32);
         g.bias = params + p.b2; g.resid = a.x1; g.ld_resid = E; g.out_f32 = a.y2; g.ld_out_f32 = E;
+        if (y16u) { g.flags = EPI_BIAS | EPI_RESID_T | EPI_OUT_T; g.aux = a.x1_t; g.ld_aux = E; g.out_t = a.y2; g.ld_out_t = E; }
         PFN_TRY(launch_gemm_nt(g, prec, s));
         if (pdrop > 0.f) PFN_TRY(launch_dropout_add(a.y2, a.x1, M, E, dseed(l, 3), pdrop, s));
       }
-      PFN_TRY(launch_layernorm_fwd(a.y2, params + p.g2, params + p.be2, top ? x2_f32 : a.x2, a.x2_t, a.mean2, a.rstd2, Ml, E, d->ln_eps, prec, s));
+      // (fp16 sums: only the last layer's f32 output has a reader -- the decoder gather, or the caller when there is no decoder)
+      float* x2_out = top ? x2_f32 : ((y16u && l < d->nlayers - 1) ? nullptr : a.x2);
+      PFN_TRY(launch_layernorm_fwd(a.y2, params + p.g2, params + p.be2, x2_out, a.x2_t, a.mean2, a.rstd2, Ml, E, d->ln_eps, prec, s, y16u));
     }
     xin = a.x2; xin_t = a.x2_t;
   }
@@ -627,7 +643,9 @@ static int stack_backward_impl(const pfn_model_desc* d, const float* params, con
   const char* sh = (const char*)shadow;
   auto W = [&](int64_t off) { return (const void*)(sh + off * es); };
   auto WT = [&](int64_t off) { return (const void*)(sh + (L.total + off) * es); };
-  const bool y16 = residual16(*d) && ln_gemm_probe(*d, w, params, sh, M);      // the forward stored the pre-LayerNorm sums in operand precision (same rule, same pointers)
+  const bool ln_ok = ln_gemm_probe(*d, w, params, sh, M);
+  // the forward stored the pre-LayerNorm sums in operand precision (same rules, same pointers): inside the LayerNorm-fused GEMMs, or from a GEMM ahead of layernorm_fwd
+  const bool y16 = (residual16(*d) && ln_ok) || residual16_separate_ln(*d, ln_ok && F % 32 == 0 && (E <= 512 || (d->schedule & PFN_SCHED_FUSE_LN_WIDE)));
 
   // fp16 operands: the backward chain runs on dlogits * 2^k, k from max|dlogits| on the device; every kernel that writes a parameter gradient takes 2^k out again
   if (prec == PFN_PREC_FP16 && Mt > 0) {

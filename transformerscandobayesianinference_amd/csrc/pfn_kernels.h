@@ -300,8 +300,8 @@ int launch_sbe_to_bse(const float* src, float* out_f32, void* out_t, int S, int 
 int launch_bse_to_sbe(const float* src_bse, float* dst_sbe, int S, int B, int E, hipStream_t s, const float* scale_amax = nullptr);      // (* 2^-k)
 
 // y = LN(x) * gamma + beta over E; writes f32 and T copies, mean/rstd per row
-int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
-                         float* mean, float* rstd, long rows, int E, float eps, int precision, hipStream_t s);
+int launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, float* y_f32, void* y_t,
+                         float* mean, float* rstd, long rows, int E, float eps, int precision, hipStream_t s, int x_is_t = 0);      // x_is_t: x in operand precision
 // dx = LN'(dy) (dy f32, or T when dy_is_t); dx written f32 + T; dgamma/dbeta accumulated with atomics; optional dbias_extra
 // accumulates colsum(dx) (the bias gradient of the linear that produced x's pre-LN sum).
 int launch_layernorm_bwd(const void* dy, int dy_is_t, const void* x, const float* gamma, const float* mean, const float* rstd,

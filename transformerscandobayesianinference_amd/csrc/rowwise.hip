@@ -744,9 +744,11 @@ int launch_zero_row_prefix(void* base, int S, int B, int nrows, long row_bytes, 
 // LayerNorm: one wave per row, the row lives in registers (NV float4 per lane, E <= 256*NV)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, const float* gamma, const float* beta, float* y32, T* yt,
-                                                            float* mean_o, float* rstd_o, long rows, int E, float eps) {
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x_any, const float* gamma, const float* beta, float* y32, T* yt,
+                                                            float* mean_o, float* rstd_o, long rows, int E, float eps, int x_is_t) {
   operand_store_mode<T>();
+  const float* x = reinterpret_cast<const float*>(x_any);      // the pre-LayerNorm sums: f32, or operand precision when x_is_t (fp16 models: the GEMM in front stored them so)
+  const T* x_t = reinterpret_cast<const T*>(x_any);
   const int lane = threadIdx.x & 63;
   const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const float invE = 1.f / (float)E;
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, cons
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 64 + lane) * 4;
-      v[k] = (c < E) ? *reinterpret_cast<const f32x4*>(x + row * E + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[k] = (c < E) ? (x_is_t ? ld4<T>(x_t + row * E + c) : *reinterpret_cast<const f32x4*>(x + row * E + c)) : f32x4{0.f, 0.f, 0.f, 0.f};
       s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
     }
     const float mu = wave_sum(s) * invE;
@@ -785,12 +787,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, cons
     if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rstd; }
   }
 }
-int launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y32, void* yt, float* mean, float* rstd,
-                         long rows, int E, float eps, int precision, hipStream_t s) {
-  if (E % 4 || E > 2048) return PFN_ERR_UNSUPPORTED;
+int launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, float* y32, void* yt, float* mean, float* rstd,
+                         long rows, int E, float eps, int precision, hipStream_t s, int x_is_t) {
+  if (E % 4 || E > 2048 || (x_is_t && !prec_is16(precision))) return PFN_ERR_UNSUPPORTED;
   if (rows == 0) return PFN_OK;
   const int grid = grid_for(rows, 4, 8192);
-#define LN_FWD(TT, NV) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, NV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, y32, (TT*)yt, mean, rstd, rows, E, eps)
+#define LN_FWD(TT, NV) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, NV>), dim3(grid), dim3(256), 0, s, x, gamma, beta, y32, (TT*)yt, mean, rstd, rows, E, eps, x_is_t)
 #define LN_FWD_NV(TT) do { if (E <= 256) LN_FWD(TT, 1); else if (E <= 512) LN_FWD(TT, 2); else if (E <= 1024) LN_FWD(TT, 4); else LN_FWD(TT, 8); } while (0)
   PFN_DISPATCH_OP(precision, LN_FWD_NV(T));
   return PFN_LAUNCH_OK();
