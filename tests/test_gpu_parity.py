@@ -199,11 +199,11 @@ def test_fp16_pre_layernorm_sums_in_operand_precision_vs_f32(E, H):
             loss.backward()
             g = {k: p.grad.double().cpu() for k, p in model.named_parameters()}
             err = math.sqrt(sum(((g[k] - grads_o[k]) ** 2).sum().item() for k in g)) / tot
-            within(f'{name}, sep {sep}: logits rel l2 vs oracle', relerr(logits, logits_o), 1.5e-3)       # (measured: 5.8e-4 with f32 sums, 7.3e-4 with fp16 sums)
+            within(f'{name}, sep {sep}: logits rel l2 vs oracle', relerr(logits, logits_o), 1.7e-3)       # (measured: 5.8-6.0e-4 with f32 sums; fp16 sums 7.3e-4 inside the fused GEMMs, 8.5e-4 ahead of layernorm_fwd at emsize 1024)
             within(f'{name}, sep {sep}: loss rel vs oracle', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), 2.5e-5)
-            within(f'{name}, sep {sep}: global gradient rel l2 vs oracle', err, 1.2e-3)
+            within(f'{name}, sep {sep}: global gradient rel l2 vs oracle', err, 1.4e-3)
             out[name] = (logits.detach(), g)
-        within(f'sep {sep}: logits, fp16 sums vs f32 sums, rel l2', relerr(out['fp16 sums'][0], out['f32 sums'][0]), 1.3e-3)
+        within(f'sep {sep}: logits, fp16 sums vs f32 sums, rel l2', relerr(out['fp16 sums'][0], out['f32 sums'][0]), 1.6e-3)
         assert not torch.equal(out['fp16 sums'][0], out['f32 sums'][0])      # (the bit does select another arithmetic)
 
 
@@ -260,14 +260,14 @@ def test_config5_width_vs_oracle(precision, H):
     loss = model.criterion(logits.reshape(-1, cfg['nbars']), y[sep:].to(DEV).flatten()).mean()
     tight = precision == 'f32'
     within(f'{precision} H{H} loss rel', abs(loss.item() - loss_o.item()) / abs(loss_o.item()), tol3(precision, 1e-4, 1e-3, 1.0e-4))
-    within(f'{precision} H{H} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 1e-2, 1.4e-3))
+    within(f'{precision} H{H} logits rel l2', relerr(logits, logits_o), tol3(precision, 1e-4, 1e-2, 1.8e-3))
     within(f'{precision} H{H} means max / target range', mean_err(model.criterion.mean(logits), pfn_oracle.bar_mean(logits_o, sd['criterion.borders']), y), tol3(precision, 1e-5, 1e-3, 2.4e-5))
     # (exact-f32 at head dim 256, round 5: the backward runs the plain vector-ALU attention kernels -- csrc/attention.hip attn_bwd_plain_* -- and is held to the
     # same 2e-4 "any layout mistake fails" bound as every other f32 shape)
     loss.backward()
     tot_err = math.sqrt(sum(((p.grad.double().cpu() - grads_o[k]) ** 2).sum().item() for k, p in model.named_parameters()))
     tot = math.sqrt(sum((g ** 2).sum().item() for g in grads_o.values()))
-    within(f'{precision} H{H} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2, 1.3e-3))
+    within(f'{precision} H{H} global gradient rel l2', tot_err / tot, tol3(precision, 2e-4, 1.2e-2, 1.6e-3))
 
 
 def test_full_size_properties_bf16():
@@ -1506,7 +1506,7 @@ def test_training_loop_vs_reference_train_golden(precision, aggregate_streams, a
     assert lrs == pytest.approx(rec['batch_lr'], rel=1e-12, abs=0) and lrs[0] == 0.0
     tight = precision == 'f32'
     # (measured: f32 5.4e-7 / 2.4e-7 / 2.6e-4, bf16 7.5e-4 / 1.3e-4 / 4.2e-2 -- profiles/r04_parity_measured.json)
-    within(f'{precision} batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses, rec['batch_losses'])), tol3(precision, 1e-4, 2e-3, 3.0e-4))
+    within(f'{precision} batch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(losses, rec['batch_losses'])), tol3(precision, 1e-4, 2e-3, 2.6e-4))
     epoch = [sum(losses[e * cfg['steps_per_epoch']:(e + 1) * cfg['steps_per_epoch']]) / cfg['steps_per_epoch'] for e in range(cfg['epochs'])]
     within(f'{precision} epoch losses, max rel', max(abs(a - b) / abs(b) for a, b in zip(epoch, rec['epoch_losses'])), tol3(precision, 1e-4, 2e-3, 1.0e-4))
     within(f'{precision} returned total loss rel', abs(total - rec['returned_total_loss']) / abs(rec['returned_total_loss']), tol3(precision, 1e-4, 2e-3, 1.0e-4))
@@ -1760,7 +1760,7 @@ def test_deterministic_schedule_gradients_at_a_benchmark_like_shape(precision):
     g1, g2 = grad(md), grad(md)
     assert torch.equal(g1, g2)
     g0 = grad(build(False))
-    within(f'{precision} deterministic vs default schedule: gradient rel l2', relerr(g1, g0), tol3(precision, 1e-5, 5e-3, 2.6e-4))
+    within(f'{precision} deterministic vs default schedule: gradient rel l2', relerr(g1, g0), tol3(precision, 1e-5, 5e-3, 2.5e-4))
 
 
 @pytest.mark.parametrize('E,H', [(256, 4), (512, 4), (1024, 4)], ids=['head-dim-64', 'head-dim-128', 'head-dim-256'])
