@@ -258,7 +258,7 @@ def test_model_state_dict_keys_match_reference():
     d = TransformerModel(encoders.Linear(3, 64), 8, 64, 2, 128, 2, 0.25, y_encoder=encoders.Linear(1, 64))
     desc = d._make_desc()
     assert (desc.num_features, desc.emsize, desc.nhead, desc.nhid, desc.nlayers, desc.n_out) == (3, 64, 2, 128, 2, 8)
-    assert abs(desc.dropout - 0.25) < 1e-7 and desc.precision == _hip.PREC_BF16 and d.eval_precision == 'f32'
+    assert abs(desc.dropout - 0.25) < 1e-7 and desc.precision == _hip.PREC_FP16 and d.eval_precision == 'f32'
     assert d._make_desc('f32').precision == _hip.PREC_F32
     assert _hip.lib().pfn_workspace_bytes(desc, 2, 64) > _hip.lib().pfn_workspace_bytes(m._make_desc(), 2, 64) * 0   # (host-only size query works without a GPU)
     s1, s2 = d._next_dropout_seed(), d._next_dropout_seed()

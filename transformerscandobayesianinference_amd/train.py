@@ -69,7 +69,7 @@ def train(priordataloader_class, criterion, encoder_generator, emsize=200, nhid=
           epochs=10, steps_per_epoch=100, batch_size=200, bptt=10, lr=None, warmup_epochs=10, input_normalization=False,
           y_encoder_generator=None, pos_encoder_generator=None, decoder=None, extra_prior_kwargs_dict={},
           scheduler=get_cosine_schedule_with_warmup, load_weights_from_this_state_dict=None, validation_period=10,
-          single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='bf16', micro_streams=2, epoch_callback=None,
+          single_eval_pos_gen=None, gpu_device='cuda:0', aggregate_k_gradients=1, verbose=True, precision='fp16', micro_streams=2, epoch_callback=None,
           aggregate_streams=None, deterministic=False, aggregate_stacked=None):
     device = gpu_device if torch.cuda.is_available() else 'cpu:0'
     print(f'Using {device} device')
@@ -292,7 +292,7 @@ def main(argv=None):
     parser.add_argument('--steps_per_epoch', default=10, type=int)
     parser.add_argument('--batch_size', default=1000, type=int)
     parser.add_argument('--lr', '--learning_rate', default=.001, type=float)
-    parser.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'f32'])
+    parser.add_argument('--precision', default='fp16', choices=['bf16', 'fp16', 'f32'])
     args, _ = _parse_args(config_parser, parser, argv)
     cfg = dict(args.__dict__)
     cfg.pop('config', None)
