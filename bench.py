@@ -52,19 +52,21 @@ IN_STEP_TRACE = os.path.join(ROOT, 'profiles', 'r06_in_step_kernels_config{confi
 PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r06_pmc_traffic_config{config}.json')
 TRAINED = os.path.join(ROOT, 'profiles', 'r03_trained_config2.json')
 
-# BASELINE.json configs (index = position in the list; 3 is configs[1] on 8 GPUs)
+# BASELINE.json configs (index = position in the list; 3 is configs[1] on 8 GPUs).  batch / streams: datasets per GPU per optimizer step and the micro-batch streams they
+# run on -- BASELINE.json fixes neither; rounds 2-5 ran 64 x 2 (8 x 2 at bptt 4000), the second half of round 6 measured three streams of 64 (128; 8) datasets 3.2 % (9 %; 1.5 %)
+# faster on one box (profiles/r06_step_experiments.txt, GPU calls 19 / 20): fewer, larger launches per dataset and a third stream in the others' tails.
 CONFIGS = {
     2: dict(prior='fast_gp', bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, criterion='bar', num_bars=1000,
-            hyperparameters=dict(noise=1e-4, outputscale=1.0, lengthscale=0.6), batch=64, streams=2, eval_pos='weighted', parity_batch=2, parity_sep=1755,
+            hyperparameters=dict(noise=1e-4, outputscale=1.0, lengthscale=0.6), batch=192, streams=3, eval_pos='weighted', parity_batch=2, parity_sep=1755,
             metric='synthetic datasets/sec (GP prior, bptt=2000)',
             workload='priors.fast_gp, bptt=2000, num_features=18, emsize=512, nhead=4, nhid=1024, nlayers=6, 1000 bars (BASELINE.json configs[1])'),
     4: dict(prior='mlp', bptt=1000, num_features=60, emsize=512, nhead=4, nhid=1024, nlayers=6, criterion='bce', num_bars=1,
-            hyperparameters=None, batch=64, streams=2, eval_pos='uniform', parity_batch=2, parity_sep=500,
+            hyperparameters=None, batch=384, streams=3, eval_pos='uniform', parity_batch=2, parity_sep=500,
             metric='synthetic datasets/sec (BNN prior, bptt=1000)',
             workload='priors.mlp (tabular_model_bnn BNN prior, batch_size_per_gp_sample=8), bptt=1000, num_features=60, emsize=512, nhead=4, nhid=1024, '
                      'nlayers=6, BCE head (BASELINE.json configs[3])'),
     5: dict(prior='fast_gp_mix', bptt=4000, num_features=18, emsize=1024, nhead=4, nhid=2048, nlayers=12, criterion='bar', num_bars=1000,
-            hyperparameters={}, batch=8, streams=2, eval_pos='weighted', parity_batch=1, parity_sep=3549,
+            hyperparameters={}, batch=24, streams=3, eval_pos='weighted', parity_batch=1, parity_sep=3549,
             metric='synthetic datasets/sec (GP-mixture prior, bptt=4000)',
             workload='priors.fast_gp_mix default hyper-prior, bptt=4000, num_features=18, emsize=1024, nhead=4 (head dim 256), nhid=2048, nlayers=12, '
                      '1000 bars (BASELINE.json configs[4])'),
