@@ -1101,6 +1101,21 @@ def main():
         release(r)
         del model
         result['other_configs'] = {}
+        # the same configuration with bf16 operands (rounds 1-5's timed path; BASELINE configs[1] says "bf16"): throughput and timed-path parity beside the fp16 line
+        if args.precision != 'bf16':
+            t0 = time.time()
+            rb16 = run_config(2, device, 0, 1, 'bf16', steps=args.steps, warmup=args.warmup)      # (straight after the main line, same step counts: the chip in the same state)
+            tb16 = throughput_fields(rb16, 1)
+            entry = dict(dtype='bf16', value=tb16['value'], unit='datasets/s', ms_per_step=tb16['ms_per_step'], steps=args.steps, warmup=args.warmup, per_gpu_batch=rb16['batch'],
+                         step_roofline_frac=tb16['frac'])
+            if not args.no_parity:
+                par16, _ = parity_check(rb16['model'], CONFIGS[2], device, 'bf16')
+                tf16 = par16['training_forward']
+                entry['parity_timed_path'] = dict(precision='bf16', nll_rel=tf16['nll_rel'], mean_rel_l2=tf16['mean_rel_l2'], logits_rel_l2=tf16['logits_rel_l2'])
+            entry['seconds'] = time.time() - t0
+            result['also_bf16'] = entry
+            release(rb16)
+            del rb16
         for cfg in (4, 5):
             t0 = time.time()
             rc = run_config(cfg, device, 0, 1, args.precision, steps=10, warmup=3)
@@ -1118,21 +1133,6 @@ def main():
             result['other_configs'][f'configs[{cfg - 1}]'] = entry
             release(rc)
             del rc
-        # the same configuration with bf16 operands (rounds 1-5's timed path; BASELINE configs[1] says "bf16"): throughput and timed-path parity beside the fp16 line
-        if args.precision != 'bf16':
-            t0 = time.time()
-            rb16 = run_config(2, device, 0, 1, 'bf16', steps=10, warmup=3)
-            tb16 = throughput_fields(rb16, 1)
-            entry = dict(dtype='bf16', value=tb16['value'], unit='datasets/s', ms_per_step=tb16['ms_per_step'], steps=10, warmup=3, per_gpu_batch=rb16['batch'],
-                         step_roofline_frac=tb16['frac'])
-            if not args.no_parity:
-                par16, _ = parity_check(rb16['model'], CONFIGS[2], device, 'bf16')
-                tf16 = par16['training_forward']
-                entry['parity_timed_path'] = dict(precision='bf16', nll_rel=tf16['nll_rel'], mean_rel_l2=tf16['mean_rel_l2'], logits_rel_l2=tf16['logits_rel_l2'])
-            entry['seconds'] = time.time() - t0
-            result['also_bf16'] = entry
-            release(rb16)
-            del rb16
         # the small-batch regime of the reference's notebooks (SetupForGPFittingExperiments.ipynb:143-149 trains configs[1] at batch_size 4 with
         # aggregate_k_gradients 25): per-GPU batch 4 x 25 batches per optimizer step, then 8 / 16 / 32 with one batch per step
         result['batch_sweep'] = []
