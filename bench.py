@@ -1020,7 +1020,8 @@ def main():
         # kernels are launched per micro-batch (column group of the batch, streams.py): time them at THAT shape
         groups = r['micro_groups']
         mean_sep = int(round(sum(seps) / len(seps)))
-        ks = kernel_breakdown(batch // groups, mean_sep, w, fused_ln_wide=bool(tuning.get(5)), top_rows=top_rows_of(batch // groups, mean_sep), precision=args.precision)
+        mb = -(-batch // groups)      # (the larger group when the batch does not divide)
+        ks = kernel_breakdown(mb, mean_sep, w, fused_ln_wide=bool(tuning.get(5)), top_rows=top_rows_of(mb, mean_sep), precision=args.precision)
         in_step = r.get('in_step', {})
         in_solo = r.get('in_step_solo', {})
         for k in ks:

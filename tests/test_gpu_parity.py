@@ -651,7 +651,8 @@ def test_train_entry_point_with_every_prior():
 
 
 def test_micro_batch_streams_match_single_stream():
-    """Two concurrent half-batches on two HIP streams (streams.py) give the full-batch loss and gradients."""
+    """Concurrent column groups of a batch on two / three / four HIP streams (streams.py) give the full-batch loss and gradients; three groups of a batch of 8
+    are 3 + 3 + 2 datasets, each weighted by its share."""
     from transformerscandobayesianinference_amd.priors import fast_gp
     from transformerscandobayesianinference_amd.streams import MicroBatchStreams
     torch.manual_seed(2)
@@ -667,7 +668,7 @@ def test_micro_batch_streams_match_single_stream():
     model.to(DEV).train()
     loss_fn = lambda out, tg: model.criterion(out.reshape(-1, nb), tg[sep:].reshape(-1)).view(out.shape[0], -1)
     grads = []
-    for n in (1, 2, 4):
+    for n in (1, 2, 3, 4):
         flat, g = model.flat_parameters()
         g.zero_()
         losses = MicroBatchStreams(n).forward_backward(model, (x, y), target, sep, loss_fn)

@@ -27,7 +27,8 @@ class MicroBatchStreams:
         # `+=` on its parameters (views of the flat buffer) is not atomic across the two streams
         # ... nor a deterministic model (PFN_SCHED_DETERMINISTIC): its gradient kernels write each element from one place, in stream order
         fused = getattr(model, '_fused_embedding', lambda: False)() and not getattr(model, '_custom_decoder', False) and not getattr(model, 'deterministic', False)
-        return self.n if (self.streams and fused and batch % self.n == 0 and batch >= 2 * self.n) else 1
+        # (the groups need not be equal: `batch % n` of them take one dataset more, each weighted by its share of the batch)
+        return self.n if (self.streams and fused and batch >= 2 * self.n) else 1
 
     def forward_backward(self, model, data, targets, single_eval_pos, loss_fn):
         """data = (x[T,B,F], y[T,B]); targets [T,B] (already sliced to the test rows by the caller's loss_fn if needed).
@@ -43,15 +44,18 @@ class MicroBatchStreams:
         main = torch.cuda.current_stream()
         model.flat_parameters()
         model._refresh_shadow(_hip.stream_ptr(x.device))      # operand copies of the weights: once, before the fork
-        h = x.shape[1] // n
+        B = x.shape[1]
+        h, rem = divmod(B, n)
         outs = []
+        lo = 0
         for i, s in enumerate(self.streams[:n]):
             s.wait_stream(main)
             with torch.cuda.stream(s):
-                sl = slice(i * h, (i + 1) * h)
+                sl = slice(lo, lo + h + (1 if i < rem else 0))
+                lo = sl.stop
                 output = model((x[:, sl], y[:, sl]), single_eval_pos=single_eval_pos)
                 losses = loss_fn(output, targets[:, sl])
-                (losses.mean() / n).backward()
+                (losses.mean() * ((sl.stop - sl.start) / B)).backward()      # the mean over the whole batch: every group by its share of the datasets
                 outs.append(losses.detach())
             for t in (x, y, targets):
                 t.record_stream(s)
